@@ -1,0 +1,828 @@
+// libfokl_hip.so -- context management and kernel launches behind the C ABI of include/fokl_hip.h.
+// gfx950 only; no PyTorch, no BLAS libraries: device work is the hand-written kernels of fokl_kernels.hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/fokl_hip.h"
+#include "fokl_kernels.hip.h"
+
+using namespace fokl;
+
+// ---------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------
+
+static std::mutex g_err_mutex;
+static std::string g_err;
+
+void fokl_set_global_error(const std::string &msg)
+{
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    g_err = msg;
+}
+
+struct TimingSlot {
+    double ms = 0.0;
+    int64_t launches = 0;
+    double bytes = 0.0;
+    double flops = 0.0;
+};
+
+struct PendingEvent {
+    int kernel_id;
+    hipEvent_t start, stop;
+};
+
+struct fokl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // dataset
+    bool have_data = false;
+    int64_t n = 0, ld = 0;
+    int m = 0, kernel = 0, n_basis = 0, width = 0;
+    double *d_x = nullptr;      // [m][ld]
+    double *d_phis = nullptr;
+    size_t phis_doubles = 0;
+
+    // slots
+    static constexpr int CHUNK_SLOTS = 16;
+    std::vector<double *> chunks;
+    std::vector<double *> slot_ptr;     // host copy of the table
+    double **d_slot_ptr = nullptr;      // device table, capacity table_cap
+    int table_cap = 0;
+
+    // workspaces (grow only)
+    char *d_args = nullptr;
+    char *h_args = nullptr;             // pinned
+    size_t args_cap = 0;
+    double *d_slab = nullptr;
+    size_t slab_doubles = 0;
+    double *d_out = nullptr;
+    double *h_out = nullptr;            // pinned
+    size_t out_doubles = 0;
+    hipEvent_t args_free = nullptr;     // recorded after the last H2D copy out of h_args
+
+    // timing
+    bool timing = false;
+    TimingSlot tslot[FOKL_K_COUNT];
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    // RCCL (lazily loaded)
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    double *d_comm = nullptr;
+    size_t comm_doubles = 0;
+};
+
+static int fail(fokl_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    fokl_set_global_error(msg);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(ctx, FOKL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// timing helpers: HIP events on the context's own stream
+// ---------------------------------------------------------------------------------------------------------
+
+static hipEvent_t take_event(fokl_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct TimedRegion {
+    fokl_ctx *ctx;
+    int id;
+    hipEvent_t start = nullptr, stop = nullptr;
+    TimedRegion(fokl_ctx *c, int kernel_id, double bytes, double flops) : ctx(c), id(kernel_id)
+    {
+        if (!ctx->timing) return;
+        ctx->tslot[id].launches += 1;
+        ctx->tslot[id].bytes += bytes;
+        ctx->tslot[id].flops += flops;
+        start = take_event(ctx);
+        stop = take_event(ctx);
+        if (start && stop) (void)hipEventRecord(start, ctx->stream);
+    }
+    ~TimedRegion()
+    {
+        if (!ctx->timing || !start || !stop) return;
+        (void)hipEventRecord(stop, ctx->stream);
+        ctx->pending.push_back({id, start, stop});
+    }
+};
+
+static void drain_events(fokl_ctx *ctx)
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess)
+            ctx->tslot[p.kernel_id].ms += ms;
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// workspace management
+// ---------------------------------------------------------------------------------------------------------
+
+static int ensure_args(fokl_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->args_cap) return FOKL_OK;
+    size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_args) HIP_TRY(ctx, hipFree(ctx->d_args));
+    if (ctx->h_args) HIP_TRY(ctx, hipHostFree(ctx->h_args));
+    ctx->d_args = nullptr;
+    ctx->h_args = nullptr;
+    ctx->args_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_args, cap));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_args, cap, hipHostMallocDefault));
+    ctx->args_cap = cap;
+    return FOKL_OK;
+}
+
+static int ensure_slab(fokl_ctx *ctx, size_t doubles)
+{
+    if (doubles <= ctx->slab_doubles) return FOKL_OK;
+    size_t cap = std::max<size_t>(doubles + doubles / 2, 1 << 16);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_slab) HIP_TRY(ctx, hipFree(ctx->d_slab));
+    ctx->d_slab = nullptr;
+    ctx->slab_doubles = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slab, cap * sizeof(double)));
+    ctx->slab_doubles = cap;
+    return FOKL_OK;
+}
+
+static int ensure_out(fokl_ctx *ctx, size_t doubles)
+{
+    if (doubles <= ctx->out_doubles) return FOKL_OK;
+    size_t cap = std::max<size_t>(doubles * 2, 1 << 12);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_out) HIP_TRY(ctx, hipFree(ctx->d_out));
+    if (ctx->h_out) HIP_TRY(ctx, hipHostFree(ctx->h_out));
+    ctx->d_out = nullptr;
+    ctx->h_out = nullptr;
+    ctx->out_doubles = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_out, cap * sizeof(double)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_out, cap * sizeof(double), hipHostMallocDefault));
+    ctx->out_doubles = cap;
+    return FOKL_OK;
+}
+
+// Stage `bytes` of launch arguments: wait until the previous copy out of the pinned buffer has finished,
+// let the caller fill it, then copy asynchronously.
+static int begin_args(fokl_ctx *ctx, size_t bytes)
+{
+    int rc = ensure_args(ctx, bytes);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->args_free));
+    return FOKL_OK;
+}
+
+static int push_args(fokl_ctx *ctx, size_t bytes)
+{
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_args, ctx->h_args, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->args_free, ctx->stream));
+    return FOKL_OK;
+}
+
+static void free_slots(fokl_ctx *ctx)
+{
+    for (double *c : ctx->chunks) (void)hipFree(c);
+    ctx->chunks.clear();
+    ctx->slot_ptr.clear();
+}
+
+static int check_slots(fokl_ctx *ctx, const int32_t *slots, int count, const char *who)
+{
+    if (!slots && count > 0) return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": null slot list");
+    const int cap = (int)ctx->slot_ptr.size();
+    for (int i = 0; i < count; ++i)
+        if (slots[i] < 0 || slots[i] >= cap)
+            return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": slot " + std::to_string(slots[i]) +
+                                               " outside [0, " + std::to_string(cap) + ")");
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// library / context
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_version(void) { return 100; }
+
+extern "C" int fokl_device_count(int *count)
+{
+    if (!count) return fail(nullptr, FOKL_ERR_ARG, "fokl_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, FOKL_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return FOKL_OK;
+}
+
+extern "C" const char *fokl_last_error(const fokl_ctx *ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+extern "C" int fokl_ctx_create(int device, fokl_ctx **out)
+{
+    if (!out) return fail(nullptr, FOKL_ERR_ARG, "fokl_ctx_create: null output pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: no HIP device available (" +
+                                               std::string(hipGetErrorString(e)) + ")");
+    if (device < 0 || device >= n)
+        return fail(nullptr, FOKL_ERR_ARG, "fokl_ctx_create: device index out of range");
+    fokl_ctx *ctx = new fokl_ctx();
+    ctx->device = device;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        std::string arch = prop.gcnArchName;
+        delete ctx;
+        return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: device is " + arch + ", this library is built for gfx950 only");
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->args_free, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: cannot create stream / event");
+    }
+    (void)hipEventRecord(ctx->args_free, ctx->stream);
+    *out = ctx;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_comm_destroy(fokl_ctx *ctx);
+
+extern "C" void fokl_ctx_destroy(fokl_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)fokl_comm_destroy(ctx);
+    drain_events(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    free_slots(ctx);
+    if (ctx->d_slot_ptr) (void)hipFree(ctx->d_slot_ptr);
+    if (ctx->d_x) (void)hipFree(ctx->d_x);
+    if (ctx->d_phis) (void)hipFree(ctx->d_phis);
+    if (ctx->d_args) (void)hipFree(ctx->d_args);
+    if (ctx->h_args) (void)hipHostFree(ctx->h_args);
+    if (ctx->d_slab) (void)hipFree(ctx->d_slab);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->d_comm) (void)hipFree(ctx->d_comm);
+    if (ctx->args_free) (void)hipEventDestroy(ctx->args_free);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int fokl_sync(fokl_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_sync: null context");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_slot_capacity(const fokl_ctx *ctx) { return ctx ? (int)ctx->slot_ptr.size() : 0; }
+extern "C" int64_t fokl_rows(const fokl_ctx *ctx) { return ctx ? ctx->n : 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// slots
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_reserve_slots(fokl_ctx *ctx, int n_slots)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_reserve_slots: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_reserve_slots: call fokl_upload first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bool grew = false;
+    while ((int)ctx->slot_ptr.size() < n_slots) {
+        double *chunk = nullptr;
+        const size_t bytes = (size_t)fokl_ctx::CHUNK_SLOTS * ctx->ld * sizeof(double);
+        HIP_TRY(ctx, hipMalloc((void **)&chunk, bytes));
+        ctx->chunks.push_back(chunk);
+        for (int i = 0; i < fokl_ctx::CHUNK_SLOTS; ++i) ctx->slot_ptr.push_back(chunk + (size_t)i * ctx->ld);
+        grew = true;
+    }
+    if (grew) {
+        const int cap = (int)ctx->slot_ptr.size();
+        if (cap > ctx->table_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_slot_ptr) HIP_TRY(ctx, hipFree(ctx->d_slot_ptr));
+            ctx->d_slot_ptr = nullptr;
+            ctx->table_cap = 0;
+            const int new_cap = std::max(cap * 2, 256);
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_slot_ptr, (size_t)new_cap * sizeof(double *)));
+            ctx->table_cap = new_cap;
+        }
+        // synchronous copy: the host vector may be reallocated by a later call
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_slot_ptr, ctx->slot_ptr.data(), (size_t)cap * sizeof(double *),
+                               hipMemcpyHostToDevice));
+    }
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dataset upload
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
+                           const double *phis, int n_basis, int width)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_upload: null context");
+    if (!x || !y || !phis) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: null pointer");
+    if (n <= 0 || m <= 0 || m > 4096) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: need n > 0 and 0 < m <= 4096");
+    if (kernel != FOKL_KERNEL_SPLINES && kernel != FOKL_KERNEL_BERNOULLI)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_upload: unknown kernel id");
+    if (n_basis <= 0 || width <= 0) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: empty coefficient table");
+    if (kernel == FOKL_KERNEL_BERNOULLI && width < n_basis + 1)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_upload: Bernoulli table needs width >= n_basis + 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+
+    // release the previous dataset
+    free_slots(ctx);
+    if (ctx->d_x) HIP_TRY(ctx, hipFree(ctx->d_x));
+    if (ctx->d_phis) HIP_TRY(ctx, hipFree(ctx->d_phis));
+    ctx->d_x = nullptr;
+    ctx->d_phis = nullptr;
+    ctx->have_data = false;
+
+    ctx->n = n;
+    ctx->m = m;
+    ctx->ld = (n + 63) / 64 * 64;
+    ctx->kernel = kernel;
+    ctx->n_basis = n_basis;
+    ctx->width = width;
+    ctx->phis_doubles = (kernel == FOKL_KERNEL_SPLINES) ? (size_t)n_basis * 4 * width : (size_t)n_basis * width;
+
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_x, (size_t)m * ctx->ld * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_phis, ctx->phis_doubles * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_phis, phis, ctx->phis_doubles * sizeof(double), hipMemcpyHostToDevice));
+
+    ctx->have_data = true;
+    int rc = fokl_reserve_slots(ctx, fokl_ctx::CHUNK_SLOTS);
+    if (rc) return rc;
+
+    // raw row-major copy in a temporary, transposed on the device
+    double *d_raw = nullptr, *d_y = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_raw, (size_t)n * m * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&d_y, (size_t)n * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(d_raw, x, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d_y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    const int blocks = (int)std::min<int64_t>((ctx->ld + 255) / 256, 4096);
+    hipLaunchKernelGGL(transpose_inputs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, d_y, n, m, ctx->ld,
+                       ctx->d_x, ctx->slot_ptr[FOKL_SLOT_ONES], ctx->slot_ptr[FOKL_SLOT_Y]);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_raw));
+    HIP_TRY(ctx, hipFree(d_y));
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1 launch planning
+// ---------------------------------------------------------------------------------------------------------
+
+static int cu_count(fokl_ctx *ctx)
+{
+    static int cached = 0;
+    if (cached) return cached;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) cached = prop.multiProcessorCount;
+    if (cached <= 0) cached = 256;
+    return cached;
+}
+
+// LDS available to one workgroup of the basis kernel; the factor table takes 4 KB per distinct factor.
+static constexpr size_t K1_LDS_BUDGET = 144 * 1024;
+
+static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slots, int t_begin, int t_end)
+{
+    const int m = ctx->m;
+    const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
+    // distinct (input, order) factors of this group, ordered by input then order
+    std::map<std::pair<int, int>, int> fac_id;
+    for (int j = t_begin; j < t_end; ++j)
+        for (int k = 0; k < m; ++k) {
+            const int o = terms[(size_t)j * m + k];
+            if (o != 0) fac_id.emplace(std::make_pair(k, o), 0);
+        }
+    int U = 0;
+    for (auto &kv : fac_id) kv.second = U++;
+    const int T = t_end - t_begin;
+
+    // spline orders staged in LDS (most used first would be ideal; any K1_MAX_LDS_SLABS distinct ones do)
+    std::vector<int> slab_orders;
+    if (splines) {
+        for (auto &kv : fac_id) {
+            const int o = kv.first.second;
+            if (std::find(slab_orders.begin(), slab_orders.end(), o) == slab_orders.end() &&
+                (int)slab_orders.size() < K1_MAX_LDS_SLABS)
+                slab_orders.push_back(o);
+        }
+    }
+    const int NS = (int)slab_orders.size();
+    size_t slab_doubles = splines ? (((size_t)NS * 4 * ctx->width + 1) & ~(size_t)1) : 0;
+    size_t lds_bytes = slab_doubles * sizeof(double) + (size_t)std::max(U, 1) * K1_THREADS * sizeof(d2);
+
+    size_t n_fac_entries = 0;
+    for (int j = t_begin; j < t_end; ++j)
+        for (int k = 0; k < m; ++k) n_fac_entries += terms[(size_t)j * m + k] != 0;
+
+    const size_t n_ints = (size_t)3 * U + K1_MAX_LDS_SLABS + (T + 1) + n_fac_entries + T;
+    const size_t plan_bytes = sizeof(BasisPlan);
+    const size_t bytes = plan_bytes + n_ints * sizeof(int);
+    int rc = begin_args(ctx, bytes);
+    if (rc) return rc;
+    BasisPlan *plan = reinterpret_cast<BasisPlan *>(ctx->h_args);
+    plan->n_fac = U;
+    plan->n_terms = T;
+    plan->n_slabs = NS;
+    plan->pad = 0;
+    int *arr = reinterpret_cast<int *>(ctx->h_args + plan_bytes);
+    int *fac_input = arr, *fac_order = arr + U, *fac_slab = arr + 2 * U, *slab_order = arr + 3 * U;
+    int *term_off = slab_order + K1_MAX_LDS_SLABS, *term_fac = term_off + (T + 1);
+    int *term_slot = term_fac + n_fac_entries;
+    for (auto &kv : fac_id) {
+        const int u = kv.second;
+        fac_input[u] = kv.first.first;
+        fac_order[u] = kv.first.second;
+        int s = -1;
+        for (int q = 0; q < NS; ++q)
+            if (slab_orders[q] == kv.first.second) s = q;
+        fac_slab[u] = s;
+    }
+    for (int q = 0; q < K1_MAX_LDS_SLABS; ++q) slab_order[q] = q < NS ? slab_orders[q] : 1;
+    int off = 0;
+    for (int j = t_begin; j < t_end; ++j) {
+        term_off[j - t_begin] = off;
+        for (int k = 0; k < m; ++k) {
+            const int o = terms[(size_t)j * m + k];
+            if (o != 0) term_fac[off++] = fac_id[std::make_pair(k, o)];
+        }
+        term_slot[j - t_begin] = slots[j];
+    }
+    term_off[T] = off;
+    rc = push_args(ctx, bytes);
+    if (rc) return rc;
+
+    const int64_t n_tiles = (ctx->n + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cu_count(ctx) * per_cu);
+    const BasisPlan *d_plan = reinterpret_cast<const BasisPlan *>(ctx->d_args);
+    const int *d_arr = reinterpret_cast<const int *>(ctx->d_args + plan_bytes);
+
+    int m_used = 0;
+    {
+        int last = -1;
+        for (auto &kv : fac_id)
+            if (kv.first.first != last) {
+                last = kv.first.first;
+                ++m_used;
+            }
+    }
+    const double alg_bytes = 8.0 * (double)ctx->n * (double)(m_used + T);
+    TimedRegion timed(ctx, FOKL_K_BASIS, alg_bytes, 0.0);
+    if (splines) {
+        if (lds_bytes > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(basis_build_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BUDGET + 4096));
+        hipLaunchKernelGGL(basis_build_kernel<true>, dim3(grid), dim3(K1_THREADS), lds_bytes, ctx->stream, ctx->d_x,
+                           ctx->ld, ctx->n, ctx->d_phis, ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
+    } else {
+        if (lds_bytes > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(basis_build_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BUDGET + 4096));
+        hipLaunchKernelGGL(basis_build_kernel<false>, dim3(grid), dim3(K1_THREADS), lds_bytes, ctx->stream, ctx->d_x,
+                           ctx->ld, ctx->n, ctx->d_phis, ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return FOKL_OK;
+}
+
+extern "C" int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_build_terms: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_build_terms: call fokl_upload first");
+    if (T < 0 || (T > 0 && (!terms || !slots))) return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: null pointer");
+    if (T == 0) return FOKL_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, slots, T, "fokl_build_terms");
+    if (rc) return rc;
+    const int m = ctx->m;
+    for (int j = 0; j < T; ++j) {
+        if (slots[j] < FOKL_SLOT_FIRST_FREE)
+            return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: slots 0 and 1 are reserved (ones, y)");
+        int nz = 0;
+        for (int k = 0; k < m; ++k) {
+            const int o = terms[(size_t)j * m + k];
+            if (o < 0 || o > ctx->n_basis)
+                return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: basis order " + std::to_string(o) +
+                                                   " outside [0, " + std::to_string(ctx->n_basis) + "]");
+            nz += o != 0;
+        }
+        if (nz == 0) return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: term with no input (all-zero row)");
+    }
+    // Split into launches whose distinct-factor table fits the LDS budget.
+    const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
+    const size_t slab_bytes = splines ? (size_t)K1_MAX_LDS_SLABS * 4 * ctx->width * sizeof(double) + 16 : 0;
+    const int max_fac = (int)((K1_LDS_BUDGET - slab_bytes) / (K1_THREADS * sizeof(d2)));
+    int begin = 0;
+    while (begin < T) {
+        std::map<std::pair<int, int>, int> seen;
+        int end = begin;
+        while (end < T) {
+            std::vector<std::pair<int, int>> add;
+            for (int k = 0; k < m; ++k) {
+                const int o = terms[(size_t)end * m + k];
+                if (o != 0 && !seen.count({k, o})) add.push_back({k, o});
+            }
+            if ((int)(seen.size() + add.size()) > max_fac) break;
+            for (auto &p : add) seen[p] = 1;
+            ++end;
+        }
+        if (end == begin)
+            return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: a single term has more factors than fit in LDS");
+        rc = launch_basis(ctx, terms, slots, begin, end);
+        if (rc) return rc;
+        begin = end;
+    }
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: Gram blocks
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_comm_allreduce_sum_f64(fokl_ctx *ctx, double *buf, int count);
+
+template <int TI, int TJW>
+static void launch_gram_mfma(fokl_ctx *ctx, dim3 grid, const int *d_rows, int nr, const int *d_cols, int nc, int nr_pad,
+                             int nc_pad)
+{
+    hipLaunchKernelGGL((gram_mfma_kernel<TI, TJW>), grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
+                       nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+}
+
+extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
+                         double *out, int path, int allreduce)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_gram: call fokl_upload first");
+    if (nr <= 0 || nc <= 0 || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: empty block or null output");
+    if (path < 0 || path > 2) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: path must be 0, 1 or 2");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, row_slots, nr, "fokl_gram");
+    if (rc) return rc;
+    rc = check_slots(ctx, col_slots, nc, "fokl_gram");
+    if (rc) return rc;
+
+    const size_t arg_bytes = (size_t)(nr + nc) * sizeof(int);
+    rc = begin_args(ctx, arg_bytes);
+    if (rc) return rc;
+    int *h = reinterpret_cast<int *>(ctx->h_args);
+    std::memcpy(h, row_slots, (size_t)nr * sizeof(int));
+    std::memcpy(h + nr, col_slots, (size_t)nc * sizeof(int));
+    rc = push_args(ctx, arg_bytes);
+    if (rc) return rc;
+    const int *d_rows = reinterpret_cast<const int *>(ctx->d_args);
+    const int *d_cols = d_rows + nr;
+
+    // path choice: the VALU kernel re-reads operands once per 4x4 register tile, fine while the block is small;
+    // the MFMA kernel reads every column of a panel once per row chunk.
+    const bool use_mfma = path == 2 || (path == 0 && (int64_t)nr * nc > 64);
+    const int cus = cu_count(ctx);
+    int S, nr_pad, nc_pad;
+    dim3 grid;
+    int variant = 0;
+    if (use_mfma) {
+        int BI, BJ;
+        if (nr > 32) {
+            variant = 2;  BI = 64;  BJ = 128;
+        } else if (nr > 16) {
+            variant = 1;  BI = 32;  BJ = 64;
+        } else {
+            variant = 0;  BI = 16;  BJ = 64;
+        }
+        const int gz = (nr + BI - 1) / BI, gy = (nc + BJ - 1) / BJ;
+        nr_pad = gz * BI;
+        nc_pad = gy * BJ;
+        const int64_t n_chunks = (ctx->n + GM_R - 1) / GM_R;
+        const int target = std::max(1, (3 * cus) / (gz * gy));
+        S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+        grid = dim3(S, gy, gz);
+    } else {
+        const int gz = (nr + GV_TI - 1) / GV_TI, gy = (nc + GV_TJ - 1) / GV_TJ;
+        nr_pad = gz * GV_TI;
+        nc_pad = gy * GV_TJ;
+        const int64_t n_row_blocks = (ctx->n + GV_THREADS * 2 - 1) / (GV_THREADS * 2);
+        const int target = std::max(1, (8 * cus) / (gz * gy));
+        S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, target));
+        grid = dim3(S, gy, gz);
+    }
+    rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
+    if (rc) return rc;
+    rc = ensure_out(ctx, (size_t)nr * nc);
+    if (rc) return rc;
+
+    {
+        const double bytes = 8.0 * (double)ctx->n * (double)(nr + nc);
+        const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
+        TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);
+        if (use_mfma) {
+            if (variant == 2)
+                launch_gram_mfma<4, 2>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
+            else if (variant == 1)
+                launch_gram_mfma<2, 1>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
+            else
+                launch_gram_mfma<1, 1>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
+        } else {
+            hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr,
+                               d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        const int total = nr * nc;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_slab, S,
+                           nr, nc, nr_pad, nc_pad, ctx->d_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nr * nc * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->h_out, (size_t)nr * nc * sizeof(double));
+    if (allreduce && ctx->comm) {
+        rc = fokl_comm_allreduce_sum_f64(ctx, out, nr * nc);
+        if (rc) return rc;
+    }
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: residual moments
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
+                              int allreduce)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_bic_resid: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid: call fokl_upload first");
+    if (nc <= 0 || !betahat || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid: empty model or null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, slots, nc, "fokl_bic_resid");
+    if (rc) return rc;
+
+    const size_t beta_off = ((size_t)nc * sizeof(int) + 7) & ~(size_t)7;
+    const size_t arg_bytes = beta_off + (size_t)nc * sizeof(double);
+    rc = begin_args(ctx, arg_bytes);
+    if (rc) return rc;
+    std::memcpy(ctx->h_args, slots, (size_t)nc * sizeof(int));
+    std::memcpy(ctx->h_args + beta_off, betahat, (size_t)nc * sizeof(double));
+    rc = push_args(ctx, arg_bytes);
+    if (rc) return rc;
+
+    const int64_t n_row_blocks = (ctx->n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, (int64_t)cu_count(ctx) * 8));
+    rc = ensure_slab(ctx, (size_t)S * 2);
+    if (rc) return rc;
+    rc = ensure_out(ctx, 2);
+    if (rc) return rc;
+    {
+        TimedRegion timed(ctx, FOKL_K_RESID, 8.0 * (double)ctx->n * (double)(nc + 1), 2.0 * (double)ctx->n * nc);
+        hipLaunchKernelGGL(resid_kernel, dim3(S), dim3(RS_THREADS), 0, ctx->stream, ctx->d_slot_ptr,
+                           reinterpret_cast<const int *>(ctx->d_args),
+                           nc, reinterpret_cast<const double *>(ctx->d_args + beta_off),
+                           ctx->slot_ptr[FOKL_SLOT_Y], ctx->n, ctx->d_slab);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
+                           ctx->d_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = ctx->h_out[0];
+    out[1] = ctx->h_out[1];
+    if (allreduce && ctx->comm) {
+        rc = fokl_comm_allreduce_sum_f64(ctx, out, 2);
+        if (rc) return rc;
+    }
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// slot access (tests, evaluate)
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_read_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, double *host)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_read_slot: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_read_slot: call fokl_upload first");
+    int32_t s = slot;
+    int rc = check_slots(ctx, &s, 1, "fokl_read_slot");
+    if (rc) return rc;
+    if (row0 < 0 || nrows < 0 || row0 + nrows > ctx->n || (nrows > 0 && !host))
+        return fail(ctx, FOKL_ERR_ARG, "fokl_read_slot: row range outside the dataset");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(host, ctx->slot_ptr[slot] + row0, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost));
+    return FOKL_OK;
+}
+
+extern "C" int fokl_write_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, const double *host)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_write_slot: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_write_slot: call fokl_upload first");
+    int32_t s = slot;
+    int rc = check_slots(ctx, &s, 1, "fokl_write_slot");
+    if (rc) return rc;
+    if (row0 < 0 || nrows < 0 || row0 + nrows > ctx->n || (nrows > 0 && !host))
+        return fail(ctx, FOKL_ERR_ARG, "fokl_write_slot: row range outside the dataset");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->slot_ptr[slot] + row0, host, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
+    return FOKL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_timing_enable(fokl_ctx *ctx, int on)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_timing_enable: null context");
+    ctx->timing = on != 0;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_timing_reset(fokl_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_timing_reset: null context");
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_events(ctx);
+    for (auto &t : ctx->tslot) t = TimingSlot();
+    return FOKL_OK;
+}
+
+extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
+                               double *flops)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_timing_get: null context");
+    if (kernel_id < 0 || kernel_id >= FOKL_K_COUNT) return fail(ctx, FOKL_ERR_ARG, "fokl_timing_get: bad kernel id");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    if (total_ms) *total_ms = ctx->tslot[kernel_id].ms;
+    if (launches) *launches = ctx->tslot[kernel_id].launches;
+    if (bytes) *bytes = ctx->tslot[kernel_id].bytes;
+    if (flops) *flops = ctx->tslot[kernel_id].flops;
+    return FOKL_OK;
+}
+
+// the RCCL half lives in fokl_comm.hip; it needs the context layout
+#include "fokl_comm.inc"
+#include "fokl_predict.inc"

@@ -1,0 +1,446 @@
+// Device kernels of libfokl_hip.so (gfx950 / CDNA4 only; 64-wide wavefronts, fp64 throughout).
+//
+//   K1  basis_build_kernel   fused _inputs_to_phind + evaluate_basis + term products   (HBM write bound)
+//   K2a gram_valu_kernel     Gram block with per-thread register tiles + wavefront reductions
+//   K2b gram_mfma_kernel     Gram block on v_mfma_f64_16x16x4_f64 tiles staged through LDS
+//   K3  resid_kernel         residual moments for the BIC
+//       reduce_slabs_kernel  fixed-order combination of per-workgroup partial sums
+//
+// Compiled with -ffp-contract=off: the reference rounds every product and sum separately
+// (FoKLRoutines.py:836, 843) and K1 reproduces those roundings; fma() is used only where it is wanted
+// (error-free products of the double-double power chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fokl {
+
+constexpr int WAVE = 64;
+constexpr int K1_THREADS = 256;
+constexpr int K1_ROWS_PER_THREAD = 2;                       // 16-byte loads / stores per lane
+constexpr int K1_TILE_ROWS = K1_THREADS * K1_ROWS_PER_THREAD;
+constexpr int K1_MAX_LDS_SLABS = 4;                         // spline orders staged in LDS per launch
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: basis build
+// ---------------------------------------------------------------------------------------------------------
+
+// One launch builds T columns that share U distinct (input, order) factors.  The host plans the launch
+// (fokl_hip.hip: plan_basis_launch) and ships this descriptor in device memory.
+struct BasisPlan {
+    int n_fac;           // U
+    int n_terms;         // T
+    int n_slabs;         // distinct spline orders staged in LDS (0 => gather from global / L2)
+    int pad;
+    // followed in memory by int32 arrays (offsets in ints from the start of the arrays block):
+    //   fac_input[U], fac_order[U] (1-based), fac_slab[U] (index into slab list or -1)
+    //   slab_order[K1_MAX_LDS_SLABS]
+    //   term_off[T + 1], term_fac[term_off[T]], term_slot[T]
+};
+
+__device__ __forceinline__ void dd_mul_d(double &hi, double &lo, double x)
+{
+    // (hi + lo) * x as an unevaluated sum, error ~ 2^-104 relative.
+    double t = hi * x;
+    double e = __builtin_fma(hi, x, -t);
+    e = e + lo * x;
+    double s = t + e;
+    lo = e - (s - t);
+    hi = s;
+}
+
+// Bernoulli basis of order `order` (coefficients c[0 .. order + 1]):  c0 + sum_{j>=1} c_j * RN(x**j),
+// the sum taken from 0 in ascending j with every product and addition rounded (ref FR:843).
+__device__ __forceinline__ double bernoulli_basis(const double *__restrict__ c, int order, double x)
+{
+    double ph = x, pl = 0.0;
+    double s = c[1] * x;                    // 0 + c1*x
+    for (int j = 2; j <= order + 1; ++j) {
+        dd_mul_d(ph, pl, x);                // ph = RN(x**j)
+        s = s + c[j] * ph;
+    }
+    return c[0] + s;
+}
+
+// Cubic piece: c0 + c1*t + c2*RN(t**2) + c3*RN(t**3), left to right (ref FR:836).
+__device__ __forceinline__ double cubic_basis(double c0, double c1, double c2, double c3, double t)
+{
+    double p2 = t * t;
+    double e2 = __builtin_fma(t, t, -p2);
+    double p3h = p2, p3l = e2;
+    dd_mul_d(p3h, p3l, t);
+    double r = c0 + c1 * t;
+    r = r + c2 * p2;
+    r = r + c3 * p3h;
+    return r;
+}
+
+// Spline piece index and local coordinate (ref FR:570-589): phind = ceil(x*l) (0 -> 1) - 1, xsm = l*x - phind.
+__device__ __forceinline__ void spline_locate(double x, int width, int &piece, double &t)
+{
+    double xl = x * (double)width;
+    int p = (int)ceil(xl);
+    if (p == 0) p = 1;
+    p -= 1;
+    t = xl - (double)p;
+    piece = min(max(p, 0), width - 1);      // host validated the range (FR:590-591); clamp guards the LDS read
+}
+
+template <bool SPLINES>
+__global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
+    const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
+    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
+    const int *fac_input = arr;
+    const int *fac_order = arr + U;
+    const int *fac_slab = arr + 2 * U;
+    const int *slab_order = arr + 3 * U;
+    const int *term_off = arr + 3 * U + K1_MAX_LDS_SLABS;
+    const int *term_fac = term_off + (T + 1);
+    const int *term_slot = term_fac + term_off[T];
+
+    const int tid = threadIdx.x;
+    double *slabs = lds;                                               // [NS][4][width]
+    const int slab_doubles = SPLINES ? ((NS * 4 * width + 1) & ~1) : 0; // keep the factor table 16-B aligned
+    d2 *fac = reinterpret_cast<d2 *>(lds + slab_doubles);              // [U][K1_THREADS]
+
+    if (SPLINES) {
+        for (int s = 0; s < NS; ++s) {
+            const double *src = phis + (size_t)(slab_order[s] - 1) * 4 * width;
+            for (int i = tid; i < 4 * width; i += K1_THREADS) slabs[s * 4 * width + i] = src[i];
+        }
+        __syncthreads();
+    }
+
+    const int64_t n_tiles = (n + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r0 = tile * K1_TILE_ROWS + (int64_t)tid * K1_ROWS_PER_THREAD;
+        // ld is a multiple of 64 rows and the buffers are ld long, so the 16-byte access at r0 stays in bounds
+        // whenever r0 < ld; rows >= n hold unspecified values and are never stored.
+        const bool in0 = r0 < n, in1 = r0 + 1 < n;
+
+        // phase 1: every distinct (input, order) factor once per row, parked in LDS
+        int cur_input = -1;
+        d2 x = {0.0, 0.0};
+        for (int u = 0; u < U; ++u) {
+            const int k = fac_input[u], order = fac_order[u];
+            if (k != cur_input) {
+                cur_input = k;
+                if (in0) x = *reinterpret_cast<const d2 *>(xT + (size_t)k * ld + r0);
+            }
+            d2 v;
+            if (SPLINES) {
+                int p0, p1;
+                double t0, t1;
+                spline_locate(x.x, width, p0, t0);
+                spline_locate(x.y, width, p1, t1);
+                const int s = fac_slab[u];
+                if (s >= 0) {
+                    const double *sl = slabs + s * 4 * width;
+                    v.x = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
+                    v.y = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
+                } else {
+                    const double *sl = phis + (size_t)(order - 1) * 4 * width;
+                    v.x = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
+                    v.y = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
+                }
+            } else {
+                const double *c = phis + (size_t)(order - 1) * width;
+                v.x = bernoulli_basis(c, order, x.x);
+                v.y = bernoulli_basis(c, order, x.y);
+            }
+            fac[u * K1_THREADS + tid] = v;
+        }
+
+        // phase 2: T products of those factors, one 16-byte store per lane and column
+        for (int j = 0; j < T; ++j) {
+            const int b = term_off[j], e = term_off[j + 1];
+            d2 phi = fac[term_fac[b] * K1_THREADS + tid];         // 1 * first factor
+            for (int f = b + 1; f < e; ++f) {
+                const d2 g = fac[term_fac[f] * K1_THREADS + tid];
+                phi.x = phi.x * g.x;
+                phi.y = phi.y * g.y;
+            }
+            double *col = slot_ptr[term_slot[j]];
+            if (in1) {
+                *reinterpret_cast<d2 *>(col + r0) = phi;
+            } else if (in0) {
+                col[r0] = phi.x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// upload helpers
+// ---------------------------------------------------------------------------------------------------------
+
+// x [n, m] row-major -> xT [m][ld]; also fills the ones column and copies y.
+__global__ void transpose_inputs_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t n, int m,
+                                        int64_t ld, double *__restrict__ xT, double *__restrict__ ones,
+                                        double *__restrict__ ycol)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool in = i < n;
+        for (int k = 0; k < m; ++k) xT[(size_t)k * ld + i] = in ? x[(size_t)i * m + k] : 0.0;
+        ones[i] = in ? 1.0 : 0.0;
+        ycol[i] = in ? y[i] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// block-level sum of a small per-thread vector: DPP/shuffle inside the wavefront, LDS across the 4 waves
+// ---------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;   // valid in lane 0
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2a: Gram block, VALU register tiles + wavefront reductions
+// ---------------------------------------------------------------------------------------------------------
+
+constexpr int GV_THREADS = 256;
+constexpr int GV_TI = 4, GV_TJ = 4;
+
+// grid = (S row splits, ceil(nc / GV_TJ), ceil(nr / GV_TI)); slab layout [S][nr_pad][nc_pad]
+__global__ __launch_bounds__(GV_THREADS) void gram_valu_kernel(double *const *__restrict__ slot_ptr,
+                                                               const int *__restrict__ row_slots, int nr,
+                                                               const int *__restrict__ col_slots, int nc, int64_t n,
+                                                               double *__restrict__ slab, int nr_pad, int nc_pad)
+{
+    __shared__ double red[GV_THREADS / WAVE][GV_TI * GV_TJ];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.z * GV_TI, j0 = blockIdx.y * GV_TJ;
+    const double *a[GV_TI], *b[GV_TJ];
+#pragma unroll
+    for (int i = 0; i < GV_TI; ++i) a[i] = slot_ptr[row_slots[min(i0 + i, nr - 1)]];
+#pragma unroll
+    for (int j = 0; j < GV_TJ; ++j) b[j] = slot_ptr[col_slots[min(j0 + j, nc - 1)]];
+
+    double acc[GV_TI][GV_TJ];
+#pragma unroll
+    for (int i = 0; i < GV_TI; ++i)
+#pragma unroll
+        for (int j = 0; j < GV_TJ; ++j) acc[i][j] = 0.0;
+
+    const int64_t stride = (int64_t)gridDim.x * GV_THREADS * 2;
+    for (int64_t r = ((int64_t)blockIdx.x * GV_THREADS + tid) * 2; r < n; r += stride) {
+        d2 av[GV_TI], bv[GV_TJ];
+        const bool two = r + 1 < n;
+#pragma unroll
+        for (int i = 0; i < GV_TI; ++i) {
+            av[i] = *reinterpret_cast<const d2 *>(a[i] + r);
+            if (!two) av[i].y = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < GV_TJ; ++j) {
+            bv[j] = *reinterpret_cast<const d2 *>(b[j] + r);
+            if (!two) bv[j].y = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < GV_TI; ++i)
+#pragma unroll
+            for (int j = 0; j < GV_TJ; ++j) acc[i][j] = __builtin_fma(av[i].y, bv[j].y, __builtin_fma(av[i].x, bv[j].x, acc[i][j]));
+    }
+
+    const int wave = tid / WAVE, lane = tid % WAVE;
+#pragma unroll
+    for (int i = 0; i < GV_TI; ++i)
+#pragma unroll
+        for (int j = 0; j < GV_TJ; ++j) {
+            double s = wave_sum(acc[i][j]);
+            if (lane == 0) red[wave][i * GV_TJ + j] = s;
+        }
+    __syncthreads();
+    if (tid < GV_TI * GV_TJ) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < GV_THREADS / WAVE; ++w) s += red[w][tid];
+        const int i = i0 + tid / GV_TJ, j = j0 + tid % GV_TJ;
+        slab[((size_t)blockIdx.x * nr_pad + i) * nc_pad + j] = s;
+    }
+}
+
+// out[e] = sum_{s < S} slab[s][e] in ascending s: bitwise reproducible.  Compacts [nr_pad][nc_pad] -> [nr][nc].
+__global__ void reduce_slabs_kernel(const double *__restrict__ slab, int S, int nr, int nc, int nr_pad, int nc_pad,
+                                    double *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nr * nc) return;
+    const int i = e / nc, j = e % nc;
+    const size_t plane = (size_t)nr_pad * nc_pad;
+    const double *p = slab + (size_t)i * nc_pad + j;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += p[k * plane];
+    out[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2b: Gram block on fp64 MFMA tiles (v_mfma_f64_16x16x4_f64)
+// ---------------------------------------------------------------------------------------------------------
+//
+// Workgroup = 4 wavefronts = (16*TI) row-side columns x (64*TJW) column-side columns.  Per step a chunk of
+// GM_R rows of every column of both panels is staged in LDS as [column][GM_R + 2] (the 2-double pad makes
+// the 16-column x 4-row fragment reads conflict free: bank pair = 4*col + 2*row mod 64), wave w owns the
+// 16-wide j-tiles {w, w + 4, ...} of all TI i-tiles.  The next chunk's global loads are issued before the
+// MFMAs of the current one (register double buffering).
+//
+// Operand maps (cdna_hip_programming.md section 3, f64 form): lane l supplies A[m = l & 15][k = l >> 4] and
+// B[k = l >> 4][n = l & 15]; result register v of lane l is D[m = (l >> 4) + 4 v][n = l & 15].
+
+constexpr int GM_THREADS = 256;
+constexpr int GM_R = 32;
+constexpr int GM_PITCH = GM_R + 2;
+
+template <int TI, int TJW>
+__global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__restrict__ slot_ptr,
+                                                               const int *__restrict__ row_slots, int nr,
+                                                               const int *__restrict__ col_slots, int nc, int64_t n,
+                                                               double *__restrict__ slab, int nr_pad, int nc_pad)
+{
+    constexpr int BI = 16 * TI, BJ = 64 * TJW, NCOL = BI + BJ;
+    constexpr int LOADS = (NCOL + 7) / 8;                  // per thread: 8 columns per wave-wide pass of the block
+    __shared__ __attribute__((aligned(16))) double tile[NCOL * GM_PITCH];
+    __shared__ const double *colptr[NCOL];
+
+    const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
+    const int i0 = blockIdx.z * BI, j0 = blockIdx.y * BJ;
+
+    for (int c = tid; c < NCOL; c += GM_THREADS) {
+        const double *p = nullptr;
+        if (c < BI) {
+            if (i0 + c < nr) p = slot_ptr[row_slots[i0 + c]];
+        } else {
+            if (j0 + (c - BI) < nc) p = slot_ptr[col_slots[j0 + (c - BI)]];
+        }
+        colptr[c] = p;
+    }
+    __syncthreads();
+
+    d4 acc[TI][TJW];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // staging map: thread t loads row (t & 31) of column (t >> 5) + 8 * pass
+    const int srow = tid & (GM_R - 1), scol = tid >> 5;
+    const int64_t n_chunks = (n + GM_R - 1) / GM_R;
+    double stage[LOADS];
+
+    auto issue = [&](int64_t chunk) {
+        const int64_t r = chunk * GM_R + srow;
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) {
+            const int c = scol + 8 * p;
+            double v = 0.0;
+            if (c < NCOL) {
+                const double *cp = colptr[c];
+                if (cp != nullptr && r < n) v = cp[r];
+            }
+            stage[p] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int p = 0; p < LOADS; ++p) {
+            const int c = scol + 8 * p;
+            if (c < NCOL) tile[c * GM_PITCH + srow] = stage[p];
+        }
+    };
+
+    int64_t chunk = blockIdx.x;
+    if (chunk < n_chunks) issue(chunk);
+    const int fm = lane & 15, fk = lane >> 4;
+    while (chunk < n_chunks) {
+        commit();
+        __syncthreads();
+        const int64_t next = chunk + gridDim.x;
+        if (next < n_chunks) issue(next);
+#pragma unroll
+        for (int k0 = 0; k0 < GM_R; k0 += 4) {
+            double af[TI], bf[TJW];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = tile[(16 * i + fm) * GM_PITCH + k0 + fk];
+#pragma unroll
+            for (int j = 0; j < TJW; ++j) bf[j] = tile[(BI + 16 * (wave + 4 * j) + fm) * GM_PITCH + k0 + fk];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        chunk = next;
+    }
+
+    double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJW; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gi = i0 + 16 * i + fk + 4 * v;
+                const int gj = j0 + 16 * (wave + 4 * j) + fm;
+                out[(size_t)gi * nc_pad + gj] = acc[i][j][v];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: residual moments  r = y - sum_j beta_j X_j ;  partial (sum r, sum r^2) per workgroup
+// ---------------------------------------------------------------------------------------------------------
+
+constexpr int RS_THREADS = 256;
+
+__global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__restrict__ slot_ptr,
+                                                           const int *__restrict__ slots, int nc,
+                                                           const double *__restrict__ beta,
+                                                           const double *__restrict__ y, int64_t n,
+                                                           double *__restrict__ slab)
+{
+    __shared__ double red[RS_THREADS / WAVE][2];
+    const int tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * RS_THREADS * 2;
+    for (int64_t r = ((int64_t)blockIdx.x * RS_THREADS + tid) * 2; r < n; r += stride) {
+        d2 fit = {0.0, 0.0};
+#pragma unroll 8
+        for (int j = 0; j < nc; ++j) {
+            const double bj = beta[j];
+            const d2 xv = *reinterpret_cast<const d2 *>(slot_ptr[slots[j]] + r);
+            fit.x = __builtin_fma(bj, xv.x, fit.x);
+            fit.y = __builtin_fma(bj, xv.y, fit.y);
+        }
+        const d2 yv = *reinterpret_cast<const d2 *>(y + r);
+        const double r0 = yv.x - fit.x;
+        const double r1 = (r + 1 < n) ? yv.y - fit.y : 0.0;
+        s1 += r0 + r1;
+        s2 += r0 * r0 + r1 * r1;
+    }
+    const int wave = tid / WAVE, lane = tid % WAVE;
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < RS_THREADS / WAVE; ++w) s += red[w][tid];
+        slab[(size_t)blockIdx.x * 2 + tid] = s;
+    }
+}
+
+}  // namespace fokl

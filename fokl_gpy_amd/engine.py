@@ -1,0 +1,378 @@
+"""
+Forward-variable-selection driver: the host orchestration of the hot path of ``FoKL.fit``.
+
+Restates the control flow of the reference's driver loop (FoKLRoutines.py "FR" 1602-1760: term enumeration,
+one ``gibbs`` evaluation per sub-stage, sequential kill tests, BIC stop rule) on top of a device backend:
+
+    K1  backend.build_terms   -- new basis columns, written once per sub-stage into device "slots"
+    K2  backend.gram          -- Gram block of the new columns against [1 | model | new | y]
+    K3  backend.bic_resid     -- residual moments of a candidate model (any column subset)
+    G3  _capi.gibbs_chain     -- the Gibbs chain in the eigenbasis, numpy-legacy random stream (host C++)
+
+Where the reference rebuilds every surviving new column and the full Gram matrix for each kill test
+(FR:1676-1683), every kill-test design is a column subset of the sub-stage's own design, so its XtX / Xty
+are sub-blocks of the sub-stage Gram held on the host; the BIC still comes from an explicit
+residual pass over the device columns, never from the cancellation-prone Gram identity.
+The *logical* candidate-term count (what the reference would have built) is tallied per call.
+"""
+import math
+
+import numpy as np
+from scipy.linalg import eigh as _eigh
+
+from . import _capi
+
+SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = _capi.SLOT_ONES, _capi.SLOT_Y, _capi.SLOT_FIRST_FREE
+
+
+# ---------------------------------------------------------------------------------------------------------
+# term enumeration (F4)
+# ---------------------------------------------------------------------------------------------------------
+
+def distinct_arrangements(indvec):
+    """All distinct orderings of the multiset ``indvec`` in ascending lexicographic order, float64 rows.
+
+    Equals ``np.unique(perms(indvec), axis=0)`` of the reference (FR:1350-1354, FR:1616) without enumerating
+    M! tuples -- the reference's itertools.permutations cannot run beyond M ~ 10 inputs.
+    """
+    cur = sorted(float(v) for v in indvec)
+    n = len(cur)
+    rows = [tuple(cur)]
+    while True:
+        i = n - 2
+        while i >= 0 and cur[i] >= cur[i + 1]:
+            i -= 1
+        if i < 0:
+            break
+        j = n - 1
+        while cur[j] <= cur[i]:
+            j -= 1
+        cur[i], cur[j] = cur[j], cur[i]
+        cur[i + 1:] = cur[:i:-1]
+        rows.append(tuple(cur))
+    return np.array(rows, dtype=np.float64).reshape(len(rows), n)
+
+
+def deal_indvec(ind, m, sett):
+    """Spread ``ind`` units round-robin over the first ``sett`` entries of a length-m vector (FR:1605-1613)."""
+    if min(int(ind), int(sett)) > m:
+        raise IndexError(f"index {m} is out of bounds for axis 0 with size {m}")   # as the reference's indvec[j]
+    indvec = np.zeros(m)
+    q, r = divmod(int(ind), int(sett))
+    indvec[:sett] = q
+    indvec[:r] += 1
+    return indvec
+
+
+def advance_indvec(indvec, m, way3):
+    """Next sub-stage pattern of the same total order (FR:1722-1740).  Returns False when the stage is exhausted."""
+    if m == 1:
+        return False
+    if way3:
+        if indvec[1] > indvec[2]:
+            indvec[0] += 1
+            indvec[1] -= 1
+        elif indvec[2]:
+            indvec[1] += 1
+            indvec[2] -= 1
+            if indvec[1] > indvec[0]:
+                indvec[0] += 1
+                indvec[1] -= 1
+        else:
+            return False
+        return True
+    if indvec[1]:
+        indvec[0] += 1
+        indvec[1] -= 1
+        return True
+    return False
+
+
+# ---------------------------------------------------------------------------------------------------------
+# eigen-decomposition with the shared sign convention
+# ---------------------------------------------------------------------------------------------------------
+
+def eigh_canonical(A):
+    """``scipy.linalg.eigh`` (as the reference, FR:1499) + "largest-magnitude component positive" per eigenvector.
+
+    LAPACK's eigenvector signs flip under 1-ulp changes of XtX, and each flip changes the realised draw
+    Q diag(d^1/2) vec (FR:1525-1528); the convention makes draws comparable across summation orders.
+    """
+    lam, Q = _eigh(A)
+    piv = np.argmax(np.abs(Q), axis=0)
+    sgn = np.sign(Q[piv, np.arange(Q.shape[1])])
+    sgn[sgn == 0] = 1.0
+    return lam, Q * sgn
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device backend protocol
+# ---------------------------------------------------------------------------------------------------------
+
+class HipBackend:
+    """The shipped backend: a ``_capi.DeviceContext`` on one MI355X.  No CPU path exists in the product."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def upload(self, inputs, data, kernel_id, packed, n_basis, width):
+        self.ctx.upload(inputs, data, kernel_id, packed, n_basis, width)
+
+    def reserve_slots(self, count):
+        self.ctx.reserve_slots(count)
+
+    def build_terms(self, terms, slots):
+        self.ctx.build_terms(terms, slots)
+
+    def gram(self, row_slots, col_slots, allreduce=False):
+        return self.ctx.gram(row_slots, col_slots, 0, allreduce)
+
+    def bic_resid(self, slots, betahat, allreduce=False):
+        return self.ctx.bic_resid(slots, betahat, allreduce)
+
+    def predict(self, slots, betas, cut=None):
+        return self.ctx.predict(slots, betas, cut)
+
+
+class SlotPool:
+    """Free list of device column slots (slot 0 = ones, slot 1 = y are never handed out)."""
+
+    def __init__(self, backend, initial=64):
+        self.backend = backend
+        self.capacity = 0
+        self.free = []
+        self.grow(initial)
+
+    def grow(self, capacity):
+        if capacity <= self.capacity:
+            return
+        self.backend.reserve_slots(capacity)
+        lo = max(self.capacity, SLOT_FIRST_FREE)
+        self.free.extend(range(capacity - 1, lo - 1, -1))
+        self.capacity = capacity
+
+    def take(self, count):
+        if len(self.free) < count:
+            self.grow(self.capacity + max(count - len(self.free), self.capacity // 2, 32))
+        out = [self.free.pop() for _ in range(count)]
+        return out
+
+    def give(self, slots):
+        self.free.extend(sorted(slots, reverse=True))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the driver
+# ---------------------------------------------------------------------------------------------------------
+
+class GibbsOutcome:
+    __slots__ = ('w', 'Q', 'betahat', 'ev', 'idx', '_betas')
+
+    def __init__(self, w, Q, betahat, ev, idx):
+        self.w, self.Q, self.betahat, self.ev, self.idx = w, Q, betahat, ev, idx
+        self._betas = None
+
+    @property
+    def betas(self):
+        """Posterior draws in model coordinates, betas = w Q' (FR:1528); formed on first use."""
+        if self._betas is None:
+            self._betas = self.w @ self.Q.T
+        return self._betas
+
+
+class ForwardSelection:
+    """
+    One ``fit`` worth of forward selection on an uploaded dataset.
+
+    Parameters mirror the locals of FoKL.fit (FR:1302-1315, 1371-1374): hyper-parameters, ``n`` rows, ``m``
+    inputs, ``n_phis = len(phis)`` (the search stops when the stage index exceeds it, FR:1747).
+    ``stream`` is the numpy legacy RNG state the chain continues.  ``comm`` (optional) shards kill-test
+    proposals over ranks (see dist.py).
+    """
+
+    def __init__(self, backend, n, m, n_phis, a, b, atau, btau, tolerance, draws_total, draws_keep, gimmie, way3,
+                 threshav, threshstda, threshstdb, aic, stream, console=False, comm=None, row_sharded=False,
+                 n_global=None):
+        self.backend = backend
+        self.n_local = int(n)
+        self.n = int(n_global) if n_global is not None else int(n)
+        self.m = int(m)
+        self.n_phis = int(n_phis)
+        self.a, self.b, self.atau, self.btau = a, b, atau, btau
+        self.tolerance = tolerance
+        self.draws = int(draws_total)
+        self.draws_keep = int(draws_keep)
+        self.gimmie, self.way3, self.aic = bool(gimmie), bool(way3), bool(aic)
+        self.threshav, self.threshstda, self.threshstdb = threshav, threshstda, threshstdb
+        self.stream = stream
+        self.console = console
+        self.comm = comm
+        self.allreduce = bool(row_sharded)
+        self.sigsqd0 = b / (1 + a)          # FR:1371
+        self.tausqd0 = btau / (1 + atau)    # FR:1372
+        self.pool = SlotPool(backend)
+        self.trace = []                     # one record per gibbs evaluation
+        self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0)
+
+    # -- one model evaluation (G1-G4) -------------------------------------------------------------------
+    def _evaluate(self, gram, slots, idx, n_prev_cols, kill):
+        """
+        gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
+        slots : device slot of each active column
+        idx   : active-column indices of this candidate model (idx[0] == 0, the intercept)
+        """
+        idx = np.asarray(idx, dtype=np.intp)
+        p1 = idx.shape[0]
+        ycol = gram.shape[0] - 1
+        XtX = gram[np.ix_(idx, idx)]
+        Xty = gram[idx, ycol]
+        dtd = gram[ycol, ycol]
+        n = self.n
+
+        lamb, Q = eigh_canonical(XtX)
+        qty = Q.T @ Xty
+        betahat = Q @ (qty / lamb)                                  # FR:1502-1504
+
+        astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508 (mmtx + 1 == p1)
+        atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
+        w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0,
+                              self.draws, self.stream)
+
+        s1, s2 = self.backend.bic_resid([slots[i] for i in idx], betahat, self.allreduce)
+        siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
+        lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
+        ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554
+        if self.aic:
+            ev = ev + (2 - math.log(n)) * p1                         # FR:1653-1654 / FR:1684-1685
+
+        built = p1 - n_prev_cols
+        self.stats['gibbs_calls'] += 1
+        self.stats['kill_tests'] += int(kill)
+        self.stats['terms_logical'] += built
+        self.trace.append(dict(cols=p1, built=built, ev=float(ev), kill=bool(kill)))
+        return GibbsOutcome(w, Q, betahat, ev, idx)
+
+    # -- the search ---------------------------------------------------------------------------------------
+    def run(self):
+        m, n = self.m, self.n
+        draws = self.draws
+        half1 = int(math.ceil(draws / 2 + 1))      # FR:1656
+        half0 = int(math.ceil(draws / 2))          # FR:1658, FR:1671
+        sett = 1 if m == 1 else (3 if self.way3 else 2)   # FR:1595-1600
+
+        # Gram of [ones, y] seeds the cache: n, sum y, y'y
+        model_slots = []                            # device slots of accepted terms (aligned with damtx rows)
+        damtx = np.zeros((0, m))
+        base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], self.allreduce)
+        model_gram = np.array([[base[0, 0]]])       # Gram over [ones] + model columns
+        model_xty = np.array([base[0, 1]])
+        dtd = base[1, 1]
+
+        evs = np.array([])
+        betas = mtx = None
+        last = None
+        last_damtx = damtx
+        ind = 1
+        greater = 0
+        finished = False
+
+        while True:
+            indvec = deal_indvec(ind, m, sett)
+            while True:
+                vecs = distinct_arrangements(indvec)
+                vm = vecs.shape[0]
+                damtx = np.append(damtx, vecs, axis=0)
+                dam = damtx.shape[0]
+                n_prev = 1 + len(model_slots)
+
+                # K1 + K2: build the vm new columns once, extend the Gram
+                new_slots = self.pool.take(vm)
+                self.backend.build_terms(vecs.astype(np.int32), new_slots)
+                self.stats['terms_physical'] += vm
+                active_slots = [SLOT_ONES] + model_slots + new_slots
+                A = len(active_slots)
+                block = self.backend.gram(new_slots, active_slots + [SLOT_Y], self.allreduce)   # [vm, A + 1]
+                gram = np.empty((A + 1, A + 1))
+                gram[:n_prev, :n_prev] = model_gram
+                gram[:n_prev, A] = model_xty
+                gram[A, :n_prev] = model_xty
+                gram[A, A] = dtd
+                gram[n_prev:A, :A] = block[:, :A]
+                gram[:n_prev, n_prev:A] = block[:, :n_prev].T
+                gram[n_prev:A, A] = block[:, A]
+                gram[A, n_prev:A] = block[:, A]
+
+                full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False)
+                best = full
+                ev = full.ev
+
+                # statistics of the new terms (FR:1656-1664)
+                beters = full.betas
+                new = slice(dam - vm + 1, dam + 1)
+                mean_abs = np.abs(np.mean(beters[half1:draws, new], axis=0))
+                rel_std = np.divide(np.std(beters[half1:draws, new], axis=0),
+                                    np.abs(np.mean(beters[half0:draws, new], axis=0)))
+                order = np.argsort(mean_abs)
+                cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
+                mean_abs, rel_std = mean_abs[order], rel_std[order]
+
+                # sequential kill tests (FR:1666-1690): proposals in ascending |mean beta|
+                killed = []                                           # active-column indices removed so far
+                evmin = ev
+                for i in range(vm):
+                    thresh0 = self.threshav * np.mean(np.abs(np.mean(best.betas[half0:draws, 0])))
+                    if rel_std[i] > self.threshstdb or (rel_std[i] > self.threshstda and mean_abs[i] < thresh0):
+                        trial = set(killed)
+                        trial.add(int(cand_col[i]))
+                        idx = [c for c in range(A) if c not in trial]
+                        res = self._evaluate(gram, active_slots, idx, n_prev, kill=True)
+                        if res.ev < evmin:
+                            killed = sorted(trial)
+                            evmin = res.ev
+                            best = res
+                ev = evmin
+
+                # commit the surviving columns (FR:1691-1695)
+                keep = [c for c in range(A) if c not in set(killed)]
+                if killed:
+                    damtx = np.delete(damtx, [c - 1 for c in killed], axis=0)
+                    self.pool.give([active_slots[c] for c in killed])
+                model_slots = [active_slots[c] for c in keep[1:]]
+                model_gram = gram[np.ix_(keep, keep)]
+                model_xty = gram[keep, A]
+                self.stats['substages'] += 1
+                last, last_damtx = best, damtx
+
+                if self.console:
+                    print([ind, float(ev)])
+
+                # best-model bookkeeping and stop rule (FR:1701-1721)
+                if evs.size > 0:
+                    if ev < np.min(evs):
+                        betas, mtx, greater = best, damtx, 1
+                        evs = np.append(evs, ev)
+                    elif greater < self.tolerance:
+                        greater += 1
+                        evs = np.append(evs, ev)
+                    else:
+                        finished = True
+                        evs = np.append(evs, ev)
+                        break
+                else:
+                    greater += 1
+                    betas, mtx = best, damtx
+                    evs = np.append(evs, ev)
+
+                if not advance_indvec(indvec, m, self.way3):
+                    break
+
+            if finished:
+                break
+            ind += 1
+            if ind > self.n_phis:                  # FR:1747
+                break
+
+        if self.gimmie:                            # FR:1751-1753
+            betas, mtx = last, last_damtx
+        out_betas = betas.betas[-self.draws_keep::, :]
+        return out_betas, np.array(mtx, dtype=np.float64), evs

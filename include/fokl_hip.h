@@ -1,0 +1,202 @@
+/*
+ * fokl_hip.h -- C ABI of libfokl_hip.so, the MI355X (gfx950) implementation of FoKL-GPy's
+ * forward-variable-selection hot path (FoKLRoutines.FoKL.fit: basis build -> Gram / X'y -> Gibbs -> BIC).
+ *
+ * The reference is pure Python and has no FFI seam of its own: the hot path is closure code inside
+ * FoKL.fit (/root/reference/src/FoKL/FoKLRoutines.py:1350-1760, "FR" below).  This header is the seam a
+ * maintainer binds with ctypes directly under that method (INTEGRATION.md shows the stub); each entry
+ * point names the reference lines whose work it replaces.  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 (FOKL_OK) or a negative FOKL_ERR_* code; fokl_last_error() gives the text;
+ *   - a context owns one HIP stream on one device; use one context per host thread;
+ *   - the design matrix lives on the device as column "slots" (one basis column of N fp64 values each).
+ *     Slot 0 is the intercept column of ones and slot 1 holds the observations y; both are filled by
+ *     fokl_upload().  All other slots are handed out by the caller (the host driver keeps the free list);
+ *   - matrices crossing the ABI are dense row-major fp64 in host memory.
+ */
+#ifndef FOKL_HIP_H
+#define FOKL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOKL_OK             0
+#define FOKL_ERR_HIP       -1   /* a HIP runtime call failed (no device, out of memory, launch failure ...) */
+#define FOKL_ERR_ARG       -2   /* invalid argument (null pointer, slot out of range, size mismatch ...)      */
+#define FOKL_ERR_STATE     -3   /* call out of order (e.g. build before upload)                               */
+#define FOKL_ERR_COMM      -4   /* RCCL failure                                                               */
+#define FOKL_ERR_NUMERIC   -5   /* sampler received non-finite spectrum / hyper-parameters                    */
+
+#define FOKL_KERNEL_SPLINES   0 /* 'Cubic Splines'          (FR:199, FR:834-836) */
+#define FOKL_KERNEL_BERNOULLI 1 /* 'Bernoulli Polynomials'  (FR:199, FR:841-843) */
+
+#define FOKL_SLOT_ONES 0
+#define FOKL_SLOT_Y    1
+#define FOKL_SLOT_FIRST_FREE 2
+
+/* ids for fokl_timing_get() */
+#define FOKL_K_BASIS   0        /* K1 basis-build kernel                */
+#define FOKL_K_GRAM    1        /* K2 Gram kernels (+ slab reduction)   */
+#define FOKL_K_RESID   2        /* K3 residual / BIC kernel             */
+#define FOKL_K_PREDICT 3        /* evaluate(): X * beta^T + order stats */
+#define FOKL_K_COUNT   4
+
+typedef struct fokl_ctx fokl_ctx;
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* library / context                                                                                      */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_version(void);
+/* Number of visible HIP devices (0 and FOKL_ERR_HIP when the runtime finds none). */
+int fokl_device_count(int *count);
+int fokl_ctx_create(int device, fokl_ctx **out);
+void fokl_ctx_destroy(fokl_ctx *ctx);
+/* Text of the last error raised on `ctx` (or, with ctx == NULL, by fokl_ctx_create / pure host functions). */
+const char *fokl_last_error(const fokl_ctx *ctx);
+int fokl_sync(fokl_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* dataset: replaces the per-fit constants of FR:1357-1361 (_inputs_to_phind, FR:544-592) and FR:1374     */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Copy one (shard of a) normalised dataset to the device and lay it out for the kernels:
+ *   x      [n, m] row-major, already normalised to [0, 1] (what FoKL.clean produces, FR:441-507);
+ *   y      [n];
+ *   kernel FOKL_KERNEL_*;
+ *   phis   dense coefficient table: splines [n_basis, 4, width] (width = 499 pieces, coefficient k of
+ *          piece p of basis i at (i*4 + k)*width + p); Bernoulli [n_basis, width] zero padded, basis i
+ *          (order i + 1) uses its first i + 2 entries (the reference's tuple-of-lists, GK:221-267, GK:308-326).
+ * Inputs are transposed to structure-of-arrays on the device; the spline piece index / local coordinate
+ * (FR:570-589) are recomputed inside the basis kernel from x instead of being stored.
+ * Invalidates every slot; slots 0 (ones) and 1 (y) are rebuilt.
+ */
+int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
+                const double *phis, int n_basis, int width);
+
+/* Make sure slots [0, n_slots) exist (grows in chunks; existing slot contents are preserved). */
+int fokl_reserve_slots(fokl_ctx *ctx, int n_slots);
+int fokl_slot_capacity(const fokl_ctx *ctx);
+int64_t fokl_rows(const fokl_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K1: basis-matrix columns.  Replaces the X-build triple loop of gibbs(), FR:1446-1485, with              */
+/* evaluate_basis (FR:807-849, d = 0) and _inputs_to_phind (FR:570-589) fused in.                          */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * terms [T, m] int32 row-major: entry = basis order (1-based) of that input in the term, 0 = input absent
+ *       (a row of the reference's interaction matrix `discmtx`, FR:1473);
+ * slots [T]: destination slot of each term's column.
+ * Column j = prod_{k: terms[j,k] != 0} basis_{terms[j,k]}(x[:, k]), factors multiplied in ascending k and
+ * every operation rounded separately exactly like the reference's scalar code (no FMA contraction,
+ * x**k correctly rounded).  Asynchronous on the context's stream.
+ */
+int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K2: Gram blocks.  Replaces XtX = X'X, Xty = X'y (FR:1492-1494) and dtd = y'y (FR:1374).                 */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * out[a, b] = sum_i col(row_slots[a])[i] * col(col_slots[b])[i]   (nr x nc, row-major, host memory).
+ * Passing FOKL_SLOT_Y among the column slots yields X'y, FOKL_SLOT_ONES yields column sums.
+ * `path`: 0 = choose automatically, 1 = force the wavefront-reduction (VALU) kernel, 2 = force the fp64
+ * MFMA tile kernel.  Partial sums are combined in a fixed order, so results are bitwise reproducible.
+ * If a communicator is attached (fokl_comm_init) and `allreduce` != 0 the block is summed over ranks
+ * (row-sharded data) before it is returned.  Blocking.
+ */
+int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
+              double *out, int path, int allreduce);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K3: residual moments for the BIC.  Replaces siglik = var(y - X betahat), FR:1551 (and FR:1505).         */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * out[0] = sum_i r_i, out[1] = sum_i r_i^2 with r = y - sum_j betahat[j] * col(slots[j]); the caller forms
+ * the population variance out[1]/n - (out[0]/n)^2 and the BIC (FR:1553-1554).  Blocking; optional all-reduce.
+ */
+int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
+                   int allreduce);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* evaluate(): posterior-mean prediction and 95 % bounds on the device.  Replaces FR:966-978.              */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * For the rows currently uploaded: modells[i, d] = sum_j betas[d, j] * col(slots[j])[i] (FR:966-968),
+ * mean[i] = mean_d modells[i, d] (FR:969) and, when `bounds` != NULL, bounds[i] = (sorted[cut],
+ * sorted[draws - cut]) of row i's draws (FR:973-977).  betas is [draws, nc] row-major in host memory.
+ */
+int fokl_predict(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betas, int draws, int cut,
+                 double *mean, double *bounds);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* test / debug access to slots                                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_read_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, double *host);
+int fokl_write_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, const double *host);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* per-kernel timing with HIP events on the context's stream (bench.py's roofline figures)                 */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_timing_enable(fokl_ctx *ctx, int on);
+int fokl_timing_reset(fokl_ctx *ctx);
+/* Accumulated device time (ms), launch count and algorithmic bytes / flops of kernel family `kernel_id`. */
+int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
+                    double *flops);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* G2/G3: the Gibbs chain (host C++, N-independent).  Replaces the D-iteration loop FR:1519-1548.           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Runs `draws` iterations in the eigenbasis of XtX = Q diag(lamb) Q':
+ *     d   = 1 / (lamb + 1/tausqd)                                   (FR:1521-1522)
+ *     w   = d * qty + sqrt(sigsqd) * sqrt(d) * vec,  vec ~ N(0, I)  (FR:1524-1528; beta = Q w)
+ *     bstar = b + (w'diag(lamb)w - 2 w'qty + dtd + w'w / tausqd)/2  (FR:1532-1533)
+ *     sigsqd = 1 / Gamma(astar, 1/bstar)   (NaN, and no draw, if bstar < 0; FR:1538-1541)
+ *     tausqd = 1 / Gamma(atau_star, 1/(w'w/(2 sigsqd) + btau))      (FR:1545-1547)
+ * with qty = Q'Xty.  Random numbers come from numpy's legacy global stream, continued bit for bit:
+ * mt_key[624] / mt_pos / has_gauss / gauss_cache are the fields of np.random.get_state() and are updated
+ * in place (MT19937 -> 53-bit doubles -> polar Gaussian with one cached value -> Marsaglia-Tsang gamma).
+ * w_out [draws, p1] receives w per iteration (the caller forms betas = w_out Q'); sigs_out / taus_out
+ * [draws] may be NULL.
+ */
+int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar, double atau_star,
+                     double b, double btau, double dtd, double sigsqd0, double tausqd0, int draws,
+                     uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     double *w_out, double *sigs_out, double *taus_out);
+
+/* Raw access to the same generator (parity tests against numpy): n standard normals / n std gammas. */
+int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     int64_t n, double *out);
+int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                    double shape, double scale, int64_t n, double *out);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* multi-GPU: one process per GPU, RCCL over xGMI                                                          */
+/* ------------------------------------------------------------------------------------------------------ */
+
+#define FOKL_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id and hands the bytes to the other ranks through any host channel. */
+int fokl_comm_unique_id(char id[FOKL_UNIQUE_ID_BYTES]);
+int fokl_comm_init(fokl_ctx *ctx, const char id[FOKL_UNIQUE_ID_BYTES], int rank, int world);
+int fokl_comm_destroy(fokl_ctx *ctx);
+/* recv[r*count .. (r+1)*count) = send of rank r: the per-candidate BIC gather of the kill-test shard. */
+int fokl_comm_allgather_f64(fokl_ctx *ctx, const double *send, int count, double *recv);
+/* In-place sum over ranks (row-sharded Gram blocks / residual moments). */
+int fokl_comm_allreduce_sum_f64(fokl_ctx *ctx, double *buf, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOKL_HIP_H */

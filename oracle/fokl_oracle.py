@@ -1,0 +1,470 @@
+"""
+ORACLE -- test infrastructure, NOT the product.
+
+CPU restatement (numpy + a small C helper, oracle_c.c) of the forward-variable-selection hot path of
+FoKL-GPy's ``FoKLRoutines.FoKL.fit``.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product (``fokl_gpy_amd``) never does.
+
+Parity pin: ``tests/golden/*.npz`` were produced by importing the real reference in the build container
+(``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` checks every function here against
+them (selected interaction matrix exactly, BIC trace and posterior draws to ~1e-12).
+
+Every function cites the reference lines it restates; ``FR`` = /root/reference/src/FoKL/FoKLRoutines.py.
+
+Third-party arithmetic the reference leans on and this oracle uses *as is* (it is the same dependency,
+not a re-implementation): numpy's legacy global RandomState (``np.random.normal`` / ``np.random.gamma``,
+MT19937 + polar Gaussian with cache + Marsaglia-Tsang gamma; call sites FR:1527, 1541, 1547),
+``scipy.linalg.eigh`` (FR:1499) and BLAS ``dot`` (FR:1492-1494).
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+from scipy.linalg import eigh as _scipy_eigh
+
+KERNEL_SPLINES = 0
+KERNEL_BERNOULLI = 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# eigen-decomposition with a deterministic sign convention
+# ---------------------------------------------------------------------------------------------------------
+
+def canonical_signs(Q):
+    """Flip every eigenvector so that its largest-magnitude component is positive."""
+    Q = np.array(Q, dtype=np.float64, copy=True)
+    piv = np.argmax(np.abs(Q), axis=0)
+    sgn = np.sign(Q[piv, np.arange(Q.shape[1])])
+    sgn[sgn == 0] = 1.0
+    return Q * sgn
+
+
+def eigh_reference(A):
+    """``scipy.linalg.eigh`` exactly as the reference calls it (FR:17, FR:1499)."""
+    return _scipy_eigh(A)
+
+
+def eigh_canonical(A):
+    """Reference eigh followed by the sign canonicalisation shared by patched reference, oracle and product."""
+    lam, Q = _scipy_eigh(A)
+    return lam, canonical_signs(Q)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# F1, F2: spline indexing and scalar basis evaluation
+# ---------------------------------------------------------------------------------------------------------
+
+def inputs_to_phind(inputs, l_phis):
+    """F1 (FR:570-589): piece index and local coordinate of normalised inputs for the spline kernel."""
+    phind = np.array(np.ceil(inputs * l_phis), dtype=np.uint16)
+    if phind.ndim == 1:
+        phind = phind[:, np.newaxis]
+    phind = phind + (phind == 0)
+    phind = phind - 1
+    xsm = np.array(l_phis * inputs - phind, dtype=inputs.dtype)
+    if np.max(phind) > 499 or np.min(phind) < 0:
+        raise ValueError('Inputs are not normalized correctly')
+    return phind, xsm
+
+
+def evaluate_basis(c, x, kernel):
+    """F2 (FR:834-843), d = 0.  ``x`` must be a numpy float64 scalar so that ``**`` is libm pow as in the reference."""
+    if kernel == KERNEL_SPLINES:
+        return c[0] + c[1] * x + c[2] * (x ** 2) + c[3] * (x ** 3)
+    return c[0] + sum(c[k] * (x ** k) for k in range(1, len(c)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# F4: term enumeration
+# ---------------------------------------------------------------------------------------------------------
+
+def distinct_arrangements(indvec):
+    """
+    F4 (FR:1350-1354, FR:1616): ``np.unique(perms(indvec), axis=0)`` == all distinct arrangements of the
+    multiset ``indvec`` in ascending lexicographic order, as float64 rows.  Generated directly with the
+    classic next-permutation step instead of enumerating M! tuples.
+    """
+    cur = sorted(float(v) for v in indvec)
+    rows = [list(cur)]
+    n = len(cur)
+    while True:
+        i = n - 2
+        while i >= 0 and cur[i] >= cur[i + 1]:
+            i -= 1
+        if i < 0:
+            break
+        j = n - 1
+        while cur[j] <= cur[i]:
+            j -= 1
+        cur[i], cur[j] = cur[j], cur[i]
+        cur[i + 1:] = reversed(cur[i + 1:])
+        rows.append(list(cur))
+    return np.array(rows, dtype=np.float64)
+
+
+def deal_indvec(ind, m, sett):
+    """FR:1605-1613: spread ``ind`` units round-robin over the first ``sett`` slots of a length-m vector."""
+    indvec = np.zeros(m)
+    left = ind
+    while left:
+        for j in range(sett):
+            indvec[j] += 1
+            left -= 1
+            if left == 0:
+                break
+    return indvec
+
+
+# ---------------------------------------------------------------------------------------------------------
+# F3: basis-matrix columns (faithful scalar path in Python; same arithmetic in C for anything bigger)
+# ---------------------------------------------------------------------------------------------------------
+
+def pack_phis(phis, kernel):
+    if kernel == KERNEL_SPLINES:
+        nb, npiece = len(phis), len(phis[0][0])
+        out = np.empty((nb, 4, npiece))
+        for i in range(nb):
+            for k in range(4):
+                out[i, k] = phis[i][k]
+        return np.ascontiguousarray(out), nb, npiece
+    nb = len(phis)
+    width = max(len(p) for p in phis)
+    out = np.zeros((nb, width))
+    for i in range(nb):
+        out[i, :len(phis[i])] = phis[i]
+    return np.ascontiguousarray(out), nb, width
+
+
+def build_columns_scalar(xsm, phind, phis, kernel, terms):
+    """F3 (FR:1461-1485) with the reference's own per-element loop structure.  Slow: small cases only."""
+    n, m = xsm.shape
+    terms = np.atleast_2d(terms)
+    out = np.zeros((n, terms.shape[0]))
+    for i in range(n):
+        for j in range(terms.shape[0]):
+            phi = 1
+            for k in range(m):
+                num = terms[j][k]
+                if num != 0:
+                    nid = int(num - 1)
+                    if kernel == KERNEL_SPLINES:
+                        coeffs = [phis[nid][order][phind[i, k]] for order in range(4)]
+                    else:
+                        coeffs = phis[nid]
+                    phi = phi * evaluate_basis(coeffs, xsm[i, k], kernel)
+            out[i][j] = phi
+    return out
+
+
+_LIB = None
+
+
+def build_c_helper(force=False):
+    """Compile oracle_c.c -> oracle/liboracle_c.so (gcc, no FMA contraction) and return the path."""
+    so = os.path.join(_HERE, 'liboracle_c.so')
+    src = os.path.join(_HERE, 'oracle_c.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-fPIC', '-shared', '-o', so, src, '-lm'])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_c_helper())
+        _LIB.oracle_build_columns.restype = None
+        _LIB.oracle_gram.restype = None
+        _LIB.oracle_inputs_to_phind.restype = None
+    return _LIB
+
+
+def build_columns_c(xsm, phind, phis, kernel, terms):
+    """F3 through oracle_c.c -- identical arithmetic (libm pow, no FMA) to ``build_columns_scalar``; returns [N, T]."""
+    lib = _lib()
+    xsm = np.ascontiguousarray(xsm, dtype=np.float64)
+    n, m = xsm.shape
+    terms = np.ascontiguousarray(np.atleast_2d(terms), dtype=np.int32)
+    t = terms.shape[0]
+    packed, nb, width = pack_phis(phis, kernel)
+    out = np.empty((t, n), dtype=np.float64)
+    if kernel == KERNEL_SPLINES:
+        ph = np.ascontiguousarray(phind, dtype=np.uint16)
+        ph_ptr = ph.ctypes.data_as(ctypes.c_void_p)
+    else:
+        ph_ptr = ctypes.c_void_p(0)
+    lib.oracle_build_columns(xsm.ctypes.data_as(ctypes.c_void_p), ph_ptr, ctypes.c_int64(n), ctypes.c_int(m),
+                             ctypes.c_int(kernel), packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nb),
+                             ctypes.c_int(width), terms.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(t),
+                             out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n))
+    return np.ascontiguousarray(out.T)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# G1-G4: one gibbs() call
+# ---------------------------------------------------------------------------------------------------------
+
+class GibbsResult:
+    __slots__ = ('betas', 'sigs', 'taus', 'betahat', 'X', 'ev', 'XtX', 'Xty', 'lamb', 'Q')
+
+
+def gibbs(inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, draws, phind, xsm, sigsqd, tausqd, dtd,
+          eigh=eigh_reference, build=build_columns_c):
+    """
+    One model evaluation (FR:1396-1558): build the missing columns of X (F3), XtX / Xty (G1, FR:1492-1494),
+    spectral least squares (G2, FR:1499-1505), ``draws`` Gibbs iterations (G3, FR:1519-1548) and the
+    BIC (G4, FR:1551-1554).  Consumes numpy's global legacy RNG exactly like the reference.
+    """
+    n_obs = inputs.shape[0]
+    discmtx = np.atleast_2d(discmtx)
+    mmtx = discmtx.shape[0]
+    if np.size(Xin) == 0:
+        Xin = np.ones((n_obs, 1))
+    nxin = Xin.shape[1]
+    if mmtx + 1 > nxin:
+        new_cols = build(xsm, phind, phis, kernel, discmtx[nxin - 1:mmtx])
+        X = np.concatenate([Xin, new_cols], axis=1)
+    else:
+        X = Xin
+
+    XtX = np.transpose(X).dot(X)
+    Xty = np.transpose(X).dot(data)
+
+    lamb, Q = eigh(XtX)
+    betahat = Q.dot(np.diag(1 / lamb)).dot(np.transpose(Q)).dot(Xty)
+
+    n = len(data)
+    astar = a + 1 + n / 2 + (mmtx + 1) / 2
+    atau_star = atau + mmtx / 2
+
+    betas = np.zeros((draws, mmtx + 1))
+    sigs = np.zeros((draws, 1))
+    taus = np.zeros((draws, 1))
+    eye = np.identity(mmtx + 1)
+    for k in range(draws):
+        shifted = np.diag(lamb) + (1 / tausqd) * eye
+        shifted_inv = np.diag(1 / np.diag(shifted))
+        mun = Q.dot(shifted_inv).dot(np.transpose(Q)).dot(Xty)
+        S = Q.dot(np.diag(np.diag(shifted_inv) ** (1 / 2)))
+        vec = np.random.normal(loc=0, scale=1, size=(mmtx + 1, 1))
+        betas[k][:] = np.transpose(mun + sigsqd ** (1 / 2) * S.dot(vec))
+        bk = betas[k][:]
+        bstar = b + 0.5 * (bk.dot(XtX.dot(np.transpose([bk]))) - 2 * bk.dot(Xty) + dtd
+                           + bk.dot(np.transpose([bk])) / tausqd)
+        if bstar < 0:
+            sigsqd = math.nan
+        else:
+            sigsqd = 1 / np.random.gamma(astar, 1 / bstar)
+        sigs[k] = sigsqd
+        btau_star = (1 / (2 * sigsqd)) * (bk.dot(np.reshape(bk, (len(bk), 1)))) + btau
+        tausqd = 1 / np.random.gamma(atau_star, 1 / btau_star)
+        taus[k] = tausqd
+
+    siglik = np.var(data - np.matmul(X, betahat))
+    lik = -(n / 2) * np.log(siglik) - (n - 1) / 2
+    ev = (mmtx + 1) * np.log(n) - 2 * np.max(lik)
+
+    res = GibbsResult()
+    res.betas, res.sigs, res.taus, res.betahat = betas, sigs, taus, betahat
+    res.X, res.ev, res.XtX, res.Xty, res.lamb, res.Q = X[:, :mmtx + 1], ev, XtX, Xty, lamb, Q
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# G5, G6, D0: the forward-selection driver
+# ---------------------------------------------------------------------------------------------------------
+
+DEFAULT_HYPERS = dict(a=4, b=None, atau=4, btau=None, tolerance=3, burnin=1000, draws=1000, gimmie=False,
+                      way3=False, threshav=0.05, threshstda=0.5, threshstdb=2, aic=False)
+
+
+def default_b_btau(data, a, atau, b=None, btau=None):
+    """D0 (FR:1322-1348): data-driven defaults of the two inverse-gamma scale parameters."""
+    sigmasq = np.var(data)
+    data_mean = np.mean(data)
+    if b is None:
+        b = sigmasq * (a + 1)
+    if btau is None:
+        btau = (np.abs(data_mean) / sigmasq) * (atau + 1)
+    return b, btau
+
+
+def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, trace=None, **hypers):
+    """
+    Forward variable selection (FR:1350-1760) on already normalised ``inputs`` [N, M] and ``data`` [N, 1].
+
+    Returns (betas[-draws:], mtx, evs).  ``trace`` (optional list) receives one dict per gibbs() call with
+    the number of columns, how many were (re)built, the BIC and whether it was a kill test -- the
+    "logical candidate-term" count of SURVEY 8(d) is ``sum(t['built'] for t in trace)``.
+    """
+    hp = dict(DEFAULT_HYPERS)
+    for key, val in hypers.items():
+        if key not in hp:
+            raise ValueError(f"Unexpected keyword argument: '{key}'")
+        hp[key] = val
+    a, atau = hp['a'], hp['atau']
+    b, btau = default_b_btau(data, a, atau, hp['b'], hp['btau'])
+    tolerance, way3, aic = hp['tolerance'], hp['way3'], hp['aic']
+    threshav, threshstda, threshstdb = hp['threshav'], hp['threshstda'], hp['threshstdb']
+    draws = hp['burnin'] + hp['draws']
+
+    if kernel == KERNEL_SPLINES:
+        phind, xsm = inputs_to_phind(inputs, len(phis[0][0]))
+    else:
+        phind, xsm = None, inputs
+
+    sigsqd0 = b / (1 + a)
+    tausqd0 = btau / (1 + atau)
+    dtd = np.transpose(data).dot(data)
+
+    def run(Xin, discmtx, kill):
+        nxin = 1 if np.size(Xin) == 0 else Xin.shape[1]
+        res = gibbs(inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, draws, phind, xsm,
+                    sigsqd0, tausqd0, dtd, eigh=eigh, build=build)
+        if trace is not None:
+            trace.append(dict(cols=discmtx.shape[0] + 1, built=discmtx.shape[0] + 1 - nxin, ev=float(res.ev),
+                              kill=kill))
+        return res
+
+    n, m = inputs.shape
+    damtx = np.zeros((0, m))
+    evs = np.array([])
+    X = []
+    ind = 1
+    greater = 0
+    finished = False
+    sett = 1 if m == 1 else (3 if way3 else 2)
+    half1 = int(np.ceil((draws / 2) + 1))
+    half0 = int(np.ceil(draws / 2))
+    betas = mtx = beters = None
+
+    while True:
+        indvec = deal_indvec(ind, m, sett)
+        while True:
+            vecs = distinct_arrangements(indvec)
+            vm = vecs.shape[0]
+            damtx = np.append(damtx, vecs, axis=0)
+            dam = damtx.shape[0]
+
+            res = run(X, damtx, False)
+            beters, xers, ev = res.betas, res.X, res.ev
+            if aic:
+                ev = ev + (2 - np.log(n)) * (dam + 1)
+
+            new = slice(dam - vm + 1, dam + 1)
+            mean_abs = np.abs(np.mean(beters[half1:draws, new], axis=0))
+            rel_std = np.divide(np.std(np.array(beters[half1:draws, new]), axis=0),
+                                np.abs(np.mean(beters[half0:draws, dam - vm + 1:dam + 2], axis=0)))
+            ids = np.array(range(dam - vm + 2, dam + 2))
+            table = np.transpose(np.array([mean_abs, rel_std, ids]))
+            if table.shape[1] > 0:
+                table = table[np.argsort(table[:, 0])]
+
+            killset = []
+            evmin = ev
+            for i in range(vm):
+                if table[i, 1] > threshstdb or table[i, 1] > threshstda and table[i, 0] < threshav * \
+                        np.mean(np.abs(np.mean(beters[half0:draws, 0]))):
+                    killtest = np.append(killset, (table[i, 2] - 1))
+                    if killtest.size > 1:
+                        killtest[::-1].sort()
+                    damtx_test = damtx
+                    for k in range(np.size(killtest)):
+                        damtx_test = np.delete(damtx_test, int(np.array(killtest[k]) - 1), 0)
+                    damtest = damtx_test.shape[0]
+                    res_t = run(X, damtx_test, True)
+                    evtest = res_t.ev
+                    if aic:
+                        evtest = evtest + (2 - np.log(n)) * (damtest + 1)
+                    if evtest < evmin:
+                        killset = killtest
+                        evmin = evtest
+                        xers = res_t.X
+                        beters = res_t.betas
+            for k in range(np.size(killset)):
+                damtx = np.delete(damtx, int(np.array(killset[k]) - 1), 0)
+
+            ev = evmin
+            X = xers
+
+            if np.size(evs) > 0:
+                if ev < np.min(evs):
+                    betas, mtx, greater = beters, damtx, 1
+                    evs = np.append(evs, ev)
+                elif greater < tolerance:
+                    greater += 1
+                    evs = np.append(evs, ev)
+                else:
+                    finished = True
+                    evs = np.append(evs, ev)
+                    break
+            else:
+                greater += 1
+                betas, mtx = beters, damtx
+                evs = np.append(evs, ev)
+
+            if m == 1:
+                break
+            elif way3:
+                if indvec[1] > indvec[2]:
+                    indvec[0] += 1
+                    indvec[1] -= 1
+                elif indvec[2]:
+                    indvec[1] += 1
+                    indvec[2] -= 1
+                    if indvec[1] > indvec[0]:
+                        indvec[0] += 1
+                        indvec[1] -= 1
+                else:
+                    break
+            elif indvec[1]:
+                indvec[0] += 1
+                indvec[1] -= 1
+            else:
+                break
+
+        if finished:
+            break
+        ind += 1
+        if ind > len(phis):
+            break
+
+    if hp['gimmie']:
+        betas, mtx = beters, damtx
+    return betas[-hp['draws']::, :], mtx, evs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# evaluate / coverage3 numerics (kept class surface; FR:929-978, FR:1193)
+# ---------------------------------------------------------------------------------------------------------
+
+def evaluate(inputs, betas, mtx, phis, kernel, draws, setnos, return_bounds=False, build=build_columns_c):
+    """Posterior-mean prediction (FR:941-978) for normalised ``inputs`` with an explicit draw selection ``setnos``."""
+    inputs = np.asarray(inputs)
+    n = inputs.shape[0]
+    if kernel == KERNEL_SPLINES:
+        phind, xsm = inputs_to_phind(inputs, len(phis[0][0]))
+    else:
+        phind, xsm = None, inputs
+    X = np.concatenate([np.ones((n, 1)), build(xsm, phind, phis, kernel, np.atleast_2d(mtx))], axis=1)
+    modells = np.zeros((n, draws))
+    for i in range(draws):
+        modells[:, i] = np.transpose(np.matmul(X, np.transpose(np.array(betas[setnos[i], :]))))
+    mean = np.mean(modells, 1)
+    if not return_bounds:
+        return mean
+    bounds = np.zeros((n, 2))
+    cut = int(np.floor(draws * 0.025) + 1)
+    for i in range(n):
+        drawset = np.sort(modells[i, :])
+        bounds[i, 0] = drawset[cut]
+        bounds[i, 1] = drawset[draws - cut]
+    return mean, bounds
+
+
+def coverage_rmse(mean, data):
+    """FR:1193 computes ``sqrt(mean(mean - data) ** 2)`` with an (n,) - (n,1) broadcast; its value is
+    ``|mean(mean) - mean(data)|`` up to rounding.  Evaluated here without the n x n temporary."""
+    return np.sqrt((np.mean(mean) - np.mean(data)) ** 2)

@@ -1,0 +1,107 @@
+"""Shared test helpers: golden-fixture loading and a CPU stand-in for the device backend.
+
+``OracleBackend`` implements the backend protocol of ``fokl_gpy_amd.engine`` with the oracle's column builder and
+numpy so that the HOST logic (search driver, slot bookkeeping, Gram cache, sampler hand-off, class surface) can be
+exercised by the ``-m "not gpu"`` suite.  It lives under tests/ on purpose: the product never routes through it.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import fokl_oracle as O  # noqa: E402
+from fokl_gpy_amd import getKernels  # noqa: E402
+
+FIT_CASES = ['bern_m1', 'bern_m3', 'bern_m3_gimmie_tol1', 'bern_m4_way3', 'bern_m6_aic', 'bern_m8_capped',
+             'testdata10_default', 'testdata10_changed', 'splines_m4', 'sigmoid_splines']
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    hy = dict(zip([str(k) for k in g['hyper_keys']], [float(v) for v in g['hyper_vals']]))
+    for k in ('burnin', 'draws', 'tolerance'):
+        if k in hy:
+            hy[k] = int(hy[k])
+    for k in ('gimmie', 'way3', 'aic'):
+        if k in hy:
+            hy[k] = bool(hy[k])
+    for k in ('a', 'atau'):
+        if k in hy and float(hy[k]).is_integer():
+            hy[k] = int(hy[k])
+    kernel_name = str(g['kernel'])
+    if kernel_name == 'Cubic Splines':
+        phis = getKernels.table_to_phis(np.load(os.path.join(GOLDEN, 'spline_phis.npz'))['table'])
+        kid = O.KERNEL_SPLINES
+    else:
+        phis = getKernels.bernoulli()
+        cap = int(g['phis_cap'])
+        if cap > 0:
+            phis = phis[:cap]
+        kid = O.KERNEL_BERNOULLI
+    return g, hy, kernel_name, kid, phis
+
+
+def unpack_phis(packed, kernel_id, n_basis, width):
+    if kernel_id == O.KERNEL_SPLINES:
+        return getKernels.table_to_phis(np.asarray(packed).reshape(n_basis, 4, width))
+    tab = np.asarray(packed).reshape(n_basis, width)
+    return tuple(list(tab[i, :i + 2]) for i in range(n_basis))
+
+
+class OracleBackend:
+    """CPU stand-in for ``HipBackend`` built from the oracle (tests only)."""
+
+    def __init__(self):
+        self.cols = {}
+        self.capacity = 0
+        self.calls = dict(build=0, gram=0, resid=0)
+
+    def upload(self, inputs, data, kernel_id, packed, n_basis, width):
+        self.inputs = np.ascontiguousarray(inputs, dtype=np.float64)
+        self.kernel = kernel_id
+        self.phis = unpack_phis(packed, kernel_id, n_basis, width)
+        n = self.inputs.shape[0]
+        self.cols = {0: np.ones(n), 1: np.asarray(data, dtype=np.float64).reshape(-1).copy()}
+        if kernel_id == O.KERNEL_SPLINES:
+            self.phind, self.xsm = O.inputs_to_phind(self.inputs, len(self.phis[0][0]))
+        else:
+            self.phind, self.xsm = None, self.inputs
+        self.capacity = 16
+        self.n = n
+
+    def reserve_slots(self, count):
+        self.capacity = max(self.capacity, count)
+
+    def build_terms(self, terms, slots):
+        self.calls['build'] += 1
+        X = O.build_columns_c(self.xsm, self.phind, self.phis, self.kernel, np.atleast_2d(terms))
+        for j, s in enumerate(slots):
+            assert 2 <= s < self.capacity, "slot outside the reserved range"
+            self.cols[int(s)] = X[:, j].copy()
+
+    def gram(self, row_slots, col_slots, allreduce=False):
+        self.calls['gram'] += 1
+        A = np.stack([self.cols[int(s)] for s in row_slots], axis=1)
+        B = np.stack([self.cols[int(s)] for s in col_slots], axis=1)
+        return A.T @ B
+
+    def bic_resid(self, slots, betahat, allreduce=False):
+        self.calls['resid'] += 1
+        X = np.stack([self.cols[int(s)] for s in slots], axis=1)
+        r = self.cols[1] - X @ np.reshape(betahat, -1)
+        return float(np.sum(r)), float(np.sum(r * r))
+
+    def predict(self, slots, betas, cut=None):
+        X = np.stack([self.cols[int(s)] for s in slots], axis=1)
+        mod = X @ np.asarray(betas).T
+        mean = np.mean(mod, axis=1)
+        if cut is None:
+            return mean
+        srt = np.sort(mod, axis=1)
+        draws = mod.shape[1]
+        return mean, np.stack([srt[:, cut], srt[:, draws - cut]], axis=1)
