@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the forward-selection hot path on MI355X -- BASELINE.json's metric:
+
+    candidate-terms/sec (basis build + Gibbs + BIC), N = 1e6, M = 8
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One *step* = one complete forward-selection fit (FoKL.fit's search: every sub-stage's basis build, Gram,
+Gibbs chains, BIC and kill tests) over the synthetic configs[2] workload -- N = 1e6 rows, M = 8 inputs,
+Bernoulli-polynomial kernel, 2-way interactions, reference-default hyper-parameters (burnin 1000, draws 1000,
+tolerance 3) -- with the normalised inputs already resident in HBM when the timed region starts.
+
+`value` = candidate terms / second, where the numerator is the reference-equivalent (logical) count: the sum
+over all gibbs evaluations of the columns the reference builds for that evaluation (FoKLRoutines.py:1461),
+tallied per call by the search driver.  `terms_physical` is what the GPU really built.
+
+N > 1: every rank fits its own dataset of the same shape (independent fits are the unit that shards without a
+data-path collective, BASELINE configs[4]); per-rank time and term counts are exchanged with one RCCL
+all-gather; value = all ranks' terms / max-over-ranks time ("weak" scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
+
+
+def make_workload(seed, n, m):
+    """U[0,1) inputs, y = sin(4 x0) + x1 x2 + 0.3 x3^2 + 0.5 x4 x5 + 0.05 N(0,1)."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, m))
+    y = np.sin(4.0 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.5 * x[:, 4] * x[:, 5]
+    y = y + 0.05 * rng.standard_normal(n)
+    return x, y
+
+
+def cpu_baseline(x, y, n_sample=60000):
+    """
+    The reference's algorithm on the host (oracle, kind "port"): the first two gibbs evaluations of the same
+    workload (T = 8 main effects, then + 28 two-way terms) on the first `n_sample` rows with the reference's own
+    per-element Python loop structure (FoKLRoutines.py:1446-1485), one core.  The reference's cost at this N is
+    its O(N * T * M) X-build, so the rate is extrapolated linearly in N to the benchmark's row count.
+    """
+    from oracle import fokl_oracle as O
+    from fokl_gpy_amd import getKernels
+    phis = getKernels.bernoulli()
+    n_full, m = x.shape
+    xs = np.ascontiguousarray(x[:n_sample])
+    ys = np.ascontiguousarray(y[:n_sample])[:, None]
+    a = atau = 4
+    b, btau = O.default_b_btau(ys, a, atau)
+    dtd = ys.T.dot(ys)
+    t1 = O.distinct_arrangements(O.deal_indvec(1, m, 2))
+    t2 = O.distinct_arrangements(O.deal_indvec(2, m, 2))
+    state = np.random.get_state()
+    np.random.seed(12345)
+    t0 = time.perf_counter()
+    r1 = O.gibbs(xs, ys, phis, O.KERNEL_BERNOULLI, [], t1, a, b, atau, btau, 2000, None, xs, b / (1 + a),
+                 btau / (1 + atau), dtd, build=O.build_columns_scalar)
+    O.gibbs(xs, ys, phis, O.KERNEL_BERNOULLI, r1.X, np.vstack([t1, t2]), a, b, atau, btau, 2000, None, xs,
+            b / (1 + a), btau / (1 + atau), dtd, build=O.build_columns_scalar)
+    dt = time.perf_counter() - t0
+    np.random.set_state(state)
+    terms = t1.shape[0] + t2.shape[0]
+    rate_sample = terms / dt
+    return dict(value=rate_sample * n_sample / n_full, unit='candidate-terms/s', cores=1, kind='port',
+                sample=f'oracle scalar path (reference loop structure), first 2 gibbs evaluations ({terms} terms, '
+                       f'2000 draws each) on the first {n_sample} of {n_full} rows in {dt:.1f} s; '
+                       f'rate scaled by {n_sample}/{n_full} (X-build is linear in N)',
+                seconds=dt, terms=terms)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--rows', type=int, default=1_000_000)
+    ap.add_argument('--inputs', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from fokl_gpy_amd import dist
+    rank, world, local = dist.env_rank_world()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    os.environ['FOKL_DEVICE'] = str(local)
+
+    from fokl_gpy_amd import FoKLRoutines, _capi
+    backend = FoKLRoutines.device_backend(local)          # raises without libfokl_hip.so / a gfx950 device
+    ctx = backend.ctx
+    comm = dist.RcclComm(ctx, rank, world) if world > 1 else dist.SingleComm()
+
+    n, m = args.rows, args.inputs
+    x, y = make_workload(12 + rank, n, m)
+    seed_fit = 1000 + rank
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FoKLRoutines.FoKL(kernel='Bernoulli Polynomials', UserWarnings=False, ConsoleOutput=False)
+        t0 = time.perf_counter()
+        model._prepare_fit(x, y, dict(clean=True))         # format, normalise, defaults, H2D upload (untimed)
+        prep_s = time.perf_counter() - t0
+
+        def one_step():
+            np.random.seed(seed_fit)
+            model._search(backend, n, m)
+            ctx.sync()
+            return model.fit_stats
+
+        for _ in range(args.warmup):
+            one_step()
+
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        comm.barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        logical = physical = calls = 0
+        for _ in range(args.steps):
+            st = one_step()
+            logical += st['terms_logical']
+            physical += st['terms_physical']
+            calls += st['gibbs_calls']
+        ctx.sync()
+        comm.barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.timing_enable(False)
+
+    kern = {name: ctx.timing_get(kid) for name, kid in
+            (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID))}
+
+    gathered = comm.allgather([elapsed, logical, physical, calls])
+    if rank != 0:
+        comm.close()
+        return
+    t_max = float(np.max(gathered[:, 0]))
+    tot_logical = float(np.sum(gathered[:, 1]))
+    tot_physical = float(np.sum(gathered[:, 2]))
+
+    def roof(name, bound):
+        k = kern[name]
+        if k['launches'] == 0 or k['ms'] <= 0:
+            return None
+        avg_ms = k['ms'] / k['launches']
+        if bound == 'hbm':
+            achieved = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
+            return dict(kernel=name, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
+                        total_ms=k['ms'])
+        achieved = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
+        return dict(kernel=name, bound='mfma', achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
+                    total_ms=k['ms'])
+
+    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm')}
+    dominant = max((k for k in kernels.values() if k), key=lambda k: k['total_ms'])
+    gpu_ms = sum(k['total_ms'] for k in kernels.values() if k)
+
+    line = {
+        'metric': 'candidate-terms/sec (basis build + Gibbs + BIC)',
+        'value': tot_logical / t_max,
+        'unit': 'candidate-terms/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * t_max / max(args.steps, 1),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': f'configs[2]: synthetic N={n}, M={m}, Bernoulli Polynomials, 2-way interactions, '
+                               f'burnin 1000 + draws 1000, one full forward-selection fit per step',
+                   'rows': n, 'inputs': m, 'parallelism': f'independent fits x{world}' if world > 1 else 'single GPU',
+                   'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
+        'terms_logical_per_step': tot_logical / world / max(args.steps, 1),
+        'terms_physical_per_step': tot_physical / world / max(args.steps, 1),
+        'gibbs_calls_per_step': float(np.sum(gathered[:, 3])) / world / max(args.steps, 1),
+        'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
+        'host_prepare_s': prep_s,
+        'roofline': dominant,
+        'kernels': kernels,
+    }
+    if not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(x, y)
+    comm.close()
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

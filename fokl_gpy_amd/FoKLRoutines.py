@@ -109,6 +109,17 @@ def device_backend(device=None):
     return _CONTEXTS[device]
 
 
+def _host_blas_threads():
+    """The per-candidate host algebra is tiny ((P+1)^2 eigenproblems, draws x (P+1) products): a BLAS pool sized for
+    a 256-thread host spends more time waking threads than computing.  Cap it (FOKL_HOST_THREADS, default 4)."""
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        return contextlib.nullcontext()
+    return threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '4')), user_api='blas')
+
+
 _CLEAN_DEFAULTS = {'train': 1, 'AutoTranspose': True, 'SingleInstance': False, 'bit': 64,
                    'normalize': True, 'minmax': None, 'pillow': None, 'pillow_type': 'percent'}
 
@@ -434,6 +445,11 @@ class FoKL:
         BIC of every sub-stage.  Keywords: any hyper-parameter, ``clean`` (+ the keywords of ``clean``),
         ``ConsoleOutput``.
         """
+        backend, n, m = self._prepare_fit(inputs, data, kwargs)
+        return self._search(backend, n, m)
+
+    def _prepare_fit(self, inputs, data, kwargs):
+        """Everything ``fit`` does before the search: keyword triage, cleaning, data-driven defaults, upload."""
         fit_opts = {'ConsoleOutput': _str_to_bool(kwargs.get('ConsoleOutput', self.ConsoleOutput)),
                     'clean': _str_to_bool(kwargs.get('clean', False))}
         clean_defaults = dict(_CLEAN_DEFAULTS)
@@ -516,15 +532,20 @@ class FoKL:
 
         backend = self._backend()
         self._upload(backend, inputs, data)
-        n, m = np.shape(inputs)
+        return backend, np.shape(inputs)[0], np.shape(inputs)[1]
+
+    def _search(self, backend, n, m, n_global=None, row_sharded=False):
+        """Forward selection on the dataset currently resident on ``backend`` (the timed region of bench.py)."""
         stream = _capi.LegacyStream()
         search = _engine.ForwardSelection(
-            backend, n, m, len(self.phis), a, b, atau, btau, self.tolerance, self.burnin + self.draws, self.draws,
-            self.gimmie, self.way3, self.threshav, self.threshstda, self.threshstdb, self.aic, stream,
-            console=self.ConsoleOutput, comm=getattr(self, '_comm', None))
+            backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
+            self.burnin + self.draws, self.draws, self.gimmie, self.way3, self.threshav, self.threshstda,
+            self.threshstdb, self.aic, stream, console=self.ConsoleOutput, comm=getattr(self, '_comm', None),
+            row_sharded=row_sharded, n_global=n_global)
         t0 = time.perf_counter()
         try:
-            betas, mtx, evs = search.run()
+            with _host_blas_threads():
+                betas, mtx, evs = search.run()
         finally:
             stream.publish()           # numpy's global stream ends where the reference's would
         self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0)

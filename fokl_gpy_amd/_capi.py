@@ -34,6 +34,8 @@ SIGNATURES = {
     'fokl_build_terms': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_gram': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
+    'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
+    'fokl_bic_resid_fetch': (c_int, [c_vp, c_vp, c_int]),
     'fokl_predict': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     'fokl_read_slot': (c_int, [c_vp, c_int, c_i64, c_i64, c_vp]),
     'fokl_write_slot': (c_int, [c_vp, c_int, c_i64, c_i64, c_vp]),
@@ -219,6 +221,18 @@ class DeviceContext:
             raise ValueError("one coefficient per column")
         out = np.empty(2, dtype=np.float64)
         self._ck(self._lib.fokl_bic_resid(self._h, _ptr(s), s.shape[0], _ptr(bh), _ptr(out), int(bool(allreduce))))
+        return out[0], out[1]
+
+    def bic_resid_launch(self, slots, betahat):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        bh = np.ascontiguousarray(np.reshape(betahat, -1), dtype=np.float64)
+        if s.shape[0] != bh.shape[0]:
+            raise ValueError("one coefficient per column")
+        self._ck(self._lib.fokl_bic_resid_launch(self._h, _ptr(s), s.shape[0], _ptr(bh)))
+
+    def bic_resid_fetch(self, allreduce=False):
+        out = np.empty(2, dtype=np.float64)
+        self._ck(self._lib.fokl_bic_resid_fetch(self._h, _ptr(out), int(bool(allreduce))))
         return out[0], out[1]
 
     def predict(self, slots, betas, cut=None):

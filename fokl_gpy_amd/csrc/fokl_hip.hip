@@ -73,6 +73,7 @@ struct fokl_ctx {
     double *h_out = nullptr;            // pinned
     size_t out_doubles = 0;
     hipEvent_t args_free = nullptr;     // recorded after the last H2D copy out of h_args
+    bool resid_pending = false;         // fokl_bic_resid_launch issued, result not fetched yet
 
     // timing
     bool timing = false;
@@ -708,14 +709,14 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
 // K3: residual moments
 // ---------------------------------------------------------------------------------------------------------
 
-extern "C" int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
-                              int allreduce)
+extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat)
 {
-    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_bic_resid: null context");
-    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid: call fokl_upload first");
-    if (nc <= 0 || !betahat || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid: empty model or null pointer");
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_bic_resid_launch: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_launch: call fokl_upload first");
+    if (nc <= 0 || !betahat) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_launch: empty model or null pointer");
+    if (ctx->resid_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_launch: previous launch not fetched");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = check_slots(ctx, slots, nc, "fokl_bic_resid");
+    int rc = check_slots(ctx, slots, nc, "fokl_bic_resid_launch");
     if (rc) return rc;
 
     const size_t beta_off = ((size_t)nc * sizeof(int) + 7) & ~(size_t)7;
@@ -745,14 +746,33 @@ extern "C" int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->resid_pending = true;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce)
+{
+    if (!ctx || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_fetch: null pointer");
+    if (!ctx->resid_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_fetch: nothing was launched");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->resid_pending = false;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_out[0];
     out[1] = ctx->h_out[1];
     if (allreduce && ctx->comm) {
-        rc = fokl_comm_allreduce_sum_f64(ctx, out, 2);
+        int rc = fokl_comm_allreduce_sum_f64(ctx, out, 2);
         if (rc) return rc;
     }
     return FOKL_OK;
+}
+
+extern "C" int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
+                              int allreduce)
+{
+    if (!out) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid: null output");
+    int rc = fokl_bic_resid_launch(ctx, slots, nc, betahat);
+    if (rc) return rc;
+    return fokl_bic_resid_fetch(ctx, out, allreduce);
 }
 
 // ---------------------------------------------------------------------------------------------------------

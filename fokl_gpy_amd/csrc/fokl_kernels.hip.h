@@ -52,13 +52,13 @@ __device__ __forceinline__ void dd_mul_d(double &hi, double &lo, double x)
     hi = s;
 }
 
-// Bernoulli basis of order `order` (coefficients c[0 .. order + 1]):  c0 + sum_{j>=1} c_j * RN(x**j),
+// Bernoulli basis of order `order` (order + 1 coefficients c[0 .. order]):  c0 + sum_{j>=1} c_j * RN(x**j),
 // the sum taken from 0 in ascending j with every product and addition rounded (ref FR:843).
 __device__ __forceinline__ double bernoulli_basis(const double *__restrict__ c, int order, double x)
 {
     double ph = x, pl = 0.0;
     double s = c[1] * x;                    // 0 + c1*x
-    for (int j = 2; j <= order + 1; ++j) {
+    for (int j = 2; j <= order; ++j) {
         dd_mul_d(ph, pl, x);                // ph = RN(x**j)
         s = s + c[j] * ph;
     }

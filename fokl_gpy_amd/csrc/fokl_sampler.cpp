@@ -7,11 +7,21 @@
 // cache shared by normal and gamma -> Marsaglia-Tsang gamma) is restated here and pinned bit-for-bit
 // against numpy itself in tests/test_sampler_host.py.
 //
+// Throughput structure (the stream is inherently serial, the arithmetic on it is not):
+//   * normals are produced in blocks: a branch-free rejection pass collects accepted (x1, x2, r2) triples,
+//     a second pass evaluates sqrt(-2 log(r2) / r2) for all of them (independent iterations, so the
+//     out-of-order core overlaps the libm calls) -- the values and their order are exactly those of
+//     numpy's one-at-a-time loop;
+//   * per Gibbs iteration the element-wise part (1 / (lamb + 1/tau2), sqrt, w) runs as a vectorisable loop
+//     over the block of normals, the three quadratic forms as a second pass.
+//
 // Must be compiled with -ffp-contract=off: numpy's baseline build rounds every product separately.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/fokl_hip.h"
 
@@ -19,34 +29,33 @@ extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 
 namespace {
 
+constexpr int MT_N = 624, MT_M = 397;
+
 struct LegacyRng {
     uint32_t *key;      // 624 words, caller owned (np.random.get_state()[1])
     int pos;
     int has_gauss;
     double gauss;
 
-    inline void refill()
+    void refill()
     {
         constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
-        int kk = 0;
-        uint32_t y;
-        for (; kk < 624 - 397; ++kk) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        uint32_t *k = key;
+        for (int i = 0; i < MT_N - MT_M; ++i) {
+            const uint32_t y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+            k[i] = k[i + MT_M] ^ (y >> 1) ^ ((0u - (y & 1u)) & MAG);
         }
-        for (; kk < 623; ++kk) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        for (int i = MT_N - MT_M; i < MT_N - 1; ++i) {
+            const uint32_t y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+            k[i] = k[i + (MT_M - MT_N)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MAG);
         }
-        y = (key[623] & UPPER) | (key[0] & LOWER);
-        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        const uint32_t y = (k[MT_N - 1] & UPPER) | (k[0] & LOWER);
+        k[MT_N - 1] = k[MT_M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MAG);
         pos = 0;
     }
 
-    inline uint32_t next32()
+    static inline uint32_t temper(uint32_t y)
     {
-        if (pos >= 624) refill();
-        uint32_t y = key[pos++];
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
@@ -54,10 +63,52 @@ struct LegacyRng {
         return y;
     }
 
+    inline uint32_t next32()
+    {
+        if (pos >= MT_N) refill();
+        return temper(key[pos++]);
+    }
+
+    static inline double to_double(uint32_t wa, uint32_t wb)
+    {
+        const int32_t a = (int32_t)(wa >> 5), b = (int32_t)(wb >> 6);
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+
     inline double next_double()
     {
-        int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
-        return (a * 67108864.0 + b) / 9007199254740992.0;
+        const uint32_t wa = next32();
+        const uint32_t wb = next32();
+        return to_double(wa, wb);
+    }
+
+    // `count` accepted polar pairs -> 2 * count normals in numpy's order (f * x2 first, then the value numpy
+    // would have cached, f * x1).  x1 / x2 / r2 are scratch of length >= count + 1.
+    void polar_pairs(int count, double *out, double *x1s, double *x2s, double *r2s)
+    {
+        int have = 0;
+        while (have < count) {
+            double x1, x2;
+            if (pos + 4 <= MT_N) {                       // fast path: four words without refill checks
+                const uint32_t *k = key + pos;
+                x1 = 2.0 * to_double(temper(k[0]), temper(k[1])) - 1.0;
+                x2 = 2.0 * to_double(temper(k[2]), temper(k[3])) - 1.0;
+                pos += 4;
+            } else {
+                x1 = 2.0 * next_double() - 1.0;
+                x2 = 2.0 * next_double() - 1.0;
+            }
+            const double r2 = x1 * x1 + x2 * x2;
+            x1s[have] = x1;
+            x2s[have] = x2;
+            r2s[have] = r2;
+            have += (r2 < 1.0) & (r2 != 0.0);            // branch-free accept
+        }
+        for (int i = 0; i < count; ++i) {
+            const double f = std::sqrt(-2.0 * std::log(r2s[i]) / r2s[i]);
+            out[2 * i] = f * x2s[i];
+            out[2 * i + 1] = f * x1s[i];
+        }
     }
 
     inline double gauss_draw()
@@ -116,10 +167,47 @@ struct LegacyRng {
     }
 };
 
+// Scratch for block generation, reused across calls on a thread.
+struct Scratch {
+    std::vector<double> vals, x1, x2, r2;
+    void reserve(int n_normals)
+    {
+        const size_t pairs = (size_t)n_normals / 2 + 2;
+        if (vals.size() < 2 * pairs) vals.resize(2 * pairs);
+        if (x1.size() < pairs + 1) {
+            x1.resize(pairs + 1);
+            x2.resize(pairs + 1);
+            r2.resize(pairs + 1);
+        }
+    }
+};
+
+// n successive gauss_draw() results, produced block-wise; identical values, order and final (cache, position).
+void fill_normals(LegacyRng &r, Scratch &s, int n, double *out)
+{
+    int i = 0;
+    if (n > 0 && r.has_gauss) {
+        out[0] = r.gauss;
+        r.has_gauss = 0;
+        r.gauss = 0.0;
+        i = 1;
+    }
+    const int remaining = n - i;
+    if (remaining <= 0) return;
+    const int pairs = (remaining + 1) / 2;
+    s.reserve(2 * pairs);
+    r.polar_pairs(pairs, s.vals.data(), s.x1.data(), s.x2.data(), s.r2.data());
+    std::memcpy(out + i, s.vals.data(), (size_t)remaining * sizeof(double));
+    if (remaining & 1) {
+        r.gauss = s.vals[2 * pairs - 1];
+        r.has_gauss = 1;
+    }
+}
+
 inline bool bind_rng(LegacyRng &r, uint32_t *key, const int32_t *pos, const int32_t *has_gauss, const double *cache)
 {
     if (!key || !pos || !has_gauss || !cache) return false;
-    if (*pos < 0 || *pos > 624) return false;
+    if (*pos < 0 || *pos > MT_N) return false;
     r.key = key;
     r.pos = *pos;
     r.has_gauss = *has_gauss ? 1 : 0;
@@ -134,17 +222,33 @@ inline void release_rng(const LegacyRng &r, int32_t *pos, int32_t *has_gauss, do
     *cache = r.gauss;
 }
 
+thread_local Scratch t_scratch;
+
+// w = d * qty + sig * sqrt(d) * vec with d = 1 / (lamb + 1/tau2): element-wise, so SIMD lanes change nothing
+// in the results (IEEE div / sqrt / mul / add per element, no contraction); an AVX2 clone is picked at load time.
+__attribute__((target_clones("avx2", "default")))
+void draw_in_eigenbasis(const double *__restrict__ lamb, const double *__restrict__ qty, const double *__restrict__ v,
+                        int p1, double inv_tau, double sig, double *__restrict__ w)
+{
+    for (int i = 0; i < p1; ++i) {
+        const double d = 1.0 / (lamb[i] + inv_tau);
+        w[i] = d * qty[i] + sig * (std::sqrt(d) * v[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                                 int64_t n, double *out)
 {
     LegacyRng r;
-    if (!bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache) || (n > 0 && !out)) {
+    if (!bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache) || (n > 0 && !out) || n < 0) {
         fokl_set_global_error("fokl_rng_normals: bad RNG state or output pointer");
         return FOKL_ERR_ARG;
     }
-    for (int64_t i = 0; i < n; ++i) out[i] = r.gauss_draw();
+    const int64_t block = 256;
+    for (int64_t done = 0; done < n; done += block)
+        fill_normals(r, t_scratch, (int)std::min<int64_t>(block, n - done), out + done);
     release_rng(r, mt_pos, has_gauss, gauss_cache);
     return FOKL_OK;
 }
@@ -178,17 +282,19 @@ extern "C" int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, d
         return FOKL_ERR_NUMERIC;
     }
 
+    Scratch &scratch = t_scratch;
+    std::vector<double> vec((size_t)p1);
     double sigsqd = sigsqd0, tausqd = tausqd0;
     for (int k = 0; k < draws; ++k) {
         const double inv_tau = 1.0 / tausqd;
         const double sig = std::sqrt(sigsqd);          // sigsqd ** (1/2), FR:1528
-        double *w = w_out + (size_t)k * p1;
+        double *__restrict__ w = w_out + (size_t)k * p1;
+        const double *__restrict__ v = vec.data();
+        fill_normals(r, scratch, p1, vec.data());      // np.random.normal(0, 1, (p1, 1)), C order
+        draw_in_eigenbasis(lamb, qty, v, p1, inv_tau, sig, w);
         double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
-        for (int i = 0; i < p1; ++i) {
-            const double d = 1.0 / (lamb[i] + inv_tau);
-            const double v = r.gauss_draw();           // np.random.normal(0, 1, (p1, 1)), C order
-            const double wi = d * qty[i] + sig * (std::sqrt(d) * v);
-            w[i] = wi;
+        for (int i = 0; i < p1; ++i) {                 // quadratic forms, ascending i
+            const double wi = w[i];
             q_lam += lamb[i] * (wi * wi);
             q_ty += wi * qty[i];
             q_ww += wi * wi;

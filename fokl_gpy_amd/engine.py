@@ -130,6 +130,12 @@ class HipBackend:
     def bic_resid(self, slots, betahat, allreduce=False):
         return self.ctx.bic_resid(slots, betahat, allreduce)
 
+    def bic_resid_launch(self, slots, betahat):
+        self.ctx.bic_resid_launch(slots, betahat)
+
+    def bic_resid_fetch(self, allreduce=False):
+        return self.ctx.bic_resid_fetch(allreduce)
+
     def predict(self, slots, betas, cut=None):
         return self.ctx.predict(slots, betas, cut)
 
@@ -233,12 +239,22 @@ class ForwardSelection:
         qty = Q.T @ Xty
         betahat = Q @ (qty / lamb)                                  # FR:1502-1504
 
+        # K3 streams the residuals of this candidate on the device while the host runs its Gibbs chain
+        cand_slots = [slots[i] for i in idx]
+        overlap = hasattr(self.backend, 'bic_resid_launch')
+        if overlap:
+            self.backend.bic_resid_launch(cand_slots, betahat)
+
         astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508 (mmtx + 1 == p1)
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0,
-                              self.draws, self.stream)
-
-        s1, s2 = self.backend.bic_resid([slots[i] for i in idx], betahat, self.allreduce)
+        try:
+            w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0,
+                                  self.draws, self.stream)
+        finally:
+            if overlap:
+                s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
+        if not overlap:
+            s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
         siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
         lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
         ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554

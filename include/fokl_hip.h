@@ -124,6 +124,14 @@ int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *co
  */
 int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
                    int allreduce);
+/*
+ * The same in two halves so that the host can run the (N-independent) Gibbs chain of a candidate while the
+ * device streams its residuals: _launch enqueues kernel + copy-back on the context's stream and returns,
+ * _fetch waits and delivers.  At most one launch may be outstanding, and no other blocking call
+ * (fokl_gram, fokl_bic_resid, fokl_predict) may be issued on the context in between.
+ */
+int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat);
+int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* evaluate(): posterior-mean prediction and 95 % bounds on the device.  Replaces FR:966-978.              */

@@ -325,7 +325,7 @@ def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, 
                     sigsqd0, tausqd0, dtd, eigh=eigh, build=build)
         if trace is not None:
             trace.append(dict(cols=discmtx.shape[0] + 1, built=discmtx.shape[0] + 1 - nxin, ev=float(res.ev),
-                              kill=kill))
+                              kill=kill, xtx=res.XtX if len(trace) < 12 else None))
         return res
 
     n, m = inputs.shape

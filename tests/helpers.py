@@ -17,7 +17,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 from oracle import fokl_oracle as O  # noqa: E402
 from fokl_gpy_amd import getKernels  # noqa: E402
 
-FIT_CASES = ['bern_m1', 'bern_m3', 'bern_m3_gimmie_tol1', 'bern_m4_way3', 'bern_m6_aic', 'bern_m8_capped',
+FIT_CASES = ['bern_m1', 'bern_m3', 'bern_m3_gimmie_tol1', 'bern_m4_way3', 'bern_m6', 'bern_m8_capped',
              'testdata10_default', 'testdata10_changed', 'splines_m4', 'sigmoid_splines']
 
 
@@ -105,3 +105,5 @@ class OracleBackend:
         srt = np.sort(mod, axis=1)
         draws = mod.shape[1]
         return mean, np.stack([srt[:, cut], srt[:, draws - cut]], axis=1)
+
+UNITS_PATH = os.path.join(GOLDEN, 'units.npz')

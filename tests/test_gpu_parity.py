@@ -1,0 +1,351 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle and the reference fixtures.
+
+Tolerances:
+  * K1 columns: splines bit-identical to the reference's scalar arithmetic; Bernoulli bit-identical wherever glibc's
+    pow is correctly rounded (> 99.5 % of entries) and otherwise within 2^-50 * prod_k sum_j |c_j x^j| (one ulp
+    of the largest monomial per factor) -- the kernel rounds x**j correctly, libm's pow is off by 1 ulp in ~0.08 %;
+  * K2 / K3 / predict: exact on small-integer data (any summation order), <= 1e-12 relative on real data;
+  * fits: selected interaction matrix exact, BIC trace <= 1e-9 relative, draws <= 1e-9 * max|column|.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, FIT_CASES, load_case
+from fokl_gpy_amd import _capi, getKernels, FoKLRoutines, engine
+from oracle import fokl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BERN = getKernels.bernoulli()
+SPL = getKernels.table_to_phis(np.load(os.path.join(GOLDEN, 'spline_phis.npz'))['table'])
+
+
+def upload(ctx, x, y, kid):
+    phis = SPL if kid == O.KERNEL_SPLINES else BERN
+    packed, nb, width = getKernels.pack_phis(phis, kid)
+    ctx.upload(x, y, kid, packed, nb, width)
+    return phis
+
+
+def build_and_read(ctx, terms):
+    terms = np.asarray(terms, dtype=np.int32)
+    T = terms.shape[0]
+    ctx.reserve_slots(2 + T)
+    slots = np.arange(2, 2 + T, dtype=np.int32)
+    ctx.build_terms(terms, slots)
+    return np.stack([ctx.read_slot(int(s)) for s in slots], axis=1)
+
+
+def oracle_columns(x, kid, phis, terms):
+    if kid == O.KERNEL_SPLINES:
+        phind, xsm = O.inputs_to_phind(x, len(phis[0][0]))
+    else:
+        phind, xsm = None, x
+    return O.build_columns_c(xsm, phind, phis, kid, np.asarray(terms, dtype=np.int32))
+
+
+def bernoulli_bound(x, terms):
+    """prod over the term's inputs of sum_j |c_j| |x|^j -- the magnitude one ulp of a monomial is measured against."""
+    out = np.ones((x.shape[0], len(terms)))
+    for j, term in enumerate(terms):
+        for k, o in enumerate(term):
+            if o:
+                c = np.abs(np.asarray(BERN[o - 1]))
+                out[:, j] *= sum(c[p] * np.abs(x[:, k]) ** p for p in range(len(c)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K1 basis build
+# ---------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 511, 512, 513, 4099])
+def test_k1_ragged_row_counts(device_ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 3))
+    y = rng.standard_normal(n)
+    for kid in (O.KERNEL_SPLINES, O.KERNEL_BERNOULLI):
+        phis = upload(device_ctx, x, y, kid)
+        terms = np.array([[1, 0, 0], [0, 2, 0], [1, 1, 0], [2, 0, 3], [1, 2, 3]])
+        got = build_and_read(device_ctx, terms)
+        want = oracle_columns(x, kid, phis, terms)
+        assert got.shape == want.shape
+        if kid == O.KERNEL_SPLINES:
+            assert np.array_equal(got, want)
+        else:
+            assert np.all(np.abs(got - want) <= 2.0 ** -50 * bernoulli_bound(x, terms))
+        assert np.all(device_ctx.read_slot(0) == 1.0) and np.array_equal(device_ctx.read_slot(1), y)
+
+
+def test_k1_splines_bit_identical_including_knots_and_ends(device_ctx):
+    rng = np.random.default_rng(1)
+    knots = np.arange(0, 500) / 499.0
+    col = np.concatenate([rng.random(3000), knots, [0.0, 1.0, 1e-300, 1 - 1e-16, 0.5, 1 / 499 + 1e-17, 2 / 499 - 1e-17]])
+    x = np.stack([col, rng.permutation(col), col[::-1]], axis=1)
+    phis = upload(device_ctx, x, np.zeros(x.shape[0]), O.KERNEL_SPLINES)
+    terms = [[a, b, c] for a in (0, 1, 5, 24) for b in (0, 2, 9) for c in (0, 3)][1:]
+    got = build_and_read(device_ctx, terms)           # > 4 distinct orders: exercises LDS-staged and global slabs
+    assert np.array_equal(got, oracle_columns(x, O.KERNEL_SPLINES, phis, terms))
+
+
+def test_k1_bernoulli_low_orders_almost_always_bit_identical(device_ctx):
+    rng = np.random.default_rng(2)
+    x = rng.random((20000, 8))
+    x[:3] = [[0.0] * 8, [1.0] * 8, [0.5] * 8]
+    upload(device_ctx, x, np.zeros(x.shape[0]), O.KERNEL_BERNOULLI)
+    terms = np.vstack([engine.distinct_arrangements([1] + [0] * 7), engine.distinct_arrangements([2, 1] + [0] * 6),
+                       engine.distinct_arrangements([3, 2] + [0] * 6)[:40]]).astype(np.int32)
+    got = build_and_read(device_ctx, terms)
+    want = oracle_columns(x, O.KERNEL_BERNOULLI, BERN, terms)
+    assert np.mean(got == want) > 0.995
+    assert np.all(np.abs(got - want) <= 2.0 ** -50 * bernoulli_bound(x, terms))
+
+
+def test_k1_bernoulli_all_twenty_orders(device_ctx):
+    rng = np.random.default_rng(3)
+    x = rng.random((5000, 2))
+    upload(device_ctx, x, np.zeros(5000), O.KERNEL_BERNOULLI)
+    terms = np.array([[o, 0] for o in range(1, 21)] + [[20, 19], [7, 13], [1, 20]])
+    got = build_and_read(device_ctx, terms)
+    want = oracle_columns(x, O.KERNEL_BERNOULLI, BERN, terms)
+    assert np.all(np.abs(got - want) <= 2.0 ** -49 * bernoulli_bound(x, terms))
+
+
+def test_k1_many_terms_split_over_launches(device_ctx):
+    """More distinct (input, order) factors than one LDS factor table holds -> several launches, same result."""
+    rng = np.random.default_rng(4)
+    x = rng.random((3001, 6))
+    upload(device_ctx, x, np.zeros(3001), O.KERNEL_BERNOULLI)
+    terms = np.array([[(i + k) % 9 if (i + k) % 3 else 0 for k in range(6)] for i in range(1, 140)])
+    terms = terms[terms.sum(1) > 0]
+    got = build_and_read(device_ctx, terms)
+    want = oracle_columns(x, O.KERNEL_BERNOULLI, BERN, terms)
+    assert np.all(np.abs(got - want) <= 2.0 ** -49 * bernoulli_bound(x, terms))
+
+
+def test_k1_single_input(device_ctx):
+    x = np.linspace(0, 1, 257)[:, None]
+    upload(device_ctx, x, np.zeros(257), O.KERNEL_SPLINES)
+    got = build_and_read(device_ctx, [[1], [2], [7]])
+    assert np.array_equal(got, oracle_columns(x, O.KERNEL_SPLINES, SPL, [[1], [2], [7]]))
+
+
+def test_argument_errors_are_reported(device_ctx):
+    upload(device_ctx, np.random.default_rng(0).random((100, 2)), np.zeros(100), O.KERNEL_BERNOULLI)
+    device_ctx.reserve_slots(8)
+    with pytest.raises(_capi.FoklNativeError) as e:
+        device_ctx.build_terms([[1, 0]], [1])                       # reserved slot
+    assert e.value.code == -2
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.build_terms([[21, 0]], [2])                      # order beyond the table
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.build_terms([[0, 0]], [2])                       # empty term
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.gram([0, 99999], [0])                            # slot out of range
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.read_slot(2, 50, 100)                            # row range
+    fresh = _capi.DeviceContext(device_ctx.device)
+    with pytest.raises(_capi.FoklNativeError) as e:
+        fresh.build_terms([[1, 0]], [2])                            # before upload
+    assert e.value.code == -3
+    fresh.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K2 Gram, K3 residual, predict
+# ---------------------------------------------------------------------------------------------------------
+
+def load_columns(ctx, cols):
+    n, k = cols.shape
+    ctx.reserve_slots(2 + k)
+    for j in range(k):
+        ctx.write_slot(2 + j, cols[:, j])
+
+
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 1000, 4099])
+def test_k2_exact_on_integer_data(device_ctx, n):
+    rng = np.random.default_rng(n)
+    upload(device_ctx, rng.random((n, 1)), rng.integers(-3, 4, n).astype(float), O.KERNEL_BERNOULLI)
+    cols = rng.integers(-3, 4, size=(n, 150)).astype(np.float64)
+    load_columns(device_ctx, cols)
+    for nr, nc in [(1, 1), (2, 3), (8, 10), (16, 16), (17, 33), (28, 38), (56, 66), (65, 131), (70, 150)]:
+        rs = (2 + rng.permutation(150)[:nr]).astype(np.int32)
+        cs = (2 + rng.permutation(150)[:nc]).astype(np.int32)
+        want = cols[:, rs - 2].T @ cols[:, cs - 2]
+        for path in (0, 1, 2):
+            assert np.array_equal(device_ctx.gram(rs, cs, path=path), want), (nr, nc, path)
+    g = device_ctx.gram([0, 1, 2], [0, 1, 2])
+    y = device_ctx.read_slot(1)
+    assert g[0, 0] == n and g[0, 1] == y.sum() and g[1, 1] == y @ y and g[0, 2] == cols[:, 0].sum()
+
+
+def test_k2_paths_agree_and_are_reproducible(device_ctx):
+    rng = np.random.default_rng(9)
+    n = 50000
+    upload(device_ctx, rng.random((n, 1)), rng.standard_normal(n), O.KERNEL_BERNOULLI)
+    cols = rng.standard_normal((n, 70)) * np.exp(rng.standard_normal(70))
+    load_columns(device_ctx, cols)
+    rs = np.arange(2, 58, dtype=np.int32)
+    cs = np.concatenate([[0], np.arange(2, 72), [1]]).astype(np.int32)
+    full = np.concatenate([np.ones((n, 1)), cols, device_ctx.read_slot(1)[:, None]], axis=1)
+    want = cols[:, :56].T @ full
+    scale = np.sqrt(np.outer(np.sum(cols[:, :56] ** 2, 0), np.sum(full ** 2, 0)))
+    g1 = device_ctx.gram(rs, cs, path=1)
+    g2 = device_ctx.gram(rs, cs, path=2)
+    assert np.max(np.abs(g1 - want) / scale) < 1e-13 and np.max(np.abs(g2 - want) / scale) < 1e-13
+    assert np.array_equal(g2, device_ctx.gram(rs, cs, path=2))          # fixed-order reduction: bitwise repeatable
+    assert np.array_equal(g1, device_ctx.gram(rs, cs, path=1))
+
+
+def test_k3_residual_moments(device_ctx):
+    rng = np.random.default_rng(10)
+    for n in (1, 513, 20001):
+        y = rng.standard_normal(n)
+        upload(device_ctx, rng.random((n, 1)), y, O.KERNEL_BERNOULLI)
+        cols = rng.standard_normal((n, 40))
+        load_columns(device_ctx, cols)
+        beta = rng.standard_normal(41)
+        sl = np.concatenate([[0], np.arange(2, 42)]).astype(np.int32)
+        r = y - (beta[0] + cols @ beta[1:])
+        s1, s2 = device_ctx.bic_resid(sl, beta)
+        assert abs(s1 - r.sum()) <= 1e-12 * np.abs(r).sum() + 1e-300
+        assert abs(s2 - r @ r) <= 1e-12 * (r @ r)
+        device_ctx.bic_resid_launch(sl, beta)                           # split form gives the same numbers
+        assert device_ctx.bic_resid_fetch() == (s1, s2)
+        s1z, s2z = device_ctx.bic_resid([0], [0.0])                     # linearity anchor: beta = 0 -> moments of y
+        assert abs(s1z - y.sum()) <= 1e-12 * np.abs(y).sum() and abs(s2z - y @ y) <= 1e-12 * (y @ y)
+
+
+def test_predict_mean_and_order_statistics(device_ctx):
+    rng = np.random.default_rng(11)
+    n = 3000
+    upload(device_ctx, rng.random((n, 1)), np.zeros(n), O.KERNEL_BERNOULLI)
+    cols = rng.standard_normal((n, 12))
+    load_columns(device_ctx, cols)
+    sl = np.concatenate([[0], np.arange(2, 14)]).astype(np.int32)
+    X = np.concatenate([np.ones((n, 1)), cols], axis=1)
+    for draws in (40, 1000):
+        betas = rng.standard_normal((draws, 13))
+        cut = int(np.floor(draws * 0.025) + 1)
+        mean, bounds = device_ctx.predict(sl, betas, cut)
+        mod = X @ betas.T
+        srt = np.sort(mod, axis=1)
+        assert np.max(np.abs(mean - mod.mean(1))) < 1e-12
+        assert np.max(np.abs(bounds[:, 0] - srt[:, cut])) < 1e-12 and np.max(np.abs(bounds[:, 1] - srt[:, draws - cut])) < 1e-12
+        assert np.max(np.abs(device_ctx.predict(sl, betas) - mean)) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole fits through the HIP backend vs the reference fixtures
+# ---------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', [c for c in FIT_CASES if not c.startswith('testdata10')])
+def test_fit_matches_reference_on_gpu(name):
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture not generated')
+    g, hy, kname, kid, phis = load_case(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FoKLRoutines.FoKL(kernel=kname, phis=phis, UserWarnings=False, ConsoleOutput=False, **hy)
+        np.random.seed(int(g['seed']))
+        betas, mtx, evs = model.fit(g['raw_inputs'], g['raw_data'], clean=True)
+        assert mtx.shape == g['canon_mtx'].shape and np.array_equal(mtx, g['canon_mtx'])
+        assert len(evs) == len(g['canon_evs'])
+        assert np.max(np.abs(evs - g['canon_evs']) / np.abs(g['canon_evs'])) < 1e-9
+        gb = g['canon_betas']
+        tol = 1e-6 if name == 'sigmoid_splines' else 1e-9
+        assert np.max(np.abs(betas - gb) / np.max(np.abs(gb), axis=0)) < tol
+        assert [t['cols'] for t in model.fit_trace] == g['canon_gibbs_sizes'].tolist()
+        if 'canon_cov_mean' in g.files:
+            mean, bounds, rmse = model.coverage3()
+            scale = np.max(np.abs(g['canon_cov_mean']))
+            ctol = 1e-6 if name == 'sigmoid_splines' else 1e-10
+            assert np.array_equal(model.setnos, g['canon_setnos'])
+            assert np.max(np.abs(mean - g['canon_cov_mean'])) < ctol * scale
+            assert np.max(np.abs(bounds - g['canon_cov_bounds'])) < ctol * scale
+            assert abs(rmse - float(g['canon_cov_rmse'])) < 1e-9
+
+
+def test_reference_test_dataset_on_gpu():
+    g, hy, kname, kid, phis = load_case('testdata10_default')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FoKLRoutines.FoKL(kernel=kname, phis=phis, UserWarnings=False, ConsoleOutput=False, **hy)
+        np.random.seed(int(g['seed']))
+        betas, mtx, evs = model.fit(g['raw_inputs'], g['raw_data'], clean=True)
+    assert np.max(np.abs(evs[:7] - g['canon_evs'][:7]) / np.abs(g['canon_evs'][:7])) < 1e-9
+    assert betas.shape[0] == 1000
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties at N = 1e6, M = 8
+# ---------------------------------------------------------------------------------------------------------
+
+def test_full_size_properties(device_ctx):
+    rng = np.random.default_rng(12)
+    n, m = 1_000_000, 8
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.05 * rng.standard_normal(n)
+    upload(device_ctx, x, y, O.KERNEL_BERNOULLI)
+    terms = np.vstack([engine.distinct_arrangements([1] + [0] * 7),
+                       engine.distinct_arrangements([2, 1] + [0] * 6)]).astype(np.int32)
+    T = terms.shape[0]
+    device_ctx.reserve_slots(2 + T)
+    slots = np.arange(2, 2 + T, dtype=np.int32)
+    device_ctx.build_terms(terms, slots)
+    # (1) random row sample of every column against the oracle
+    pick = np.sort(rng.choice(n, 4000, replace=False))
+    want = O.build_columns_c(np.ascontiguousarray(x[pick]), None, BERN, O.KERNEL_BERNOULLI, terms)
+    got = np.stack([device_ctx.read_slot(int(s))[pick] for s in slots[:8]], axis=1)
+    assert np.all(np.abs(got - want[:, :8]) <= 2.0 ** -50 * bernoulli_bound(x[pick], terms[:8]))
+    blockrows = np.stack([device_ctx.read_slot(int(s), 123456, 2048) for s in slots], axis=1)
+    want_b = O.build_columns_c(np.ascontiguousarray(x[123456:123456 + 2048]), None, BERN, O.KERNEL_BERNOULLI, terms)
+    assert np.all(np.abs(blockrows - want_b) <= 2.0 ** -50 * bernoulli_bound(x[123456:123456 + 2048], terms))
+    # (2) checksum of checksums: column sums via the Gram kernels == sums of the downloaded columns
+    allc = np.concatenate([[0], slots, [1]]).astype(np.int32)
+    g_mfma = device_ctx.gram(slots, allc, path=2)
+    g_valu = device_ctx.gram(slots[:8], allc, path=1)
+    col0 = device_ctx.read_slot(int(slots[0]))
+    col5 = device_ctx.read_slot(int(slots[5]))
+    assert abs(g_mfma[0, 0] - col0.sum()) <= 1e-12 * np.abs(col0).sum()
+    assert abs(g_mfma[5, 1 + 5] - col5 @ col5) <= 1e-12 * (col5 @ col5)
+    assert abs(g_mfma[0, -1] - col0 @ y) <= 1e-12 * np.abs(col0 * y).sum()
+    # (3) the two Gram paths agree, and the new-vs-new block is symmetric
+    scale = np.sqrt(np.outer(np.diag(g_mfma[:, 1:1 + T]), np.concatenate([[n], np.diag(g_mfma[:, 1:1 + T]), [y @ y]])))
+    assert np.max(np.abs(g_mfma[:8] - g_valu) / scale[:8]) < 1e-13
+    sq = g_mfma[:, 1:1 + T]
+    assert np.max(np.abs(sq - sq.T) / scale[:, 1:1 + T]) < 1e-13
+    # (4) residual linearity: r(beta) moments from K3 == those implied by the Gram blocks
+    beta = np.zeros(T + 1)
+    beta[0] = y.mean()
+    beta[1:9] = 0.01 * rng.standard_normal(8)
+    s1, s2 = device_ctx.bic_resid(np.concatenate([[0], slots]).astype(np.int32), beta)
+    gfull = device_ctx.gram(np.concatenate([[0], slots[:8]]).astype(np.int32),
+                            np.concatenate([[0], slots[:8], [1]]).astype(np.int32))
+    b9 = beta[:9]
+    s1_gram = y.sum() - gfull[0, :9] @ b9
+    s2_gram = y @ y - 2 * b9 @ gfull[:, 9] + b9 @ gfull[:, :9] @ b9
+    assert abs(s1 - s1_gram) <= 1e-9 * n and abs(s2 - s2_gram) <= 1e-9 * s2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RCCL plumbing (world of one on the single-GPU box; the N > 1 logic is covered by tests/test_dist_gloo.py)
+# ---------------------------------------------------------------------------------------------------------
+
+def test_rccl_world_of_one():
+    from fokl_gpy_amd import dist
+    ctx = _capi.DeviceContext(0)
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    comm = dist.RcclComm(ctx, 0, 1, unique_id=uid)
+    v = np.array([1.5, -2.0, 3.25])
+    assert np.array_equal(comm.allgather(v), v[None, :])
+    assert np.array_equal(comm.allreduce_sum(v), v)
+    comm.barrier()
+    upload(ctx, np.random.default_rng(0).random((1000, 1)), np.ones(1000), O.KERNEL_BERNOULLI)
+    assert ctx.gram([0], [0, 1], allreduce=True).tolist() == [[1000.0, 1000.0]]
+    comm.close()
+    ctx.close()

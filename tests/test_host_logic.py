@@ -1,0 +1,324 @@
+"""Host side of the product on CPU: search driver, Gram cache, slot bookkeeping, sampler hand-off, class surface.
+
+The device backend is replaced by ``helpers.OracleBackend`` (tests only -- the product has no CPU path), so what
+is checked here is everything *around* the HIP kernels, against the reference fixtures:
+selected interaction matrix exactly, BIC trace <= 1e-9 relative, posterior draws <= 1e-9 * max|column|
+(1e-6 on the degenerate sigmoid grid), identical consumption of numpy's global random stream.
+"""
+import os
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, FIT_CASES, OracleBackend, load_case, UNITS_PATH
+from fokl_gpy_amd import FoKLRoutines, engine, _capi, getKernels
+from oracle import fokl_oracle as O
+
+
+def make_model(kname, phis, hy):
+    model = FoKLRoutines.FoKL(kernel=kname, phis=phis, UserWarnings=False, ConsoleOutput=False, **hy)
+    model._backend_override = OracleBackend()
+    return model
+
+
+def fit_case(name):
+    g, hy, kname, kid, phis = load_case(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = make_model(kname, phis, hy)
+        np.random.seed(int(g['seed']))
+        betas, mtx, evs = model.fit(g['raw_inputs'], g['raw_data'], clean=True)
+    return g, model, betas, mtx, evs
+
+
+def rng_fingerprint():
+    import hashlib
+    st = np.random.get_state()
+    return float(int(hashlib.sha256(st[1].tobytes()).hexdigest()[:16], 16) % (2 ** 53)), st[2], st[3], st[4]
+
+
+REGULAR = [c for c in FIT_CASES if not c.startswith('testdata10')]
+
+
+@pytest.mark.parametrize('name', REGULAR)
+def test_fit_matches_reference(name):
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture not generated')
+    g, model, betas, mtx, evs = fit_case(name)
+    assert mtx.dtype == np.float64 and mtx.shape == g['canon_mtx'].shape
+    assert np.array_equal(mtx, g['canon_mtx'])                                   # bit-exact selection
+    assert len(evs) == len(g['canon_evs'])
+    assert np.max(np.abs(evs - g['canon_evs']) / np.abs(g['canon_evs'])) < 1e-9  # BIC trace
+    gb = g['canon_betas']
+    tol = 1e-6 if name == 'sigmoid_splines' else 1e-9
+    assert betas.shape == gb.shape
+    assert np.max(np.abs(betas - gb) / np.max(np.abs(gb), axis=0)) < tol         # posterior draws
+    # the global numpy stream ends exactly where the reference's does
+    fp = rng_fingerprint()
+    assert fp[0] == g['canon_rng_after_fit'][0] and fp[1] == g['canon_rng_after_fit'][1]
+    assert fp[2] == g['canon_rng_after_fit'][2] and fp[3] == float(g['canon_rng_cache_after_fit'])
+    # same number and sizes of model evaluations as the reference made
+    assert [t['cols'] for t in model.fit_trace] == g['canon_gibbs_sizes'].tolist()
+    assert model.fit_stats['terms_logical'] == sum(t['built'] for t in model.fit_trace)
+    # side effects of fit (FR:1316-1317, 1344, 1348, 1755-1758)
+    assert np.array_equal(model.inputs, g['canon_norm_inputs']) and np.array_equal(model.data, g['canon_norm_data'])
+    assert np.allclose(np.array(model.minmax, dtype=float), g['canon_minmax'])
+    assert model.b == pytest.approx(float(g['canon_b']), rel=1e-14)
+    assert model.btau == pytest.approx(float(g['canon_btau']), rel=1e-14)
+    assert np.allclose(model.avg_betas, np.mean(betas, axis=0))
+
+
+@pytest.mark.parametrize('name', [c for c in REGULAR if c not in ('bern_m8_capped', 'splines_m4')])
+def test_coverage3_matches_reference(name):
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture not generated')
+    g, model, betas, mtx, evs = fit_case(name)
+    if 'canon_cov_mean' not in g.files:
+        pytest.skip('no coverage fixture')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        mean, bounds, rmse = model.coverage3()
+    assert np.array_equal(model.setnos, g['canon_setnos'])           # np.random.choice consumed identically
+    scale = np.max(np.abs(g['canon_cov_mean']))
+    tol = 1e-6 if name == 'sigmoid_splines' else 1e-10
+    assert np.max(np.abs(mean - g['canon_cov_mean'])) < tol * scale
+    assert np.max(np.abs(bounds - g['canon_cov_bounds'])) < tol * scale
+    assert mean.shape == (model.inputs.shape[0],) and bounds.shape == (model.inputs.shape[0], 2)
+    assert np.shape(rmse) == ()
+    assert abs(rmse - float(g['canon_cov_rmse'])) < 1e-9
+
+
+@pytest.mark.parametrize('name', ['testdata10_default', 'testdata10_changed'])
+def test_reference_test_dataset_until_saturation(name):
+    """The reference's own 10-row test set (test/testdatatest.csv, seeds of test/makingdata.py).  With 10 rows the
+    model saturates (P + 1 >= N) after 7 sub-stages and XtX becomes numerically singular; from there the reference's
+    numbers are rounding noise of its own BLAS.  Parity is pinned on everything before that point."""
+    g, model, betas, mtx, evs = fit_case(name)
+    ge = g['canon_evs']
+    k = 7
+    assert np.max(np.abs(evs[:k] - ge[:k]) / np.abs(ge[:k])) < 1e-9
+    sizes = g['canon_gibbs_sizes'].tolist()
+    upto = sizes.index(10) if 10 in sizes else len(sizes)
+    assert [t['cols'] for t in model.fit_trace][:upto] == sizes[:upto]
+    assert betas.shape[0] == 1000 and mtx.shape[1] == 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# driver pieces
+# ---------------------------------------------------------------------------------------------------------
+
+def test_enumeration_matches_reference_vectors():
+    units = np.load(UNITS_PATH)
+    for key in units.files:
+        if key.startswith('enum_'):
+            pattern = [int(v) for v in key[len('enum_'):].split('_')]
+            assert np.array_equal(engine.distinct_arrangements(pattern), units[key]), key
+
+
+def test_indvec_progression_matches_oracle():
+    for m, way3 in ((1, False), (2, False), (5, False), (4, True), (8, True)):
+        sett = 1 if m == 1 else (3 if way3 else 2)
+        for ind in range(1, 9):
+            assert np.array_equal(engine.deal_indvec(ind, m, sett), O.deal_indvec(ind, m, sett))
+    seq = []
+    v = engine.deal_indvec(6, 5, 3)
+    while True:
+        seq.append(v.copy().tolist())
+        if not engine.advance_indvec(v, 5, True):
+            break
+    assert seq == [[2, 2, 2, 0, 0], [3, 2, 1, 0, 0], [4, 1, 1, 0, 0], [4, 2, 0, 0, 0], [5, 1, 0, 0, 0],
+                   [6, 0, 0, 0, 0]]
+
+
+def test_way3_with_two_inputs_raises_like_the_reference():
+    with pytest.raises(IndexError):
+        v = engine.deal_indvec(1, 2, 3)
+        engine.advance_indvec(v, 2, True)
+
+
+def test_slot_pool_never_hands_out_reserved_slots():
+    be = OracleBackend()
+    be.upload(np.zeros((4, 1)), np.zeros(4), O.KERNEL_BERNOULLI, *getKernels.pack_phis(getKernels.bernoulli(), 1))
+    pool = engine.SlotPool(be, initial=8)
+    got = pool.take(6)
+    assert sorted(got) == [2, 3, 4, 5, 6, 7]
+    more = pool.take(5)                       # forces growth
+    assert min(more) >= 8 and be.capacity >= 13
+    pool.give(got[:2])
+    assert sorted(pool.take(2)) == sorted(got[:2])
+
+
+def test_kill_tests_reuse_the_substage_gram():
+    """One basis build and one Gram block per sub-stage; every other model evaluation is a sub-matrix lookup."""
+    g, model, *_ = fit_case('bern_m3')
+    be = model._backend_override
+    st = model.fit_stats
+    assert be.calls['build'] == st['substages']
+    assert be.calls['gram'] == st['substages'] + 1               # + the [ones, y] seed block
+    assert st['gibbs_calls'] == st['substages'] + st['kill_tests']
+    assert st['terms_physical'] < st['terms_logical']
+
+
+# ---------------------------------------------------------------------------------------------------------
+# class surface (reference: FoKLRoutines.py constructor / fit / evaluate keyword handling, test/test_FoKL.py)
+# ---------------------------------------------------------------------------------------------------------
+
+def test_constructor_defaults_and_unknown_keyword():
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    assert model.kernel == 'Bernoulli Polynomials' and len(model.phis) == 20 and len(model.phis[3]) == 5
+    assert (model.a, model.atau, model.tolerance, model.burnin, model.draws) == (4, 4, 3, 1000, 1000)
+    assert model.b is None and model.btau is None and model.relats_in == [] and model.setnos is None
+    assert (model.threshav, model.threshstda, model.threshstdb) == (0.05, 0.5, 2)
+    with pytest.raises(ValueError, match="Unexpected keyword argument: 'backend'"):
+        FoKLRoutines.FoKL(backend='hip')
+    assert FoKLRoutines.FoKL(kernel=1, aic='on', way3='off', UserWarnings='no').aic is True
+
+
+def test_default_kernel_is_cubic_splines_with_500_bases():
+    model = FoKLRoutines.FoKL(UserWarnings=False)
+    assert model.kernel == 'Cubic Splines' and len(model.phis) == 500
+    assert len(model.phis[0]) == 4 and model.phis[0][0].shape == (499,)
+
+
+def test_fit_rejects_unknown_keyword_and_needs_data():
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False, ConsoleOutput=False)
+    model._backend_override = OracleBackend()
+    with pytest.raises(ValueError, match="Unexpected keyword argument"):
+        model.fit(np.zeros((5, 1)), np.zeros(5), clean=True, device=0)
+    with pytest.raises(IndexError):        # the reference formats `None` before reporting (FR:1275 -> FR:292)
+        model.fit(clean=True)
+
+
+def test_fit_accepts_pandas_and_returns_ndarrays():
+    """test/test_FoKL.py::test_fit_for_shaping: outputs are ndarrays even for pandas inputs."""
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    df = pd.DataFrame({'x': rng.random(80), 'y': rng.random(80)})
+    data = pd.Series(np.sin(3 * df['x']) + 0.1 * rng.standard_normal(80))
+    model = FoKLRoutines.FoKL(kernel=1, burnin=40, draws=40, UserWarnings=False, ConsoleOutput=False)
+    model._backend_override = OracleBackend()
+    np.random.seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        betas, mtx, evs = model.fit(df, data, clean=True)
+    assert isinstance(betas, np.ndarray) and isinstance(mtx, np.ndarray) and isinstance(evs, np.ndarray)
+    assert betas.shape == (40, mtx.shape[0] + 1) and mtx.shape[1] == 2
+    assert model.inputs.shape == (80, 2) and model.data.shape == (80, 1)
+    assert model.inputs.min() == 0.0 and model.inputs.max() == 1.0
+
+
+def test_hyperparameters_can_be_overridden_in_fit():
+    rng = np.random.default_rng(4)
+    x = rng.random((60, 2))
+    y = x[:, 0] + 0.05 * rng.standard_normal(60)
+    model = FoKLRoutines.FoKL(kernel=1, burnin=30, draws=30, UserWarnings=False, ConsoleOutput=False)
+    model._backend_override = OracleBackend()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.fit(x, y, clean=True, aic='on', a=3, b=1.8, atau=17, btau=2100.5, tolerance=1)
+    assert model.aic is True and (model.a, model.b, model.atau, model.btau, model.tolerance) == (3, 1.8, 17, 2100.5, 1)
+
+
+def test_relats_in_behaviour_matches_reference_quirks():
+    x = np.random.default_rng(0).random((30, 3))
+    y = x[:, 0]
+    for relats, exc in (([[1, 0, 0]], TypeError), ([1, 0, 1], NameError)):
+        model = FoKLRoutines.FoKL(kernel=1, relats_in=relats, UserWarnings=False, ConsoleOutput=False)
+        model._backend_override = OracleBackend()
+        with pytest.raises(exc):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                model.fit(x, y, clean=True)
+
+
+def test_out_of_scope_entry_points_say_so():
+    model = FoKLRoutines.FoKL(kernel=1, update=True, UserWarnings=False, ConsoleOutput=False)
+    model._backend_override = OracleBackend()
+    with pytest.raises(NotImplementedError):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model.fit(np.random.default_rng(0).random((20, 1)), np.zeros(20), clean=True)
+    for name in ('bss_derivatives', 'to_pyomo'):
+        with pytest.raises(NotImplementedError):
+            getattr(model, name)()
+
+
+def test_evaluate_requires_minmax_and_validates_draws():
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    with pytest.raises(ValueError, match='minmax'):
+        model.evaluate(np.zeros((3, 1)))
+    g, model, betas, mtx, evs = fit_case('bern_m1')
+    with pytest.raises(ValueError, match='exceeds the number of draws'):
+        model.evaluate(model.inputs, draws=10 ** 6)
+
+
+def test_evaluate_basis_api_matches_reference_values():
+    units = np.load(UNITS_PATH)
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    c = model.phis[4]
+    vals = [model.evaluate_basis(c, np.float64(x)) for x in units['bern_x'][:20]]
+    assert np.array_equal(np.array(vals), units['bern_vals'][4, :20])
+    assert model.evaluate_basis([1.0, 2.0, 3.0, 4.0], 2.0, kernel=0, d=1) == 2 + 2 * 3 * 2 + 3 * 4 * 4
+    assert model.evaluate_basis([1.0, 2.0, 3.0, 4.0], 2.0, kernel='Cubic Splines', d=2) == 2 * 3 + 6 * 4 * 2
+    with pytest.raises(ValueError):
+        model.evaluate_basis(c, 0.5, kernel='Fourier')
+
+
+def test_clean_formats_like_the_reference():
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        x, y = model.clean([[1.0, 2.0, 3.0, 4.0], [10.0, 20.0, 30.0, 50.0]], [1, 2, 3, 4])
+    assert x.shape == (4, 2) and y.shape == (4, 1) and y.dtype == np.float64        # auto-transposed
+    assert model.minmax == [[1.0, 4.0], [10.0, 50.0]] and x[:, 1].tolist() == [0.0, 0.25, 0.5, 1.0]
+    assert model.trainlog is None
+    with pytest.raises(ValueError, match="'data' must be a vector"):
+        model._format(np.zeros((3, 2)), np.zeros((3, 2)))
+    with pytest.raises(ValueError):
+        model.clean(np.zeros((4, 1)), pillow=[0.1, 0.1])    # the reference rejects the 2-element flat form too
+    m2 = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        xp = m2.clean(np.array([[0.0], [10.0]]), pillow=0.1)
+    assert np.allclose(m2.minmax, [[-1.0, 11.0]]) and np.allclose(xp[:, 0], [1 / 12, 11 / 12])
+
+
+def test_trainlog_fraction_uses_the_global_stream():
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model.clean(np.arange(50.0)[:, None], np.arange(50.0), train=0.5)
+    assert model.trainlog.dtype == bool and model.trainlog.sum() == 25
+    xi, yi = model.trainset()
+    assert xi.shape == (25, 1) and yi.shape == (25, 1)
+
+
+def test_save_load_roundtrip_keeps_results(tmp_path):
+    g, model, betas, mtx, evs = fit_case('bern_m1')
+    path = model.save('m', str(tmp_path))
+    assert path.endswith('m.fokl')
+    again = FoKLRoutines.load(path)
+    assert np.array_equal(again.betas, betas) and np.array_equal(again.mtx, mtx) and again.kernel == model.kernel
+    assert not hasattr(again, '_backend_override')
+    pickle.dumps(model.fit_stats)
+
+
+def test_clear_keeps_hyperparameters():
+    g, model, *_ = fit_case('bern_m1')
+    model.clear()
+    assert not hasattr(model, 'betas') and hasattr(model, 'phis') and hasattr(model, 'a')
+
+
+def test_product_has_no_cpu_fallback():
+    """Without the override hook the class goes to the HIP backend, which must raise on a GPU-less host."""
+    if _capi.device_count() > 0:
+        pytest.skip('a GPU is present')
+    FoKLRoutines._CONTEXTS.clear()
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False, ConsoleOutput=False)
+    with pytest.raises(_capi.FoklNativeError):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model.fit(np.random.default_rng(0).random((20, 1)), np.zeros(20), clean=True)
