@@ -604,12 +604,60 @@ extern "C" int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, cons
 
 extern "C" int fokl_comm_allreduce_sum_f64(fokl_ctx *ctx, double *buf, int count);
 
-template <int TI, int TJW>
-static void launch_gram_mfma(fokl_ctx *ctx, dim3 grid, const int *d_rows, int nr, const int *d_cols, int nc, int nr_pad,
-                             int nc_pad)
+// Output elements handled by one 256-thread block of the slab reduction: few elements -> many parts per element.
+static int reduce_elements_per_block(int total)
 {
-    hipLaunchKernelGGL((gram_mfma_kernel<TI, TJW>), grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
-                       nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+    int epb = 1;
+    while (epb < 64 && epb * 64 < total) epb *= 2;     // keep >= 64 blocks in flight before widening
+    return epb;
+}
+
+// Resident workgroups per CU for a kernel (occupancy API; advisory, only used to size the row split).
+template <typename F>
+static int blocks_per_cu(F fn, int threads, size_t dyn_lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, dyn_lds) != hipSuccess || nb < 1) nb = 1;
+    return std::min(nb, 8);
+}
+
+// One instantiation per tile configuration; the dispatcher below picks the smallest that covers the block.
+typedef void (*gram_mfma_fn)(double *const *, const int *, int, const int *, int, int64_t, double *, int, int);
+
+template <int TJ>
+static gram_mfma_fn pick_isplit()
+{
+    return gram_mfma_kernel<4, TJ, true>;
+}
+
+static gram_mfma_fn isplit_kernel(int tj)
+{
+    switch (tj) {
+        case 1: return pick_isplit<1>();
+        case 2: return pick_isplit<2>();
+        case 3: return pick_isplit<3>();
+        case 4: return pick_isplit<4>();
+        case 5: return pick_isplit<5>();
+        case 6: return pick_isplit<6>();
+        case 7: return pick_isplit<7>();
+        case 8: return pick_isplit<8>();
+        case 9: return pick_isplit<9>();
+        case 10: return pick_isplit<10>();
+        case 11: return pick_isplit<11>();
+        default: return pick_isplit<12>();
+    }
+}
+
+static gram_mfma_fn jsplit_kernel(int ti, int tj)
+{
+    if (ti == 1) {
+        if (tj == 1) return gram_mfma_kernel<1, 1, false>;
+        if (tj == 2) return gram_mfma_kernel<1, 2, false>;
+        return gram_mfma_kernel<1, 3, false>;
+    }
+    if (tj == 1) return gram_mfma_kernel<2, 1, false>;
+    if (tj == 2) return gram_mfma_kernel<2, 2, false>;
+    return gram_mfma_kernel<2, 3, false>;
 }
 
 extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
@@ -642,21 +690,31 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
     const int cus = cu_count(ctx);
     int S, nr_pad, nc_pad;
     dim3 grid;
-    int variant = 0;
+    gram_mfma_fn mfma_fn = nullptr;
     if (use_mfma) {
         int BI, BJ;
-        if (nr > 32) {
-            variant = 2;  BI = 64;  BJ = 128;
-        } else if (nr > 16) {
-            variant = 1;  BI = 32;  BJ = 64;
-        } else {
-            variant = 0;  BI = 16;  BJ = 64;
+        const int j_tiles = (nc + 15) / 16;
+        if (nr > 32) {                                   // i-split: wave w <-> i-tile w, panel of TJ j-tiles
+            const int panels = (j_tiles + 11) / 12;
+            const int tj = (j_tiles + panels - 1) / panels;
+            mfma_fn = isplit_kernel(tj);
+            BI = 64;
+            BJ = 16 * tj;
+        } else {                                         // j-split: every wave all i-tiles, j-tiles dealt over waves
+            const int ti = nr > 16 ? 2 : 1;
+            const int per_wave = (j_tiles + 3) / 4;
+            const int panels = (per_wave + 2) / 3;
+            const int tj = (per_wave + panels - 1) / panels;
+            mfma_fn = jsplit_kernel(ti, tj);
+            BI = 16 * ti;
+            BJ = 64 * tj;
         }
         const int gz = (nr + BI - 1) / BI, gy = (nc + BJ - 1) / BJ;
         nr_pad = gz * BI;
         nc_pad = gy * BJ;
         const int64_t n_chunks = (ctx->n + GM_R - 1) / GM_R;
-        const int target = std::max(1, (3 * cus) / (gz * gy));
+        const int per_cu = blocks_per_cu(mfma_fn, GM_THREADS, 0);
+        const int target = std::max(1, (per_cu * cus) / (gz * gy));
         S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
         grid = dim3(S, gy, gz);
     } else {
@@ -678,20 +736,17 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
         const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
         TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);
         if (use_mfma) {
-            if (variant == 2)
-                launch_gram_mfma<4, 2>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
-            else if (variant == 1)
-                launch_gram_mfma<2, 1>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
-            else
-                launch_gram_mfma<1, 1>(ctx, grid, d_rows, nr, d_cols, nc, nr_pad, nc_pad);
+            hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols, nc,
+                               ctx->n, ctx->d_slab, nr_pad, nc_pad);
         } else {
             hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr,
                                d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
         }
         HIP_TRY(ctx, hipGetLastError());
         const int total = nr * nc;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_slab, S,
-                           nr, nc, nr_pad, nc_pad, ctx->d_out);
+        const int epb = reduce_elements_per_block(total);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
+                           ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, ctx->d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nr * nc * sizeof(double), hipMemcpyDeviceToHost,
@@ -741,8 +796,8 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
                            nc, reinterpret_cast<const double *>(ctx->d_args + beta_off),
                            ctx->slot_ptr[FOKL_SLOT_Y], ctx->n, ctx->d_slab);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
-                           ctx->d_out);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
+                           2, ctx->d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -270,29 +270,61 @@ __global__ __launch_bounds__(GV_THREADS) void gram_valu_kernel(double *const *__
     }
 }
 
-// out[e] = sum_{s < S} slab[s][e] in ascending s: bitwise reproducible.  Compacts [nr_pad][nc_pad] -> [nr][nc].
-__global__ void reduce_slabs_kernel(const double *__restrict__ slab, int S, int nr, int nc, int nr_pad, int nc_pad,
-                                    double *__restrict__ out)
+// out[e] = sum over the S partial slabs of slab[s][e], combined in a FIXED order (so results are bitwise
+// reproducible) but not serially: a 256-thread block owns `epb` output elements and 256 / epb "parts"; part p
+// sums the slabs p, p + parts, p + 2 parts, ... with four independent running sums (loads in flight), then the
+// parts are added in ascending order through LDS.  Also compacts [nr_pad][nc_pad] -> [nr][nc].
+constexpr int RD_THREADS = 256;
+
+__global__ __launch_bounds__(RD_THREADS) void reduce_slabs_kernel(const double *__restrict__ slab, int S, int nr, int nc,
+                                                                  int nr_pad, int nc_pad, int epb,
+                                                                  double *__restrict__ out)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nr * nc) return;
-    const int i = e / nc, j = e % nc;
-    const size_t plane = (size_t)nr_pad * nc_pad;
-    const double *p = slab + (size_t)i * nc_pad + j;
-    double s = 0.0;
-    for (int k = 0; k < S; ++k) s += p[k * plane];
-    out[e] = s;
+    __shared__ double part_sum[RD_THREADS];
+    const int parts = RD_THREADS / epb;
+    const int el = threadIdx.x % epb, part = threadIdx.x / epb;
+    const int e = blockIdx.x * epb + el;
+    const int total = nr * nc;
+    double acc = 0.0;
+    if (e < total) {
+        const int i = e / nc, j = e % nc;
+        const size_t plane = (size_t)nr_pad * nc_pad;
+        const double *p = slab + (size_t)i * nc_pad + j;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = part;
+        for (; k + 3 * parts < S; k += 4 * parts) {
+            const double v0 = p[(size_t)k * plane], v1 = p[(size_t)(k + parts) * plane];
+            const double v2 = p[(size_t)(k + 2 * parts) * plane], v3 = p[(size_t)(k + 3 * parts) * plane];
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+        }
+        for (; k < S; k += parts) a0 += p[(size_t)k * plane];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    part_sum[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0 && e < total) {
+        double s = part_sum[el];
+        for (int q = 1; q < parts; ++q) s += part_sum[q * epb + el];
+        out[e] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // K2b: Gram block on fp64 MFMA tiles (v_mfma_f64_16x16x4_f64)
 // ---------------------------------------------------------------------------------------------------------
 //
-// Workgroup = 4 wavefronts = (16*TI) row-side columns x (64*TJW) column-side columns.  Per step a chunk of
-// GM_R rows of every column of both panels is staged in LDS as [column][GM_R + 2] (the 2-double pad makes
-// the 16-column x 4-row fragment reads conflict free: bank pair = 4*col + 2*row mod 64), wave w owns the
-// 16-wide j-tiles {w, w + 4, ...} of all TI i-tiles.  The next chunk's global loads are issued before the
-// MFMAs of the current one (register double buffering).
+// Workgroup = 4 wavefronts.  Per step a chunk of GM_R rows of every column of a row-side panel (16*TI columns)
+// and a column-side panel is staged in LDS as [column][GM_R + 2]; the 2-double pad makes the 16-column x 4-row
+// fragment reads conflict free (bank pair = 4*col + 2*row mod 64).  Two ways of splitting the 16x16 tiles:
+//   ISPLIT  (row side > 32 columns): TI == 4, wave w owns i-tile w and all TJ j-tiles (column panel 16*TJ wide)
+//   !ISPLIT (row side <= 32 columns): every wave owns all TI i-tiles and the j-tiles {w, w + 4, ...}
+//           (column panel 64*TJ wide)
+// so the padded MFMA work stays close to the real block (56 x 58 -> 64 x 64, not 64 x 128).
+// Staging uses one 16-byte load per lane (two consecutive rows of one column); the next chunk's loads are
+// issued before the MFMAs of the current one (register double buffering).
 //
 // Operand maps (cdna_hip_programming.md section 3, f64 form): lane l supplies A[m = l & 15][k = l >> 4] and
 // B[k = l >> 4][n = l & 15]; result register v of lane l is D[m = (l >> 4) + 4 v][n = l & 15].
@@ -301,14 +333,18 @@ constexpr int GM_THREADS = 256;
 constexpr int GM_R = 32;
 constexpr int GM_PITCH = GM_R + 2;
 
-template <int TI, int TJW>
+template <int TI, int TJ, bool ISPLIT>
 __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__restrict__ slot_ptr,
                                                                const int *__restrict__ row_slots, int nr,
                                                                const int *__restrict__ col_slots, int nc, int64_t n,
                                                                double *__restrict__ slab, int nr_pad, int nc_pad)
 {
-    constexpr int BI = 16 * TI, BJ = 64 * TJW, NCOL = BI + BJ;
-    constexpr int LOADS = (NCOL + 7) / 8;                  // per thread: 8 columns per wave-wide pass of the block
+    static_assert(!ISPLIT || TI == 4, "i-split needs one i-tile per wavefront");
+    constexpr int BI = 16 * TI;
+    constexpr int BJ = ISPLIT ? 16 * TJ : 64 * TJ;
+    constexpr int NCOL = BI + BJ;
+    constexpr int PASSES = (NCOL + 15) / 16;              // 16 columns x 16 row pairs per pass of the block
+    constexpr int MI = ISPLIT ? 1 : TI;                    // i-tiles per wave
     __shared__ __attribute__((aligned(16))) double tile[NCOL * GM_PITCH];
     __shared__ const double *colptr[NCOL];
 
@@ -326,35 +362,38 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     }
     __syncthreads();
 
-    d4 acc[TI][TJW];
+    d4 acc[MI][TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJW; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    // staging map: thread t loads row (t & 31) of column (t >> 5) + 8 * pass
-    const int srow = tid & (GM_R - 1), scol = tid >> 5;
+    // staging map: thread t loads rows {2 (t & 15), 2 (t & 15) + 1} of column (t >> 4) + 16 * pass
+    const int spair = tid & 15, scol = tid >> 4;
     const int64_t n_chunks = (n + GM_R - 1) / GM_R;
-    double stage[LOADS];
+    d2 stage[PASSES];
 
     auto issue = [&](int64_t chunk) {
-        const int64_t r = chunk * GM_R + srow;
+        const int64_t r = chunk * GM_R + 2 * spair;
 #pragma unroll
-        for (int p = 0; p < LOADS; ++p) {
-            const int c = scol + 8 * p;
-            double v = 0.0;
+        for (int p = 0; p < PASSES; ++p) {
+            const int c = scol + 16 * p;
+            d2 v = {0.0, 0.0};
             if (c < NCOL) {
                 const double *cp = colptr[c];
-                if (cp != nullptr && r < n) v = cp[r];
+                if (cp != nullptr && r < n) {
+                    v = *reinterpret_cast<const d2 *>(cp + r);     // r even, ld even: in bounds whenever r < n
+                    if (r + 1 >= n) v.y = 0.0;
+                }
             }
             stage[p] = v;
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int p = 0; p < LOADS; ++p) {
-            const int c = scol + 8 * p;
-            if (c < NCOL) tile[c * GM_PITCH + srow] = stage[p];
+        for (int p = 0; p < PASSES; ++p) {
+            const int c = scol + 16 * p;
+            if (c < NCOL) *reinterpret_cast<d2 *>(&tile[c * GM_PITCH + 2 * spair]) = stage[p];
         }
     };
 
@@ -368,15 +407,21 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
         if (next < n_chunks) issue(next);
 #pragma unroll
         for (int k0 = 0; k0 < GM_R; k0 += 4) {
-            double af[TI], bf[TJW];
+            double af[MI], bf[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = tile[(16 * i + fm) * GM_PITCH + k0 + fk];
+            for (int i = 0; i < MI; ++i) {
+                const int it = ISPLIT ? wave : i;
+                af[i] = tile[(16 * it + fm) * GM_PITCH + k0 + fk];
+            }
 #pragma unroll
-            for (int j = 0; j < TJW; ++j) bf[j] = tile[(BI + 16 * (wave + 4 * j) + fm) * GM_PITCH + k0 + fk];
+            for (int j = 0; j < TJ; ++j) {
+                const int jt = ISPLIT ? j : wave + 4 * j;
+                bf[j] = tile[(BI + 16 * jt + fm) * GM_PITCH + k0 + fk];
+            }
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJW; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -385,13 +430,15 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
 
     double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJW; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int gi = i0 + 16 * i + fk + 4 * v;
-                const int gj = j0 + 16 * (wave + 4 * j) + fm;
+                const int it = ISPLIT ? wave : i;
+                const int jt = ISPLIT ? j : wave + 4 * j;
+                const int gi = i0 + 16 * it + fk + 4 * v;
+                const int gj = j0 + 16 * jt + fm;
                 out[(size_t)gi * nc_pad + gj] = acc[i][j][v];
             }
 }
@@ -401,31 +448,60 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
 // ---------------------------------------------------------------------------------------------------------
 
 constexpr int RS_THREADS = 256;
+constexpr int RS_BATCH = 256;      // columns whose (pointer, coefficient) pairs sit in LDS at a time
 
+struct ResidCol {
+    const double *ptr;
+    double beta;
+};
+
+// Every lane owns two consecutive rows (one 16-byte load per column); the per-column pointer and coefficient
+// are wave-uniform and come from LDS as one broadcast ds_read_b128, so the column loop is a stream of
+// independent global loads + 2 FMAs with no dependent scalar pointer chase.
 __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__restrict__ slot_ptr,
                                                            const int *__restrict__ slots, int nc,
                                                            const double *__restrict__ beta,
                                                            const double *__restrict__ y, int64_t n,
                                                            double *__restrict__ slab)
 {
+    __shared__ __attribute__((aligned(16))) ResidCol cols[RS_BATCH];
     __shared__ double red[RS_THREADS / WAVE][2];
     const int tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * RS_THREADS * 2;
-    for (int64_t r = ((int64_t)blockIdx.x * RS_THREADS + tid) * 2; r < n; r += stride) {
+    const int64_t n_tiles = (n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+    const bool single_batch = nc <= RS_BATCH;
+    if (single_batch) {
+        for (int j = tid; j < nc; j += RS_THREADS) cols[j] = ResidCol{slot_ptr[slots[j]], beta[j]};
+        __syncthreads();
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r = (tile * RS_THREADS + tid) * 2;
+        const bool in0 = r < n, in1 = r + 1 < n;
         d2 fit = {0.0, 0.0};
+        for (int c0 = 0; c0 < nc; c0 += RS_BATCH) {
+            const int cnt = min(RS_BATCH, nc - c0);
+            if (!single_batch) {
+                __syncthreads();
+                for (int j = tid; j < cnt; j += RS_THREADS) cols[j] = ResidCol{slot_ptr[slots[c0 + j]], beta[c0 + j]};
+                __syncthreads();
+            }
+            if (in0) {
 #pragma unroll 8
-        for (int j = 0; j < nc; ++j) {
-            const double bj = beta[j];
-            const d2 xv = *reinterpret_cast<const d2 *>(slot_ptr[slots[j]] + r);
-            fit.x = __builtin_fma(bj, xv.x, fit.x);
-            fit.y = __builtin_fma(bj, xv.y, fit.y);
+                for (int j = 0; j < cnt; ++j) {
+                    const ResidCol c = cols[j];
+                    const d2 xv = *reinterpret_cast<const d2 *>(c.ptr + r);
+                    fit.x = __builtin_fma(c.beta, xv.x, fit.x);
+                    fit.y = __builtin_fma(c.beta, xv.y, fit.y);
+                }
+            }
         }
-        const d2 yv = *reinterpret_cast<const d2 *>(y + r);
-        const double r0 = yv.x - fit.x;
-        const double r1 = (r + 1 < n) ? yv.y - fit.y : 0.0;
-        s1 += r0 + r1;
-        s2 += r0 * r0 + r1 * r1;
+        if (in0) {
+            const d2 yv = *reinterpret_cast<const d2 *>(y + r);
+            const double r0 = yv.x - fit.x;
+            const double r1 = in1 ? yv.y - fit.y : 0.0;
+            s1 += r0 + r1;
+            s2 += r0 * r0 + r1 * r1;
+        }
     }
     const int wave = tid / WAVE, lane = tid % WAVE;
     s1 = wave_sum(s1);
