@@ -169,6 +169,17 @@ def main():
                     total_ms=k['ms'])
 
     kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm')}
+    # HBM traffic per launch from the committed PMC passes of this same workload (profiles/pmc_r01.json, produced by
+    # tools/profile_r01.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note).
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_r01.json')
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        if pmc.get('workload') == {'rows': n, 'inputs': m}:
+            for name, k in kernels.items():
+                if k and name in pmc['kernels']:
+                    k['traffic'] = pmc['kernels'][name]['hbm_bytes_per_launch']
+                    k['algorithmic_bytes_per_launch'] = kern[name]['bytes'] / kern[name]['launches']
     dominant = max((k for k in kernels.values() if k), key=lambda k: k['total_ms'])
     gpu_ms = sum(k['total_ms'] for k in kernels.values() if k)
 

@@ -732,15 +732,22 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
     if (rc) return rc;
 
     {
-        const double bytes = 8.0 * (double)ctx->n * (double)(nr + nc);
-        const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
-        TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);
-        if (use_mfma) {
-            hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols, nc,
-                               ctx->n, ctx->d_slab, nr_pad, nc_pad);
-        } else {
-            hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr,
-                               d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+        {
+            // algorithmic traffic: every distinct column read once (row-side columns usually reappear on the column side)
+            std::vector<int32_t> uniq(row_slots, row_slots + nr);
+            uniq.insert(uniq.end(), col_slots, col_slots + nc);
+            std::sort(uniq.begin(), uniq.end());
+            const double distinct = (double)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
+            const double bytes = 8.0 * (double)ctx->n * distinct;
+            const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
+            TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
+            if (use_mfma) {
+                hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
+                                   nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+            } else {
+                hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
+                                   nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+            }
         }
         HIP_TRY(ctx, hipGetLastError());
         const int total = nr * nc;
@@ -790,11 +797,13 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
     rc = ensure_out(ctx, 2);
     if (rc) return rc;
     {
-        TimedRegion timed(ctx, FOKL_K_RESID, 8.0 * (double)ctx->n * (double)(nc + 1), 2.0 * (double)ctx->n * nc);
-        hipLaunchKernelGGL(resid_kernel, dim3(S), dim3(RS_THREADS), 0, ctx->stream, ctx->d_slot_ptr,
-                           reinterpret_cast<const int *>(ctx->d_args),
-                           nc, reinterpret_cast<const double *>(ctx->d_args + beta_off),
-                           ctx->slot_ptr[FOKL_SLOT_Y], ctx->n, ctx->d_slab);
+        {
+            TimedRegion timed(ctx, FOKL_K_RESID, 8.0 * (double)ctx->n * (double)(nc + 1), 2.0 * (double)ctx->n * nc);
+            hipLaunchKernelGGL(resid_kernel, dim3(S), dim3(RS_THREADS), 0, ctx->stream, ctx->d_slot_ptr,
+                               reinterpret_cast<const int *>(ctx->d_args),
+                               nc, reinterpret_cast<const double *>(ctx->d_args + beta_off),
+                               ctx->slot_ptr[FOKL_SLOT_Y], ctx->n, ctx->d_slab);
+        }
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
                            2, ctx->d_out);

@@ -45,9 +45,12 @@ def _exchange_unique_id(rank, world, make_id, tag='fokl'):
     port = int(os.environ.get('MASTER_PORT', '29500'))
     from torch.distributed import TCPStore
     import datetime
-    store = TCPStore(addr, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300),
-                     wait_for_workers=False)
-    key = tag + '_rccl_id'
+    # Under torch.distributed.run the elastic agent already serves a store on MASTER_PORT and tells its workers so;
+    # then every rank (rank 0 included) connects as a client.
+    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
+    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store),
+                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    key = tag + '_rccl_id_' + os.environ.get('TORCHELASTIC_RUN_ID', '0')
     if rank == 0:
         uid = make_id()
         store.set(key, uid)

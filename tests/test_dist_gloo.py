@@ -1,0 +1,34 @@
+"""N > 1 host logic on CPU: two ranks, gloo backend, launched exactly like the driver launches bench.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from helpers import ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_collectives_rowshard_and_replicas(tmp_path):
+    env = dict(os.environ, OPENBLAS_NUM_THREADS='2', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    results = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(2)]
+    for res in results:
+        assert res['allgather_ok'] and res['allreduce_ok'] and res['shard_ok']
+        # row-sharded fit: same model on every rank as the single-process fit (sums differ only in association)
+        assert res['rowshard_mtx_equal']
+        assert res['rowshard_evs_err'] < 1e-10 and res['rowshard_betas_err'] < 1e-8
+    # throughput mode: every rank sees all ranks' counters after the single all-gather
+    assert results[0]['replica_terms'] == results[1]['replica_terms']
+    assert results[0]['replica_terms'][0] == results[0]['replica_own_terms']
+    assert results[1]['replica_terms'][1] == results[1]['replica_own_terms']
