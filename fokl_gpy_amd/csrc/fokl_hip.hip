@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -471,7 +472,30 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
     }
     const int NS = (int)slab_orders.size();
     size_t slab_doubles = splines ? (((size_t)NS * 4 * ctx->width + 1) & ~(size_t)1) : 0;
-    size_t lds_bytes = slab_doubles * sizeof(double) + (size_t)std::max(U, 1) * K1_THREADS * sizeof(d2);
+    // Workgroup size: the factor table costs 16 B per lane and factor, so big tables with 256 lanes leave only one
+    // or two workgroups per CU; smaller workgroups pack the 160 KB of LDS with more wavefronts (each staged spline
+    // slab is paid per workgroup, which pushes the other way).  FOKL_K1_THREADS overrides (experiments).
+    int threads = K1_THREADS;
+    {
+        int best_waves = -1;
+        for (int t : {256, 128, 64}) {
+            const size_t need = slab_doubles * sizeof(double) + (size_t)std::max(U, 1) * t * sizeof(d2);
+            const int blocks = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(need, 1));
+            const int waves = std::min(32, blocks * (t / 64));
+            if (waves > best_waves) {
+                best_waves = waves;
+                threads = t;
+            }
+        }
+        if (const char *env = getenv("FOKL_K1_THREADS")) {
+            const int t = atoi(env);
+            if (t == 64 || t == 128 || t == 256) threads = t;
+        }
+    }
+    const bool reg_table = U <= K1_REG_FACTORS;        // factor table in VGPRs: LDS only holds the spline slabs
+    if (reg_table) threads = K1_THREADS;
+    size_t lds_bytes = slab_doubles * sizeof(double) +
+                       (reg_table ? 0 : (size_t)std::max(U, 1) * threads * sizeof(d2));
 
     size_t n_fac_entries = 0;
     for (int j = t_begin; j < t_end; ++j)
@@ -514,8 +538,9 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
     rc = push_args(ctx, bytes);
     if (rc) return rc;
 
-    const int64_t n_tiles = (ctx->n + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    const int64_t tile_rows = (int64_t)threads * K1_ROWS_PER_THREAD;
+    const int64_t n_tiles = (ctx->n + tile_rows - 1) / tile_rows;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(reg_table ? 5 : 16, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
     const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cu_count(ctx) * per_cu);
     const BasisPlan *d_plan = reinterpret_cast<const BasisPlan *>(ctx->d_args);
     const int *d_arr = reinterpret_cast<const int *>(ctx->d_args + plan_bytes);
@@ -531,19 +556,15 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
     }
     const double alg_bytes = 8.0 * (double)ctx->n * (double)(m_used + T);
     TimedRegion timed(ctx, FOKL_K_BASIS, alg_bytes, 0.0);
-    if (splines) {
-        if (lds_bytes > 64 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(basis_build_kernel<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BUDGET + 4096));
-        hipLaunchKernelGGL(basis_build_kernel<true>, dim3(grid), dim3(K1_THREADS), lds_bytes, ctx->stream, ctx->d_x,
-                           ctx->ld, ctx->n, ctx->d_phis, ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
-    } else {
-        if (lds_bytes > 64 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(basis_build_kernel<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BUDGET + 4096));
-        hipLaunchKernelGGL(basis_build_kernel<false>, dim3(grid), dim3(K1_THREADS), lds_bytes, ctx->stream, ctx->d_x,
-                           ctx->ld, ctx->n, ctx->d_phis, ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
-    }
+    typedef void (*basis_fn)(const double *, int64_t, int64_t, const double *, int, const BasisPlan *, const int *,
+                             double *const *);
+    basis_fn fn = splines ? (reg_table ? basis_build_reg_kernel<true> : basis_build_kernel<true>)
+                          : (reg_table ? basis_build_reg_kernel<false> : basis_build_kernel<false>);
+    if (lds_bytes > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)K1_LDS_BUDGET + 4096));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n, ctx->d_phis,
+                       ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
     HIP_TRY(ctx, hipGetLastError());
     return FOKL_OK;
 }
@@ -574,7 +595,15 @@ extern "C" int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, cons
     // Split into launches whose distinct-factor table fits the LDS budget.
     const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
     const size_t slab_bytes = splines ? (size_t)K1_MAX_LDS_SLABS * 4 * ctx->width * sizeof(double) + 16 : 0;
-    const int max_fac = (int)((K1_LDS_BUDGET - slab_bytes) / (K1_THREADS * sizeof(d2)));
+    const int lds_fac = (int)((K1_LDS_BUDGET - slab_bytes) / (K1_THREADS * sizeof(d2)));
+    // groups of terms whose distinct factors fit the register table take the faster kernel; only a single term with
+    // more factors than that falls back to the LDS table
+    int max_fac = K1_REG_FACTORS;
+    for (int j = 0; j < T; ++j) {
+        int nz = 0;
+        for (int k = 0; k < m; ++k) nz += terms[(size_t)j * m + k] != 0;
+        if (nz > max_fac) max_fac = std::min(nz, lds_fac);
+    }
     int begin = 0;
     while (begin < T) {
         std::map<std::pair<int, int>, int> seen;

@@ -105,21 +105,23 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
     const int *term_slot = term_fac + term_off[T];
 
     const int tid = threadIdx.x;
+    const int nthr = blockDim.x;                                       // 64 .. K1_THREADS, chosen by the host for occupancy
     double *slabs = lds;                                               // [NS][4][width]
     const int slab_doubles = SPLINES ? ((NS * 4 * width + 1) & ~1) : 0; // keep the factor table 16-B aligned
-    d2 *fac = reinterpret_cast<d2 *>(lds + slab_doubles);              // [U][K1_THREADS]
+    d2 *fac = reinterpret_cast<d2 *>(lds + slab_doubles);              // [U][nthr]
 
     if (SPLINES) {
         for (int s = 0; s < NS; ++s) {
             const double *src = phis + (size_t)(slab_order[s] - 1) * 4 * width;
-            for (int i = tid; i < 4 * width; i += K1_THREADS) slabs[s * 4 * width + i] = src[i];
+            for (int i = tid; i < 4 * width; i += nthr) slabs[s * 4 * width + i] = src[i];
         }
         __syncthreads();
     }
 
-    const int64_t n_tiles = (n + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
+    const int tile_rows = nthr * K1_ROWS_PER_THREAD;
+    const int64_t n_tiles = (n + tile_rows - 1) / tile_rows;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * K1_TILE_ROWS + (int64_t)tid * K1_ROWS_PER_THREAD;
+        const int64_t r0 = tile * tile_rows + (int64_t)tid * K1_ROWS_PER_THREAD;
         // ld is a multiple of 64 rows and the buffers are ld long, so the 16-byte access at r0 stays in bounds
         // whenever r0 < ld; rows >= n hold unspecified values and are never stored.
         const bool in0 = r0 < n, in1 = r0 + 1 < n;
@@ -127,18 +129,20 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
         // phase 1: every distinct (input, order) factor once per row, parked in LDS
         int cur_input = -1;
         d2 x = {0.0, 0.0};
+        int p0 = 0, p1 = 0;
+        double t0 = 0.0, t1 = 0.0;
         for (int u = 0; u < U; ++u) {
             const int k = fac_input[u], order = fac_order[u];
-            if (k != cur_input) {
+            if (k != cur_input) {                                      // factors are sorted by input: one load per input
                 cur_input = k;
                 if (in0) x = *reinterpret_cast<const d2 *>(xT + (size_t)k * ld + r0);
+                if (SPLINES) {
+                    spline_locate(x.x, width, p0, t0);
+                    spline_locate(x.y, width, p1, t1);
+                }
             }
             d2 v;
             if (SPLINES) {
-                int p0, p1;
-                double t0, t1;
-                spline_locate(x.x, width, p0, t0);
-                spline_locate(x.y, width, p1, t1);
                 const int s = fac_slab[u];
                 if (s >= 0) {
                     const double *sl = slabs + s * 4 * width;
@@ -154,17 +158,110 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
                 v.x = bernoulli_basis(c, order, x.x);
                 v.y = bernoulli_basis(c, order, x.y);
             }
-            fac[u * K1_THREADS + tid] = v;
+            fac[u * nthr + tid] = v;
         }
 
         // phase 2: T products of those factors, one 16-byte store per lane and column
         for (int j = 0; j < T; ++j) {
             const int b = term_off[j], e = term_off[j + 1];
-            d2 phi = fac[term_fac[b] * K1_THREADS + tid];         // 1 * first factor
+            d2 phi = fac[term_fac[b] * nthr + tid];               // 1 * first factor
             for (int f = b + 1; f < e; ++f) {
-                const d2 g = fac[term_fac[f] * K1_THREADS + tid];
+                const d2 g = fac[term_fac[f] * nthr + tid];
                 phi.x = phi.x * g.x;
                 phi.y = phi.y * g.y;
+            }
+            double *col = slot_ptr[term_slot[j]];
+            if (in1) {
+                *reinterpret_cast<d2 *>(col + r0) = phi;
+            } else if (in0) {
+                col[r0] = phi.x;
+            }
+        }
+    }
+}
+
+// Register-resident variant: when a launch has at most K1_REG_FACTORS distinct factors the per-lane factor table
+// lives in VGPRs and is indexed with wave-uniform indices (hipcc lowers this to s_set_gpr_idx -- no scratch, no LDS),
+// so LDS holds only the staged spline slabs and occupancy is bounded by registers instead of 16 B of LDS per lane
+// and factor.  Same arithmetic, same operation order as basis_build_kernel.
+constexpr int K1_REG_FACTORS = 16;
+
+template <bool SPLINES>
+__global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
+    const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
+    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
+    const int *fac_input = arr;
+    const int *fac_order = arr + U;
+    const int *fac_slab = arr + 2 * U;
+    const int *slab_order = arr + 3 * U;
+    const int *term_off = arr + 3 * U + K1_MAX_LDS_SLABS;
+    const int *term_fac = term_off + (T + 1);
+    const int *term_slot = term_fac + term_off[T];
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    double *slabs = lds;                                               // [NS][4][width]
+    if (SPLINES) {
+        for (int s = 0; s < NS; ++s) {
+            const double *src = phis + (size_t)(slab_order[s] - 1) * 4 * width;
+            for (int i = tid; i < 4 * width; i += nthr) slabs[s * 4 * width + i] = src[i];
+        }
+        __syncthreads();
+    }
+
+    const int tile_rows = nthr * K1_ROWS_PER_THREAD;
+    const int64_t n_tiles = (n + tile_rows - 1) / tile_rows;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r0 = tile * tile_rows + (int64_t)tid * K1_ROWS_PER_THREAD;
+        const bool in0 = r0 < n, in1 = r0 + 1 < n;
+        double fx[K1_REG_FACTORS], fy[K1_REG_FACTORS];
+
+        int cur_input = -1;
+        d2 x = {0.0, 0.0};
+        int p0 = 0, p1 = 0;
+        double t0 = 0.0, t1 = 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int k = fac_input[u], order = fac_order[u];
+            if (k != cur_input) {
+                cur_input = k;
+                if (in0) x = *reinterpret_cast<const d2 *>(xT + (size_t)k * ld + r0);
+                if (SPLINES) {
+                    spline_locate(x.x, width, p0, t0);
+                    spline_locate(x.y, width, p1, t1);
+                }
+            }
+            double vx, vy;
+            if (SPLINES) {
+                const int s = fac_slab[u];
+                if (s >= 0) {
+                    const double *sl = slabs + s * 4 * width;
+                    vx = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
+                    vy = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
+                } else {
+                    const double *sl = phis + (size_t)(order - 1) * 4 * width;
+                    vx = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
+                    vy = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
+                }
+            } else {
+                const double *c = phis + (size_t)(order - 1) * width;
+                vx = bernoulli_basis(c, order, x.x);
+                vy = bernoulli_basis(c, order, x.y);
+            }
+            fx[u] = vx;
+            fy[u] = vy;
+        }
+
+        for (int j = 0; j < T; ++j) {
+            const int b = term_off[j], e = term_off[j + 1];
+            const int a0 = term_fac[b];
+            d2 phi = {fx[a0], fy[a0]};                               // 1 * first factor
+            for (int f = b + 1; f < e; ++f) {
+                const int g = term_fac[f];
+                phi.x = phi.x * fx[g];
+                phi.y = phi.y * fy[g];
             }
             double *col = slot_ptr[term_slot[j]];
             if (in1) {
