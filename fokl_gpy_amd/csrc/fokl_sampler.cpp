@@ -313,3 +313,75 @@ extern "C" int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, d
     release_rng(r, mt_pos, has_gauss, gauss_cache);
     return FOKL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The same chain in two halves.  Everything random in FR:1519-1548 is independent of the data: per iteration p1
+// standard normals, one standard gamma of shape astar and one of shape atau_star (the data only enters through
+// the gamma *scales*), unless bstar < 0 skips a draw (FR:1538-1539) -- impossible for b > 0, reported otherwise.
+// fokl_noise_tape advances the stream and records those numbers; fokl_gibbs_chain_from_tape replays the
+// arithmetic.  The host driver runs the first on a worker thread while eigh / the device residual pass of the
+// same and of later candidates proceed (engine.NoisePipeline).
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
+                               int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
+                               double *gam_tau_out)
+{
+    LegacyRng r;
+    if (p1 <= 0 || draws < 0 || !normals_out || !gam_sig_out || !gam_tau_out ||
+        !bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache)) {
+        fokl_set_global_error("fokl_noise_tape: null pointer, empty model or invalid RNG state");
+        return FOKL_ERR_ARG;
+    }
+    if (!(astar >= 0.0) || !(atau_star >= 0.0)) {
+        fokl_set_global_error("fokl_noise_tape: gamma shape parameter is negative or NaN");
+        return FOKL_ERR_NUMERIC;
+    }
+    Scratch &scratch = t_scratch;
+    for (int k = 0; k < draws; ++k) {
+        fill_normals(r, scratch, p1, normals_out + (size_t)k * p1);
+        gam_sig_out[k] = r.std_gamma(astar);
+        gam_tau_out[k] = r.std_gamma(atau_star);
+    }
+    release_rng(r, mt_pos, has_gauss, gauss_cache);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau,
+                                          double dtd, double sigsqd0, double tausqd0, int draws,
+                                          const double *normals, const double *gam_sig, const double *gam_tau,
+                                          double *w_out, double *sigs_out, double *taus_out, int32_t *bstar_negative)
+{
+    if (!lamb || !qty || !normals || !gam_sig || !gam_tau || !w_out || p1 <= 0 || draws < 0) {
+        fokl_set_global_error("fokl_gibbs_chain_from_tape: null pointer or empty model");
+        return FOKL_ERR_ARG;
+    }
+    int32_t flagged = 0;
+    double sigsqd = sigsqd0, tausqd = tausqd0;
+    for (int k = 0; k < draws; ++k) {
+        const double inv_tau = 1.0 / tausqd;
+        const double sig = std::sqrt(sigsqd);
+        double *__restrict__ w = w_out + (size_t)k * p1;
+        draw_in_eigenbasis(lamb, qty, normals + (size_t)k * p1, p1, inv_tau, sig, w);
+        double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
+        for (int i = 0; i < p1; ++i) {
+            const double wi = w[i];
+            q_lam += lamb[i] * (wi * wi);
+            q_ty += wi * qty[i];
+            q_ww += wi * wi;
+        }
+        const double bstar = b + 0.5 * (q_lam - 2.0 * q_ty + dtd + q_ww / tausqd);
+        if (bstar < 0.0) {
+            flagged = 1;                               // the tape holds a gamma the reference would not have drawn
+            sigsqd = NAN;
+        } else {
+            sigsqd = 1.0 / ((1.0 / bstar) * gam_sig[k]);
+        }
+        if (sigs_out) sigs_out[k] = sigsqd;
+        const double btau_star = (1.0 / (2.0 * sigsqd)) * q_ww + btau;
+        tausqd = 1.0 / ((1.0 / btau_star) * gam_tau[k]);
+        if (taus_out) taus_out[k] = tausqd;
+    }
+    if (bstar_negative) *bstar_negative = flagged;
+    return FOKL_OK;
+}

@@ -16,6 +16,7 @@ residual pass over the device columns, never from the cancellation-prone Gram id
 The *logical* candidate-term count (what the reference would have built) is tallied per call.
 """
 import math
+import os
 
 import numpy as np
 from scipy.linalg import eigh as _eigh
@@ -171,7 +172,80 @@ class SlotPool:
 # the driver
 # ---------------------------------------------------------------------------------------------------------
 
+class NoisePipeline:
+    """
+    Worker thread that owns the numpy-legacy random stream for the duration of a fit and records, strictly in
+    request order, the *noise tape* of every model evaluation (``_capi.noise_tape``: per Gibbs iteration p1 standard
+    normals and two standard gammas -- everything random in FR:1519-1548, none of it data dependent).
+
+    The stream is inherently serial, so this thread is the critical path of a fit at large N; the main thread
+    meanwhile does what does not need random numbers (Gram sub-block, eigh, betahat, the device residual pass, the
+    accept / reject decision on the BIC) and only blocks on a tape when somebody asks for that candidate's draws.
+    """
+
+    def __init__(self, stream, draws):
+        import queue
+        import threading
+        self.stream, self.draws = stream, int(draws)
+        self._q = queue.Queue()
+        self._thread = threading.Thread(target=self._work, name='fokl-noise', daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            fut, p1, astar, atau_star = item
+            try:
+                fut.set_result(_capi.noise_tape(p1, self.draws, astar, atau_star, self.stream))
+            except BaseException as exc:            # surfaced on .result() in the main thread
+                fut.set_exception(exc)
+
+    def request(self, p1, astar, atau_star):
+        from concurrent.futures import Future
+        fut = Future()
+        self._q.put((fut, int(p1), float(astar), float(atau_star)))
+        return fut
+
+    def close(self):
+        """Drain the queue (every requested tape advances the stream, used or not) and stop the worker."""
+        self._q.put(None)
+        self._thread.join()
+
+
 class GibbsOutcome:
+    """One model evaluation.  The BIC is known at once; the draws are materialised on first use from the noise tape
+    (chain arithmetic in the eigenbasis, then betas = w Q', FR:1528) -- most kill-test candidates never need them."""
+    __slots__ = ('lamb', 'qty', 'Q', 'betahat', 'ev', 'idx', 'dtd', '_tape', '_owner', '_w', '_betas')
+
+    def __init__(self, owner, lamb, qty, Q, betahat, ev, idx, dtd, tape):
+        self.lamb, self.qty, self.Q, self.betahat, self.ev, self.idx, self.dtd = lamb, qty, Q, betahat, ev, idx, dtd
+        self._tape, self._owner = tape, owner
+        self._w = self._betas = None
+
+    @property
+    def w(self):
+        if self._w is None:
+            o = self._owner
+            tape = self._tape.result()
+            self._w, negative = _capi.gibbs_chain_from_tape(self.lamb, self.qty, o.b, o.btau, self.dtd, o.sigsqd0,
+                                                            o.tausqd0, tape)
+            if negative:
+                raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
+                                   "cannot reproduce the reference's skipped draw (FR:1538-1539)")
+            self._tape = None
+        return self._w
+
+    @property
+    def betas(self):
+        if self._betas is None:
+            self._betas = self.w @ self.Q.T
+        return self._betas
+
+
+class EagerOutcome:
+    """Model evaluation whose chain ran in line (b <= 0: bstar < 0 may skip draws, so no tape can be recorded ahead)."""
     __slots__ = ('w', 'Q', 'betahat', 'ev', 'idx', '_betas')
 
     def __init__(self, w, Q, betahat, ev, idx):
@@ -180,7 +254,6 @@ class GibbsOutcome:
 
     @property
     def betas(self):
-        """Posterior draws in model coordinates, betas = w Q' (FR:1528); formed on first use."""
         if self._betas is None:
             self._betas = self.w @ self.Q.T
         return self._betas
@@ -217,6 +290,7 @@ class ForwardSelection:
         self.sigsqd0 = b / (1 + a)          # FR:1371
         self.tausqd0 = btau / (1 + atau)    # FR:1372
         self.pool = SlotPool(backend)
+        self.noise = None                   # NoisePipeline while run() is active (b > 0 only)
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0)
 
@@ -239,22 +313,27 @@ class ForwardSelection:
         qty = Q.T @ Xty
         betahat = Q @ (qty / lamb)                                  # FR:1502-1504
 
-        # K3 streams the residuals of this candidate on the device while the host runs its Gibbs chain
-        cand_slots = [slots[i] for i in idx]
-        overlap = hasattr(self.backend, 'bic_resid_launch')
-        if overlap:
-            self.backend.bic_resid_launch(cand_slots, betahat)
-
         astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508 (mmtx + 1 == p1)
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        try:
-            w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0,
-                                  self.draws, self.stream)
-        finally:
-            if overlap:
-                s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
-        if not overlap:
+        cand_slots = [slots[i] for i in idx]
+        if self.noise is not None:
+            # the random half of the chain is recorded by the worker thread, in call order; K3 streams the
+            # residuals on the device meanwhile; the draws themselves are formed only if somebody needs them
+            tape = self.noise.request(p1, astar, atau_star)
             s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
+            w = None
+        else:
+            overlap = hasattr(self.backend, 'bic_resid_launch')
+            if overlap:
+                self.backend.bic_resid_launch(cand_slots, betahat)
+            try:
+                w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0,
+                                      self.tausqd0, self.draws, self.stream)
+            finally:
+                if overlap:
+                    s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
+            if not overlap:
+                s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
         siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
         lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
         ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554
@@ -266,10 +345,25 @@ class ForwardSelection:
         self.stats['kill_tests'] += int(kill)
         self.stats['terms_logical'] += built
         self.trace.append(dict(cols=p1, built=built, ev=float(ev), kill=bool(kill)))
-        return GibbsOutcome(w, Q, betahat, ev, idx)
+        if self.noise is not None:
+            return GibbsOutcome(self, lamb, qty, Q, betahat, ev, idx, dtd, tape)
+        return EagerOutcome(w, Q, betahat, ev, idx)
 
     # -- the search ---------------------------------------------------------------------------------------
     def run(self):
+        """The whole search.  With b > 0 (always, unless the user forces a non-positive scale) the random stream runs
+        on a worker thread (NoisePipeline); otherwise every chain runs in line."""
+        pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
+        if pipelined:
+            self.noise = NoisePipeline(self.stream, self.draws)
+        try:
+            return self._run()
+        finally:
+            if self.noise is not None:
+                self.noise.close()          # all requested tapes are recorded -> the stream ends where it must
+                self.noise = None
+
+    def _run(self):
         m, n = self.m, self.n
         draws = self.draws
         half1 = int(math.ceil(draws / 2 + 1))      # FR:1656
@@ -336,8 +430,12 @@ class ForwardSelection:
                 killed = []                                           # active-column indices removed so far
                 evmin = ev
                 for i in range(vm):
-                    thresh0 = self.threshav * np.mean(np.abs(np.mean(best.betas[half0:draws, 0])))
-                    if rel_std[i] > self.threshstdb or (rel_std[i] > self.threshstda and mean_abs[i] < thresh0):
+                    # FR:1670-1671.  The second clause needs the intercept draws of the model accepted so far, i.e.
+                    # that candidate's chain; it is only evaluated when the first clause does not already decide
+                    # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
+                    if rel_std[i] > self.threshstdb or (
+                            rel_std[i] > self.threshstda and
+                            mean_abs[i] < self.threshav * np.mean(np.abs(np.mean(best.betas[half0:draws, 0])))):
                         trial = set(killed)
                         trial.add(int(cand_col[i]))
                         idx = [c for c in range(A) if c not in trial]

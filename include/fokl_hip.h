@@ -184,6 +184,24 @@ int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar
                      uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      double *w_out, double *sigs_out, double *taus_out);
 
+/*
+ * The same chain in two halves, so that the serial random stream can run on a worker thread ahead of the
+ * data-dependent arithmetic.  fokl_noise_tape advances the stream exactly as `draws` iterations of
+ * fokl_gibbs_chain would and records, per iteration, the p1 standard normals (normals_out [draws, p1]) and the two
+ * standard gamma variates of shapes astar / atau_star (gam_sig_out, gam_tau_out [draws]).
+ * fokl_gibbs_chain_from_tape replays the arithmetic on that tape: identical w / sigs / taus, bit for bit.
+ * The split is exact unless some iteration has bstar < 0, where the reference skips a gamma draw (FR:1538-1539;
+ * impossible for b > 0): *bstar_negative is then set to 1 and the caller must redo the candidate with
+ * fokl_gibbs_chain from the stream state it saved before the tape.
+ */
+int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
+                    int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
+                    double *gam_tau_out);
+int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau, double dtd,
+                               double sigsqd0, double tausqd0, int draws, const double *normals,
+                               const double *gam_sig, const double *gam_tau, double *w_out, double *sigs_out,
+                               double *taus_out, int32_t *bstar_negative);
+
 /* Raw access to the same generator (parity tests against numpy): n standard normals / n std gammas. */
 int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      int64_t n, double *out);

@@ -349,3 +349,56 @@ def test_rccl_world_of_one():
     assert ctx.gram([0], [0, 1], allreduce=True).tolist() == [[1000.0, 1000.0]]
     comm.close()
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole fits at BASELINE sizes against the oracle (same seed; the reference itself needs hours at these N)
+# ---------------------------------------------------------------------------------------------------------
+
+def _fit_both(x, y, kname, kid, phis, seed, **hy):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FoKLRoutines.FoKL(kernel=kname, phis=phis, UserWarnings=False, ConsoleOutput=False, **hy)
+        np.random.seed(seed)
+        betas, mtx, evs = model.fit(x, y, clean=True)
+        end_gpu = np.random.get_state()
+        np.random.seed(seed)
+        ob, om, oe = O.fit(model.inputs, model.data, phis, kid, eigh=O.eigh_canonical, **hy)
+        end_cpu = np.random.get_state()
+    assert om.shape == mtx.shape and np.array_equal(om, mtx)
+    assert len(oe) == len(evs) and np.max(np.abs(oe - evs) / np.abs(oe)) < 1e-9
+    assert np.max(np.abs(ob - betas) / np.max(np.abs(ob), axis=0)) < 1e-9
+    assert np.array_equal(end_gpu[1], end_cpu[1]) and end_gpu[2:] == end_cpu[2:]
+    return model
+
+
+def test_config1_size_splines_fit_against_oracle():
+    """BASELINE configs[1]: N = 1e5, M = 4, Cubic Splines (draws shortened so that the oracle's Python chain stays short)."""
+    rng = np.random.default_rng(11)
+    n, m = 100_000, 4
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.05 * rng.standard_normal(n)
+    model = _fit_both(x, y, 'Cubic Splines', O.KERNEL_SPLINES, SPL, 41, burnin=150, draws=150)
+    assert model.mtx.shape[0] >= 4
+
+
+def test_config2_size_bernoulli_capped_fit_against_oracle():
+    """BASELINE configs[2] at full N = 1e6, M = 8 with the phis[:2] cap of SURVEY 8(d) (sub-stages of 8, 28, 8 terms)."""
+    rng = np.random.default_rng(12)
+    n, m = 1_000_000, 8
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.5 * x[:, 4] * x[:, 5] + 0.05 * rng.standard_normal(n)
+    model = _fit_both(x, y, 'Bernoulli Polynomials', O.KERNEL_BERNOULLI, BERN[:2], 1000, burnin=100, draws=100)
+    assert model.fit_stats['terms_physical'] == 44
+
+
+def test_many_inputs_three_way_fit_against_oracle():
+    """configs[3] family: 3-way interactions with M = 12 inputs -- beyond what the reference's M! enumeration can run
+    (SURVEY 8(a) F4), so the oracle (direct enumerator) is the only checker."""
+    rng = np.random.default_rng(13)
+    n, m = 4000, 12
+    x = rng.random((n, m))
+    y = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2] * x[:, 3] + 0.05 * rng.standard_normal(n)
+    model = _fit_both(x, y, 'Bernoulli Polynomials', O.KERNEL_BERNOULLI, BERN[:3], 77, burnin=60, draws=60, way3=True,
+                      tolerance=1)
+    assert model.mtx.shape[1] == 12
