@@ -111,13 +111,14 @@ def device_backend(device=None):
 
 def _host_blas_threads():
     """The per-candidate host algebra is tiny ((P+1)^2 eigenproblems, draws x (P+1) products): a BLAS pool sized for
-    a 256-thread host spends more time waking threads than computing.  Cap it (FOKL_HOST_THREADS, default 4)."""
+    a 256-thread host spends more time waking threads than computing, and its spinning workers compete with the
+    noise-tape thread.  Cap it (FOKL_HOST_THREADS, default 1: measured best on a 2 x 64-core EPYC host)."""
     import contextlib
     try:
         from threadpoolctl import threadpool_limits
     except Exception:
         return contextlib.nullcontext()
-    return threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '4')), user_api='blas')
+    return threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '1')), user_api='blas')
 
 
 _CLEAN_DEFAULTS = {'train': 1, 'AutoTranspose': True, 'SingleInstance': False, 'bit': 64,

@@ -44,9 +44,9 @@ SIGNATURES = {
     'fokl_timing_get': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'fokl_gibbs_chain': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_gibbs_chain_from_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp, c_vp,
-                                           c_vp, c_vp, c_vp, c_vp]),
+                                           c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_rng_normals': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'fokl_rng_gammas': (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_i64, c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
@@ -155,25 +155,37 @@ def gibbs_chain(lamb, qty, astar, atau_star, b, btau, dtd, sigsqd0, tausqd0, dra
 
 
 class NoiseTape:
-    """The data-independent random numbers of one candidate's chain (include/fokl_hip.h: fokl_noise_tape)."""
-    __slots__ = ('p1', 'draws', 'normals', 'gam_sig', 'gam_tau')
+    """The data-independent random numbers of one candidate's chain (include/fokl_hip.h: fokl_noise_tape).
+    ``progress[0]`` counts the iterations recorded so far (-1 = the producer failed)."""
+    __slots__ = ('p1', 'draws', 'normals', 'gam_sig', 'gam_tau', 'progress')
 
     def __init__(self, p1, draws):
         self.p1, self.draws = int(p1), int(draws)
         self.normals = np.empty((self.draws, self.p1), dtype=np.float64)
         self.gam_sig = np.empty(self.draws, dtype=np.float64)
         self.gam_tau = np.empty(self.draws, dtype=np.float64)
+        self.progress = np.zeros(1, dtype=np.int32)
 
 
-def noise_tape(p1, draws, astar, atau_star, stream):
-    tape = NoiseTape(p1, draws)
-    _check(load().fokl_noise_tape(tape.p1, tape.draws, float(astar), float(atau_star), *stream.args(),
-                                  _ptr(tape.normals), _ptr(tape.gam_sig), _ptr(tape.gam_tau)))
+def record_noise_tape(tape, astar, atau_star, stream):
+    """Fill ``tape`` from the stream (runs on the worker thread of engine.NoisePipeline; the GIL is released)."""
+    try:
+        _check(load().fokl_noise_tape(tape.p1, tape.draws, float(astar), float(atau_star), *stream.args(),
+                                      _ptr(tape.normals), _ptr(tape.gam_sig), _ptr(tape.gam_tau),
+                                      _ptr(tape.progress)))
+    except BaseException:
+        tape.progress[0] = -1
+        raise
     return tape
 
 
-def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_sig_tau=False):
-    """Replay the chain arithmetic on a recorded tape.  Returns (w, bstar_negative[, sigs, taus])."""
+def noise_tape(p1, draws, astar, atau_star, stream):
+    return record_noise_tape(NoiseTape(p1, draws), astar, atau_star, stream)
+
+
+def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_sig_tau=False, follow=False):
+    """Replay the chain arithmetic on a tape -- with ``follow=True`` on one that is still being recorded.
+    Returns (w, bstar_negative[, sigs, taus])."""
     lamb = np.ascontiguousarray(lamb, dtype=np.float64)
     qty = np.ascontiguousarray(qty, dtype=np.float64)
     p1 = lamb.shape[0]
@@ -186,7 +198,7 @@ def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_
     _check(load().fokl_gibbs_chain_from_tape(_ptr(lamb), _ptr(qty), p1, float(b), float(btau), float(dtd),
                                              float(sigsqd0), float(tausqd0), tape.draws, _ptr(tape.normals),
                                              _ptr(tape.gam_sig), _ptr(tape.gam_tau), _ptr(w), _ptr(sigs), _ptr(taus),
-                                             ctypes.byref(flag)))
+                                             ctypes.byref(flag), _ptr(tape.progress) if follow else c_vp(0)))
     if want_sig_tau:
         return w, bool(flag.value), sigs, taus
     return w, bool(flag.value)

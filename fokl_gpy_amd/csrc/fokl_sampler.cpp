@@ -325,16 +325,18 @@ extern "C" int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, d
 
 extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
                                int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
-                               double *gam_tau_out)
+                               double *gam_tau_out, int32_t *progress)
 {
     LegacyRng r;
     if (p1 <= 0 || draws < 0 || !normals_out || !gam_sig_out || !gam_tau_out ||
         !bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache)) {
         fokl_set_global_error("fokl_noise_tape: null pointer, empty model or invalid RNG state");
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
         return FOKL_ERR_ARG;
     }
     if (!(astar >= 0.0) || !(atau_star >= 0.0)) {
         fokl_set_global_error("fokl_noise_tape: gamma shape parameter is negative or NaN");
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
         return FOKL_ERR_NUMERIC;
     }
     Scratch &scratch = t_scratch;
@@ -342,6 +344,7 @@ extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star
         fill_normals(r, scratch, p1, normals_out + (size_t)k * p1);
         gam_sig_out[k] = r.std_gamma(astar);
         gam_tau_out[k] = r.std_gamma(atau_star);
+        if (progress) __atomic_store_n(progress, k + 1, __ATOMIC_RELEASE);   // iteration k is complete and visible
     }
     release_rng(r, mt_pos, has_gauss, gauss_cache);
     return FOKL_OK;
@@ -350,15 +353,25 @@ extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star
 extern "C" int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau,
                                           double dtd, double sigsqd0, double tausqd0, int draws,
                                           const double *normals, const double *gam_sig, const double *gam_tau,
-                                          double *w_out, double *sigs_out, double *taus_out, int32_t *bstar_negative)
+                                          double *w_out, double *sigs_out, double *taus_out, int32_t *bstar_negative,
+                                          const int32_t *progress)
 {
     if (!lamb || !qty || !normals || !gam_sig || !gam_tau || !w_out || p1 <= 0 || draws < 0) {
         fokl_set_global_error("fokl_gibbs_chain_from_tape: null pointer or empty model");
         return FOKL_ERR_ARG;
     }
     int32_t flagged = 0;
+    int32_t ready = progress ? 0 : draws;
     double sigsqd = sigsqd0, tausqd = tausqd0;
     for (int k = 0; k < draws; ++k) {
+        while (ready <= k) {                           // follow a tape that is still being recorded
+            ready = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
+            if (ready < 0) {
+                fokl_set_global_error("fokl_gibbs_chain_from_tape: the noise tape producer failed");
+                return FOKL_ERR_STATE;
+            }
+            if (ready <= k) __builtin_ia32_pause();
+        }
         const double inv_tau = 1.0 / tausqd;
         const double sig = std::sqrt(sigsqd);
         double *__restrict__ w = w_out + (size_t)k * p1;

@@ -196,17 +196,20 @@ class NoisePipeline:
             item = self._q.get()
             if item is None:
                 return
-            fut, p1, astar, atau_star = item
+            fut, tape, astar, atau_star = item
             try:
-                fut.set_result(_capi.noise_tape(p1, self.draws, astar, atau_star, self.stream))
+                fut.set_result(_capi.record_noise_tape(tape, astar, atau_star, self.stream))
             except BaseException as exc:            # surfaced on .result() in the main thread
                 fut.set_exception(exc)
 
     def request(self, p1, astar, atau_star):
+        """Queue the tape of one model evaluation.  Returns (tape, future): the tape's buffers exist at once and fill
+        up in the background (``tape.progress``), the future resolves when it is complete."""
         from concurrent.futures import Future
         fut = Future()
-        self._q.put((fut, int(p1), float(astar), float(atau_star)))
-        return fut
+        tape = _capi.NoiseTape(p1, self.draws)
+        self._q.put((fut, tape, float(astar), float(atau_star)))
+        return tape, fut
 
     def close(self):
         """Drain the queue (every requested tape advances the stream, used or not) and stop the worker."""
@@ -228,9 +231,11 @@ class GibbsOutcome:
     def w(self):
         if self._w is None:
             o = self._owner
-            tape = self._tape.result()
+            tape, fut = self._tape
+            # follows the tape while the worker is still recording it (C-level acquire/release on tape.progress)
             self._w, negative = _capi.gibbs_chain_from_tape(self.lamb, self.qty, o.b, o.btau, self.dtd, o.sigsqd0,
-                                                            o.tausqd0, tape)
+                                                            o.tausqd0, tape, follow=True)
+            fut.result()
             if negative:
                 raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
                                    "cannot reproduce the reference's skipped draw (FR:1538-1539)")
@@ -242,6 +247,13 @@ class GibbsOutcome:
         if self._betas is None:
             self._betas = self.w @ self.Q.T
         return self._betas
+
+    def beta_columns(self, cols):
+        """Draws of a few coefficients only: w Q[cols, :]' -- the kill-test statistics look at the new terms and the
+        intercept, never at the whole draws x (P+1) matrix."""
+        if self._betas is not None:
+            return self._betas[:, cols]
+        return self.w @ self.Q[cols, :].T
 
 
 class EagerOutcome:
@@ -257,6 +269,11 @@ class EagerOutcome:
         if self._betas is None:
             self._betas = self.w @ self.Q.T
         return self._betas
+
+    def beta_columns(self, cols):
+        if self._betas is not None:
+            return self._betas[:, cols]
+        return self.w @ self.Q[cols, :].T
 
 
 class ForwardSelection:
@@ -417,11 +434,10 @@ class ForwardSelection:
                 ev = full.ev
 
                 # statistics of the new terms (FR:1656-1664)
-                beters = full.betas
-                new = slice(dam - vm + 1, dam + 1)
-                mean_abs = np.abs(np.mean(beters[half1:draws, new], axis=0))
-                rel_std = np.divide(np.std(beters[half1:draws, new], axis=0),
-                                    np.abs(np.mean(beters[half0:draws, new], axis=0)))
+                beters_new = full.beta_columns(np.arange(dam - vm + 1, dam + 1))
+                mean_abs = np.abs(np.mean(beters_new[half1:draws], axis=0))
+                rel_std = np.divide(np.std(beters_new[half1:draws], axis=0),
+                                    np.abs(np.mean(beters_new[half0:draws], axis=0)))
                 order = np.argsort(mean_abs)
                 cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
                 mean_abs, rel_std = mean_abs[order], rel_std[order]
@@ -435,7 +451,8 @@ class ForwardSelection:
                     # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
                     if rel_std[i] > self.threshstdb or (
                             rel_std[i] > self.threshstda and
-                            mean_abs[i] < self.threshav * np.mean(np.abs(np.mean(best.betas[half0:draws, 0])))):
+                            mean_abs[i] < self.threshav * np.mean(np.abs(np.mean(
+                                best.beta_columns(np.array([0]))[half0:draws, 0])))):
                         trial = set(killed)
                         trial.add(int(cand_col[i]))
                         idx = [c for c in range(A) if c not in trial]

@@ -193,14 +193,17 @@ int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar
  * The split is exact unless some iteration has bstar < 0, where the reference skips a gamma draw (FR:1538-1539;
  * impossible for b > 0): *bstar_negative is then set to 1 and the caller must redo the candidate with
  * fokl_gibbs_chain from the stream state it saved before the tape.
+ * `progress` (may be NULL) lets the consumer follow a tape that is still being recorded on another thread: the
+ * producer stores k + 1 (release) after finishing iteration k, or -1 on failure; the consumer waits (acquire) until
+ * iteration k is there.  Both sides must be given the same int32, initialised to 0 before the producer starts.
  */
 int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
                     int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
-                    double *gam_tau_out);
+                    double *gam_tau_out, int32_t *progress);
 int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau, double dtd,
                                double sigsqd0, double tausqd0, int draws, const double *normals,
                                const double *gam_sig, const double *gam_tau, double *w_out, double *sigs_out,
-                               double *taus_out, int32_t *bstar_negative);
+                               double *taus_out, int32_t *bstar_negative, const int32_t *progress);
 
 /* Raw access to the same generator (parity tests against numpy): n standard normals / n std gammas. */
 int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,

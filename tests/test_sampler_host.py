@@ -101,6 +101,44 @@ def test_negative_bstar_skips_the_gamma_draw_and_goes_nan():
     assert np.isfinite(w[0]).all()
 
 
+def test_noise_tape_split_is_bitwise_the_sequential_chain():
+    """fokl_noise_tape + fokl_gibbs_chain_from_tape == fokl_gibbs_chain: same draws, same stream position --
+    also when the consumer follows a tape that another thread is still recording."""
+    import threading
+    p, draws = 37, 400
+    lamb = np.linspace(2.0, 5e4, p)
+    qty = np.random.default_rng(0).standard_normal(p) * 50
+    args = (12.0, 3.0, 9e4, 0.4, 0.9)
+    np.random.seed(5)
+    st = _capi.LegacyStream()
+    w1, s1, t1 = _capi.gibbs_chain(lamb, qty, 3e3, 22.5, *args, draws, st, want_sig_tau=True)
+    end1 = st.as_numpy_state()
+
+    np.random.seed(5)
+    st2 = _capi.LegacyStream()
+    tape = _capi.noise_tape(p, draws, 3e3, 22.5, st2)
+    w2, neg, s2, t2 = _capi.gibbs_chain_from_tape(lamb, qty, *args, tape, want_sig_tau=True)
+    end2 = st2.as_numpy_state()
+    assert not neg and np.array_equal(w1, w2) and np.array_equal(s1, s2) and np.array_equal(t1, t2)
+    assert np.array_equal(end1[1], end2[1]) and end1[2:] == end2[2:]
+
+    np.random.seed(5)
+    st3 = _capi.LegacyStream()
+    live = _capi.NoiseTape(p, draws)
+    producer = threading.Thread(target=_capi.record_noise_tape, args=(live, 3e3, 22.5, st3))
+    producer.start()
+    w3, neg3 = _capi.gibbs_chain_from_tape(lamb, qty, *args, live, follow=True)
+    producer.join()
+    assert not neg3 and np.array_equal(w1, w3) and int(live.progress[0]) == draws
+
+    # b < 0 can make bstar negative: the split reports it instead of silently diverging from FR:1538-1541
+    np.random.seed(5)
+    st4 = _capi.LegacyStream()
+    tape4 = _capi.noise_tape(2, 3, 10.0, 5.0, st4)
+    _, neg4 = _capi.gibbs_chain_from_tape(np.array([1.0, 2.0]), np.array([0.5, -0.25]), -1e9, 1.0, 0.0, 1.0, 1.0, tape4)
+    assert neg4
+
+
 def test_bad_arguments_are_rejected():
     st = _capi.LegacyStream()
     with pytest.raises(_capi.FoklNativeError):

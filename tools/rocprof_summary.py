@@ -22,7 +22,7 @@ def find(dirname, suffix):
 
 def short(name):
     name = name.replace('void ', '')
-    for key in ('basis_build_kernel', 'gram_mfma_kernel', 'gram_valu_kernel', 'resid_kernel', 'reduce_slabs_kernel',
+    for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_mfma_kernel', 'gram_valu_kernel', 'resid_kernel', 'reduce_slabs_kernel',
                 'transpose_inputs_kernel', 'predict_kernel'):
         if key in name:
             tag = ''
@@ -77,7 +77,8 @@ def cmd_pmc(dirname, out, counters):
 
 
 def family(name):
-    for key, fam in (('basis_build_kernel', 'basis_build'), ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
+    for key, fam in (('basis_build_reg_kernel', 'basis_build'), ('basis_build_kernel', 'basis_build'),
+                     ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
                      ('resid_kernel', 'resid')):
         if key in name:
             return fam
