@@ -54,6 +54,7 @@ struct fokl_ctx {
     int64_t n = 0, ld = 0;
     int m = 0, kernel = 0, n_basis = 0, width = 0;
     double *d_x = nullptr;      // [m][ld]
+    double *d_zero = nullptr;   // [ld] zeros: stands in for padding columns of Gram panels
     double *d_phis = nullptr;
     size_t phis_doubles = 0;
 
@@ -310,6 +311,7 @@ extern "C" void fokl_ctx_destroy(fokl_ctx *ctx)
     if (ctx->d_slot_ptr) (void)hipFree(ctx->d_slot_ptr);
     if (ctx->d_x) (void)hipFree(ctx->d_x);
     if (ctx->d_phis) (void)hipFree(ctx->d_phis);
+    if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->d_args) (void)hipFree(ctx->d_args);
     if (ctx->h_args) (void)hipHostFree(ctx->h_args);
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
@@ -392,8 +394,10 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
     free_slots(ctx);
     if (ctx->d_x) HIP_TRY(ctx, hipFree(ctx->d_x));
     if (ctx->d_phis) HIP_TRY(ctx, hipFree(ctx->d_phis));
+    if (ctx->d_zero) HIP_TRY(ctx, hipFree(ctx->d_zero));
     ctx->d_x = nullptr;
     ctx->d_phis = nullptr;
+    ctx->d_zero = nullptr;
     ctx->have_data = false;
 
     ctx->n = n;
@@ -406,6 +410,8 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
 
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_x, (size_t)m * ctx->ld * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_phis, ctx->phis_doubles * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zero, (size_t)ctx->ld * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(ctx->d_zero, 0, (size_t)ctx->ld * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_phis, phis, ctx->phis_doubles * sizeof(double), hipMemcpyHostToDevice));
 
     ctx->have_data = true;
@@ -651,7 +657,8 @@ static int blocks_per_cu(F fn, int threads, size_t dyn_lds)
 }
 
 // One instantiation per tile configuration; the dispatcher below picks the smallest that covers the block.
-typedef void (*gram_mfma_fn)(double *const *, const int *, int, const int *, int, int64_t, double *, int, int);
+typedef void (*gram_mfma_fn)(double *const *, const int *, int, const int *, int, int64_t, double *, int, int,
+                             const double *);
 
 template <int TJ>
 static gram_mfma_fn pick_isplit()
@@ -772,7 +779,7 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
             TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
             if (use_mfma) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
-                                   nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
+                                   nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);
             } else {
                 hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
                                    nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);

@@ -24,6 +24,17 @@ constexpr int K1_MAX_LDS_SLABS = 4;                         // spline orders sta
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Column pointers come out of a table in memory, so the compiler only knows them as generic ("flat") pointers and
+// would emit flat_load / flat_store, which also count on the LDS counter (lgkmcnt) and so serialise against every
+// ds_read wait.  All slot memory is hipMalloc'ed global memory: say so.
+typedef __attribute__((address_space(1))) const d2 *global_cd2_ptr;
+typedef __attribute__((address_space(1))) d2 *global_d2_ptr;
+typedef __attribute__((address_space(1))) double *global_d_ptr;
+
+__device__ __forceinline__ d2 load_d2(const double *p) { return *(global_cd2_ptr)(p); }
+__device__ __forceinline__ void store_d2(double *p, d2 v) { *(global_d2_ptr)(p) = v; }
+__device__ __forceinline__ void store_d1(double *p, double v) { *(global_d_ptr)(p) = v; }
+
 // ---------------------------------------------------------------------------------------------------------
 // K1: basis build
 // ---------------------------------------------------------------------------------------------------------
@@ -172,9 +183,9 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
             }
             double *col = slot_ptr[term_slot[j]];
             if (in1) {
-                *reinterpret_cast<d2 *>(col + r0) = phi;
+                store_d2(col + r0, phi);
             } else if (in0) {
-                col[r0] = phi.x;
+                store_d1(col + r0, phi.x);
             }
         }
     }
@@ -265,9 +276,9 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
             }
             double *col = slot_ptr[term_slot[j]];
             if (in1) {
-                *reinterpret_cast<d2 *>(col + r0) = phi;
+                store_d2(col + r0, phi);
             } else if (in0) {
-                col[r0] = phi.x;
+                store_d1(col + r0, phi.x);
             }
         }
     }
@@ -335,12 +346,12 @@ __global__ __launch_bounds__(GV_THREADS) void gram_valu_kernel(double *const *__
         const bool two = r + 1 < n;
 #pragma unroll
         for (int i = 0; i < GV_TI; ++i) {
-            av[i] = *reinterpret_cast<const d2 *>(a[i] + r);
+            av[i] = load_d2(a[i] + r);
             if (!two) av[i].y = 0.0;
         }
 #pragma unroll
         for (int j = 0; j < GV_TJ; ++j) {
-            bv[j] = *reinterpret_cast<const d2 *>(b[j] + r);
+            bv[j] = load_d2(b[j] + r);
             if (!two) bv[j].y = 0.0;
         }
 #pragma unroll
@@ -434,7 +445,8 @@ template <int TI, int TJ, bool ISPLIT>
 __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__restrict__ slot_ptr,
                                                                const int *__restrict__ row_slots, int nr,
                                                                const int *__restrict__ col_slots, int nc, int64_t n,
-                                                               double *__restrict__ slab, int nr_pad, int nc_pad)
+                                                               double *__restrict__ slab, int nr_pad, int nc_pad,
+                                                               const double *__restrict__ zero_col)
 {
     static_assert(!ISPLIT || TI == 4, "i-split needs one i-tile per wavefront");
     constexpr int BI = 16 * TI;
@@ -443,21 +455,16 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     constexpr int PASSES = (NCOL + 15) / 16;              // 16 columns x 16 row pairs per pass of the block
     constexpr int MI = ISPLIT ? 1 : TI;                    // i-tiles per wave
     __shared__ __attribute__((aligned(16))) double tile[NCOL * GM_PITCH];
-    __shared__ const double *colptr[NCOL];
+    const double *const *colptr = nullptr;
 
     const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
     const int i0 = blockIdx.z * BI, j0 = blockIdx.y * BJ;
 
-    for (int c = tid; c < NCOL; c += GM_THREADS) {
-        const double *p = nullptr;
-        if (c < BI) {
-            if (i0 + c < nr) p = slot_ptr[row_slots[i0 + c]];
-        } else {
-            if (j0 + (c - BI) < nc) p = slot_ptr[col_slots[j0 + (c - BI)]];
-        }
-        colptr[c] = p;
-    }
-    __syncthreads();
+    // Column pointers of this thread's staging passes live in registers for the whole kernel; columns beyond the
+    // block (padding) read a zero-filled column, so every pass is one unconditional 16-byte load and all of them
+    // are in flight together (a data-dependent fix-up or branch right after a load would serialise them).
+    constexpr int PCHUNK = (NCOL + 15) / 16;
+    (void)colptr;
 
     d4 acc[MI][TJ];
 #pragma unroll
@@ -468,29 +475,36 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     // staging map: thread t loads rows {2 (t & 15), 2 (t & 15) + 1} of column (t >> 4) + 16 * pass
     const int spair = tid & 15, scol = tid >> 4;
     const int64_t n_chunks = (n + GM_R - 1) / GM_R;
+    const double *cp[PCHUNK];
+#pragma unroll
+    for (int p = 0; p < PCHUNK; ++p) {
+        const int c = scol + 16 * p;                       // NCOL is a multiple of 16: always a valid panel column
+        const double *ptr = zero_col;
+        if (c < BI) {
+            if (i0 + c < nr) ptr = slot_ptr[row_slots[i0 + c]];
+        } else {
+            if (j0 + (c - BI) < nc) ptr = slot_ptr[col_slots[j0 + (c - BI)]];
+        }
+        cp[p] = ptr;
+    }
     d2 stage[PASSES];
+    int64_t staged_row = 0;
 
     auto issue = [&](int64_t chunk) {
         const int64_t r = chunk * GM_R + 2 * spair;
+        staged_row = r;
+        const int64_t rc = r < n ? r : 0;                  // rows past the end are masked at commit time
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int c = scol + 16 * p;
-            d2 v = {0.0, 0.0};
-            if (c < NCOL) {
-                const double *cp = colptr[c];
-                if (cp != nullptr && r < n) {
-                    v = *reinterpret_cast<const d2 *>(cp + r);     // r even, ld even: in bounds whenever r < n
-                    if (r + 1 >= n) v.y = 0.0;
-                }
-            }
-            stage[p] = v;
-        }
+        for (int p = 0; p < PASSES; ++p) stage[p] = load_d2(cp[p] + rc);
     };
     auto commit = [&]() {
+        const bool ok0 = staged_row < n, ok1 = staged_row + 1 < n;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int c = scol + 16 * p;
-            if (c < NCOL) *reinterpret_cast<d2 *>(&tile[c * GM_PITCH + 2 * spair]) = stage[p];
+            d2 v = stage[p];
+            if (!ok0) v.x = 0.0;
+            if (!ok1) v.y = 0.0;
+            *reinterpret_cast<d2 *>(&tile[(scol + 16 * p) * GM_PITCH + 2 * spair]) = v;
         }
     };
 
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
 #pragma unroll 8
                 for (int j = 0; j < cnt; ++j) {
                     const ResidCol c = cols[j];
-                    const d2 xv = *reinterpret_cast<const d2 *>(c.ptr + r);
+                    const d2 xv = load_d2(c.ptr + r);
                     fit.x = __builtin_fma(c.beta, xv.x, fit.x);
                     fit.y = __builtin_fma(c.beta, xv.y, fit.y);
                 }
