@@ -191,6 +191,11 @@ def main():
                     total_ms=k['ms'])
 
     kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm')}
+    if kernels['gram']:
+        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings
+        gm = roof('gram', 'mfma')
+        kernels['gram']['mfma_achieved_tflops'] = gm['achieved']
+        kernels['gram']['mfma_frac'] = gm['frac']
     # HBM traffic per launch from the committed PMC passes of this same workload (profiles/pmc_r01.json, produced by
     # tools/profile_r01.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note).
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_r01.json')
