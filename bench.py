@@ -101,6 +101,19 @@ def main():
             sys.exit(2)
     os.environ['FOKL_DEVICE'] = str(local)
 
+    # Keep this rank's two busy threads (search driver + random-stream worker) on cores that share an L3: the noise
+    # tapes (about 1 MB each) are handed from one to the other.  Eight consecutive logical CPUs per rank.
+    pinned = None
+    if os.environ.get('FOKL_BENCH_PIN', '1') != '0' and hasattr(os, 'sched_setaffinity'):
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+            want = [c for c in range(8 * local, 8 * local + 8) if c in allowed]
+            if len(want) >= 2:
+                os.sched_setaffinity(0, want)
+                pinned = want
+        except OSError:
+            pinned = None
+
     from fokl_gpy_amd import FoKLRoutines, _capi
     backend = FoKLRoutines.device_backend(local)          # raises without libfokl_hip.so / a gfx950 device
     ctx = backend.ctx
@@ -132,11 +145,14 @@ def main():
         ctx.sync()
         t0 = time.perf_counter()
         logical = physical = calls = 0
+        host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0)
         for _ in range(args.steps):
             st = one_step()
             logical += st['terms_logical']
             physical += st['terms_physical']
             calls += st['gibbs_calls']
+            for key in host:
+                host[key] += st.get(key, 0)
         ctx.sync()
         comm.barrier()
         elapsed = time.perf_counter() - t0
@@ -232,6 +248,8 @@ def main():
         'gibbs_calls_per_step': float(np.sum(gathered[:, 3])) / world / max(args.steps, 1),
         'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
         'host_prepare_s': prep_s,
+        'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
+        'cpu_pinning': pinned,
         'roofline': dominant,
         'kernels': kernels,
         'basis_build_sustained': hot,

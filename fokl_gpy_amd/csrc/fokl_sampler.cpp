@@ -31,11 +31,65 @@ namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
 
+// Element-wise pieces of the generator, written as plain loops over arrays so that the compiler vectorises them
+// (an AVX2 clone is selected at load time; IEEE operations per element, so lanes change nothing in the results).
+__attribute__((target_clones("avx2", "default")))
+void words_to_doubles(const uint32_t *__restrict__ k, int count, double *__restrict__ out)
+{
+    for (int j = 0; j < count; ++j) {                   // tempering + numpy's 53-bit double from two words
+        uint32_t wa = k[2 * j], wb = k[2 * j + 1];
+        wa ^= (wa >> 11);
+        wb ^= (wb >> 11);
+        wa ^= (wa << 7) & 0x9d2c5680u;
+        wb ^= (wb << 7) & 0x9d2c5680u;
+        wa ^= (wa << 15) & 0xefc60000u;
+        wb ^= (wb << 15) & 0xefc60000u;
+        wa ^= (wa >> 18);
+        wb ^= (wb >> 18);
+        out[j] = ((double)(int32_t)(wa >> 5) * 67108864.0 + (double)(int32_t)(wb >> 6)) / 9007199254740992.0;
+    }
+}
+
+__attribute__((target_clones("avx2", "default")))
+void polar_candidates(const double *__restrict__ d, int attempts, double *__restrict__ t1, double *__restrict__ t2,
+                      double *__restrict__ tr)
+{
+    for (int i = 0; i < attempts; ++i) {
+        const double x1 = 2.0 * d[2 * i] - 1.0, x2 = 2.0 * d[2 * i + 1] - 1.0;
+        t1[i] = x1;
+        t2[i] = x2;
+        tr[i] = x1 * x1 + x2 * x2;
+    }
+}
+
+__attribute__((target_clones("avx2", "default")))
+void polar_finish(const double *__restrict__ lg, const double *__restrict__ x1, const double *__restrict__ x2,
+                  const double *__restrict__ r2, int count, double *__restrict__ out)
+{
+    double f[MT_N / 4];                                  // callers pass count <= MT_N / 4
+    for (int i = 0; i < count; ++i) f[i] = std::sqrt(-2.0 * lg[i] / r2[i]);   // contiguous: vectorised div + sqrt
+    for (int i = 0; i < count; ++i) {
+        out[2 * i] = f[i] * x2[i];
+        out[2 * i + 1] = f[i] * x1[i];
+    }
+}
+
 struct LegacyRng {
     uint32_t *key;      // 624 words, caller owned (np.random.get_state()[1])
     int pos;
     int has_gauss;
     double gauss;
+    // doubles of the current 624-word block, converted in one vectorised pass: entry j <-> words dbase + 2j, + 1
+    int dbase = -1, dcount = 0;
+    double dbuf[MT_N / 2];
+    double t1[MT_N / 4 + 1], t2[MT_N / 4 + 1], tr[MT_N / 4 + 1];
+
+    inline void build_dbuf()
+    {
+        dbase = pos;
+        dcount = (MT_N - pos) / 2;
+        words_to_doubles(key + pos, dcount, dbuf);
+    }
 
     void refill()
     {
@@ -52,6 +106,7 @@ struct LegacyRng {
         const uint32_t y = (k[MT_N - 1] & UPPER) | (k[0] & LOWER);
         k[MT_N - 1] = k[MT_M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MAG);
         pos = 0;
+        dbase = -1;
     }
 
     static inline uint32_t temper(uint32_t y)
@@ -77,9 +132,25 @@ struct LegacyRng {
 
     inline double next_double()
     {
-        const uint32_t wa = next32();
-        const uint32_t wb = next32();
-        return to_double(wa, wb);
+        for (;;) {
+            if (dbase >= 0) {
+                const int j = (pos - dbase) >> 1;
+                if (j < dcount) {
+                    pos += 2;
+                    return dbuf[j];
+                }
+            }
+            if (pos >= MT_N) refill();
+            if (pos + 1 < MT_N) {
+                build_dbuf();
+                continue;
+            }
+            // a single word is left in this block: the double straddles the refill
+            const uint32_t wa = next32();
+            const uint32_t wb = next32();
+            dbase = -1;
+            return to_double(wa, wb);
+        }
     }
 
     // `count` accepted polar pairs -> 2 * count normals in numpy's order (f * x2 first, then the value numpy
@@ -88,26 +159,39 @@ struct LegacyRng {
     {
         int have = 0;
         while (have < count) {
-            double x1, x2;
-            if (pos + 4 <= MT_N) {                       // fast path: four words without refill checks
-                const uint32_t *k = key + pos;
-                x1 = 2.0 * to_double(temper(k[0]), temper(k[1])) - 1.0;
-                x2 = 2.0 * to_double(temper(k[2]), temper(k[3])) - 1.0;
-                pos += 4;
-            } else {
-                x1 = 2.0 * next_double() - 1.0;
-                x2 = 2.0 * next_double() - 1.0;
+            int j0 = dbase >= 0 ? (pos - dbase) >> 1 : dcount;
+            if (dbase < 0 || dcount - j0 < 2) {
+                // block (nearly) exhausted or not converted yet: one attempt through the general path
+                const double x1 = 2.0 * next_double() - 1.0;
+                const double x2 = 2.0 * next_double() - 1.0;
+                const double r2 = x1 * x1 + x2 * x2;
+                x1s[have] = x1;
+                x2s[have] = x2;
+                r2s[have] = r2;
+                have += (r2 < 1.0) & (r2 != 0.0);
+                continue;
             }
-            const double r2 = x1 * x1 + x2 * x2;
-            x1s[have] = x1;
-            x2s[have] = x2;
-            r2s[have] = r2;
-            have += (r2 < 1.0) & (r2 != 0.0);            // branch-free accept
+            const int need = count - have;
+            const int attempts = std::min((dcount - j0) / 2, need + need / 2 + 8);
+            polar_candidates(dbuf + j0, attempts, t1, t2, tr);
+            int used = attempts;
+            for (int i = 0; i < attempts; ++i) {         // branch-free compaction of the accepted attempts
+                x1s[have] = t1[i];
+                x2s[have] = t2[i];
+                r2s[have] = tr[i];
+                have += (tr[i] < 1.0) & (tr[i] != 0.0);
+                if (have == count) {
+                    used = i + 1;
+                    break;
+                }
+            }
+            pos += 4 * used;                             // attempts computed beyond `used` were never drawn
         }
-        for (int i = 0; i < count; ++i) {
-            const double f = std::sqrt(-2.0 * std::log(r2s[i]) / r2s[i]);
-            out[2 * i] = f * x2s[i];
-            out[2 * i + 1] = f * x1s[i];
+        double *lg = t1;                                 // scratch: count <= MT_N / 4 + 1 is not guaranteed -> chunk
+        for (int base = 0; base < count; base += MT_N / 4) {
+            const int c = std::min(MT_N / 4, count - base);
+            for (int i = 0; i < c; ++i) lg[i] = std::log(r2s[base + i]);
+            polar_finish(lg, x1s + base, x2s + base, r2s + base, c, out + 2 * base);
         }
     }
 

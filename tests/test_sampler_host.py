@@ -25,6 +25,22 @@ def test_stream_is_bit_identical_to_numpy(seed):
     assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
 
 
+@pytest.mark.parametrize('start', [1, 2, 311, 620, 621, 622, 623, 624])
+def test_stream_from_any_word_position(start):
+    """The block-wise double conversion pairs words relative to the CURRENT position: odd positions (left by 32-bit
+    draws of other numpy calls) and doubles that straddle a 624-word refill must still match numpy."""
+    np.random.seed(99)
+    base = np.random.get_state()
+    np.random.set_state(('MT19937', base[1], start, 0, 0.0))
+    st = _capi.LegacyStream()
+    want = np.concatenate([np.random.normal(size=701), np.atleast_1d(np.random.gamma(7.5, 2.0)),
+                           np.random.normal(size=1300)])
+    got = np.concatenate([st.normals(701), st.gammas(7.5, 2.0, 1), st.normals(1300)])
+    assert np.array_equal(want, got)
+    a, b = np.random.get_state(), st.as_numpy_state()
+    assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
 def test_small_shape_branches_match_numpy():
     np.random.seed(3)
     st = _capi.LegacyStream()
