@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--rows', type=int, default=1_000_000)
     ap.add_argument('--inputs', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-microbench', action='store_true',
+                    help='skip the back-to-back basis-build launches after the timed region (used for profiler runs)')
     args = ap.parse_args()
 
     from fokl_gpy_amd import dist
@@ -165,7 +167,7 @@ def main():
     # Inside a fit the GPU idles between launches (the fit is bound by the serial random stream on the host), so the
     # in-situ average above is taken at idle clocks; this is the same kernel at sustained clocks.
     hot = {}
-    if rank == 0:
+    if rank == 0 and not args.no_microbench:
         from fokl_gpy_amd import engine
         ctx.timing_enable(True)
         ctx.reserve_slots(2 + 56)

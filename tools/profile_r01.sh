@@ -6,12 +6,12 @@ set -x
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_r01
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-microbench > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-microbench > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-microbench > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 python3 bench.py --steps 3 --warmup 1 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rm -f $OUT/summary.md
-echo "## kernel trace + stats: python3 bench.py --steps 3 --warmup 1" >> $OUT/summary.md
+echo "## kernel trace + stats: python3 bench.py --steps 3 --warmup 1 --no-microbench" >> $OUT/summary.md
 python3 tools/rocprof_summary.py stats $OUT/stats $OUT/summary.md
 echo "## PMC FETCH_SIZE (KiB per dispatch, raw): python3 bench.py --steps 1 --warmup 0" >> $OUT/summary.md
 python3 tools/rocprof_summary.py pmc $OUT/pmc_fetch $OUT/summary.md FETCH_SIZE
