@@ -1,6 +1,7 @@
 // Device kernels of libfokl_hip.so (gfx950 / CDNA4 only; 64-wide wavefronts, fp64 throughout).
 //
-//   K1  basis_build_kernel   fused _inputs_to_phind + evaluate_basis + term products   (HBM write bound)
+//   K1  basis_build_reg_kernel  fused _inputs_to_phind + evaluate_basis + term products (HBM write bound);
+//       basis_build_kernel      the same with the factor table in LDS (terms with more than 16 factors)
 //   K2a gram_valu_kernel     Gram block with per-thread register tiles + wavefront reductions
 //   K2b gram_mfma_kernel     Gram block on v_mfma_f64_16x16x4_f64 tiles staged through LDS
 //   K3  resid_kernel         residual moments for the BIC
@@ -455,7 +456,6 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     constexpr int PASSES = (NCOL + 15) / 16;              // 16 columns x 16 row pairs per pass of the block
     constexpr int MI = ISPLIT ? 1 : TI;                    // i-tiles per wave
     __shared__ __attribute__((aligned(16))) double tile[NCOL * GM_PITCH];
-    const double *const *colptr = nullptr;
 
     const int tid = threadIdx.x, wave = tid / WAVE, lane = tid % WAVE;
     const int i0 = blockIdx.z * BI, j0 = blockIdx.y * BJ;
@@ -464,7 +464,6 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     // block (padding) read a zero-filled column, so every pass is one unconditional 16-byte load and all of them
     // are in flight together (a data-dependent fix-up or branch right after a load would serialise them).
     constexpr int PCHUNK = (NCOL + 15) / 16;
-    (void)colptr;
 
     d4 acc[MI][TJ];
 #pragma unroll
