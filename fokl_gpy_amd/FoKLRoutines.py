@@ -3,13 +3,13 @@
 
 Keeps the reference's public surface (``src/FoKL/FoKLRoutines.py``, "FR"): the constructor keywords and
 defaults (FR:205-216), ``clean`` (FR:441), ``fit`` (FR:1202), ``evaluate`` (FR:851), ``coverage3`` (FR:982),
-``evaluate_basis`` (FR:807), ``save`` / ``load`` / ``clear`` and the result attributes ``betas, avg_betas, mtx,
-evs, inputs, data, minmax, trainlog``.  The numerics of ``fit`` and ``evaluate`` run on the GPU through
-``libfokl_hip.so`` (see ``engine.py`` and ``include/fokl_hip.h``); there is no CPU fallback -- without the
-library or a gfx950 device ``fit`` raises.
+``bss_derivatives`` (FR:594), ``evaluate_basis`` (FR:807), ``save`` / ``load`` / ``clear`` and the result attributes
+``betas, avg_betas, mtx, evs, inputs, data, minmax, trainlog``.  The numerics of ``fit``, ``evaluate`` and
+``bss_derivatives`` run on the GPU through ``libfokl_hip.so`` (see ``engine.py`` and ``include/fokl_hip.h``); there
+is no CPU fallback -- without the library or a gfx950 device they raise.
 
-Deliberately NOT rebuilt (out of the hot-path scope): ``bss_derivatives``, ``fitupdate``
-(``update=True``), ``to_pyomo``; calling them raises ``NotImplementedError``.
+Deliberately NOT rebuilt (out of the hot-path scope): ``fitupdate`` (``update=True``),
+``to_pyomo``; calling them raises ``NotImplementedError``.
 
 Device selection is by environment (``FOKL_DEVICE``, else ``LOCAL_RANK``, else 0), never by a new keyword:
 unknown keywords must keep raising ``ValueError`` exactly like the reference (FR:78).
@@ -813,7 +813,146 @@ class FoKL:
         return path
 
     def bss_derivatives(self, **kwargs):
-        raise NotImplementedError("bss_derivatives (FR:594-805) is outside the scope of this build")
+        """
+        Gradient (and optionally second partial derivatives) of the fitted model with respect to the inputs
+        (FR:594-805).  Keywords: inputs, kernel, d1, d2, draws, betas, phis, mtx, minmax, IndividualDraws,
+        ReturnFullArray, ReturnBasis -- same meaning, defaults and output shapes as the reference.
+
+        On the device: for every requested (input m, order) pair the terms that contain x_m are rebuilt with the
+        factor of x_m replaced by its derivative (``fokl_build_terms_deriv``), and the columns are contracted with
+        the draws (``fokl_predict`` for the mean over draws).
+        """
+        current = _process_kwargs({'inputs': None, 'kernel': self.kernel, 'd1': None, 'd2': None, 'draws': self.draws,
+                                   'betas': None, 'phis': None, 'mtx': self.mtx, 'minmax': self.minmax,
+                                   'IndividualDraws': False, 'ReturnFullArray': False, 'ReturnBasis': False}, kwargs)
+        for flag in ('IndividualDraws', 'ReturnFullArray', 'ReturnBasis'):
+            current[flag] = _str_to_bool(current[flag])
+        inputs = self.inputs if current['inputs'] is None else current['inputs']
+        betas = self.betas if current['betas'] is None else current['betas']
+        phis = self.phis if current['phis'] is None else current['phis']
+        kernel, draws, mtx, span = current['kernel'], current['draws'], current['mtx'], current['minmax']
+
+        inputs = np.array(inputs)
+        if inputs.ndim == 1:
+            inputs = inputs[:, np.newaxis]
+        if isinstance(betas, list):
+            betas = np.array(betas)
+            if betas.ndim == 1:
+                betas = betas[:, np.newaxis]
+        if isinstance(mtx, int):
+            mtx = np.array(mtx)[np.newaxis, np.newaxis]
+        else:
+            mtx = np.array(mtx)
+            if mtx.ndim == 1:
+                mtx = mtx[:, np.newaxis]
+        if len(span) == 2 and not isinstance(span[0], (list, np.ndarray)):
+            span = [span]
+        if np.max(np.max(inputs)) > 1 or np.min(np.min(inputs)) < 0:
+            warnings.warn("Input 'inputs' should be normalized (0-1). Auto-normalization is in-development.",
+                          category=UserWarning)
+
+        N = np.shape(inputs)[0]
+        B, M = np.shape(mtx)
+        if B != np.shape(betas)[1] - 1:
+            betas = np.transpose(betas)
+            if B != np.shape(betas)[1] - 1:
+                raise ValueError("The shape of 'betas' does not align with the shape of 'mtx'. Transposing did not "
+                                 "fix this.")
+
+        derv = []
+        for which, di in enumerate((current['d1'], current['d2'])):
+            ok = False
+            if di is None:
+                di, ok = (np.ones(M, dtype=bool) if which == 0 else np.zeros(M, dtype=bool)), True
+            elif isinstance(di, str):
+                di, ok = (np.ones(M, dtype=bool) if _str_to_bool(di) else np.zeros(M, dtype=bool)), True
+            elif isinstance(di, list):
+                if len(di) == 1:
+                    di = di[0]
+                elif len(di) == M:
+                    di, ok = np.array(di) != 0, True
+                else:
+                    raise ValueError("Keyword input 'd1' and/or 'd2', if entered as a list, must be of equal length to "
+                                     "the number of input variables.")
+            if isinstance(di, bool):
+                di, ok = np.ones(M, dtype=bool) * di, True
+            elif isinstance(di, int):
+                which_input, di = di, np.zeros(M, dtype=bool)
+                di[which_input] = True
+                ok = True
+            if not ok:
+                raise ValueError("Keyword input 'd1' and/or 'd2' is limited to an integer indexing an input variable, "
+                                 "or to a list of booleans corresponding to the input variables.")
+            derv.append(di)
+        orders = [di for di in (0, 1) if any(derv[di])]
+        if not orders:
+            warnings.warn("Function 'bss_derivatives' was called but no derivatives were requested.",
+                          category=UserWarning)
+            return
+
+        span_m = [span[m][1] - span[m][0] for m in range(M)]
+        kid = getKernels.KERNEL_SPLINES if kernel == self.kernels[0] else getKernels.KERNEL_BERNOULLI
+        L_phis = len(phis[0][0]) if kid == getKernels.KERNEL_SPLINES else 1
+        inputs64 = np.ascontiguousarray(inputs, dtype=np.float64)
+        if kid == getKernels.KERNEL_SPLINES:
+            self._inputs_to_phind(inputs64, phis, kernel)                # range validation (FR:590-591)
+        backend = self._backend()
+        packed, nb, width = getKernels.pack_phis(phis, kid)
+        backend.upload(inputs64, np.zeros(N), kid, packed, nb, width)
+        pool = _engine.SlotPool(backend, initial=max(64, B + 2))
+
+        individual = current['IndividualDraws'] or not draws > 1
+        dy = np.zeros([N, M, 2, draws if individual else 1])
+        coef_all = np.asarray(betas)[-draws:, :]
+        for m in range(M):
+            rows = [b for b in range(B) if int(mtx[b, m]) != 0]         # other terms do not depend on x_m (FR:785-787)
+            if not rows:
+                continue
+            for di in orders:
+                if not derv[di][m]:
+                    continue
+                span_L = span_m[m] / L_phis
+                divisor = [1, span_L, span_L ** 2][di + 1]                # FR:758-759
+                slots = pool.take(len(rows))
+                backend.build_terms_deriv(np.asarray(mtx[rows], dtype=np.int32), slots, m, di + 1, divisor)
+                coef = np.ascontiguousarray(coef_all[:, [b + 1 for b in rows]], dtype=np.float64)
+                if individual:
+                    cols = np.stack([backend.read_slot(s) for s in slots], axis=1)
+                    dy[:, m, di, :] = cols @ coef.T
+                else:
+                    dy[:, m, di, 0] = backend.predict(slots, coef)       # mean over the draws (FR:793-794)
+                pool.give(slots)
+
+        if not current['ReturnFullArray']:
+            dy = np.concatenate([dy[:, :, 0, :], dy[:, :, 1, :]], axis=1)
+            dy = dy[:, ~np.all(dy == 0, axis=0)]
+        dy = np.squeeze(dy)
+
+        if current['ReturnBasis']:
+            # the reference keeps overwriting `basis[n]` inside its loops (FR:783-784); what survives is the basis
+            # function of the last (term, input) pair it visits
+            basis = np.zeros(N)
+            last_m = max(m for m in range(M) if any(derv[di][m] for di in orders))
+            b = B - 1
+            visited = []
+            for md in range(M):
+                if int(mtx[b, md]):
+                    visited.append(md)
+                elif md == last_m:
+                    break
+            if visited:
+                md = visited[-1]
+                num = int(mtx[b, md]) - 1
+                if kid == getKernels.KERNEL_SPLINES:
+                    X, phind, _ = self._inputs_to_phind(inputs64, phis, kernel)
+                    for n in range(N):
+                        c = [phis[num][k][int(phind[n, md])] for k in range(4)]
+                        basis[n] = self.evaluate_basis(c, X[n, md], kernel=kernel)
+                else:
+                    for n in range(N):
+                        basis[n] = self.evaluate_basis(phis[num], inputs64[n, md], kernel=kernel)
+            return dy, basis
+        return dy
 
     def fitupdate(self, inputs, data):
         raise NotImplementedError("fitupdate (FR:1850-2583) is outside the scope of this build")

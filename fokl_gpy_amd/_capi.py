@@ -32,6 +32,7 @@ SIGNATURES = {
     'fokl_slot_capacity': (c_int, [c_vp]),
     'fokl_rows': (c_i64, [c_vp]),
     'fokl_build_terms': (c_int, [c_vp, c_vp, c_int, c_vp]),
+    'fokl_build_terms_deriv': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl]),
     'fokl_gram': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
     'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
@@ -258,6 +259,14 @@ class DeviceContext:
         if terms.shape[0] != slots.shape[0]:
             raise ValueError("one slot per term")
         self._ck(self._lib.fokl_build_terms(self._h, _ptr(terms), terms.shape[0], _ptr(slots)))
+
+    def build_terms_deriv(self, terms, slots, wrt_input, order, divisor):
+        terms = np.ascontiguousarray(np.atleast_2d(terms), dtype=np.int32)
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        if terms.shape[0] != slots.shape[0]:
+            raise ValueError("one slot per term")
+        self._ck(self._lib.fokl_build_terms_deriv(self._h, _ptr(terms), terms.shape[0], _ptr(slots), int(wrt_input),
+                                                  int(order), float(divisor)))
 
     def gram(self, row_slots, col_slots, path=0, allreduce=False):
         rs = np.ascontiguousarray(row_slots, dtype=np.int32)

@@ -451,7 +451,8 @@ static int cu_count(fokl_ctx *ctx)
 // LDS available to one workgroup of the basis kernel; the factor table takes 4 KB per distinct factor.
 static constexpr size_t K1_LDS_BUDGET = 144 * 1024;
 
-static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slots, int t_begin, int t_end)
+static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slots, int t_begin, int t_end,
+                        const DerivSpec &deriv)
 {
     const int m = ctx->m;
     const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
@@ -563,19 +564,42 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
     const double alg_bytes = 8.0 * (double)ctx->n * (double)(m_used + T);
     TimedRegion timed(ctx, FOKL_K_BASIS, alg_bytes, 0.0);
     typedef void (*basis_fn)(const double *, int64_t, int64_t, const double *, int, const BasisPlan *, const int *,
-                             double *const *);
+                             double *const *, DerivSpec);
     basis_fn fn = splines ? (reg_table ? basis_build_reg_kernel<true> : basis_build_kernel<true>)
                           : (reg_table ? basis_build_reg_kernel<false> : basis_build_kernel<false>);
     if (lds_bytes > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)K1_LDS_BUDGET + 4096));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n, ctx->d_phis,
-                       ctx->width, d_plan, d_arr, ctx->d_slot_ptr);
+                       ctx->width, d_plan, d_arr, ctx->d_slot_ptr, deriv);
     HIP_TRY(ctx, hipGetLastError());
     return FOKL_OK;
 }
 
+static int build_terms_impl(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots, const DerivSpec &deriv);
+
 extern "C" int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots)
+{
+    const DerivSpec plain = {-1, 0, 1.0, 0};
+    return build_terms_impl(ctx, terms, T, slots, plain);
+}
+
+extern "C" int fokl_build_terms_deriv(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots, int wrt_input,
+                                      int order, double divisor)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_build_terms_deriv: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_build_terms_deriv: call fokl_upload first");
+    if (wrt_input < 0 || wrt_input >= ctx->m || (order != 1 && order != 2) || !(divisor != 0.0))
+        return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms_deriv: need 0 <= wrt_input < m, order 1 or 2, divisor != 0");
+    for (int j = 0; j < T; ++j)
+        if (terms && terms[(size_t)j * ctx->m + wrt_input] == 0)
+            return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms_deriv: a term does not contain the differentiated input "
+                                           "(its derivative is the zero column; leave it out)");
+    const DerivSpec spec = {wrt_input, order, divisor, 1};
+    return build_terms_impl(ctx, terms, T, slots, spec);
+}
+
+static int build_terms_impl(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots, const DerivSpec &deriv)
 {
     if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_build_terms: null context");
     if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_build_terms: call fokl_upload first");
@@ -626,7 +650,7 @@ extern "C" int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, cons
         }
         if (end == begin)
             return fail(ctx, FOKL_ERR_ARG, "fokl_build_terms: a single term has more factors than fit in LDS");
-        rc = launch_basis(ctx, terms, slots, begin, end);
+        rc = launch_basis(ctx, terms, slots, begin, end, deriv);
         if (rc) return rc;
         begin = end;
     }

@@ -90,21 +90,102 @@ __device__ __forceinline__ double cubic_basis(double c0, double c1, double c2, d
     return r;
 }
 
+// Derivatives of the same basis functions (evaluate_basis with d = 1, 2; ref FR:837-847), again with the reference's
+// operation order: `k * c[k] * (x ** (k - 1))` is ((k c_k) RN(x**(k-1))), sums start from 0 in ascending k.
+__device__ __forceinline__ double bernoulli_basis_d1(const double *__restrict__ c, int order, double x)
+{
+    double s = 0.0;
+    double ph = 1.0, pl = 0.0;              // x**(k-1), k = 2 -> x
+    for (int k = 2; k <= order; ++k) {
+        dd_mul_d(ph, pl, x);
+        s = s + ((double)k * c[k]) * ph;
+    }
+    return c[1] + s;
+}
+
+__device__ __forceinline__ double bernoulli_basis_d2(const double *__restrict__ c, int order, double x)
+{
+    double s = 0.0;
+    double ph = 1.0, pl = 0.0;              // x**(k-2), k = 2 -> 1
+    for (int k = 2; k <= order; ++k) {
+        if (k > 2) dd_mul_d(ph, pl, x);
+        s = s + ((double)((k - 1) * k) * c[k]) * ph;
+    }
+    return s;
+}
+
+// c1 + 2 c2 t + 3 c3 t**2   and   2 c2 + 6 c3 t   (ref FR:838, FR:840)
+__device__ __forceinline__ double cubic_basis_d1(double c1, double c2, double c3, double t)
+{
+    double r = c1 + (2.0 * c2) * t;
+    return r + (3.0 * c3) * (t * t);
+}
+
+__device__ __forceinline__ double cubic_basis_d2(double c2, double c3, double t) { return 2.0 * c2 + (6.0 * c3) * t; }
+
 // Spline piece index and local coordinate (ref FR:570-589): phind = ceil(x*l) (0 -> 1) - 1, xsm = l*x - phind.
-__device__ __forceinline__ void spline_locate(double x, int width, int &piece, double &t)
+// `twice_normalised` selects the other coordinate the reference derives from the same index, X = (x - phind r) / r
+// with r = 1 / l (FR:584-586) -- the one bss_derivatives evaluates its basis functions at (FR:742, 778-781).
+__device__ __forceinline__ void spline_locate(double x, int width, bool twice_normalised, int &piece, double &t)
 {
     double xl = x * (double)width;
     int p = (int)ceil(xl);
     if (p == 0) p = 1;
     p -= 1;
-    t = xl - (double)p;
+    if (twice_normalised) {
+        const double r = 1.0 / (double)width;
+        t = (x - (double)p * r) / r;
+    } else {
+        t = xl - (double)p;
+    }
     piece = min(max(p, 0), width - 1);      // host validated the range (FR:590-591); clamp guards the LDS read
+}
+
+// What a launch differentiates: the factor of input `input` is replaced by its `order`-th derivative divided by
+// `div` (= (span / l) ** order, FR:758-759, 781-782); input < 0 = plain basis build.
+struct DerivSpec {
+    int input;
+    int order;
+    double div;
+    int twice_normalised;
+};
+
+// One (input, order) factor for the two rows of a lane.  `sl` = the spline slab of this order (LDS or global).
+template <bool SPLINES>
+__device__ __forceinline__ void evaluate_factor(const double *__restrict__ sl, const double *__restrict__ bern, int order,
+                                                int width, d2 x, int p0, int p1, double t0, double t1, int deriv,
+                                                double div, double &vx, double &vy)
+{
+    if (SPLINES) {
+        if (deriv == 0) {
+            vx = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
+            vy = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
+        } else if (deriv == 1) {
+            vx = cubic_basis_d1(sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0) / div;
+            vy = cubic_basis_d1(sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1) / div;
+        } else {
+            vx = cubic_basis_d2(sl[2 * width + p0], sl[3 * width + p0], t0) / div;
+            vy = cubic_basis_d2(sl[2 * width + p1], sl[3 * width + p1], t1) / div;
+        }
+    } else {
+        if (deriv == 0) {
+            vx = bernoulli_basis(bern, order, x.x);
+            vy = bernoulli_basis(bern, order, x.y);
+        } else if (deriv == 1) {
+            vx = bernoulli_basis_d1(bern, order, x.x) / div;
+            vy = bernoulli_basis_d1(bern, order, x.y) / div;
+        } else {
+            vx = bernoulli_basis_d2(bern, order, x.x) / div;
+            vy = bernoulli_basis_d2(bern, order, x.y) / div;
+        }
+    }
 }
 
 template <bool SPLINES>
 __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
     const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
-    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr)
+    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr,
+    DerivSpec deriv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
@@ -149,26 +230,21 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
                 cur_input = k;
                 if (in0) x = *reinterpret_cast<const d2 *>(xT + (size_t)k * ld + r0);
                 if (SPLINES) {
-                    spline_locate(x.x, width, p0, t0);
-                    spline_locate(x.y, width, p1, t1);
+                    spline_locate(x.x, width, deriv.twice_normalised != 0, p0, t0);
+                    spline_locate(x.y, width, deriv.twice_normalised != 0, p1, t1);
                 }
             }
             d2 v;
-            if (SPLINES) {
-                const int s = fac_slab[u];
-                if (s >= 0) {
-                    const double *sl = slabs + s * 4 * width;
-                    v.x = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
-                    v.y = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
-                } else {
-                    const double *sl = phis + (size_t)(order - 1) * 4 * width;
-                    v.x = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
-                    v.y = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
-                }
-            } else {
-                const double *c = phis + (size_t)(order - 1) * width;
-                v.x = bernoulli_basis(c, order, x.x);
-                v.y = bernoulli_basis(c, order, x.y);
+            {
+                const int s = SPLINES ? fac_slab[u] : -1;
+                const double *sl = SPLINES ? (s >= 0 ? slabs + s * 4 * width : phis + (size_t)(order - 1) * 4 * width)
+                                           : nullptr;
+                const double *bern = SPLINES ? nullptr : phis + (size_t)(order - 1) * width;
+                double vx, vy;
+                evaluate_factor<SPLINES>(sl, bern, order, width, x, p0, p1, t0, t1, k == deriv.input ? deriv.order : 0,
+                                         deriv.div, vx, vy);
+                v.x = vx;
+                v.y = vy;
             }
             fac[u * nthr + tid] = v;
         }
@@ -201,7 +277,8 @@ constexpr int K1_REG_FACTORS = 16;
 template <bool SPLINES>
 __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
     const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
-    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr)
+    const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr,
+    DerivSpec deriv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
@@ -241,26 +318,18 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
                 cur_input = k;
                 if (in0) x = *reinterpret_cast<const d2 *>(xT + (size_t)k * ld + r0);
                 if (SPLINES) {
-                    spline_locate(x.x, width, p0, t0);
-                    spline_locate(x.y, width, p1, t1);
+                    spline_locate(x.x, width, deriv.twice_normalised != 0, p0, t0);
+                    spline_locate(x.y, width, deriv.twice_normalised != 0, p1, t1);
                 }
             }
             double vx, vy;
-            if (SPLINES) {
-                const int s = fac_slab[u];
-                if (s >= 0) {
-                    const double *sl = slabs + s * 4 * width;
-                    vx = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
-                    vy = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
-                } else {
-                    const double *sl = phis + (size_t)(order - 1) * 4 * width;
-                    vx = cubic_basis(sl[p0], sl[width + p0], sl[2 * width + p0], sl[3 * width + p0], t0);
-                    vy = cubic_basis(sl[p1], sl[width + p1], sl[2 * width + p1], sl[3 * width + p1], t1);
-                }
-            } else {
-                const double *c = phis + (size_t)(order - 1) * width;
-                vx = bernoulli_basis(c, order, x.x);
-                vy = bernoulli_basis(c, order, x.y);
+            {
+                const int s = SPLINES ? fac_slab[u] : -1;
+                const double *sl = SPLINES ? (s >= 0 ? slabs + s * 4 * width : phis + (size_t)(order - 1) * 4 * width)
+                                           : nullptr;
+                const double *bern = SPLINES ? nullptr : phis + (size_t)(order - 1) * width;
+                evaluate_factor<SPLINES>(sl, bern, order, width, x, p0, p1, t0, t1, k == deriv.input ? deriv.order : 0,
+                                         deriv.div, vx, vy);
             }
             fx[u] = vx;
             fy[u] = vy;

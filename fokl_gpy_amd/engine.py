@@ -126,6 +126,12 @@ class HipBackend:
     def build_terms(self, terms, slots):
         self.ctx.build_terms(terms, slots)
 
+    def build_terms_deriv(self, terms, slots, wrt_input, order, divisor):
+        self.ctx.build_terms_deriv(terms, slots, wrt_input, order, divisor)
+
+    def read_slot(self, slot):
+        return self.ctx.read_slot(slot)
+
     def gram(self, row_slots, col_slots, allreduce=False):
         return self.ctx.gram(row_slots, col_slots, 0, allreduce)
 

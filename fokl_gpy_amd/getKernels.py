@@ -47,7 +47,14 @@ def spline_table(n_basis=N_GRID):
     """
     from scipy.interpolate import CubicSpline
     x, k = _kappa1(N_GRID)
-    lam, vec = np.linalg.eigh(k)
+    # LAPACK's result depends (in the last bits) on the BLAS thread count, and the local-coordinate coefficients
+    # amplify that by up to 499**3: pin the decomposition to one thread so that the table is reproducible
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1, user_api='blas'):
+            lam, vec = np.linalg.eigh(k)
+    except ImportError:
+        lam, vec = np.linalg.eigh(k)
     order = np.argsort(lam)[::-1]
     lam = lam[order]
     vec = vec[:, order]

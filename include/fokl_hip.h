@@ -99,6 +99,16 @@ int64_t fokl_rows(const fokl_ctx *ctx);
  */
 int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots);
 
+/*
+ * The same columns with the factor of input `wrt_input` replaced by its `order`-th derivative (1 or 2) divided
+ * by `divisor`: replaces the per-term product of bss_derivatives (FR:764-787; evaluate_basis d = 1, 2, FR:837-847).
+ * As in the reference every factor is evaluated at the twice-normalised coordinate X of FR:584-586 (splines), the
+ * caller passes divisor = (span_m / l) ** order (FR:758-759) and leaves out terms that do not contain `wrt_input`
+ * (their derivative is zero, FR:785-787).
+ */
+int fokl_build_terms_deriv(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots, int wrt_input,
+                           int order, double divisor);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* K2: Gram blocks.  Replaces XtX = X'X, Xty = X'y (FR:1492-1494) and dtd = y'y (FR:1374).                 */
 /* ------------------------------------------------------------------------------------------------------ */

@@ -70,11 +70,19 @@ def inputs_to_phind(inputs, l_phis):
     return phind, xsm
 
 
-def evaluate_basis(c, x, kernel):
-    """F2 (FR:834-843), d = 0.  ``x`` must be a numpy float64 scalar so that ``**`` is libm pow as in the reference."""
+def evaluate_basis(c, x, kernel, d=0):
+    """F2 (FR:834-847).  ``x`` must be a numpy float64 scalar so that ``**`` is libm pow as in the reference."""
     if kernel == KERNEL_SPLINES:
-        return c[0] + c[1] * x + c[2] * (x ** 2) + c[3] * (x ** 3)
-    return c[0] + sum(c[k] * (x ** k) for k in range(1, len(c)))
+        if d == 0:
+            return c[0] + c[1] * x + c[2] * (x ** 2) + c[3] * (x ** 3)
+        if d == 1:
+            return c[1] + 2 * c[2] * x + 3 * c[3] * (x ** 2)
+        return 2 * c[2] + 6 * c[3] * x
+    if d == 0:
+        return c[0] + sum(c[k] * (x ** k) for k in range(1, len(c)))
+    if d == 1:
+        return c[1] + sum(k * c[k] * (x ** (k - 1)) for k in range(2, len(c)))
+    return sum((k - 1) * k * c[k] * (x ** (k - 2)) for k in range(2, len(c)))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -468,3 +476,63 @@ def coverage_rmse(mean, data):
     """FR:1193 computes ``sqrt(mean(mean - data) ** 2)`` with an (n,) - (n,1) broadcast; its value is
     ``|mean(mean) - mean(data)|`` up to rounding.  Evaluated here without the n x n temporary."""
     return np.sqrt((np.mean(mean) - np.mean(data)) ** 2)
+
+
+def twice_normalised(inputs, l_phis):
+    """The other output of _inputs_to_phind (FR:584-586): X = (inputs - (phind - 1) r) / r with the 1-based phind."""
+    phind = np.array(np.ceil(inputs * l_phis), dtype=np.uint16)
+    if phind.ndim == 1:
+        phind = phind[:, np.newaxis]
+    phind = phind + (phind == 0)
+    r = 1 / l_phis
+    xmin = np.array((phind - 1) * r, dtype=inputs.dtype)
+    return (inputs - xmin) / r, phind - 1
+
+
+def bss_derivatives(inputs, betas, mtx, phis, kernel, minmax, d1, d2, draws):
+    """
+    N2 (FR:735-791): first / second partial derivatives of the fitted model, per draw.  ``d1`` / ``d2`` are boolean
+    masks over the inputs.  Returns dy [N, M, 2, draws] (the array the reference holds at FR:791, before its
+    averaging / reshaping tail).  Same loop order and arithmetic as the reference; small cases only.
+    """
+    inputs = np.asarray(inputs, dtype=np.float64)
+    mtx = np.atleast_2d(np.asarray(mtx))
+    N, M = inputs.shape
+    B = mtx.shape[0]
+    span_m = [minmax[m][1] - minmax[m][0] for m in range(M)]
+    if kernel == KERNEL_SPLINES:
+        X, phind = twice_normalised(inputs, len(phis[0][0]))
+        L_phis = len(phis[0][0])
+    else:
+        X, phind, L_phis = inputs, None, 1
+    derv = [np.asarray(d1, dtype=bool), np.asarray(d2, dtype=bool)]
+    dy = np.zeros([draws, N, M, 2])
+    basis_nm = np.zeros([N, M, B])
+    for n in range(N):
+        for m in range(M):
+            for di in (0, 1):
+                if not derv[di][m]:
+                    continue
+                span_L = span_m[m] / L_phis
+                span_L = [1, span_L, span_L ** 2]
+                for b in range(B):
+                    phi = 1
+                    for md in range(M):
+                        num = int(mtx[b, md])
+                        derp = di + 1 if md == m else 0
+                        if num:
+                            if kernel == KERNEL_SPLINES:
+                                c = [phis[num - 1][k][int(phind[n, md])] for k in range(4)]
+                            else:
+                                c = phis[num - 1]
+                            if derp == 0:
+                                if basis_nm[n, md, b] == 0:
+                                    basis_nm[n, md, b] = evaluate_basis(c, X[n, md], kernel)
+                                phi *= basis_nm[n, md, b]
+                            else:
+                                phi *= evaluate_basis(c, X[n, md], kernel, d=derp) / span_L[derp]
+                        elif derp:
+                            phi = 0
+                            break
+                    dy[:, n, m, di] = dy[:, n, m, di] + betas[-draws:, b + 1] * phi
+    return np.transpose(dy, (1, 2, 3, 0))

@@ -84,6 +84,35 @@ class OracleBackend:
             assert 2 <= s < self.capacity, "slot outside the reserved range"
             self.cols[int(s)] = X[:, j].copy()
 
+    def build_terms_deriv(self, terms, slots, wrt_input, order, divisor):
+        """Derivative columns with the oracle's scalar evaluate_basis at the twice-normalised coordinate (FR:778-782)."""
+        terms = np.atleast_2d(terms)
+        if self.kernel == O.KERNEL_SPLINES:
+            X, phind = O.twice_normalised(self.inputs, len(self.phis[0][0]))
+        else:
+            X, phind = self.inputs, None
+        for j, s in enumerate(slots):
+            col = np.ones(self.n)
+            for n in range(self.n):
+                phi = 1
+                for md in range(terms.shape[1]):
+                    num = int(terms[j, md])
+                    if not num:
+                        continue
+                    if self.kernel == O.KERNEL_SPLINES:
+                        c = [self.phis[num - 1][k][int(phind[n, md])] for k in range(4)]
+                    else:
+                        c = self.phis[num - 1]
+                    if md == wrt_input:
+                        phi *= O.evaluate_basis(c, X[n, md], self.kernel, d=order) / divisor
+                    else:
+                        phi *= O.evaluate_basis(c, X[n, md], self.kernel)
+                col[n] = phi
+            self.cols[int(s)] = col
+
+    def read_slot(self, slot):
+        return self.cols[int(slot)].copy()
+
     def gram(self, row_slots, col_slots, allreduce=False):
         self.calls['gram'] += 1
         A = np.stack([self.cols[int(s)] for s in row_slots], axis=1)

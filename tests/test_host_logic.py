@@ -240,9 +240,10 @@ def test_out_of_scope_entry_points_say_so():
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model.fit(np.random.default_rng(0).random((20, 1)), np.zeros(20), clean=True)
-    for name in ('bss_derivatives', 'to_pyomo'):
-        with pytest.raises(NotImplementedError):
-            getattr(model, name)()
+    with pytest.raises(NotImplementedError):
+        model.to_pyomo()
+    with pytest.raises(NotImplementedError):
+        model.fitupdate(None, None)
 
 
 def test_evaluate_requires_minmax_and_validates_draws():
