@@ -19,7 +19,6 @@ namespace fokl {
 constexpr int WAVE = 64;
 constexpr int K1_THREADS = 256;
 constexpr int K1_ROWS_PER_THREAD = 2;                       // 16-byte loads / stores per lane
-constexpr int K1_TILE_ROWS = K1_THREADS * K1_ROWS_PER_THREAD;
 constexpr int K1_MAX_LDS_SLABS = 4;                         // spline orders staged in LDS per launch
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -41,7 +40,7 @@ __device__ __forceinline__ void store_d1(double *p, double v) { *(global_d_ptr)(
 // ---------------------------------------------------------------------------------------------------------
 
 // One launch builds T columns that share U distinct (input, order) factors.  The host plans the launch
-// (fokl_hip.hip: plan_basis_launch) and ships this descriptor in device memory.
+// (fokl_hip.hip: launch_basis) and ships this descriptor in device memory.
 struct BasisPlan {
     int n_fac;           // U
     int n_terms;         // T

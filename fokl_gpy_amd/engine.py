@@ -326,8 +326,11 @@ class ForwardSelection:
 
     Parameters mirror the locals of FoKL.fit (FR:1302-1315, 1371-1374): hyper-parameters, ``n`` rows, ``m``
     inputs, ``n_phis = len(phis)`` (the search stops when the stage index exceeds it, FR:1747).
-    ``stream`` is the numpy legacy RNG state the chain continues.  ``comm`` (optional) shards kill-test
-    proposals over ranks (see dist.py).
+    ``stream`` is the numpy legacy RNG state the chain continues.  With ``row_sharded=True`` the backend holds one
+    shard of the rows (``n`` local, ``n_global`` in total) and sums its Gram blocks / residual moments over ranks
+    inside ``gram`` / ``bic_resid``; the sampler then runs replicated on every rank from identical inputs.
+    ``comm`` is not used by the search itself (collectives live in the backend) and is kept for callers that want
+    the communicator next to the search object.
     """
 
     def __init__(self, backend, n, m, n_phis, a, b, atau, btau, tolerance, draws_total, draws_keep, gimmie, way3,
