@@ -119,7 +119,9 @@ def main():
     from fokl_gpy_amd import FoKLRoutines, _capi
     backend = FoKLRoutines.device_backend(local)          # raises without libfokl_hip.so / a gfx950 device
     ctx = backend.ctx
-    comm = dist.RcclComm(ctx, rank, world) if world > 1 else dist.SingleComm()
+    # FOKL_BENCH_FORCE_RCCL=1 takes the RCCL bootstrap + collectives also in a world of one (launcher smoke test)
+    use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
+    comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
 
     n, m = args.rows, args.inputs
     x, y = make_workload(12 + rank, n, m)
@@ -259,7 +261,9 @@ def main():
     if not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(x, y)
     comm.close()
-    print(json.dumps(line))
+    dist.flush_c_streams()
+    sys.stderr.flush()
+    print(json.dumps(line), flush=True)          # the ONE JSON line, last thing on stdout
 
 
 if __name__ == '__main__':

@@ -7,8 +7,8 @@ The forward-selection path has exactly two exchange steps, both tiny:
   * all-reduce(sum) of Gram blocks / residual moments when *rows* are sharded over ranks.
 
 ``RcclComm`` drives them on the GPU; ``GlooComm`` offers the same interface over ``torch.distributed``'s gloo
-backend so that the N > 1 host logic is testable on CPU (tests/test_dist_gloo.py).  torch is used for
-rendezvous / CPU testing only -- never on the device path.
+backend so that the N > 1 host logic is testable on CPU (tests/test_dist_gloo.py).  torch is used for that CPU
+test only: a GPU process never imports it (its bundled HIP / RCCL copies must not share a process with ours).
 """
 import os
 
@@ -20,6 +20,15 @@ def env_rank_world():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
     return rank, world, local
+
+
+def flush_c_streams():
+    """Flush C stdio buffers (librccl writes its banner there) so that they cannot land after later Python output."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
 
 
 class SingleComm:
@@ -39,24 +48,39 @@ class SingleComm:
         pass
 
 
-def _exchange_unique_id(rank, world, make_id, tag='fokl'):
-    """Rank 0 creates the 128-byte RCCL id; the others fetch it from a TCP store at MASTER_ADDR:MASTER_PORT."""
-    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
-    port = int(os.environ.get('MASTER_PORT', '29500'))
-    from torch.distributed import TCPStore
-    import datetime
-    # Under torch.distributed.run the elastic agent already serves a store on MASTER_PORT and tells its workers so;
-    # then every rank (rank 0 included) connects as a client.
-    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
-    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store),
-                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
-    key = tag + '_rccl_id_' + os.environ.get('TORCHELASTIC_RUN_ID', '0')
+def _exchange_unique_id(rank, world, make_id, tag='fokl', timeout_s=300.0):
+    """
+    Rank 0 creates the 128-byte RCCL id, the other ranks of the node read it.
+
+    One node, one process per GPU (the launch contract), so the hand-off is a file in the node's temp directory,
+    written atomically and named after what all ranks of one launch share: MASTER_PORT and the launcher's pid.
+    Deliberately NOT torch.distributed's TCPStore: importing torch loads its private copies of the HIP runtime and
+    of librccl into the process, and RCCL then initialises against the wrong runtime ("unhandled cuda error").
+    """
+    import tempfile
+    import time
+    port = os.environ.get('MASTER_PORT', '0')
+    launch = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+    path = os.path.join(tempfile.gettempdir(), f'{tag}_rccl_id_{port}_{launch}_{os.getppid()}.bin')
     if rank == 0:
-        uid = make_id()
-        store.set(key, uid)
-    else:
-        uid = store.get(key)
-    return bytes(uid), store
+        uid = bytes(make_id())
+        tmp = path + f'.{os.getpid()}.tmp'
+        with open(tmp, 'wb') as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.monotonic() + timeout_s
+    while True:
+        try:
+            with open(path, 'rb') as fh:
+                uid = fh.read()
+            if len(uid) == 128:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 at {path} after {timeout_s:.0f} s")
+        time.sleep(0.01)
 
 
 class RcclComm:
@@ -64,10 +88,27 @@ class RcclComm:
 
     def __init__(self, ctx, rank, world, unique_id=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
-        self._store = None
+        self._id_file = None
         if unique_id is None:
-            unique_id, self._store = _exchange_unique_id(self.rank, self.world, ctx.comm_unique_id)
-        ctx.comm_init(unique_id, self.rank, self.world)
+            unique_id, self._id_file = _exchange_unique_id(self.rank, self.world, ctx.comm_unique_id)
+        # librccl prints a version banner on C stdout during init; benchmark drivers parse stdout, so route file
+        # descriptor 1 to stderr for the duration of the call
+        import sys
+        sys.stdout.flush()
+        flush_c_streams()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            ctx.comm_init(unique_id, self.rank, self.world)  # collective: returns once every rank has joined
+            flush_c_streams()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        if self._id_file is not None and self.rank == 0:
+            try:
+                os.remove(self._id_file)                      # everybody has read it by now
+            except OSError:
+                pass
 
     def allgather(self, values):
         return self.ctx.allgather(np.asarray(values, dtype=np.float64).reshape(-1), self.world)
@@ -81,6 +122,7 @@ class RcclComm:
 
     def close(self):
         self.ctx.comm_destroy()
+        flush_c_streams()
 
 
 class GlooComm:
