@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfokl_hip.so')
+LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.so'))   # override: A/B builds
 
 UNIQUE_ID_BYTES = 128
 K_BASIS, K_GRAM, K_RESID, K_PREDICT = 0, 1, 2, 3

@@ -32,7 +32,9 @@ typedef __attribute__((address_space(1))) d2 *global_d2_ptr;
 typedef __attribute__((address_space(1))) double *global_d_ptr;
 
 __device__ __forceinline__ d2 load_d2(const double *p) { return *(global_cd2_ptr)(p); }
-__device__ __forceinline__ void store_d2(double *p, d2 v) { *(global_d2_ptr)(p) = v; }
+// Basis columns are written once and are far larger than L2 before anybody reads them: non-temporal stores
+// (measured on K1, N = 1e6: T = 56 Bernoulli 4.5 -> 5.2 TB/s, splines 3.5 -> 5.1 TB/s).
+__device__ __forceinline__ void store_d2(double *p, d2 v) { __builtin_nontemporal_store(v, (global_d2_ptr)(p)); }
 __device__ __forceinline__ void store_d1(double *p, double v) { *(global_d_ptr)(p) = v; }
 
 // ---------------------------------------------------------------------------------------------------------
