@@ -103,13 +103,23 @@ def main():
             sys.exit(2)
     os.environ['FOKL_DEVICE'] = str(local)
 
-    # Keep this rank's two busy threads (search driver + random-stream worker) on cores that share an L3: the noise
-    # tapes (about 1 MB each) are handed from one to the other.  Eight consecutive logical CPUs per rank.
+    # Keep this rank's host threads (search driver + the native noise / chain / spectral threads, about ten) on the
+    # logical CPUs of ONE L3 domain: noise tapes (about 1 MB each) are handed from thread to thread.  Rank r takes the
+    # domain of CPU 8 r (8 cores x 2 SMT threads on the EPYC hosts of this pool).
     pinned = None
     if os.environ.get('FOKL_BENCH_PIN', '1') != '0' and hasattr(os, 'sched_setaffinity'):
         try:
-            allowed = sorted(os.sched_getaffinity(0))
-            want = [c for c in range(8 * local, 8 * local + 8) if c in allowed]
+            allowed = set(os.sched_getaffinity(0))
+            want = set(range(8 * local, 8 * local + 8))
+            try:
+                with open(f'/sys/devices/system/cpu/cpu{8 * local}/cache/index3/shared_cpu_list') as fh:
+                    want = set()
+                    for part in fh.read().strip().split(','):
+                        lo, _, hi = part.partition('-')
+                        want.update(range(int(lo), int(hi or lo) + 1))
+            except (OSError, ValueError):
+                pass
+            want = sorted(want & allowed)
             if len(want) >= 2:
                 os.sched_setaffinity(0, want)
                 pinned = want
@@ -149,7 +159,8 @@ def main():
         ctx.sync()
         t0 = time.perf_counter()
         logical = physical = calls = 0
-        host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0)
+        host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
+                    pool_finish_s=0.0, pool_spectral_s=0.0)
         for _ in range(args.steps):
             st = one_step()
             logical += st['terms_logical']

@@ -45,9 +45,22 @@ SIGNATURES = {
     'fokl_timing_get': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'fokl_gibbs_chain': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                c_vp]),
     'fokl_gibbs_chain_from_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp, c_vp,
-                                           c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_destroy': (None, [c_vp]),
+    'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_poll': (c_int, [c_vp]),
+    'fokl_pool_wait': (c_int, [c_vp]),
+    'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_finish_tape_blocks': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'fokl_gibbs_chain_from_finished_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp,
+                                                    c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'fokl_rng_normals': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'fokl_rng_gammas': (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_i64, c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
@@ -87,7 +100,9 @@ def load():
 
 
 def _ptr(arr):
-    return arr.ctypes.data_as(c_vp) if arr is not None else c_vp(0)
+    """Address of a numpy buffer as a plain integer (accepted by every c_void_p parameter; far cheaper than
+    ``arr.ctypes.data_as``, which showed up at 3 us a call on the search's critical thread)."""
+    return arr.__array_interface__['data'][0] if arr is not None else None
 
 
 def _check(rc, ctx=None):
@@ -156,24 +171,74 @@ def gibbs_chain(lamb, qty, astar, atau_star, b, btau, dtd, sigsqd0, tausqd0, dra
 
 
 class NoiseTape:
-    """The data-independent random numbers of one candidate's chain (include/fokl_hip.h: fokl_noise_tape).
-    ``progress[0]`` counts the iterations recorded so far (-1 = the producer failed)."""
-    __slots__ = ('p1', 'draws', 'normals', 'gam_sig', 'gam_tau', 'progress')
+    """The data-independent random numbers of one candidate's chain (include/fokl_hip.h: fokl_noise_tape): per
+    iteration p1 normals -- accepted polar pairs left unfinished, see the header -- and two standard gammas.
+    ``progress[0]`` counts the iterations recorded so far (-1 = the producer failed); ``block_done`` are the flags of
+    fokl_finish_tape_blocks (blocks of BLOCK iterations).
+    One allocation, carved up by address: a tape is made for every model evaluation on the search's critical thread."""
+    __slots__ = ('p1', 'draws', '_buf', '_addr', '_off', '_ints')
+    BLOCK = 16                                                # = FOKL_TAPE_BLOCK
 
-    def __init__(self, p1, draws):
-        self.p1, self.draws = int(p1), int(draws)
-        self.normals = np.empty((self.draws, self.p1), dtype=np.float64)
-        self.gam_sig = np.empty(self.draws, dtype=np.float64)
-        self.gam_tau = np.empty(self.draws, dtype=np.float64)
-        self.progress = np.zeros(1, dtype=np.int32)
+    @classmethod
+    def _layout(cls, p1, d):
+        half = p1 // 2 + 1
+        nblocks = -(-d // cls.BLOCK)
+        pad = lambda count: -(-count // 8) * 8                # regions start on 64-byte lines (in doubles)
+        # int32 area: progress (a line of its own: polled by other threads) | block_done [nblocks] | lead [d]
+        ints = (16, 16 + -(-nblocks // 16) * 16)
+        off = [0]
+        for count in (d * p1, d * half, d, d):
+            off.append(off[-1] + pad(count))
+        return tuple(off), ints, off[4] + pad((ints[1] + d + 1) // 2) + 8
+
+    @classmethod
+    def doubles_needed(cls, p1, draws):
+        return cls._layout(int(p1), int(draws))[2]
+
+    def __init__(self, p1, draws, raw=None):
+        """raw: a float64 buffer of at least doubles_needed(p1, draws) elements to build the tape in (recycled memory
+        is already mapped and probably cached), else a fresh allocation."""
+        self.p1, self.draws = p1, d = int(p1), int(draws)
+        off, ints, total = self._layout(p1, d)
+        self._off, self._ints = off, ints
+        if raw is None:
+            raw = np.empty(total, dtype=np.float64)
+        elif raw.shape[0] < total:
+            raise ValueError("buffer too small for this tape")
+        shift = ((-raw.__array_interface__['data'][0]) % 64) // 8
+        self._buf = raw[shift:]
+        self._addr = self._buf.__array_interface__['data'][0]
+        self._buf[off[4]:off[4] + ints[1] // 2] = 0.0         # progress and block flags start at zero
+
+    def _int_area(self):
+        return self._buf[self._off[4]:].view(np.int32)
+
+    normals = property(lambda self: self._buf[:self.draws * self.p1].reshape(self.draws, self.p1))
+    pair_r2 = property(lambda self: self._buf[self._off[1]:self._off[1] + self.draws * (self.p1 // 2 + 1)]
+                       .reshape(self.draws, self.p1 // 2 + 1))
+    gam_sig = property(lambda self: self._buf[self._off[2]:self._off[2] + self.draws])
+    gam_tau = property(lambda self: self._buf[self._off[3]:self._off[3] + self.draws])
+    progress = property(lambda self: self._int_area()[:1])
+    block_done = property(lambda self: self._int_area()[self._ints[0]:self._ints[0] + -(-self.draws // self.BLOCK)])
+    lead = property(lambda self: self._int_area()[self._ints[1]:self._ints[1] + self.draws])
+
+    def pointers(self):
+        """normals, pair_r2, lead, gam_sig, gam_tau -- the argument order of the C entry points."""
+        a, off = self._addr, self._off
+        return (a, a + 8 * off[1], a + 8 * off[4] + 4 * self._ints[1], a + 8 * off[2], a + 8 * off[3])
+
+    def progress_pointer(self):
+        return self._addr + 8 * self._off[4]
+
+    def block_done_pointer(self):
+        return self._addr + 8 * self._off[4] + 4 * self._ints[0]
 
 
 def record_noise_tape(tape, astar, atau_star, stream):
-    """Fill ``tape`` from the stream (runs on the worker thread of engine.NoisePipeline; the GIL is released)."""
+    """Fill ``tape`` from the stream on the calling thread."""
     try:
         _check(load().fokl_noise_tape(tape.p1, tape.draws, float(astar), float(atau_star), *stream.args(),
-                                      _ptr(tape.normals), _ptr(tape.gam_sig), _ptr(tape.gam_tau),
-                                      _ptr(tape.progress)))
+                                      *tape.pointers(), tape.progress_pointer()))
     except BaseException:
         tape.progress[0] = -1
         raise
@@ -197,12 +262,158 @@ def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_
     taus = np.empty(tape.draws) if want_sig_tau else None
     flag = ctypes.c_int32(0)
     _check(load().fokl_gibbs_chain_from_tape(_ptr(lamb), _ptr(qty), p1, float(b), float(btau), float(dtd),
-                                             float(sigsqd0), float(tausqd0), tape.draws, _ptr(tape.normals),
-                                             _ptr(tape.gam_sig), _ptr(tape.gam_tau), _ptr(w), _ptr(sigs), _ptr(taus),
-                                             ctypes.byref(flag), _ptr(tape.progress) if follow else c_vp(0)))
+                                             float(sigsqd0), float(tausqd0), tape.draws, *tape.pointers(), _ptr(w),
+                                             _ptr(sigs), _ptr(taus), ctypes.byref(flag),
+                                             tape.progress_pointer() if follow else None))
     if want_sig_tau:
         return w, bool(flag.value), sigs, taus
     return w, bool(flag.value)
+
+
+def finish_tape_blocks(tape, part=0, parts=1, follow=False):
+    """Complete the normals of the tape's blocks part, part + parts, ... in place (fokl_finish_tape_blocks)."""
+    ptr = tape.pointers()
+    _check(load().fokl_finish_tape_blocks(tape.p1, tape.draws, ptr[0], ptr[1], ptr[2],
+                                          tape.progress_pointer() if follow else None, int(part), int(parts),
+                                          tape.BLOCK, tape.block_done_pointer()))
+
+
+def gibbs_chain_from_finished_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, follow=False):
+    """The recursion on a tape completed by finish_tape_blocks.  Returns (w, bstar_negative)."""
+    lamb = np.ascontiguousarray(lamb, dtype=np.float64)
+    qty = np.ascontiguousarray(qty, dtype=np.float64)
+    p1 = lamb.shape[0]
+    if p1 != tape.p1:
+        raise ValueError("tape was recorded for a different model size")
+    w = np.empty((tape.draws, p1), dtype=np.float64)
+    flag = ctypes.c_int32(0)
+    ptr = tape.pointers()
+    _check(load().fokl_gibbs_chain_from_finished_tape(_ptr(lamb), _ptr(qty), p1, float(b), float(btau), float(dtd),
+                                                      float(sigsqd0), float(tausqd0), tape.draws, ptr[0], ptr[3],
+                                                      ptr[4], tape.block_done_pointer() if follow else None,
+                                                      tape.BLOCK, _ptr(w), None, None, ctypes.byref(flag)))
+    return w, bool(flag.value)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host threads of one fit
+# ---------------------------------------------------------------------------------------------------------
+
+def _scipy_dsyevr_address():
+    """Address of the dsyevr that scipy.linalg.eigh itself calls (Fortran ABI, 32-bit integers)."""
+    from scipy.linalg import cython_lapack
+    capsule = cython_lapack.__pyx_capi__['dsyevr']
+    api = ctypes.pythonapi
+    api.PyCapsule_GetName.restype = ctypes.c_char_p
+    api.PyCapsule_GetName.argtypes = [ctypes.py_object]
+    api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+    api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+    name = api.PyCapsule_GetName(capsule)
+    if name is None or name.count(b'int *') != 11 or b'long' in name:
+        raise FoklNativeError(-2, f"unexpected signature of scipy's dsyevr: {name!r}")
+    return api.PyCapsule_GetPointer(capsule, name)
+
+
+class PoolJob:
+    """A job on a HostPool.  Keeps the buffers the job reads / writes alive; ``wait()`` may be called repeatedly."""
+    __slots__ = ('_h', 'keep', 'result', 'recycle')
+
+    def __init__(self, handle, keep, result=None):
+        self._h, self.keep, self.result = handle, keep, result
+        self.recycle = None                 # raw buffers the owner of the pool may reuse once the job has run
+
+    def done(self):
+        """True once the job has run (its native record is then released, the buffers may go)."""
+        if self._h is not None and load().fokl_pool_poll(self._h):
+            self.wait()
+        return self._h is None
+
+    def wait(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            _check(load().fokl_pool_wait(h))
+        return self.result
+
+
+class SpectralResult:
+    """Outputs of fokl_pool_submit_spectral: lamb, Qt (row j = eigenvector j), qty = Q'Xty, betahat."""
+    __slots__ = ('lamb', 'Qt', 'qty', 'betahat', '_buf', '_addr')
+
+    def __init__(self, p1):
+        buf = self._buf = np.empty(p1 * (p1 + 3), dtype=np.float64)
+        self._addr = buf.__array_interface__['data'][0]
+        self.lamb, self.qty, self.betahat = buf[:p1], buf[p1:2 * p1], buf[2 * p1:3 * p1]
+        self.Qt = buf[3 * p1:].reshape(p1, p1)
+
+    def pointers(self, p1):
+        """lamb_out, qt_out, qty_out, betahat_out"""
+        a = self._addr
+        return (a, a + 24 * p1, a + 8 * p1, a + 16 * p1)
+
+
+class HostPool:
+    """include/fokl_hip.h: fokl_pool_* -- the noise thread (owns ``stream`` until close()), chain threads and
+    spectral threads of one fit."""
+
+    def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1):
+        self._lib = load()
+        self.stream = stream
+        self._h = None
+        h = c_vp(0)
+        fn = _scipy_dsyevr_address() if spectral_threads > 0 else None
+        self.finish_threads = int(finish_threads)
+        _check(self._lib.fokl_pool_create(int(chain_threads), self.finish_threads, int(spectral_threads), int(noise_cpu),
+                                          c_vp(fn),
+                                          *stream.args(),
+                                          ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        """Runs everything still queued (each submitted tape advances the stream), then stops the threads."""
+        if self._h:
+            self._lib.fokl_pool_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def submit_noise(self, tape, astar, atau_star):
+        h = c_vp(0)
+        _check(self._lib.fokl_pool_submit_noise(self._h, tape.p1, tape.draws, float(astar), float(atau_star),
+                                                *tape.pointers(), tape.progress_pointer(), ctypes.byref(h)))
+        return PoolJob(h, (tape,), tape)
+
+    def submit_chain(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw=None):
+        """Returns a job whose result is (w [draws, p1], bstar_negative int32[1]); w is carved out of the float64 buffer
+        w_raw if that is given."""
+        p1 = lamb.shape[0]
+        if p1 != tape.p1:
+            raise ValueError("tape was recorded for a different model size")
+        if w_raw is None:
+            w = np.empty((tape.draws, p1), dtype=np.float64)
+        else:
+            w = w_raw[:tape.draws * p1].reshape(tape.draws, p1)
+        flag = np.zeros(1, dtype=np.int32)
+        h = c_vp(0)
+        _check(self._lib.fokl_pool_submit_chain(self._h, _ptr(lamb), _ptr(qty), p1, float(b), float(btau), float(dtd),
+                                                float(sigsqd0), float(tausqd0), tape.draws, *tape.pointers(),
+                                                tape.progress_pointer(),
+                                                tape.block_done_pointer() if self.finish_threads else None,
+                                                tape.BLOCK, _ptr(w), _ptr(flag), ctypes.byref(h)))
+        return PoolJob(h, (lamb, qty, tape, w, flag), (w, flag))
+
+    def submit_spectral(self, gram, idx, ycol):
+        """gram: C-contiguous float64 [L, L]; idx: int32 [p1].  Returns a job whose result is a SpectralResult."""
+        p1 = idx.shape[0]
+        res = SpectralResult(p1)
+        h = c_vp(0)
+        _check(self._lib.fokl_pool_submit_spectral(self._h, _ptr(gram), gram.shape[1], _ptr(idx), p1, int(ycol),
+                                                   *res.pointers(p1), ctypes.byref(h)))
+        return PoolJob(h, (gram, idx, res), res)
+
+    def busy_seconds(self):
+        v = [c_dbl(0) for _ in range(4)]
+        _check(self._lib.fokl_pool_busy_seconds(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value)
 
 
 # ---------------------------------------------------------------------------------------------------------

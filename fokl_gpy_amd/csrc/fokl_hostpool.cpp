@@ -1,0 +1,463 @@
+// Host threads of one fit (G2/G3 of SURVEY 8(a) are N-independent and latency bound, so they stay on the host; this
+// file keeps them off the Python driver thread).  Four kinds of work, each on its own queue(s):
+//
+//   noise    ONE thread that owns the numpy legacy random stream for the lifetime of the pool and records noise
+//            tapes strictly in submission order (fokl_noise_tape) -- the stream is serial by definition;
+//   finish   threads that complete the normals of a tape in place (the log / sqrt half of the polar method), all of
+//            them on every tape, block-interleaved, while it is still being recorded;
+//   chain    threads that turn a tape into the draws of one candidate (the sequential recursion FR:1521-1548),
+//            following the finished blocks;
+//   spectral threads that diagonalise a candidate's XtX sub-block: LAPACK dsyevr exactly as scipy.linalg.eigh calls
+//            it (FoKLRoutines.py:1499; the function pointer is scipy's own, handed in by the Python side), the sign
+//            convention of engine.eigh_canonical, Q'Xty and betahat (FR:1502-1504).  These carry no random numbers,
+//            so the driver may submit them speculatively for models it might evaluate next.
+//
+// Buffers named in a job belong to the caller and must stay alive until fokl_pool_wait returned for that job.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
+
+#include "../../include/fokl_hip.h"
+
+extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
+
+namespace {
+
+using dsyevr_fn = void (*)(char *jobz, char *range, char *uplo, int *n, double *a, int *lda, double *vl, double *vu,
+                           int *il, int *iu, double *abstol, int *m, double *w, double *z, int *ldz, int *isuppz,
+                           double *work, int *lwork, int *iwork, int *liwork, int *info);
+
+enum class Kind { noise, chain, finish, spectral };
+
+struct Queue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<fokl_host_job *> q;
+    bool stop = false;
+};
+
+}  // namespace
+
+struct fokl_host_job {
+    Kind kind;
+    std::atomic<int> done{0};
+    int status = FOKL_OK;
+    std::string error;
+    // noise / chain
+    int p1 = 0, draws = 0;
+    double astar = 0, atau_star = 0;
+    double *normals = nullptr, *pair_r2 = nullptr, *gam_sig = nullptr, *gam_tau = nullptr;
+    int32_t *lead = nullptr, *progress = nullptr;
+    // chain
+    const double *lamb = nullptr, *qty = nullptr;
+    double b = 0, btau = 0, dtd = 0, sigsqd0 = 0, tausqd0 = 0;
+    double *w_out = nullptr;
+    int32_t *bstar_negative = nullptr;
+    // finish (internal, freed by the thread that ran it) and chain on a tape finished by those
+    int32_t *block_done = nullptr;
+    int block = 0, part = 0, parts = 0;
+    bool self_owned = false;
+    // spectral
+    const double *gram = nullptr;
+    int ld = 0, ycol = 0;
+    std::vector<int32_t> idx;
+    double *lamb_out = nullptr, *qt_out = nullptr, *qty_out = nullptr, *betahat_out = nullptr;
+};
+
+struct fokl_host_pool {
+    Queue noise_q, chain_q, spectral_q;
+    std::deque<Queue> finish_q;             // one per finish thread: every tape is split over all of them
+    std::vector<std::thread> threads;
+    dsyevr_fn dsyevr = nullptr;
+    // the random stream (caller-owned storage, updated in place by the noise thread only)
+    uint32_t *mt_key = nullptr;
+    int32_t *mt_pos = nullptr, *has_gauss = nullptr;
+    double *gauss_cache = nullptr;
+    std::atomic<int64_t> noise_busy_ns{0}, chain_busy_ns{0}, finish_busy_ns{0}, spectral_busy_ns{0};
+};
+
+namespace {
+
+void finish(fokl_host_job *job, int status, const char *what)
+{
+    job->status = status;
+    if (status != FOKL_OK) job->error = what;
+    job->done.store(1, std::memory_order_release);
+}
+
+// XtX sub-block -> (lamb, Q', Q'Xty, betahat).  Column-major copy + uplo 'L', abstol 0, range 'A', workspace from a
+// query: the call scipy.linalg.eigh(XtX) makes (driver 'evr'), so the eigenpairs are the reference's bit for bit.
+int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
+{
+    const int n = (int)job->idx.size();
+    const int32_t *idx = job->idx.data();
+    const double *g = job->gram;
+    const size_t ld = (size_t)job->ld;
+    std::vector<double> a((size_t)n * n), xty((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double *row = g + (size_t)idx[i] * ld;
+        for (int j = 0; j < n; ++j) a[(size_t)j * n + i] = row[idx[j]];       // a(i, j) column-major = XtX[i][j]
+        xty[i] = row[job->ycol];
+    }
+    char jobz = 'V', range = 'A', uplo = 'L';
+    int nn = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwork_query = 0;
+    double vl = 0.0, vu = 1.0, abstol = 0.0, work_query = 0.0;
+    std::vector<int> isuppz((size_t)2 * std::max(1, n));
+    double *z = job->qt_out;                                // z(i, j) at z[j * n + i]: row j of Q' = eigenvector j
+    pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
+                 isuppz.data(), &work_query, &lwork, &iwork_query, &liwork, &info);
+    if (info != 0) {
+        err = "dsyevr workspace query failed";
+        return FOKL_ERR_NUMERIC;
+    }
+    lwork = (int)work_query;
+    liwork = iwork_query;
+    std::vector<double> work((size_t)std::max(1, lwork));
+    std::vector<int> iwork((size_t)std::max(1, liwork));
+    pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
+                 isuppz.data(), work.data(), &lwork, iwork.data(), &liwork, &info);
+    if (info != 0 || m != n) {
+        err = "dsyevr did not converge (info = " + std::to_string(info) + ")";
+        return FOKL_ERR_NUMERIC;
+    }
+    // sign convention of engine.eigh_canonical: the largest-magnitude component (first one on ties) is positive
+    for (int j = 0; j < n; ++j) {
+        double *v = z + (size_t)j * n;
+        int piv = 0;
+        double best = std::fabs(v[0]);
+        for (int i = 1; i < n; ++i)
+            if (std::fabs(v[i]) > best) {
+                best = std::fabs(v[i]);
+                piv = i;
+            }
+        if (v[piv] < 0.0)
+            for (int i = 0; i < n; ++i) v[i] = -v[i];
+    }
+    // qty = Q'Xty, betahat = Q (qty / lamb)   (FR:1502-1504)
+    double *qty = job->qty_out, *bh = job->betahat_out;
+    for (int j = 0; j < n; ++j) {
+        const double *v = z + (size_t)j * n;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += v[i] * xty[i];
+        qty[j] = s;
+    }
+    for (int i = 0; i < n; ++i) bh[i] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double *v = z + (size_t)j * n;
+        const double c = qty[j] / job->lamb_out[j];
+        for (int i = 0; i < n; ++i) bh[i] += v[i] * c;
+    }
+    return FOKL_OK;
+}
+
+void run(fokl_host_pool *pool, fokl_host_job *job)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = FOKL_OK;
+    std::string err;
+    std::atomic<int64_t> *busy = nullptr;
+    switch (job->kind) {
+    case Kind::noise:
+        rc = fokl_noise_tape(job->p1, job->draws, job->astar, job->atau_star, pool->mt_key, pool->mt_pos,
+                             pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead, job->gam_sig,
+                             job->gam_tau, job->progress);
+        if (rc != FOKL_OK) err = "noise tape: invalid arguments or gamma shape";
+        busy = &pool->noise_busy_ns;
+        break;
+    case Kind::finish:
+        rc = fokl_finish_tape_blocks(job->p1, job->draws, job->normals, job->pair_r2, job->lead, job->progress,
+                                     job->part, job->parts, job->block, job->block_done);
+        busy = &pool->finish_busy_ns;
+        break;
+    case Kind::chain:
+        if (job->block_done) {
+            rc = fokl_gibbs_chain_from_finished_tape(job->lamb, job->qty, job->p1, job->b, job->btau, job->dtd,
+                                                     job->sigsqd0, job->tausqd0, job->draws, job->normals,
+                                                     job->gam_sig, job->gam_tau, job->block_done, job->block,
+                                                     job->w_out, nullptr, nullptr, job->bstar_negative);
+            if (rc != FOKL_OK) err = "chain: invalid arguments or the tape producer failed";
+            busy = &pool->chain_busy_ns;
+            break;
+        }
+        rc = fokl_gibbs_chain_from_tape(job->lamb, job->qty, job->p1, job->b, job->btau, job->dtd, job->sigsqd0,
+                                        job->tausqd0, job->draws, job->normals, job->pair_r2, job->lead, job->gam_sig,
+                                        job->gam_tau, job->w_out, nullptr, nullptr, job->bstar_negative,
+                                        job->progress);
+        if (rc != FOKL_OK) err = "chain: invalid arguments or the tape producer failed";
+        busy = &pool->chain_busy_ns;
+        break;
+    case Kind::spectral:
+        rc = spectral(pool, job, err);
+        busy = &pool->spectral_busy_ns;
+        break;
+    }
+    const auto dt = std::chrono::steady_clock::now() - t0;
+    busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
+    if (job->self_owned) {
+        delete job;                                         // failures reach the chain job through block_done
+        return;
+    }
+    finish(job, rc, err.c_str());
+}
+
+void worker(fokl_host_pool *pool, Queue *queue)
+{
+    for (;;) {
+        fokl_host_job *job;
+        {
+            std::unique_lock<std::mutex> lock(queue->m);
+            queue->cv.wait(lock, [&] { return queue->stop || !queue->q.empty(); });
+            if (queue->q.empty()) return;                   // stop requested and the queue is drained
+            job = queue->q.front();
+            queue->q.pop_front();
+        }
+        run(pool, job);
+    }
+}
+
+void submit(Queue &queue, fokl_host_job *job)
+{
+    {
+        std::lock_guard<std::mutex> lock(queue.m);
+        queue.q.push_back(job);
+    }
+    queue.cv.notify_one();
+}
+
+void stop(Queue &queue)
+{
+    {
+        std::lock_guard<std::mutex> lock(queue.m);
+        queue.stop = true;
+    }
+    queue.cv.notify_all();
+}
+
+}  // namespace
+
+extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int noise_cpu, void *dsyevr,
+                                uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                                fokl_host_pool **out)
+{
+    if (!out || chain_threads < 1 || spectral_threads < 0 || chain_threads > 64 || spectral_threads > 64 ||
+        finish_threads < 0 || finish_threads > 64 || !mt_key ||
+        !mt_pos || !has_gauss || !gauss_cache || (spectral_threads > 0 && !dsyevr)) {
+        fokl_set_global_error("fokl_pool_create: bad thread counts, null RNG state or missing dsyevr");
+        return FOKL_ERR_ARG;
+    }
+    if (*mt_pos < 0 || *mt_pos > 624) {
+        fokl_set_global_error("fokl_pool_create: invalid MT19937 position");
+        return FOKL_ERR_ARG;
+    }
+    auto *pool = new fokl_host_pool();
+    pool->dsyevr = reinterpret_cast<dsyevr_fn>(dsyevr);
+    pool->mt_key = mt_key;
+    pool->mt_pos = mt_pos;
+    pool->has_gauss = has_gauss;
+    pool->gauss_cache = gauss_cache;
+    try {
+        pool->threads.emplace_back(worker, pool, &pool->noise_q);
+        if (noise_cpu >= 0 && noise_cpu < CPU_SETSIZE) {
+            // the random stream is the serial resource of a fit: its thread gets a logical CPU of its own (the caller
+            // keeps every other thread of the process off that core); failure to pin is not an error
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(noise_cpu, &set);
+            pthread_setaffinity_np(pool->threads.back().native_handle(), sizeof(set), &set);
+        }
+        for (int i = 0; i < chain_threads; ++i) pool->threads.emplace_back(worker, pool, &pool->chain_q);
+        pool->finish_q.resize((size_t)finish_threads);
+        for (auto &q : pool->finish_q) pool->threads.emplace_back(worker, pool, &q);
+        for (int i = 0; i < spectral_threads; ++i) pool->threads.emplace_back(worker, pool, &pool->spectral_q);
+    } catch (const std::exception &e) {
+        stop(pool->noise_q);
+        stop(pool->chain_q);
+        stop(pool->spectral_q);
+        for (auto &q : pool->finish_q) stop(q);
+        for (auto &t : pool->threads) t.join();
+        delete pool;
+        fokl_set_global_error(std::string("fokl_pool_create: ") + e.what());
+        return FOKL_ERR_STATE;
+    }
+    *out = pool;
+    return FOKL_OK;
+}
+
+// Finishes everything that was submitted (every recorded tape advances the stream, used or not), then stops.
+extern "C" void fokl_pool_destroy(fokl_host_pool *pool)
+{
+    if (!pool) return;
+    stop(pool->noise_q);
+    stop(pool->chain_q);
+    stop(pool->spectral_q);
+    for (auto &q : pool->finish_q) stop(q);
+    for (auto &t : pool->threads) t.join();
+    delete pool;
+}
+
+extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star,
+                                      double *normals, double *pair_r2, int32_t *lead, double *gam_sig,
+                                      double *gam_tau, int32_t *progress, fokl_host_job **out)
+{
+    if (!pool || !out || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !progress) {
+        fokl_set_global_error("fokl_pool_submit_noise: null pointer or empty model");
+        return FOKL_ERR_ARG;
+    }
+    auto *job = new fokl_host_job();
+    job->kind = Kind::noise;
+    job->p1 = p1;
+    job->draws = draws;
+    job->astar = astar;
+    job->atau_star = atau_star;
+    job->normals = normals;
+    job->pair_r2 = pair_r2;
+    job->lead = lead;
+    job->gam_sig = gam_sig;
+    job->gam_tau = gam_tau;
+    job->progress = progress;
+    *out = job;
+    submit(pool->noise_q, job);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b,
+                                      double btau, double dtd, double sigsqd0, double tausqd0, int draws,
+                                      const double *normals, const double *pair_r2, const int32_t *lead,
+                                      const double *gam_sig, const double *gam_tau, const int32_t *progress,
+                                      int32_t *block_done, int block, double *w_out, int32_t *bstar_negative,
+                                      fokl_host_job **out)
+{
+    if (!pool || !out || !lamb || !qty || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig ||
+        !gam_tau || !progress || !w_out || !bstar_negative || (block_done && block < 1)) {
+        fokl_set_global_error("fokl_pool_submit_chain: null pointer or empty model");
+        return FOKL_ERR_ARG;
+    }
+    const int parts = block_done ? (int)pool->finish_q.size() : 0;
+    for (int part = 0; part < parts; ++part) {             // the tape is completed in place by all finish threads
+        auto *fin = new fokl_host_job();
+        fin->kind = Kind::finish;
+        fin->self_owned = true;
+        fin->p1 = p1;
+        fin->draws = draws;
+        fin->normals = const_cast<double *>(normals);
+        fin->pair_r2 = const_cast<double *>(pair_r2);
+        fin->lead = const_cast<int32_t *>(lead);
+        fin->progress = const_cast<int32_t *>(progress);
+        fin->block_done = block_done;
+        fin->block = block;
+        fin->part = part;
+        fin->parts = parts;
+        submit(pool->finish_q[(size_t)part], fin);
+    }
+    auto *job = new fokl_host_job();
+    job->kind = Kind::chain;
+    job->lamb = lamb;
+    job->qty = qty;
+    job->p1 = p1;
+    job->b = b;
+    job->btau = btau;
+    job->dtd = dtd;
+    job->sigsqd0 = sigsqd0;
+    job->tausqd0 = tausqd0;
+    job->draws = draws;
+    job->normals = const_cast<double *>(normals);
+    job->pair_r2 = const_cast<double *>(pair_r2);
+    job->lead = const_cast<int32_t *>(lead);
+    job->gam_sig = const_cast<double *>(gam_sig);
+    job->gam_tau = const_cast<double *>(gam_tau);
+    job->progress = const_cast<int32_t *>(progress);
+    job->w_out = w_out;
+    job->bstar_negative = bstar_negative;
+    if (parts > 0) {
+        job->block_done = block_done;
+        job->block = block;
+    }
+    *out = job;
+    submit(pool->chain_q, job);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1,
+                                         int ycol, double *lamb_out, double *qt_out, double *qty_out,
+                                         double *betahat_out, fokl_host_job **out)
+{
+    if (!pool || !out || !gram || !idx || p1 <= 0 || ld <= 0 || ycol < 0 || ycol >= ld || !lamb_out || !qt_out ||
+        !qty_out || !betahat_out) {
+        fokl_set_global_error("fokl_pool_submit_spectral: null pointer, empty model or y column out of range");
+        return FOKL_ERR_ARG;
+    }
+    if (!pool->dsyevr) {
+        fokl_set_global_error("fokl_pool_submit_spectral: the pool was created without spectral threads");
+        return FOKL_ERR_STATE;
+    }
+    for (int i = 0; i < p1; ++i)
+        if (idx[i] < 0 || idx[i] >= ld) {
+            fokl_set_global_error("fokl_pool_submit_spectral: column index out of range");
+            return FOKL_ERR_ARG;
+        }
+    auto *job = new fokl_host_job();
+    job->kind = Kind::spectral;
+    job->gram = gram;
+    job->ld = ld;
+    job->ycol = ycol;
+    job->idx.assign(idx, idx + p1);
+    job->lamb_out = lamb_out;
+    job->qt_out = qt_out;
+    job->qty_out = qty_out;
+    job->betahat_out = betahat_out;
+    *out = job;
+    submit(pool->spectral_q, job);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_pool_poll(const fokl_host_job *job)
+{
+    return job && job->done.load(std::memory_order_acquire) ? 1 : 0;
+}
+
+// Blocks until the job has run, frees it and returns its status.
+extern "C" int fokl_pool_wait(fokl_host_job *job)
+{
+    if (!job) {
+        fokl_set_global_error("fokl_pool_wait: null job");
+        return FOKL_ERR_ARG;
+    }
+    int spins = 0;
+    while (!job->done.load(std::memory_order_acquire)) {
+        if (++spins < 20000) {
+            _mm_pause();
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    const int rc = job->status;
+    if (rc != FOKL_OK) fokl_set_global_error("host pool job failed: " + job->error);
+    delete job;
+    return rc;
+}
+
+extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *chain, double *finish,
+                                      double *spectral)
+{
+    if (!pool) {
+        fokl_set_global_error("fokl_pool_busy_seconds: null pool");
+        return FOKL_ERR_ARG;
+    }
+    if (noise) *noise = 1e-9 * (double)pool->noise_busy_ns.load();
+    if (chain) *chain = 1e-9 * (double)pool->chain_busy_ns.load();
+    if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
+    if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
+    return FOKL_OK;
+}

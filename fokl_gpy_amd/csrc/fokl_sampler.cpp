@@ -50,6 +50,18 @@ void words_to_doubles(const uint32_t *__restrict__ k, int count, double *__restr
     }
 }
 
+// x = 2 d - 1 and x^2 for every double of a block: whichever way later draws pair the doubles up (a gamma's uniform
+// shifts the pairing by one), a polar attempt is then one addition away: r2 = s[j] + s[j + 1].
+__attribute__((target_clones("avx2", "default")))
+void polar_coordinates(const double *__restrict__ d, int count, double *__restrict__ x, double *__restrict__ sq)
+{
+    for (int j = 0; j < count; ++j) {
+        const double v = 2.0 * d[j] - 1.0;
+        x[j] = v;
+        sq[j] = v * v;
+    }
+}
+
 __attribute__((target_clones("avx2", "default")))
 void polar_candidates(const double *__restrict__ d, int attempts, double *__restrict__ t1, double *__restrict__ t2,
                       double *__restrict__ tr)
@@ -81,7 +93,7 @@ struct LegacyRng {
     double gauss;
     // doubles of the current 624-word block, converted in one vectorised pass: entry j <-> words dbase + 2j, + 1
     int dbase = -1, dcount = 0;
-    double dbuf[MT_N / 2];
+    double dbuf[MT_N / 2], xbuf[MT_N / 2], sbuf[MT_N / 2];
     double t1[MT_N / 4 + 1], t2[MT_N / 4 + 1], tr[MT_N / 4 + 1];
 
     inline void build_dbuf()
@@ -89,6 +101,7 @@ struct LegacyRng {
         dbase = pos;
         dcount = (MT_N - pos) / 2;
         words_to_doubles(key + pos, dcount, dbuf);
+        polar_coordinates(dbuf, dcount, xbuf, sbuf);
     }
 
     void refill()
@@ -195,6 +208,38 @@ struct LegacyRng {
         }
     }
 
+    // `count` accepted polar attempts left unfinished: out[2i] = x2, out[2i + 1] = x1 (numpy's order of use), r2[i];
+    // the normals are f * out[..] with f = sqrt(-2 log(r2) / r2).  Same stream consumption as polar_pairs.
+    void polar_pairs_raw(int count, double *__restrict__ out, double *__restrict__ r2)
+    {
+        int have = 0;
+        while (have < count) {
+            int j = dbase >= 0 ? (pos - dbase) >> 1 : dcount;
+            if (dbase < 0 || dcount - j < 2) {
+                // block (nearly) exhausted or not converted yet: one attempt through the general path
+                const double x1 = 2.0 * next_double() - 1.0;
+                const double x2 = 2.0 * next_double() - 1.0;
+                const double rr = x1 * x1 + x2 * x2;
+                out[2 * have] = x2;
+                out[2 * have + 1] = x1;
+                r2[have] = rr;
+                have += (rr < 1.0) & (rr != 0.0);
+                continue;
+            }
+            const int j0 = j, last = dcount - 1;
+            const double *__restrict__ x = xbuf, *__restrict__ sq = sbuf;
+            while (j < last && have < count) {              // branch-free compaction of the accepted attempts
+                const double rr = sq[j] + sq[j + 1];
+                out[2 * have] = x[j + 1];
+                out[2 * have + 1] = x[j];
+                r2[have] = rr;
+                have += (rr < 1.0) & (rr != 0.0);
+                j += 2;
+            }
+            pos += 2 * (j - j0);
+        }
+    }
+
     inline double gauss_draw()
     {
         if (has_gauss) {
@@ -286,6 +331,45 @@ void fill_normals(LegacyRng &r, Scratch &s, int n, double *out)
         r.gauss = s.vals[2 * pairs - 1];
         r.has_gauss = 1;
     }
+}
+
+// The same n draws with the expensive half deferred: full pairs stay raw (see polar_pairs_raw), values that had to
+// be formed anyway (a leading cached value; a trailing half pair whose partner goes to the cache) are final.
+// *lead = 1 if out[0] is such a leading final value.  r2 has room for n / 2 + 1 entries.
+void fill_normals_raw(LegacyRng &r, int n, double *out, double *r2, int32_t *lead)
+{
+    int i = 0;
+    *lead = 0;
+    if (n > 0 && r.has_gauss) {
+        out[0] = r.gauss;
+        r.has_gauss = 0;
+        r.gauss = 0.0;
+        *lead = 1;
+        i = 1;
+    }
+    const int remaining = n - i;
+    if (remaining <= 0) return;
+    r.polar_pairs_raw(remaining / 2, out + i, r2);
+    if (remaining & 1) out[n - 1] = r.gauss_draw();      // forms the pair, caches its second value
+}
+
+// raw [n] + r2 -> vec [n]: the n normals fill_normals would have produced, bit for bit.
+// vec may be raw itself (finishing in place).
+void finish_normals(const double *raw, const double *__restrict__ r2, int lead, int n, double *vec,
+                    double *__restrict__ f)
+{
+    const int pairs = (n - lead) / 2;
+    if (lead) vec[0] = raw[0];
+    for (int j = 0; j < pairs; ++j) f[j] = std::log(r2[j]);              // libm calls, independent iterations
+    for (int j = 0; j < pairs; ++j) f[j] = std::sqrt(-2.0 * f[j] / r2[j]);
+    const double *x = raw + lead;
+    double *v = vec + lead;
+    for (int j = 0; j < pairs; ++j) {
+        const double a = f[j] * x[2 * j], b = f[j] * x[2 * j + 1];
+        v[2 * j] = a;
+        v[2 * j + 1] = b;
+    }
+    if ((n - lead) & 1) vec[n - 1] = raw[n - 1];
 }
 
 inline bool bind_rng(LegacyRng &r, uint32_t *key, const int32_t *pos, const int32_t *has_gauss, const double *cache)
@@ -408,11 +492,11 @@ extern "C" int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, d
 // ---------------------------------------------------------------------------------------------------------
 
 extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
-                               int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
-                               double *gam_tau_out, int32_t *progress)
+                               int32_t *has_gauss, double *gauss_cache, double *normals_out, double *pair_r2_out,
+                               int32_t *lead_out, double *gam_sig_out, double *gam_tau_out, int32_t *progress)
 {
     LegacyRng r;
-    if (p1 <= 0 || draws < 0 || !normals_out || !gam_sig_out || !gam_tau_out ||
+    if (p1 <= 0 || draws < 0 || !normals_out || !pair_r2_out || !lead_out || !gam_sig_out || !gam_tau_out ||
         !bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache)) {
         fokl_set_global_error("fokl_noise_tape: null pointer, empty model or invalid RNG state");
         if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
@@ -423,30 +507,70 @@ extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star
         if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
         return FOKL_ERR_NUMERIC;
     }
-    Scratch &scratch = t_scratch;
+    const size_t half = (size_t)p1 / 2 + 1;
     for (int k = 0; k < draws; ++k) {
-        fill_normals(r, scratch, p1, normals_out + (size_t)k * p1);
+        fill_normals_raw(r, p1, normals_out + (size_t)k * p1, pair_r2_out + (size_t)k * half, lead_out + k);
         gam_sig_out[k] = r.std_gamma(astar);
         gam_tau_out[k] = r.std_gamma(atau_star);
-        if (progress) __atomic_store_n(progress, k + 1, __ATOMIC_RELEASE);   // iteration k is complete and visible
+        // iterations up to k are complete and visible.  Published per block, not per iteration: every store to a
+        // line that other cores are polling costs this thread a coherence round trip.
+        if (progress && ((k + 1) % FOKL_TAPE_BLOCK == 0 || k + 1 == draws))
+            __atomic_store_n(progress, k + 1, __ATOMIC_RELEASE);
     }
     release_rng(r, mt_pos, has_gauss, gauss_cache);
     return FOKL_OK;
 }
 
+namespace {
+
+// One Gibbs iteration given its p1 normals and two standard gammas (FR:1521-1548 in the eigenbasis).
+struct ChainState {
+    double sigsqd, tausqd;
+    int32_t flagged = 0;
+};
+
+inline void chain_step(const double *__restrict__ lamb, const double *__restrict__ qty, int p1, double b, double btau,
+                       double dtd, const double *vec, double gam_sig, double gam_tau, double *__restrict__ w,
+                       ChainState &st)
+{
+    const double inv_tau = 1.0 / st.tausqd;
+    const double sig = std::sqrt(st.sigsqd);
+    draw_in_eigenbasis(lamb, qty, vec, p1, inv_tau, sig, w);
+    double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
+    for (int i = 0; i < p1; ++i) {
+        const double wi = w[i];
+        q_lam += lamb[i] * (wi * wi);
+        q_ty += wi * qty[i];
+        q_ww += wi * wi;
+    }
+    const double bstar = b + 0.5 * (q_lam - 2.0 * q_ty + dtd + q_ww / st.tausqd);
+    if (bstar < 0.0) {
+        st.flagged = 1;                                // the tape holds a gamma the reference would not have drawn
+        st.sigsqd = NAN;
+    } else {
+        st.sigsqd = 1.0 / ((1.0 / bstar) * gam_sig);
+    }
+    const double btau_star = (1.0 / (2.0 * st.sigsqd)) * q_ww + btau;
+    st.tausqd = 1.0 / ((1.0 / btau_star) * gam_tau);
+}
+
+}  // namespace
+
 extern "C" int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau,
                                           double dtd, double sigsqd0, double tausqd0, int draws,
-                                          const double *normals, const double *gam_sig, const double *gam_tau,
+                                          const double *normals, const double *pair_r2, const int32_t *lead,
+                                          const double *gam_sig, const double *gam_tau,
                                           double *w_out, double *sigs_out, double *taus_out, int32_t *bstar_negative,
                                           const int32_t *progress)
 {
-    if (!lamb || !qty || !normals || !gam_sig || !gam_tau || !w_out || p1 <= 0 || draws < 0) {
+    if (!lamb || !qty || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !w_out || p1 <= 0 || draws < 0) {
         fokl_set_global_error("fokl_gibbs_chain_from_tape: null pointer or empty model");
         return FOKL_ERR_ARG;
     }
-    int32_t flagged = 0;
     int32_t ready = progress ? 0 : draws;
-    double sigsqd = sigsqd0, tausqd = tausqd0;
+    ChainState st{sigsqd0, tausqd0};
+    const size_t half = (size_t)p1 / 2 + 1;
+    std::vector<double> vec((size_t)p1), fbuf(half);
     for (int k = 0; k < draws; ++k) {
         while (ready <= k) {                           // follow a tape that is still being recorded
             ready = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
@@ -456,29 +580,81 @@ extern "C" int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty,
             }
             if (ready <= k) __builtin_ia32_pause();
         }
-        const double inv_tau = 1.0 / tausqd;
-        const double sig = std::sqrt(sigsqd);
-        double *__restrict__ w = w_out + (size_t)k * p1;
-        draw_in_eigenbasis(lamb, qty, normals + (size_t)k * p1, p1, inv_tau, sig, w);
-        double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
-        for (int i = 0; i < p1; ++i) {
-            const double wi = w[i];
-            q_lam += lamb[i] * (wi * wi);
-            q_ty += wi * qty[i];
-            q_ww += wi * wi;
-        }
-        const double bstar = b + 0.5 * (q_lam - 2.0 * q_ty + dtd + q_ww / tausqd);
-        if (bstar < 0.0) {
-            flagged = 1;                               // the tape holds a gamma the reference would not have drawn
-            sigsqd = NAN;
-        } else {
-            sigsqd = 1.0 / ((1.0 / bstar) * gam_sig[k]);
-        }
-        if (sigs_out) sigs_out[k] = sigsqd;
-        const double btau_star = (1.0 / (2.0 * sigsqd)) * q_ww + btau;
-        tausqd = 1.0 / ((1.0 / btau_star) * gam_tau[k]);
-        if (taus_out) taus_out[k] = tausqd;
+        finish_normals(normals + (size_t)k * p1, pair_r2 + (size_t)k * half, lead[k], p1, vec.data(), fbuf.data());
+        chain_step(lamb, qty, p1, b, btau, dtd, vec.data(), gam_sig[k], gam_tau[k], w_out + (size_t)k * p1, st);
+        if (sigs_out) sigs_out[k] = st.sigsqd;
+        if (taus_out) taus_out[k] = st.tausqd;
     }
-    if (bstar_negative) *bstar_negative = flagged;
+    if (bstar_negative) *bstar_negative = st.flagged;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_finish_tape_blocks(int p1, int draws, double *normals, const double *pair_r2, const int32_t *lead,
+                                       const int32_t *progress, int part, int parts, int block, int32_t *block_done)
+{
+    if (!normals || !pair_r2 || !lead || !block_done || p1 <= 0 || draws < 0 || parts < 1 || part < 0 ||
+        part >= parts || block < 1) {
+        fokl_set_global_error("fokl_finish_tape_blocks: null pointer, empty model or bad partition");
+        return FOKL_ERR_ARG;
+    }
+    const size_t half = (size_t)p1 / 2 + 1;
+    std::vector<double> fbuf(half);
+    const int nblocks = (draws + block - 1) / block;
+    int32_t ready = progress ? 0 : draws;
+    for (int blk = part; blk < nblocks; blk += parts) {
+        const int k0 = blk * block, k1 = std::min(draws, k0 + block);
+        while (ready < k1) {
+            ready = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
+            if (ready < 0) {
+                for (int later = blk; later < nblocks; later += parts)
+                    __atomic_store_n(block_done + later, -1, __ATOMIC_RELEASE);
+                fokl_set_global_error("fokl_finish_tape_blocks: the noise tape producer failed");
+                return FOKL_ERR_STATE;
+            }
+            if (ready < k1) __builtin_ia32_pause();
+        }
+        for (int k = k0; k < k1; ++k) {
+            double *row = normals + (size_t)k * p1;
+            finish_normals(row, pair_r2 + (size_t)k * half, lead[k], p1, row, fbuf.data());
+        }
+        __atomic_store_n(block_done + blk, 1, __ATOMIC_RELEASE);
+    }
+    return FOKL_OK;
+}
+
+extern "C" int fokl_gibbs_chain_from_finished_tape(const double *lamb, const double *qty, int p1, double b,
+                                                   double btau, double dtd, double sigsqd0, double tausqd0, int draws,
+                                                   const double *normals, const double *gam_sig,
+                                                   const double *gam_tau, const int32_t *block_done, int block,
+                                                   double *w_out, double *sigs_out, double *taus_out,
+                                                   int32_t *bstar_negative)
+{
+    if (!lamb || !qty || !normals || !gam_sig || !gam_tau || !w_out || p1 <= 0 || draws < 0 ||
+        (block_done && block < 1)) {
+        fokl_set_global_error("fokl_gibbs_chain_from_finished_tape: null pointer or empty model");
+        return FOKL_ERR_ARG;
+    }
+    ChainState st{sigsqd0, tausqd0};
+    int ready_block = -1;
+    for (int k = 0; k < draws; ++k) {
+        if (block_done && k / block > ready_block) {
+            const int blk = k / block;
+            for (;;) {
+                const int32_t flag = __atomic_load_n(block_done + blk, __ATOMIC_ACQUIRE);
+                if (flag > 0) break;
+                if (flag < 0) {
+                    fokl_set_global_error("fokl_gibbs_chain_from_finished_tape: the tape producer failed");
+                    return FOKL_ERR_STATE;
+                }
+                __builtin_ia32_pause();
+            }
+            ready_block = blk;
+        }
+        chain_step(lamb, qty, p1, b, btau, dtd, normals + (size_t)k * p1, gam_sig[k], gam_tau[k],
+                   w_out + (size_t)k * p1, st);
+        if (sigs_out) sigs_out[k] = st.sigsqd;
+        if (taus_out) taus_out[k] = st.tausqd;
+    }
+    if (bstar_negative) *bstar_negative = st.flagged;
     return FOKL_OK;
 }

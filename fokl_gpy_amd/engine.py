@@ -179,117 +179,193 @@ class SlotPool:
 # the driver
 # ---------------------------------------------------------------------------------------------------------
 
-def _pin_to_l3_domain():
-    """Restrict the calling thread to the CPUs that share a last-level cache with the CPU it is running on (within its
-    current affinity mask).  Returns the previous mask, or None if nothing was changed."""
+def _cpu_list(path):
+    with open(path) as fh:
+        text = fh.read().strip()
+    cpus = set()
+    for part in text.split(','):
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _place_host_threads():
+    """CPU placement for the threads of one fit.  Restricts the calling thread (and the threads it creates next) to the
+    logical CPUs that share a last-level cache with the CPU it is running on, minus one physical core that is set
+    aside for the random-stream thread.  Returns (previous affinity mask or None, logical CPU for the noise thread or
+    -1); nothing is changed when the topology cannot be read or the mask is too small to gain anything."""
     try:
         import ctypes
         cpu = ctypes.CDLL(None).sched_getcpu()
         allowed = os.sched_getaffinity(0)
-        with open(f'/sys/devices/system/cpu/cpu{cpu}/cache/index3/shared_cpu_list') as fh:
-            text = fh.read().strip()
-        domain = set()
-        for part in text.split(','):
-            lo, _, hi = part.partition('-')
-            domain.update(range(int(lo), int(hi or lo) + 1))
-        target = domain & allowed
-        if len(target) < 2 or target == allowed:
-            return None
-        os.sched_setaffinity(0, target)
-        return allowed
+        domain = _cpu_list(f'/sys/devices/system/cpu/cpu{cpu}/cache/index3/shared_cpu_list') & allowed
+        if len(domain) < 2:
+            return None, -1
+        noise_cpu = -1
+        candidate = max(domain - {cpu})
+        siblings = _cpu_list(f'/sys/devices/system/cpu/cpu{candidate}/topology/thread_siblings_list')
+        rest = domain - siblings
+        if cpu in rest and len(rest) >= 4:
+            noise_cpu, domain = candidate, rest
+        if domain == allowed:
+            return None, noise_cpu
+        os.sched_setaffinity(0, domain)
+        return allowed, noise_cpu
     except (OSError, AttributeError, ValueError):
-        return None
+        return None, -1
 
 
-class NoisePipeline:
+class HostPipeline:
     """
-    Worker thread that owns the numpy-legacy random stream for the duration of a fit and records, strictly in
-    request order, the *noise tape* of every model evaluation (``_capi.noise_tape``: per Gibbs iteration p1 standard
-    normals and two standard gammas -- everything random in FR:1519-1548, none of it data dependent).
+    The host threads of one fit (include/fokl_hip.h: fokl_pool_*), all native, none holding the GIL:
 
-    The stream is inherently serial, so this thread is the critical path of a fit at large N; the main thread
-    meanwhile does what does not need random numbers (Gram sub-block, eigh, betahat, the device residual pass, the
-    accept / reject decision on the BIC) and only blocks on a tape when somebody asks for that candidate's draws.
+    * the noise thread owns the numpy-legacy random stream for the duration of the fit and records, strictly in
+      request order, the noise tape of every model evaluation (per Gibbs iteration p1 standard normals and two
+      standard gammas -- everything random in FR:1519-1548, none of it data dependent).  The stream is serial by
+      definition, so this thread is the critical path of a fit at large N;
+    * chain threads follow the tapes and form every candidate's draws in the eigenbasis (FR:1521-1548);
+    * spectral threads diagonalise candidate XtX sub-blocks with scipy's own LAPACK (FR:1499-1504).  That work uses
+      no random numbers, so the driver submits it ahead of time for both possible next kill-test models.
+
+    The driver thread keeps what needs Python or the device: the sequential decisions, the K1 / K2 / K3 launches.
     """
 
     def __init__(self, stream, draws):
-        import queue
-        import threading
         self.stream, self.draws = stream, int(draws)
-        self._q = queue.Queue()
-        # The tapes (about 1 MB each) are produced by the worker and consumed by the driver thread: keep the two on
-        # cores that share an L3 for the duration of the fit (measured on a 2 x 64-core EPYC host: 336 -> 264 ms per
-        # fit).  The worker inherits the affinity set here; the driver's is restored in close().  FOKL_PIN_L3=0 disables.
-        self._saved_affinity = None
+        # Tapes (about 1 MB each) are produced by one thread and consumed by others: keep all of them on cores that
+        # share an L3 for the duration of the fit, and give the noise thread -- the serial resource -- a physical core
+        # to itself (measured on a 2 x 64-core EPYC host).  The native threads inherit the affinity set here; the
+        # driver's is restored in close().  FOKL_PIN_L3=0 disables.
+        self._saved_affinity, noise_cpu = None, -1
         if os.environ.get('FOKL_PIN_L3', '1') != '0':
-            self._saved_affinity = _pin_to_l3_domain()
-        self._thread = threading.Thread(target=self._work, name='fokl-noise', daemon=True)
-        self._thread.start()
+            self._saved_affinity, noise_cpu = _place_host_threads()
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 4
+        chain = int(os.environ.get('FOKL_CHAIN_THREADS', '2'))
+        finish = int(os.environ.get('FOKL_FINISH_THREADS', str(max(0, min(3, cores - 5)))))
+        spectral = int(os.environ.get('FOKL_SPECTRAL_THREADS', str(max(1, min(3, cores - 4)))))
+        self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu)
+        # Every job names buffers the native threads read and write: they are kept here until the job has run, whether
+        # or not the driver still cares about the result (a rejected candidate's tape is recorded all the same).
+        self._live = []
+        # Tapes and draws are a few MB per model evaluation; fresh allocations would be page-faulted in by the noise
+        # and chain threads (measured: a third of the tape time).  Buffers go round in 512 KB size classes instead.
+        self._spare = {}
 
-    def _work(self):
-        while True:
-            item = self._q.get()
-            if item is None:
-                return
-            fut, tape, astar, atau_star = item
-            try:
-                fut.set_result(_capi.record_noise_tape(tape, astar, atau_star, self.stream))
-            except BaseException as exc:            # surfaced on .result() in the main thread
-                fut.set_exception(exc)
+    CLASS_DOUBLES = 65536
+
+    def _take(self, doubles):
+        cls = -(-doubles // self.CLASS_DOUBLES)
+        spare = self._spare.get(cls)
+        return spare.pop() if spare else np.empty(cls * self.CLASS_DOUBLES, dtype=np.float64)
+
+    def give(self, raw):
+        self._spare.setdefault(raw.shape[0] // self.CLASS_DOUBLES, []).append(raw)
+
+    def _reap(self):
+        live = []
+        for job in self._live:
+            if job.done():
+                if job.recycle:
+                    for raw in job.recycle:
+                        self.give(raw)
+                    job.recycle = job.keep = None
+            else:
+                live.append(job)
+        self._live = live
+
+    def _track(self, job):
+        if len(self._live) >= 24:
+            self._reap()
+        self._live.append(job)
+        return job
 
     def request(self, p1, astar, atau_star):
-        """Queue the tape of one model evaluation.  Returns (tape, future): the tape's buffers exist at once and fill
-        up in the background (``tape.progress``), the future resolves when it is complete."""
-        from concurrent.futures import Future
-        fut = Future()
-        tape = _capi.NoiseTape(p1, self.draws)
-        self._q.put((fut, tape, float(astar), float(atau_star)))
-        return tape, fut
+        """Queue the tape of one model evaluation; the buffers exist at once and fill up in the background."""
+        raw = self._take(_capi.NoiseTape.doubles_needed(p1, self.draws))
+        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star)
+        job.recycle = [raw]                 # moved to the chain job, which is the last reader of the tape
+        return self._track(job)
+
+    def spectral(self, gram, idx):
+        """Queue G2 for the model made of columns idx of gram; may be called ahead of need (no random numbers)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        return self._track(self.pool.submit_spectral(gram, idx, gram.shape[0] - 1))
+
+    def chain(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job):
+        """Queue the draws of the model whose tape is noise_job's.  Returns (job, raw buffer holding w): the caller
+        hands the buffer back (give, or job.recycle while the job runs) when nobody reads w any more."""
+        tape = noise_job.result
+        w_raw = self._take(tape.draws * tape.p1)
+        job = self.pool.submit_chain(spec.lamb, spec.qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw)
+        job.recycle, noise_job.recycle = noise_job.recycle, None
+        return self._track(job), w_raw
 
     def close(self):
-        """Drain the queue (every requested tape advances the stream, used or not) and stop the worker."""
-        self._q.put(None)
-        self._thread.join()
+        """Run everything still queued (every requested tape advances the stream, used or not), stop the threads."""
+        for job in self._live:
+            job.wait()
+        self._live = []
+        self._spare = {}
+        busy = self.pool.busy_seconds()
+        self.pool.close()
         if self._saved_affinity is not None:
             try:
                 os.sched_setaffinity(0, self._saved_affinity)
             except OSError:
                 pass
             self._saved_affinity = None
+        return busy
 
 
 class GibbsOutcome:
-    """One model evaluation.  The BIC is known at once; the draws are materialised on first use from the noise tape
-    (chain arithmetic in the eigenbasis, then betas = w Q', FR:1528) -- most kill-test candidates never need them."""
-    __slots__ = ('lamb', 'qty', 'Q', 'betahat', 'ev', 'idx', 'dtd', '_tape', '_owner', '_w', '_betas')
+    """One model evaluation.  The BIC is known at once; the draws arrive from a chain thread (chain arithmetic in the
+    eigenbasis), betas = w Q' (FR:1528) is formed only for the columns somebody looks at."""
+    __slots__ = ('lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'intercept_scale', '_jobs', '_owner', '_w', '_betas',
+                 '_w_raw', '_chain_job')
 
-    def __init__(self, owner, lamb, qty, Q, betahat, ev, idx, dtd, tape):
-        self.lamb, self.qty, self.Q, self.betahat, self.ev, self.idx, self.dtd = lamb, qty, Q, betahat, ev, idx, dtd
-        self._tape, self._owner = tape, owner
-        self._w = self._betas = None
+    def __init__(self, owner, spec, ev, idx, noise_job, chain_job, w_raw):
+        self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
+        self.ev, self.idx = ev, idx
+        self._jobs, self._owner = (noise_job, chain_job), owner
+        self._w = self._betas = self.intercept_scale = None
+        self._w_raw, self._chain_job = w_raw, chain_job
+
+    def __del__(self):
+        # w lives in a buffer of the pipeline's pool: hand it back, directly or through the job that is still writing
+        host = self._owner.host
+        if host is not None and self._w_raw is not None:
+            if self._chain_job.done():
+                host.give(self._w_raw)
+            else:
+                self._chain_job.recycle.append(self._w_raw)
+
+    @property
+    def Q(self):
+        return self.Qt.T
 
     @property
     def w(self):
         if self._w is None:
             o = self._owner
-            tape, fut = self._tape
-            # follows the tape while the worker is still recording it (C-level acquire/release on tape.progress)
+            noise_job, chain_job = self._jobs
             t0 = time.perf_counter()
-            self._w, negative = _capi.gibbs_chain_from_tape(self.lamb, self.qty, o.b, o.btau, self.dtd, o.sigsqd0,
-                                                            o.tausqd0, tape, follow=True)
-            fut.result()
+            self._w, negative = chain_job.wait()
+            noise_job.wait()
             o.stats['t_chain'] += time.perf_counter() - t0
             o.stats['chains_materialised'] += 1
-            if negative:
+            if negative[0]:
                 raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
                                    "cannot reproduce the reference's skipped draw (FR:1538-1539)")
-            self._tape = None
+            self._jobs = None
         return self._w
 
     @property
     def betas(self):
         if self._betas is None:
-            self._betas = self.w @ self.Q.T
+            self._betas = self.w @ self.Qt
         return self._betas
 
     def beta_columns(self, cols):
@@ -297,16 +373,16 @@ class GibbsOutcome:
         intercept, never at the whole draws x (P+1) matrix."""
         if self._betas is not None:
             return self._betas[:, cols]
-        return self.w @ self.Q[cols, :].T
+        return self.w @ self.Qt[:, cols]
 
 
 class EagerOutcome:
     """Model evaluation whose chain ran in line (b <= 0: bstar < 0 may skip draws, so no tape can be recorded ahead)."""
-    __slots__ = ('w', 'Q', 'betahat', 'ev', 'idx', '_betas')
+    __slots__ = ('w', 'Q', 'betahat', 'ev', 'idx', 'intercept_scale', '_betas')
 
     def __init__(self, w, Q, betahat, ev, idx):
         self.w, self.Q, self.betahat, self.ev, self.idx = w, Q, betahat, ev, idx
-        self._betas = None
+        self._betas = self.intercept_scale = None
 
     @property
     def betas(self):
@@ -354,87 +430,184 @@ class ForwardSelection:
         self.sigsqd0 = b / (1 + a)          # FR:1371
         self.tausqd0 = btau / (1 + atau)    # FR:1372
         self.pool = SlotPool(backend)
-        self.noise = None                   # NoisePipeline while run() is active (b > 0 only)
+        self.host = None                    # HostPipeline while run() is active (b > 0 only)
+        self._async_resid = hasattr(backend, 'bic_resid_launch')
+        self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
+    def _ev_from_moments(self, s1, s2, p1):
+        n = self.n
+        siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
+        lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
+        ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554
+        if self.aic:
+            ev = ev + (2 - math.log(n)) * p1                         # FR:1653-1654 / FR:1684-1685
+        return ev
+
+    def _record(self, p1, n_prev_cols, ev, kill):
+        built = p1 - n_prev_cols
+        self.stats['gibbs_calls'] += 1
+        self.stats['kill_tests'] += int(kill)
+        self.stats['terms_logical'] += built
+        self.trace.append(dict(cols=p1, built=built, ev=float(ev), kill=bool(kill)))
+
+    # The pipelined evaluation comes in three phases so that the kill-test loop can interleave them:
+    #   _begin  : G2 (waits for the spectral job) and the launch of the K3 residual pass -- deterministic, free of
+    #             random numbers, so it may run for a model whose test is not decided yet;
+    #   _commit : the noise tape request and the chain job -- consumes the random stream, strictly in reference order;
+    #   _score  : fetches the residual moments -> BIC.
+    def _begin(self, gram, slots, idx, spectral_job=None):
+        t0 = time.perf_counter()
+        if spectral_job is None:
+            spectral_job = self.host.spectral(gram, idx)
+        spec = spectral_job.wait()
+        t1 = time.perf_counter()
+        self.stats['t_eigh'] += t1 - t0
+        cand_slots = [slots[i] for i in idx]
+        if self._async_resid:
+            self.backend.bic_resid_launch(cand_slots, spec.betahat)
+        ycol = gram.shape[0] - 1
+        return spec, idx, cand_slots, gram[ycol, ycol]
+
+    def _request_noise(self, p1):
+        astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
+        atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
+        return self.host.request(p1, astar, atau_star)
+
+    def _commit(self, pending, noise_job=None):
+        """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
+        spec, idx, _, dtd = pending
+        if noise_job is None:
+            noise_job = self._request_noise(idx.shape[0])
+        chain_job, w_raw = self.host.chain(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job)
+        return noise_job, chain_job, w_raw
+
+    def _score(self, pending):
+        spec, idx, cand_slots, _ = pending
+        t0 = time.perf_counter()
+        if self._async_resid:
+            s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
+        else:
+            s1, s2 = self.backend.bic_resid(cand_slots, spec.betahat, self.allreduce)
+        self.stats['t_resid'] += time.perf_counter() - t0
+        return self._ev_from_moments(s1, s2, idx.shape[0])
+
     def _evaluate(self, gram, slots, idx, n_prev_cols, kill):
         """
         gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
         slots : device slot of each active column
         idx   : active-column indices of this candidate model (idx[0] == 0, the intercept)
         """
-        idx = np.asarray(idx, dtype=np.intp)
+        idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
-        n = self.n
-        astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508 (mmtx + 1 == p1)
-        atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        tick = time.perf_counter
-        t0 = tick()
-        if self.noise is not None:
-            # the random half of the chain depends only on the model size: the worker thread starts recording it now,
-            # in call order, while this thread diagonalises and the device streams the residuals
-            tape = self.noise.request(p1, astar, atau_star)
+        if self.host is not None:
+            # not speculative: the tape is requested first, so that it is recorded while G2 runs
+            noise_job = self._request_noise(p1)
+            pending = self._begin(gram, slots, idx)
+            jobs = self._commit(pending, noise_job)
+            ev = self._score(pending)
+            self._record(p1, n_prev_cols, ev, kill)
+            return GibbsOutcome(self, pending[0], ev, idx, *jobs)
 
+        n = self.n
+        astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508
+        atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
+        t0 = time.perf_counter()
+        cand_slots = [slots[i] for i in idx]
         ycol = gram.shape[0] - 1
+        dtd = gram[ycol, ycol]
         XtX = gram[np.ix_(idx, idx)]
         Xty = gram[idx, ycol]
-        dtd = gram[ycol, ycol]
-
         lamb, Q = eigh_canonical(XtX)
         qty = Q.T @ Xty
         betahat = Q @ (qty / lamb)                                  # FR:1502-1504
-        t1 = tick()
-        self.stats['t_eigh'] += t1 - t0
-
-        cand_slots = [slots[i] for i in idx]
-        if self.noise is not None:
-            # the draws themselves are formed only if somebody needs them (GibbsOutcome.w)
+        self.stats['t_eigh'] += time.perf_counter() - t0
+        if self._async_resid:
+            self.backend.bic_resid_launch(cand_slots, betahat)
+        try:
+            w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0,
+                                  self.tausqd0, self.draws, self.stream)
+        finally:
+            if self._async_resid:
+                s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
+        if not self._async_resid:
             s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
-            self.stats['t_resid'] += tick() - t1
-            w = None
-        else:
-            overlap = hasattr(self.backend, 'bic_resid_launch')
-            if overlap:
-                self.backend.bic_resid_launch(cand_slots, betahat)
-            try:
-                w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0,
-                                      self.tausqd0, self.draws, self.stream)
-            finally:
-                if overlap:
-                    s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
-            if not overlap:
-                s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
-        siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
-        lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
-        ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554
-        if self.aic:
-            ev = ev + (2 - math.log(n)) * p1                         # FR:1653-1654 / FR:1684-1685
-
-        built = p1 - n_prev_cols
-        self.stats['gibbs_calls'] += 1
-        self.stats['kill_tests'] += int(kill)
-        self.stats['terms_logical'] += built
-        self.trace.append(dict(cols=p1, built=built, ev=float(ev), kill=bool(kill)))
-        if self.noise is not None:
-            return GibbsOutcome(self, lamb, qty, Q, betahat, ev, idx, dtd, tape)
+        ev = self._ev_from_moments(s1, s2, p1)
+        self._record(p1, n_prev_cols, ev, kill)
         return EagerOutcome(w, Q, betahat, ev, idx)
+
+    @staticmethod
+    def _columns_without(count, removed):
+        return np.array([c for c in range(count) if c not in removed], dtype=np.int32)
+
+    def _intercept_scale(self, outcome, half0):
+        """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
+        if outcome.intercept_scale is None:
+            outcome.intercept_scale = np.mean(np.abs(np.mean(
+                outcome.beta_columns(np.array([0]))[half0:self.draws, 0])))
+        return outcome.intercept_scale
+
+    def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0):
+        """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
+
+        Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
+        what the test computes does not.  So G2 of the models the next few tests will need is submitted ahead, and
+        the residual pass of the upcoming one is in flight while this thread waits for that chain.
+        """
+        A = len(slots)
+        vm = cand_col.shape[0]
+        floor_std = min(self.threshstda, self.threshstdb)            # below it neither clause of FR:1670 can hold
+        runnable = [int(cand_col[j]) for j in range(vm) if rel_std[j] > floor_std]
+        proposal = [j for j in range(vm) if rel_std[j] > floor_std]
+        killed = frozenset()
+        evmin = best.ev
+        ahead = {}                                                    # trial set -> spectral job submitted ahead
+        last_accepted = True                                          # predictor: proposals go the way the last went
+        for pos, i in enumerate(proposal):
+            # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
+            cur = killed
+            for col in runnable[pos:pos + 1 + self.lookahead]:
+                key = cur | {col}
+                if key not in ahead:
+                    ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
+                if last_accepted:
+                    cur = key
+            trial = killed | {runnable[pos]}
+            idx = self._columns_without(A, trial)
+            pending = self._begin(gram, slots, idx, ahead.pop(trial))
+            run = rel_std[i] > self.threshstdb or (
+                rel_std[i] > self.threshstda and mean_abs[i] < self.threshav * self._intercept_scale(best, half0))
+            if not run:
+                if self._async_resid:
+                    self._score(pending)                              # drains the speculative residual pass
+                continue
+            jobs = self._commit(pending)
+            ev = self._score(pending)
+            self._record(idx.shape[0], n_prev, ev, True)
+            last_accepted = bool(ev < evmin)
+            if last_accepted:
+                killed, evmin = trial, ev
+                best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+        return sorted(killed), evmin, best
 
     # -- the search ---------------------------------------------------------------------------------------
     def run(self):
-        """The whole search.  With b > 0 (always, unless the user forces a non-positive scale) the random stream runs
-        on a worker thread (NoisePipeline); otherwise every chain runs in line."""
+        """The whole search.  With b > 0 (always, unless the user forces a non-positive scale) the random stream, the
+        chains and the eigen-decompositions run on native threads (HostPipeline); otherwise every chain runs in line."""
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
         if pipelined:
-            self.noise = NoisePipeline(self.stream, self.draws)
+            self.host = HostPipeline(self.stream, self.draws)
         try:
             return self._run()
         finally:
-            if self.noise is not None:
-                self.noise.close()          # all requested tapes are recorded -> the stream ends where it must
-                self.noise = None
+            if self.host is not None:
+                busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
+                self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
+                                  pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'])
+                self.host = None
 
     def _run(self):
         m, n = self.m, self.n
@@ -501,22 +674,23 @@ class ForwardSelection:
                 # sequential kill tests (FR:1666-1690): proposals in ascending |mean beta|
                 killed = []                                           # active-column indices removed so far
                 evmin = ev
-                for i in range(vm):
-                    # FR:1670-1671.  The second clause needs the intercept draws of the model accepted so far, i.e.
-                    # that candidate's chain; it is only evaluated when the first clause does not already decide
-                    # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
-                    if rel_std[i] > self.threshstdb or (
-                            rel_std[i] > self.threshstda and
-                            mean_abs[i] < self.threshav * np.mean(np.abs(np.mean(
-                                best.beta_columns(np.array([0]))[half0:draws, 0])))):
-                        trial = set(killed)
-                        trial.add(int(cand_col[i]))
-                        idx = [c for c in range(A) if c not in trial]
-                        res = self._evaluate(gram, active_slots, idx, n_prev, kill=True)
-                        if res.ev < evmin:
-                            killed = sorted(trial)
-                            evmin = res.ev
-                            best = res
+                if self.host is None:
+                    for i in range(vm):
+                        # FR:1670-1671.  The second clause needs the intercept draws of the model accepted so far
+                        # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
+                        if rel_std[i] > self.threshstdb or (
+                                rel_std[i] > self.threshstda and
+                                mean_abs[i] < self.threshav * self._intercept_scale(best, half0)):
+                            trial = set(killed)
+                            trial.add(int(cand_col[i]))
+                            res = self._evaluate(gram, active_slots, self._columns_without(A, trial), n_prev, kill=True)
+                            if res.ev < evmin:
+                                killed = sorted(trial)
+                                evmin = res.ev
+                                best = res
+                else:
+                    killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
+                                                                     rel_std, best, half0)
                 ev = evmin
 
                 # commit the surviving columns (FR:1691-1695)

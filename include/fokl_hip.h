@@ -197,29 +197,104 @@ int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar
 /*
  * The same chain in two halves, so that the serial random stream can run on a worker thread ahead of the
  * data-dependent arithmetic.  fokl_noise_tape advances the stream exactly as `draws` iterations of
- * fokl_gibbs_chain would and records, per iteration, the p1 standard normals (normals_out [draws, p1]) and the two
- * standard gamma variates of shapes astar / atau_star (gam_sig_out, gam_tau_out [draws]).
- * fokl_gibbs_chain_from_tape replays the arithmetic on that tape: identical w / sigs / taus, bit for bit.
+ * fokl_gibbs_chain would and records, per iteration, the p1 standard normals and the two standard gamma variates
+ * of shapes astar / atau_star (gam_sig_out, gam_tau_out [draws]).  The expensive half of the polar method is left
+ * to the consumer (which can run on any thread): row k of normals_out [draws, p1] holds, after lead_out[k] (0 or 1)
+ * finished values, (p1 - lead) / 2 accepted pairs as (x2, x1) with r2 = x1^2 + x2^2 in row k of pair_r2_out
+ * [draws, p1 / 2 + 1] -- the normals are sqrt(-2 log(r2) / r2) * (x2, x1) -- and, if p1 - lead is odd, one more
+ * finished value.  fokl_gibbs_chain_from_tape completes the normals and replays the arithmetic: identical
+ * w / sigs / taus, bit for bit.
  * The split is exact unless some iteration has bstar < 0, where the reference skips a gamma draw (FR:1538-1539;
  * impossible for b > 0): *bstar_negative is then set to 1 and the caller must redo the candidate with
  * fokl_gibbs_chain from the stream state it saved before the tape.
  * `progress` (may be NULL) lets the consumer follow a tape that is still being recorded on another thread: the
- * producer stores k + 1 (release) after finishing iteration k, or -1 on failure; the consumer waits (acquire) until
- * iteration k is there.  Both sides must be given the same int32, initialised to 0 before the producer starts.
+ * producer stores the number of complete iterations (release) after every FOKL_TAPE_BLOCK of them and at the end, or
+ * -1 on failure; the consumer waits (acquire) until iteration k is there.  Both sides must be given the same int32,
+ * initialised to 0 before the producer starts; keep it on a cache line the producer does not otherwise write.
  */
+#define FOKL_TAPE_BLOCK 16
 int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
-                    int32_t *has_gauss, double *gauss_cache, double *normals_out, double *gam_sig_out,
-                    double *gam_tau_out, int32_t *progress);
+                    int32_t *has_gauss, double *gauss_cache, double *normals_out, double *pair_r2_out,
+                    int32_t *lead_out, double *gam_sig_out, double *gam_tau_out, int32_t *progress);
 int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau, double dtd,
                                double sigsqd0, double tausqd0, int draws, const double *normals,
-                               const double *gam_sig, const double *gam_tau, double *w_out, double *sigs_out,
-                               double *taus_out, int32_t *bstar_negative, const int32_t *progress);
+                               const double *pair_r2, const int32_t *lead, const double *gam_sig,
+                               const double *gam_tau, double *w_out, double *sigs_out, double *taus_out,
+                               int32_t *bstar_negative, const int32_t *progress);
+
+/*
+ * The consumer side split once more, so that several threads can share the log / sqrt work of ONE tape:
+ * fokl_finish_tape_blocks completes, in place, the normals of iteration blocks part, part + parts, ... (`block`
+ * iterations each), waiting on `progress` as above, and stores block_done[blk] = 1 (release) after each, -1 on failure;
+ * fokl_gibbs_chain_from_finished_tape runs the recursion on finished normals, waiting on block_done (NULL: the whole
+ * tape is finished).  Results are those of fokl_gibbs_chain_from_tape bit for bit.
+ */
+int fokl_finish_tape_blocks(int p1, int draws, double *normals, const double *pair_r2, const int32_t *lead,
+                            const int32_t *progress, int part, int parts, int block, int32_t *block_done);
+int fokl_gibbs_chain_from_finished_tape(const double *lamb, const double *qty, int p1, double b, double btau,
+                                        double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
+                                        const double *gam_sig, const double *gam_tau, const int32_t *block_done,
+                                        int block, double *w_out, double *sigs_out, double *taus_out,
+                                        int32_t *bstar_negative);
 
 /* Raw access to the same generator (parity tests against numpy): n standard normals / n std gammas. */
 int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      int64_t n, double *out);
 int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                     double shape, double scale, int64_t n, double *out);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Host threads of one fit: the work of G2/G3 that must not sit on the Python driver thread.                */
+/* ------------------------------------------------------------------------------------------------------ */
+
+typedef struct fokl_host_pool fokl_host_pool;
+typedef struct fokl_host_job fokl_host_job;
+
+/*
+ * One noise thread (owns the random stream mt_key / mt_pos / has_gauss / gauss_cache -- caller storage, updated in
+ * place -- and records tapes strictly in submission order), `finish_threads` threads that complete the normals of
+ * each tape (all of them on every tape; 0 = the chain threads do it), `chain_threads` threads that run the chain
+ * recursions and `spectral_threads` threads that diagonalise XtX sub-blocks.  `dsyevr` is the address of LAPACK's dsyevr with the
+ * Fortran calling convention and 32-bit integers (the Python side passes scipy's own:
+ * scipy.linalg.cython_lapack.__pyx_capi__['dsyevr']), so that eigenpairs are those of the reference's
+ * scipy.linalg.eigh call (FR:1499) bit for bit; NULL is allowed with spectral_threads == 0.
+ * The threads inherit the CPU affinity of the caller, except that the noise thread is pinned to logical CPU
+ * `noise_cpu` if that is >= 0 (the caller then keeps its other threads off that core).  Every buffer handed to a submit call must stay alive until
+ * fokl_pool_wait has returned for that job.  fokl_pool_destroy first runs everything still queued.
+ */
+int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int noise_cpu, void *dsyevr,
+                     uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     fokl_host_pool **out);
+void fokl_pool_destroy(fokl_host_pool *pool);
+/* fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0). */
+int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, double *normals,
+                           double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau, int32_t *progress,
+                           fokl_host_job **out);
+/*
+ * The draws of one candidate from its tape (whose noise job must have been submitted): with finish threads and
+ * block_done [ceil(draws / block)] (zero-initialised) given, the tape is completed IN PLACE by the finish threads and
+ * the recursion follows them; otherwise fokl_gibbs_chain_from_tape runs on a chain thread, following `progress`.
+ */
+int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b, double btau,
+                           double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
+                           const double *pair_r2, const int32_t *lead, const double *gam_sig, const double *gam_tau,
+                           const int32_t *progress, int32_t *block_done, int block, double *w_out,
+                           int32_t *bstar_negative, fokl_host_job **out);
+/*
+ * G2 for the candidate model made of columns idx[0..p1) of `gram` (row-major, leading dimension ld, y in column
+ * ycol): XtX = gram[idx][:, idx], Xty = gram[idx, ycol].  Outputs: lamb_out [p1] ascending eigenvalues,
+ * qt_out [p1, p1] with ROW j = eigenvector j (largest-magnitude component positive), qty_out = Q'Xty,
+ * betahat_out = Q (qty / lamb) (FR:1499-1504).  No random numbers: may be submitted speculatively.
+ */
+int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
+                              double *lamb_out, double *qt_out, double *qty_out, double *betahat_out,
+                              fokl_host_job **out);
+/* 1 if the job has run.  fokl_pool_wait blocks until then, frees the job and returns its status. */
+int fokl_pool_poll(const fokl_host_job *job);
+int fokl_pool_wait(fokl_host_job *job);
+/* Accumulated time (s) the kinds of thread spent inside jobs (including their waits on the tape producer). */
+int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *chain, double *finish,
+                           double *spectral);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* multi-GPU: one process per GPU, RCCL over xGMI                                                          */
