@@ -15,6 +15,7 @@ are sub-blocks of the sub-stage Gram held on the host; the BIC stil
 residual pass over the device columns, never from the cancellation-prone Gram identity.
 The *logical* candidate-term count (what the reference would have built) is tallied per call.
 """
+import itertools
 import math
 import os
 import time
@@ -559,31 +560,42 @@ class ForwardSelection:
         """
         A = len(slots)
         vm = cand_col.shape[0]
-        floor_std = min(self.threshstda, self.threshstdb)            # below it neither clause of FR:1670 can hold
-        runnable = [int(cand_col[j]) for j in range(vm) if rel_std[j] > floor_std]
-        proposal = [j for j in range(vm) if rel_std[j] > floor_std]
+        cols = [int(c) for c in cand_col]
+        clause1 = [bool(rel_std[j] > self.threshstdb) for j in range(vm)]
+        clause2a = [bool(rel_std[j] > self.threshstda) for j in range(vm)]
+        proposal = [j for j in range(vm) if clause1[j] or clause2a[j]]     # the others cannot pass FR:1670
+        # Guess at "mean_abs < threshav * |mean intercept draw|" for proposals further down the list: the posterior mean
+        # of the intercept is close to its least-squares value, and it barely moves from one accepted model to the next.
+        scale_guess = abs(float(best.betahat[0]))
         killed = frozenset()
         evmin = best.ev
         ahead = {}                                                    # trial set -> spectral job submitted ahead
         last_accepted = True                                          # predictor: proposals go the way the last went
         for pos, i in enumerate(proposal):
+            decided = clause1[i]
+            if not decided and best.intercept_scale is not None:      # second clause without waiting for a chain
+                if not mean_abs[i] < self.threshav * best.intercept_scale:
+                    continue
+                decided = True
             # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
             cur = killed
-            for col in runnable[pos:pos + 1 + self.lookahead]:
-                key = cur | {col}
+            upcoming = itertools.islice((j for j in proposal[pos + 1:] if clause1[j] or
+                                         mean_abs[j] < self.threshav * scale_guess), self.lookahead)
+            for j in itertools.chain((i,), upcoming):
+                key = cur | {cols[j]}
                 if key not in ahead:
                     ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
                 if last_accepted:
                     cur = key
-            trial = killed | {runnable[pos]}
+            trial = killed | {cols[i]}
             idx = self._columns_without(A, trial)
             pending = self._begin(gram, slots, idx, ahead.pop(trial))
-            run = rel_std[i] > self.threshstdb or (
-                rel_std[i] > self.threshstda and mean_abs[i] < self.threshav * self._intercept_scale(best, half0))
-            if not run:
-                if self._async_resid:
-                    self._score(pending)                              # drains the speculative residual pass
-                continue
+            if not decided:
+                scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
+                if not mean_abs[i] < self.threshav * scale_guess:
+                    if self._async_resid:
+                        self._score(pending)                          # drains the speculative residual pass
+                    continue
             jobs = self._commit(pending)
             ev = self._score(pending)
             self._record(idx.shape[0], n_prev, ev, True)
