@@ -162,3 +162,32 @@ def test_bad_arguments_are_rejected():
     st.pos.value = 9999
     with pytest.raises(_capi.FoklNativeError):
         st.normals(3)
+
+
+def test_portable_and_wide_tape_recorders_agree():
+    """fokl_noise_tape picks an AVX-512 build of the recorder when the CPU has it (FOKL_SAMPLER_ISA=base forces the
+    portable one): a subprocess records the same tapes the other way; digests of the drawn values must match."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import hashlib, numpy as np\n"
+        "from fokl_gpy_amd import _capi\n"
+        "np.random.seed(99); np.random.randint(0, 2 ** 31, size=3)\n"
+        "st = _capi.LegacyStream(); h = hashlib.sha256()\n"
+        "for p in (1, 2, 9, 60, 61, 145, 320):\n"
+        "    t = _capi.noise_tape(p, 120, 5e5 + p / 2, 0.3 + p / 2, st)\n"
+        "    w, _ = _capi.gibbs_chain_from_tape(np.linspace(1, 9, p), np.ones(p), 2.0, 1.0, 50.0, 0.5, 1.0, t)\n"
+        "    for a in (w, t.gam_sig, t.gam_tau, t.lead):\n"
+        "        h.update(np.ascontiguousarray(a).tobytes())\n"
+        "h.update(st.key.tobytes()); h.update(bytes([st.pos.value % 256, st.has_gauss.value]))\n"
+        "print(h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for isa in ('base', 'auto'):
+        env = dict(os.environ, FOKL_SAMPLER_ISA=isa, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
