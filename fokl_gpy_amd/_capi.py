@@ -54,7 +54,8 @@ SIGNATURES = {
     'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
-    'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp]),
     'fokl_pool_poll': (c_int, [c_vp]),
     'fokl_pool_wait': (c_int, [c_vp]),
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -336,19 +337,21 @@ class PoolJob:
 
 
 class SpectralResult:
-    """Outputs of fokl_pool_submit_spectral: lamb, Qt (row j = eigenvector j), qty = Q'Xty, betahat."""
-    __slots__ = ('lamb', 'Qt', 'qty', 'betahat', '_buf', '_addr')
+    """Outputs of fokl_pool_submit_spectral: lamb, Qt (row j = eigenvector j), qty = Q'Xty, betahat, and the residual
+    moments (sum r, sum r^2) of y - X betahat formed from the Gram."""
+    __slots__ = ('lamb', 'Qt', 'qty', 'betahat', 'moments', '_buf', '_addr')
 
     def __init__(self, p1):
-        buf = self._buf = np.empty(p1 * (p1 + 3), dtype=np.float64)
+        buf = self._buf = np.empty(p1 * (p1 + 3) + 2, dtype=np.float64)
         self._addr = buf.__array_interface__['data'][0]
         self.lamb, self.qty, self.betahat = buf[:p1], buf[p1:2 * p1], buf[2 * p1:3 * p1]
-        self.Qt = buf[3 * p1:].reshape(p1, p1)
+        self.Qt = buf[3 * p1:3 * p1 + p1 * p1].reshape(p1, p1)
+        self.moments = buf[3 * p1 + p1 * p1:]
 
     def pointers(self, p1):
-        """lamb_out, qt_out, qty_out, betahat_out"""
+        """lamb_out, qt_out, qty_out, betahat_out, moments_out"""
         a = self._addr
-        return (a, a + 24 * p1, a + 8 * p1, a + 16 * p1)
+        return (a, a + 24 * p1, a + 8 * p1, a + 16 * p1, a + 8 * p1 * (p1 + 3))
 
 
 class HostPool:

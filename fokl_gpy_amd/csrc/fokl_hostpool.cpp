@@ -28,6 +28,7 @@
 #include <immintrin.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/prctl.h>
 
 #include "../../include/fokl_hip.h"
 
@@ -52,6 +53,7 @@ struct Queue {
 
 struct fokl_host_job {
     Kind kind;
+    fokl_host_pool *pool = nullptr;
     std::atomic<int> done{0};
     int status = FOKL_OK;
     std::string error;
@@ -73,7 +75,7 @@ struct fokl_host_job {
     const double *gram = nullptr;
     int ld = 0, ycol = 0;
     std::vector<int32_t> idx;
-    double *lamb_out = nullptr, *qt_out = nullptr, *qty_out = nullptr, *betahat_out = nullptr;
+    double *lamb_out = nullptr, *qt_out = nullptr, *qty_out = nullptr, *betahat_out = nullptr, *moments_out = nullptr;
 };
 
 struct fokl_host_pool {
@@ -86,15 +88,24 @@ struct fokl_host_pool {
     int32_t *mt_pos = nullptr, *has_gauss = nullptr;
     double *gauss_cache = nullptr;
     std::atomic<int64_t> noise_busy_ns{0}, chain_busy_ns{0}, finish_busy_ns{0}, spectral_busy_ns{0};
+    // completion of any job (fokl_pool_wait spins briefly, then sleeps here: a fit must not burn a core per waiter --
+    // eight ranks may share a CPU quota far below eight times the thread count)
+    std::mutex done_m;
+    std::condition_variable done_cv;
 };
 
 namespace {
 
 void finish(fokl_host_job *job, int status, const char *what)
 {
+    fokl_host_pool *pool = job->pool;                       // the job may be freed by its waiter right after `done`
     job->status = status;
     if (status != FOKL_OK) job->error = what;
-    job->done.store(1, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lock(pool->done_m);
+        job->done.store(1, std::memory_order_release);
+    }
+    pool->done_cv.notify_all();
 }
 
 // XtX sub-block -> (lamb, Q', Q'Xty, betahat).  Column-major copy + uplo 'L', abstol 0, range 'A', workspace from a
@@ -159,6 +170,26 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
         const double c = qty[j] / job->lamb_out[j];
         for (int i = 0; i < n; ++i) bh[i] += v[i] * c;
     }
+    if (job->moments_out) {
+        // Residual moments of y - X betahat from the Gram alone (column 0 of gram is the ones column):
+        //   sum r   = sum y - sum_j (1'x_j) b_j
+        //   sum r^2 = y'y - 2 b'Xty + b'XtX b
+        // The second cancels 3-4 digits at the signal-to-noise ratios of interest; accumulating in 80-bit extended
+        // precision leaves the rounding of the Gram entries themselves as the only error (about 1e-12 relative).
+        const double *ones = g;                                          // row 0 of gram
+        long double s1 = ones[job->ycol], cross = 0.0L, quad = 0.0L;
+        for (int i = 0; i < n; ++i) {
+            const double *row = g + (size_t)idx[i] * ld;
+            long double acc = 0.0L;
+            for (int j = 0; j < n; ++j) acc += (long double)row[idx[j]] * bh[j];
+            quad += acc * bh[i];
+            cross += (long double)xty[i] * bh[i];
+            s1 -= (long double)ones[idx[i]] * bh[i];
+        }
+        const long double yty = g[(size_t)job->ycol * ld + job->ycol];
+        job->moments_out[0] = (double)s1;
+        job->moments_out[1] = (double)(yty - 2.0L * cross + quad);
+    }
     return FOKL_OK;
 }
 
@@ -214,6 +245,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
 
 void worker(fokl_host_pool *pool, Queue *queue)
 {
+    prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);               // the short sleeps of the tape followers mean what they say
     for (;;) {
         fokl_host_job *job;
         {
@@ -316,6 +348,7 @@ extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, d
         return FOKL_ERR_ARG;
     }
     auto *job = new fokl_host_job();
+    job->pool = pool;
     job->kind = Kind::noise;
     job->p1 = p1;
     job->draws = draws;
@@ -347,6 +380,7 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
     const int parts = block_done ? (int)pool->finish_q.size() : 0;
     for (int part = 0; part < parts; ++part) {             // the tape is completed in place by all finish threads
         auto *fin = new fokl_host_job();
+        fin->pool = pool;
         fin->kind = Kind::finish;
         fin->self_owned = true;
         fin->p1 = p1;
@@ -362,6 +396,7 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
         submit(pool->finish_q[(size_t)part], fin);
     }
     auto *job = new fokl_host_job();
+    job->pool = pool;
     job->kind = Kind::chain;
     job->lamb = lamb;
     job->qty = qty;
@@ -391,7 +426,7 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
 
 extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1,
                                          int ycol, double *lamb_out, double *qt_out, double *qty_out,
-                                         double *betahat_out, fokl_host_job **out)
+                                         double *betahat_out, double *moments_out, fokl_host_job **out)
 {
     if (!pool || !out || !gram || !idx || p1 <= 0 || ld <= 0 || ycol < 0 || ycol >= ld || !lamb_out || !qt_out ||
         !qty_out || !betahat_out) {
@@ -408,6 +443,7 @@ extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gra
             return FOKL_ERR_ARG;
         }
     auto *job = new fokl_host_job();
+    job->pool = pool;
     job->kind = Kind::spectral;
     job->gram = gram;
     job->ld = ld;
@@ -417,6 +453,7 @@ extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gra
     job->qt_out = qt_out;
     job->qty_out = qty_out;
     job->betahat_out = betahat_out;
+    job->moments_out = moments_out;
     *out = job;
     submit(pool->spectral_q, job);
     return FOKL_OK;
@@ -434,13 +471,11 @@ extern "C" int fokl_pool_wait(fokl_host_job *job)
         fokl_set_global_error("fokl_pool_wait: null job");
         return FOKL_ERR_ARG;
     }
-    int spins = 0;
-    while (!job->done.load(std::memory_order_acquire)) {
-        if (++spins < 20000) {
-            _mm_pause();
-        } else {
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
-        }
+    for (int spins = 0; spins < 2000 && !job->done.load(std::memory_order_acquire); ++spins) _mm_pause();
+    if (!job->done.load(std::memory_order_acquire)) {
+        fokl_host_pool *pool = job->pool;
+        std::unique_lock<std::mutex> lock(pool->done_m);
+        pool->done_cv.wait(lock, [&] { return job->done.load(std::memory_order_acquire) != 0; });
     }
     const int rc = job->status;
     if (rc != FOKL_OK) fokl_set_global_error("host pool job failed: " + job->error);

@@ -17,12 +17,18 @@
 //
 // Must be compiled with -ffp-contract=off: numpy's baseline build rounds every product separately.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
+
+#ifdef FOKL_SAMPLER_WIDE
+#include <immintrin.h>
+#endif
 
 #include "../../include/fokl_hip.h"
 
@@ -96,6 +102,12 @@ void polar_finish(const double *__restrict__ lg, const double *__restrict__ x1, 
         out[2 * i + 1] = f[i] * x1[i];
     }
 }
+
+#ifdef FOKL_SAMPLER_WIDE
+// bit a of the index set -> bits 2a, 2a + 1 of the mask (an accepted polar attempt keeps both of its coordinates)
+constexpr uint8_t PAIR_MASK[16] = {0x00, 0x03, 0x0c, 0x0f, 0x30, 0x33, 0x3c, 0x3f,
+                                   0xc0, 0xc3, 0xcc, 0xcf, 0xf0, 0xf3, 0xfc, 0xff};
+#endif
 
 struct LegacyRng {
     uint32_t *key;      // 624 words, caller owned (np.random.get_state()[1])
@@ -239,6 +251,29 @@ struct LegacyRng {
             }
             const int j0 = j, last = dcount - 1;
             const double *__restrict__ x = xbuf, *__restrict__ sq = sbuf;
+#ifdef FOKL_SAMPLER_WIDE
+            // eight attempts per step: r2 by a de-interleaving add, accepted ones packed with vcompresspd (in
+            // registers; full-width stores stay inside the `count` entries this call fills anyway)
+            const __m512i even = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14);
+            const __m512i odd = _mm512_setr_epi64(1, 3, 5, 7, 9, 11, 13, 15);
+            const __m512d one = _mm512_set1_pd(1.0), zero = _mm512_setzero_pd();
+            while (have + 8 <= count && j + 16 <= dcount) {
+                const __m512d s0 = _mm512_loadu_pd(sq + j), s1 = _mm512_loadu_pd(sq + j + 8);
+                const __m512d rr = _mm512_add_pd(_mm512_permutex2var_pd(s0, even, s1),
+                                                 _mm512_permutex2var_pd(s0, odd, s1));      // sq[j+2a] + sq[j+2a+1]
+                const unsigned m = _mm512_cmp_pd_mask(rr, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(rr, zero, _CMP_NEQ_OQ);
+                _mm512_storeu_pd(r2 + have, _mm512_maskz_compress_pd((__mmask8)m, rr));
+                // (x2, x1) of attempt a = elements 2a+1, 2a: swap within pairs, keep the pairs of accepted attempts
+                const __m512d x0 = _mm512_permute_pd(_mm512_loadu_pd(x + j), 0x55);
+                const __m512d x1 = _mm512_permute_pd(_mm512_loadu_pd(x + j + 8), 0x55);
+                const unsigned lo = m & 15u, hi = m >> 4;
+                const int c0 = __builtin_popcount(lo);
+                _mm512_storeu_pd(out + 2 * have, _mm512_maskz_compress_pd((__mmask8)PAIR_MASK[lo], x0));
+                _mm512_storeu_pd(out + 2 * (have + c0), _mm512_maskz_compress_pd((__mmask8)PAIR_MASK[hi], x1));
+                have += c0 + __builtin_popcount(hi);
+                j += 16;
+            }
+#endif
             while (j < last && have < count) {              // branch-free compaction of the accepted attempts
                 const double rr = sq[j] + sq[j + 1];
                 out[2 * have] = x[j + 1];
@@ -291,8 +326,13 @@ struct LegacyRng {
                 }
             }
         }
-        const double b = shape - 1.0 / 3.0;
-        const double c = 1.0 / std::sqrt(9 * b);
+        return marsaglia_tsang(shape - 1.0 / 3.0, 1.0 / std::sqrt(9 * (shape - 1.0 / 3.0)));
+    }
+
+    // numpy's shape > 1 branch with its two constants b = shape - 1/3, c = 1 / sqrt(9 b) computed by the caller
+    // (once per tape instead of once per draw: the sqrt and the divide sat on the recorder's serial path)
+    double marsaglia_tsang(const double b, const double c)
+    {
         for (;;) {
             double X, V;
             do {
@@ -420,10 +460,13 @@ void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star
                  double *pair_r2_out, int32_t *lead_out, double *gam_sig_out, double *gam_tau_out, int32_t *progress)
 {
     const size_t half = (size_t)p1 / 2 + 1;
+    const bool fast_sig = astar > 1.0, fast_tau = atau_star > 1.0;     // always, for the hyper-parameters in use
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
     for (int k = 0; k < draws; ++k) {
         fill_normals_raw(r, p1, normals_out + (size_t)k * p1, pair_r2_out + (size_t)k * half, lead_out + k);
-        gam_sig_out[k] = r.std_gamma(astar);
-        gam_tau_out[k] = r.std_gamma(atau_star);
+        gam_sig_out[k] = fast_sig ? r.marsaglia_tsang(b_sig, c_sig) : r.std_gamma(astar);
+        gam_tau_out[k] = fast_tau ? r.marsaglia_tsang(b_tau, c_tau) : r.std_gamma(atau_star);
         // iterations up to k are complete and visible.  Published per block, not per iteration: every store to a
         // line that other cores are polling costs this thread a coherence round trip.
         if (progress && ((k + 1) % FOKL_TAPE_BLOCK == 0 || k + 1 == draws))
@@ -584,6 +627,17 @@ extern "C" int fokl_noise_tape(int p1, int draws, double astar, double atau_star
 
 namespace {
 
+// A thread that follows a producer: a producer at work is at most a few microseconds away (spin); one that has not
+// started yet may be far away (sleep in short steps rather than burn a core -- ranks may share a tight CPU quota).
+inline void follow_wait(int &spins)
+{
+    if (++spins < 2000) {
+        __builtin_ia32_pause();
+    } else {
+        std::this_thread::sleep_for(std::chrono::microseconds(10));
+    }
+}
+
 // One Gibbs iteration given its p1 normals and two standard gammas (FR:1521-1548 in the eigenbasis).
 struct ChainState {
     double sigsqd, tausqd;
@@ -633,13 +687,13 @@ extern "C" int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty,
     const size_t half = (size_t)p1 / 2 + 1;
     std::vector<double> vec((size_t)p1), fbuf(half);
     for (int k = 0; k < draws; ++k) {
-        while (ready <= k) {                           // follow a tape that is still being recorded
+        for (int spins = 0; ready <= k;) {             // follow a tape that is still being recorded
             ready = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
             if (ready < 0) {
                 fokl_set_global_error("fokl_gibbs_chain_from_tape: the noise tape producer failed");
                 return FOKL_ERR_STATE;
             }
-            if (ready <= k) __builtin_ia32_pause();
+            if (ready <= k) follow_wait(spins);
         }
         finish_normals(normals + (size_t)k * p1, pair_r2 + (size_t)k * half, lead[k], p1, vec.data(), fbuf.data());
         chain_step(lamb, qty, p1, b, btau, dtd, vec.data(), gam_sig[k], gam_tau[k], w_out + (size_t)k * p1, st);
@@ -664,7 +718,7 @@ extern "C" int fokl_finish_tape_blocks(int p1, int draws, double *normals, const
     int32_t ready = progress ? 0 : draws;
     for (int blk = part; blk < nblocks; blk += parts) {
         const int k0 = blk * block, k1 = std::min(draws, k0 + block);
-        while (ready < k1) {
+        for (int spins = 0; ready < k1;) {
             ready = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
             if (ready < 0) {
                 for (int later = blk; later < nblocks; later += parts)
@@ -672,7 +726,7 @@ extern "C" int fokl_finish_tape_blocks(int p1, int draws, double *normals, const
                 fokl_set_global_error("fokl_finish_tape_blocks: the noise tape producer failed");
                 return FOKL_ERR_STATE;
             }
-            if (ready < k1) __builtin_ia32_pause();
+            if (ready < k1) follow_wait(spins);
         }
         for (int k = k0; k < k1; ++k) {
             double *row = normals + (size_t)k * p1;
@@ -700,14 +754,14 @@ extern "C" int fokl_gibbs_chain_from_finished_tape(const double *lamb, const dou
     for (int k = 0; k < draws; ++k) {
         if (block_done && k / block > ready_block) {
             const int blk = k / block;
-            for (;;) {
+            for (int spins = 0;;) {
                 const int32_t flag = __atomic_load_n(block_done + blk, __ATOMIC_ACQUIRE);
                 if (flag > 0) break;
                 if (flag < 0) {
                     fokl_set_global_error("fokl_gibbs_chain_from_finished_tape: the tape producer failed");
                     return FOKL_ERR_STATE;
                 }
-                __builtin_ia32_pause();
+                follow_wait(spins);
             }
             ready_block = blk;
         }

@@ -216,6 +216,54 @@ def _place_host_threads():
         return None, -1
 
 
+def _cpu_budget():
+    """CPUs this process may keep busy: its affinity mask, capped by the cgroup CPU quota (a container that sees 256
+    CPUs may be allowed 16 CPU-seconds per second) shared among the ranks of the node (LOCAL_WORLD_SIZE)."""
+    try:
+        budget = float(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        budget = float(os.cpu_count() or 2)
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:                       # cgroup v2: "<quota|max> <period>"
+            q, period = fh.read().split()
+            if q != 'max':
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fh:      # cgroup v1
+                q = float(fh.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+                period = float(fh.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        try:
+            ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+        except ValueError:
+            ranks = 1
+        budget = min(budget, quota / ranks)
+    return budget
+
+
+def _thread_plan():
+    """(chain, finish, spectral) thread counts of the host pipeline for the CPU budget of this process; the driver and
+    the noise thread come on top.  FOKL_CHAIN_THREADS / FOKL_FINISH_THREADS / FOKL_SPECTRAL_THREADS override."""
+    budget = _cpu_budget()
+    if budget >= 8:
+        plan = (2, 3, 3)
+    elif budget >= 6:
+        plan = (1, 2, 2)
+    elif budget >= 3:
+        plan = (1, 1, 1)
+    else:
+        plan = (1, 0, 1)
+    names = ('FOKL_CHAIN_THREADS', 'FOKL_FINISH_THREADS', 'FOKL_SPECTRAL_THREADS')
+    return tuple(int(os.environ.get(name, str(default))) for name, default in zip(names, plan))
+
+
 class HostPipeline:
     """
     The host threads of one fit (include/fokl_hip.h: fokl_pool_*), all native, none holding the GIL:
@@ -240,13 +288,7 @@ class HostPipeline:
         self._saved_affinity, noise_cpu = None, -1
         if os.environ.get('FOKL_PIN_L3', '1') != '0':
             self._saved_affinity, noise_cpu = _place_host_threads()
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = os.cpu_count() or 4
-        chain = int(os.environ.get('FOKL_CHAIN_THREADS', '2'))
-        finish = int(os.environ.get('FOKL_FINISH_THREADS', str(max(0, min(3, cores - 5)))))
-        spectral = int(os.environ.get('FOKL_SPECTRAL_THREADS', str(max(1, min(3, cores - 4)))))
+        chain, finish, spectral = _thread_plan()
         self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu)
         # Every job names buffers the native threads read and write: they are kept here until the job has run, whether
         # or not the driver still cares about the result (a rejected candidate's tape is recorded all the same).
@@ -434,9 +476,17 @@ class ForwardSelection:
         self.host = None                    # HostPipeline while run() is active (b > 0 only)
         self._async_resid = hasattr(backend, 'bic_resid_launch')
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
+        # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model
+        # (it runs in the shadow of the noise tape, so it costs the search nothing); 'gram' = residual moments from the
+        # sub-stage's Gram (no device work per candidate; agrees with the device pass to about 1e-12
+        # relative); 'check' = device, recording the largest disagreement with 'gram' seen.
+        self.kill_bic = os.environ.get('FOKL_KILL_BIC', 'device')
+        if self.kill_bic not in ('gram', 'device', 'check'):
+            raise ValueError("FOKL_KILL_BIC must be gram, device or check")
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
-                          t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0)
+                          t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
+                          bic_gram_max_rel=0.0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _ev_from_moments(self, s1, s2, p1):
@@ -460,16 +510,20 @@ class ForwardSelection:
     #             random numbers, so it may run for a model whose test is not decided yet;
     #   _commit : the noise tape request and the chain job -- consumes the random stream, strictly in reference order;
     #   _score  : fetches the residual moments -> BIC.
-    def _begin(self, gram, slots, idx, spectral_job=None):
+    def _begin(self, gram, slots, idx, spectral_job=None, on_device=True):
+        """on_device: measure the residual moments with K3 (always for a sub-stage's model); otherwise they come from
+        the Gram (kill-test candidates: column subsets of that model, see self.kill_bic)."""
         t0 = time.perf_counter()
         if spectral_job is None:
             spectral_job = self.host.spectral(gram, idx)
         spec = spectral_job.wait()
         t1 = time.perf_counter()
         self.stats['t_eigh'] += t1 - t0
-        cand_slots = [slots[i] for i in idx]
-        if self._async_resid:
-            self.backend.bic_resid_launch(cand_slots, spec.betahat)
+        cand_slots = None
+        if on_device:
+            cand_slots = [slots[i] for i in idx]
+            if self._async_resid:
+                self.backend.bic_resid_launch(cand_slots, spec.betahat)
         ycol = gram.shape[0] - 1
         return spec, idx, cand_slots, gram[ycol, ycol]
 
@@ -488,13 +542,21 @@ class ForwardSelection:
 
     def _score(self, pending):
         spec, idx, cand_slots, _ = pending
+        p1 = idx.shape[0]
+        if cand_slots is None:
+            self.stats['bic_from_gram'] += 1
+            return self._ev_from_moments(spec.moments[0], spec.moments[1], p1)
         t0 = time.perf_counter()
         if self._async_resid:
             s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
         else:
             s1, s2 = self.backend.bic_resid(cand_slots, spec.betahat, self.allreduce)
         self.stats['t_resid'] += time.perf_counter() - t0
-        return self._ev_from_moments(s1, s2, idx.shape[0])
+        ev = self._ev_from_moments(s1, s2, p1)
+        if self.kill_bic == 'check':
+            other = self._ev_from_moments(spec.moments[0], spec.moments[1], p1)
+            self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
+        return ev
 
     def _evaluate(self, gram, slots, idx, n_prev_cols, kill):
         """
@@ -589,12 +651,12 @@ class ForwardSelection:
                     cur = key
             trial = killed | {cols[i]}
             idx = self._columns_without(A, trial)
-            pending = self._begin(gram, slots, idx, ahead.pop(trial))
+            pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=self.kill_bic != 'gram')
             if not decided:
                 scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
                 if not mean_abs[i] < self.threshav * scale_guess:
-                    if self._async_resid:
-                        self._score(pending)                          # drains the speculative residual pass
+                    if self._async_resid and pending[2] is not None:
+                        self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
                     continue
             jobs = self._commit(pending)
             ev = self._score(pending)

@@ -284,11 +284,14 @@ int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const doubl
  * G2 for the candidate model made of columns idx[0..p1) of `gram` (row-major, leading dimension ld, y in column
  * ycol): XtX = gram[idx][:, idx], Xty = gram[idx, ycol].  Outputs: lamb_out [p1] ascending eigenvalues,
  * qt_out [p1, p1] with ROW j = eigenvector j (largest-magnitude component positive), qty_out = Q'Xty,
- * betahat_out = Q (qty / lamb) (FR:1499-1504).  No random numbers: may be submitted speculatively.
+ * betahat_out = Q (qty / lamb) (FR:1499-1504).  moments_out [2] (may be NULL) receives sum r and sum r^2 of the
+ * residual r = y - X betahat, formed from the Gram alone -- sum y - 1'X b and y'y - 2 b'Xty + b'XtX b in extended
+ * precision; column 0 of gram must be the ones column -- the quantities fokl_bic_resid measures on the device
+ * (FR:1551).  No random numbers: may be submitted speculatively.
  */
 int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
                               double *lamb_out, double *qt_out, double *qty_out, double *betahat_out,
-                              fokl_host_job **out);
+                              double *moments_out, fokl_host_job **out);
 /* 1 if the job has run.  fokl_pool_wait blocks until then, frees the job and returns its status. */
 int fokl_pool_poll(const fokl_host_job *job);
 int fokl_pool_wait(fokl_host_job *job);

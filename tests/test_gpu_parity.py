@@ -402,3 +402,31 @@ def test_many_inputs_three_way_fit_against_oracle():
     model = _fit_both(x, y, 'Bernoulli Polynomials', O.KERNEL_BERNOULLI, BERN[:3], 77, burnin=60, draws=60, way3=True,
                       tolerance=1)
     assert model.mtx.shape[1] == 12
+
+
+def test_kill_test_bic_from_gram_agrees_with_the_device_pass(monkeypatch):
+    """Kill-test candidates take their residual moments from the sub-stage's Gram instead of a K3 pass.
+    FOKL_KILL_BIC=check runs both on every candidate of a full-size fit (N = 1e6: the cancellation in
+    y'y - 2 b'Xty + b'XtX b is at its worst there) and records the largest relative disagreement of the BIC."""
+    rng = np.random.default_rng(12)
+    n, m = 1_000_000, 8
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.5 * x[:, 4] * x[:, 5] + 0.05 * rng.standard_normal(n)
+    runs = {}
+    for mode in ('check', 'gram'):
+        monkeypatch.setenv('FOKL_KILL_BIC', mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = FoKLRoutines.FoKL(kernel='Bernoulli Polynomials', phis=BERN[:3], burnin=100, draws=100,
+                                      UserWarnings=False, ConsoleOutput=False)
+            np.random.seed(5)
+            betas, mtx, evs = model.fit(x, y, clean=True)
+        runs[mode] = (betas, mtx, evs, dict(model.fit_stats), np.random.get_state())
+    st = runs['check'][3]
+    assert st['kill_tests'] > 50 and st['bic_from_gram'] == 0
+    assert 0 < st['bic_gram_max_rel'] < 1e-10, st['bic_gram_max_rel']
+    assert runs['gram'][3]['bic_from_gram'] == runs['gram'][3]['kill_tests'] > 50
+    assert np.array_equal(runs['gram'][1], runs['check'][1])
+    np.testing.assert_allclose(runs['gram'][2], runs['check'][2], rtol=1e-10)
+    np.testing.assert_allclose(runs['gram'][0], runs['check'][0], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(runs['gram'][4][1], runs['check'][4][1]) and runs['gram'][4][2:] == runs['check'][4][2:]

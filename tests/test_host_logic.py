@@ -323,3 +323,20 @@ def test_product_has_no_cpu_fallback():
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model.fit(np.random.default_rng(0).random((20, 1)), np.zeros(20), clean=True)
+
+
+def test_kill_test_bic_from_gram_matches_explicit_residuals(monkeypatch):
+    """FOKL_KILL_BIC=check: every kill-test candidate's BIC both ways (Gram identity in extended precision vs the
+    backend's residual pass); the search itself is unchanged by the choice."""
+    name = 'bern_m6'
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture not generated')
+    monkeypatch.setenv('FOKL_KILL_BIC', 'check')
+    g, model, betas, mtx, evs = fit_case(name)
+    assert model.fit_stats['kill_tests'] > 0 and model.fit_stats['bic_from_gram'] == 0
+    assert model.fit_stats['bic_gram_max_rel'] < 1e-11
+    monkeypatch.setenv('FOKL_KILL_BIC', 'gram')
+    g, model2, betas2, mtx2, evs2 = fit_case(name)
+    assert model2.fit_stats['bic_from_gram'] == model2.fit_stats['kill_tests']
+    assert np.array_equal(mtx, mtx2)
+    np.testing.assert_allclose(evs2, evs, rtol=1e-11)
