@@ -27,13 +27,24 @@ from . import _capi
 from . import engine as _engine
 
 
+class _ModelUnpickler(pickle.Unpickler):
+    """``.fokl`` files are pickles of the model object (FR:1840); files written by the reference name its class
+    ``FoKL.FoKLRoutines.FoKL`` (or ``src.FoKL...`` from a source checkout) -- both load as this package's class, whose
+    attribute names are the reference's."""
+
+    def find_class(self, module, name):
+        if name == 'FoKL' and module.split('.')[-2:] == ['FoKL', 'FoKLRoutines']:
+            return FoKL
+        return super().find_class(module, name)
+
+
 def load(filename, directory=None):
-    """Load a pickled model written by ``FoKL.save`` (same contract as FR:24-46)."""
+    """Load a model written by ``FoKL.save`` -- this package's or the reference's (same contract as FR:24-46)."""
     if filename[-5::] != ".fokl":
         filename = filename + ".fokl"
     path = os.path.join(directory, filename) if directory is not None else filename
     with open(path, "rb") as fh:
-        return pickle.load(fh)
+        return _ModelUnpickler(fh).load()
 
 
 _TRUE_WORDS = ('yes', 'y', 'on', 'all', 'true', 'both')

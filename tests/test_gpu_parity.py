@@ -430,3 +430,16 @@ def test_kill_test_bic_from_gram_agrees_with_the_device_pass(monkeypatch):
     np.testing.assert_allclose(runs['gram'][2], runs['check'][2], rtol=1e-10)
     np.testing.assert_allclose(runs['gram'][0], runs['check'][0], rtol=1e-7, atol=1e-9)
     assert np.array_equal(runs['gram'][4][1], runs['check'][4][1]) and runs['gram'][4][2:] == runs['check'][4][2:]
+
+
+def test_model_saved_by_the_reference_evaluates_on_the_device():
+    """a .fokl file written by the reference's own ``save`` loads as this package's class and its
+    ``evaluate`` (K1 + predict kernel) reproduces the reference's numbers (fixture: make_golden.py saved_model)."""
+    want = np.load(os.path.join(GOLDEN, 'ref_saved_model_expected.npz'))
+    model = FoKLRoutines.load(os.path.join(GOLDEN, 'ref_saved_model.fokl'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        np.random.seed(6)
+        mean, bounds = model.evaluate(want['inputs'], clean=True, ReturnBounds=True)
+    np.testing.assert_allclose(mean, want['mean'], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(bounds, want['bounds'], rtol=1e-11, atol=1e-11)

@@ -340,3 +340,26 @@ def test_kill_test_bic_from_gram_matches_explicit_residuals(monkeypatch):
     assert model2.fit_stats['bic_from_gram'] == model2.fit_stats['kill_tests']
     assert np.array_equal(mtx, mtx2)
     np.testing.assert_allclose(evs2, evs, rtol=1e-11)
+
+
+def test_model_saved_by_the_reference_loads_and_evaluates():
+    """tests/golden/ref_saved_model.fokl was written by the reference's own ``save`` (make_golden.py saved_model): the
+    product's ``load`` maps the pickled class name onto its own class; ``evaluate`` must reproduce what the reference
+    returned for the reloaded model (same np.random seed -> same subset of draws, FR:934)."""
+    path = os.path.join(GOLDEN, 'ref_saved_model.fokl')
+    want = np.load(os.path.join(GOLDEN, 'ref_saved_model_expected.npz'))
+    model = FoKLRoutines.load(path)
+    assert type(model) is FoKLRoutines.FoKL
+    assert np.array_equal(model.betas, want['betas']) and np.array_equal(model.mtx, want['mtx'])
+    model._backend_override = OracleBackend()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        np.random.seed(6)
+        mean, bounds = model.evaluate(want['inputs'], clean=True, ReturnBounds=True)
+    np.testing.assert_allclose(mean, want['mean'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(bounds, want['bounds'], rtol=1e-12, atol=1e-12)
+    # and the round trip through this package's save keeps working
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        again = FoKLRoutines.load(model.save('roundtrip', tmp))
+    assert np.array_equal(again.betas, want['betas'])
