@@ -64,6 +64,8 @@ SIGNATURES = {
                                                     c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     'fokl_rng_normals': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'fokl_rng_gammas': (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_i64, c_vp]),
+    'fokl_gp_integrate': (c_int, [c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                  c_dbl, c_vp, c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
     'fokl_comm_init': (c_int, [c_vp, c_vp, c_int, c_int]),
     'fokl_comm_destroy': (c_int, [c_vp]),

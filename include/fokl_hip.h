@@ -300,6 +300,26 @@ int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *ch
                            double *spectral);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* N4: the consumer of fitted models, GP_Integrate (reference src/FoKL/GP_Integrate.py:5-282)               */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Fourth-order Runge-Kutta integration of dy_k/dt = model_k(inputs) for n_states cubic-spline BSS-ANOVA models.
+ * Model k: betas[k] [mtx_rows[k] + 1] (constant first), mtx[k] [mtx_rows[k], mtx_cols[k]] basis orders; its input
+ * vector has n_source[k] >= mtx_cols[k] entries, entry i being state source[k][i] (normalised with norms
+ * [2, n_states] = minima, maxima and clamped to [0, 1]) if source[k][i] >= 0, else column -(source[k][i] + 1) of the
+ * current row of forcing [n_steps, n_other] (already normalised; the same row serves the four stages of a step).
+ * spline_table [n_basis, 4, width] as in fokl_upload, width must be 499 (evaluated on 498 intervals, as the
+ * reference does).  y [n_states] holds the initial state and is advanced in place (the reference mutates y0 too);
+ * trajectory [n_states, n_steps + 1] receives the state before the first and after every step.  Host only.
+ */
+int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *const *betas,
+                      const int32_t *const *mtx, const int32_t *mtx_rows, const int32_t *mtx_cols,
+                      const int32_t *const *source, const int32_t *n_source, const double *forcing,
+                      const double *norms, const double *spline_table, int n_basis, int width, double h, double *y,
+                      double *trajectory);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* multi-GPU: one process per GPU, RCCL over xGMI                                                          */
 /* ------------------------------------------------------------------------------------------------------ */
 
