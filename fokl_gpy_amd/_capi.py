@@ -51,7 +51,9 @@ SIGNATURES = {
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_destroy': (None, [c_vp]),
-    'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                       c_vp]),
+    'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -319,17 +321,24 @@ def _scipy_dsyevr_address():
 
 class PoolJob:
     """A job on a HostPool.  Keeps the buffers the job reads / writes alive; ``wait()`` may be called repeatedly."""
-    __slots__ = ('_h', 'keep', 'result', 'recycle')
+    __slots__ = ('_h', 'keep', 'result', 'recycle', 'unresolved')
 
-    def __init__(self, handle, keep, result=None):
+    def __init__(self, handle, keep, result=None, tentative=False):
         self._h, self.keep, self.result = handle, keep, result
         self.recycle = None                 # raw buffers the owner of the pool may reuse once the job has run
+        self.unresolved = bool(tentative)   # a tentative noise job that has not been given its verdict yet
 
     def done(self):
         """True once the job has run (its native record is then released, the buffers may go)."""
         if self._h is not None and load().fokl_pool_poll(self._h):
             self.wait()
         return self._h is None
+
+    def resolve(self, commit):
+        """Verdict on a tentative noise job (fokl_pool_resolve)."""
+        if self.unresolved:
+            self.unresolved = False
+            _check(load().fokl_pool_resolve(self._h, int(bool(commit))))
 
     def wait(self):
         if self._h is not None:
@@ -381,11 +390,13 @@ class HostPool:
 
     __del__ = close
 
-    def submit_noise(self, tape, astar, atau_star):
+    def submit_noise(self, tape, astar, atau_star, tentative=False):
+        """tentative: record ahead of the decision; the job must then get ``resolve(commit)`` (see the header)."""
         h = c_vp(0)
         _check(self._lib.fokl_pool_submit_noise(self._h, tape.p1, tape.draws, float(astar), float(atau_star),
-                                                *tape.pointers(), tape.progress_pointer(), ctypes.byref(h)))
-        return PoolJob(h, (tape,), tape)
+                                                *tape.pointers(), tape.progress_pointer(), int(bool(tentative)),
+                                                ctypes.byref(h)))
+        return PoolJob(h, (tape,), tape, tentative)
 
     def submit_chain(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw=None):
         """Returns a job whose result is (w [draws, p1], bstar_negative int32[1]); w is carved out of the float64 buffer

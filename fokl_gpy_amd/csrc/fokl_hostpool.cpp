@@ -57,6 +57,10 @@ struct fokl_host_job {
     std::atomic<int> done{0};
     int status = FOKL_OK;
     std::string error;
+    // noise: a tentative tape is recorded ahead of the decision that it is needed; the driver then commits it (+1) or
+    // aborts it (-1: the stream is put back where the tape started)
+    bool tentative = false;
+    std::atomic<int> verdict{0};
     // noise / chain
     int p1 = 0, draws = 0;
     double astar = 0, atau_star = 0;
@@ -200,13 +204,47 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
     std::string err;
     std::atomic<int64_t> *busy = nullptr;
     switch (job->kind) {
-    case Kind::noise:
+    case Kind::noise: {
+        uint32_t saved_key[624];
+        int32_t saved_pos = 0, saved_has = 0;
+        double saved_cache = 0.0;
+        if (job->tentative && job->verdict.load(std::memory_order_acquire) < 0) {
+            __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);       // aborted before it was started
+            break;
+        }
+        if (job->tentative) {
+            std::memcpy(saved_key, pool->mt_key, sizeof(saved_key));
+            saved_pos = *pool->mt_pos;
+            saved_has = *pool->has_gauss;
+            saved_cache = *pool->gauss_cache;
+        }
         rc = fokl_noise_tape(job->p1, job->draws, job->astar, job->atau_star, pool->mt_key, pool->mt_pos,
                              pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead, job->gam_sig,
                              job->gam_tau, job->progress);
         if (rc != FOKL_OK) err = "noise tape: invalid arguments or gamma shape";
         busy = &pool->noise_busy_ns;
+        pool->noise_busy_ns.fetch_add(
+            std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+            std::memory_order_relaxed);
+        busy = nullptr;                                     // the wait for the verdict below is not work
+        if (job->tentative) {
+            for (int spins = 0; job->verdict.load(std::memory_order_acquire) == 0;) {
+                if (++spins < 4000) {
+                    _mm_pause();
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(10));
+                }
+            }
+            if (job->verdict.load(std::memory_order_acquire) < 0) {
+                std::memcpy(pool->mt_key, saved_key, sizeof(saved_key));
+                *pool->mt_pos = saved_pos;
+                *pool->has_gauss = saved_has;
+                *pool->gauss_cache = saved_cache;
+                __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);   // nobody may follow this tape
+            }
+        }
         break;
+    }
     case Kind::finish:
         rc = fokl_finish_tape_blocks(job->p1, job->draws, job->normals, job->pair_r2, job->lead, job->progress,
                                      job->part, job->parts, job->block, job->block_done);
@@ -235,7 +273,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
         break;
     }
     const auto dt = std::chrono::steady_clock::now() - t0;
-    busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
+    if (busy) busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
     if (job->self_owned) {
         delete job;                                         // failures reach the chain job through block_done
         return;
@@ -341,7 +379,7 @@ extern "C" void fokl_pool_destroy(fokl_host_pool *pool)
 
 extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star,
                                       double *normals, double *pair_r2, int32_t *lead, double *gam_sig,
-                                      double *gam_tau, int32_t *progress, fokl_host_job **out)
+                                      double *gam_tau, int32_t *progress, int tentative, fokl_host_job **out)
 {
     if (!pool || !out || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !progress) {
         fokl_set_global_error("fokl_pool_submit_noise: null pointer or empty model");
@@ -360,6 +398,7 @@ extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, d
     job->gam_sig = gam_sig;
     job->gam_tau = gam_tau;
     job->progress = progress;
+    job->tentative = tentative != 0;
     *out = job;
     submit(pool->noise_q, job);
     return FOKL_OK;
@@ -456,6 +495,22 @@ extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gra
     job->moments_out = moments_out;
     *out = job;
     submit(pool->spectral_q, job);
+    return FOKL_OK;
+}
+
+// Verdict on a tentative noise job: commit != 0 keeps the tape (it is then exactly the tape a plain submission at that
+// point of the stream would have recorded), 0 discards it and rewinds the stream to where the tape began.
+extern "C" int fokl_pool_resolve(fokl_host_job *job, int commit)
+{
+    if (!job || job->kind != Kind::noise || !job->tentative) {
+        fokl_set_global_error("fokl_pool_resolve: not a tentative noise job");
+        return FOKL_ERR_ARG;
+    }
+    int expected = 0;
+    if (!job->verdict.compare_exchange_strong(expected, commit ? 1 : -1)) {
+        fokl_set_global_error("fokl_pool_resolve: the job has been resolved already");
+        return FOKL_ERR_STATE;
+    }
     return FOKL_OK;
 }
 

@@ -325,10 +325,12 @@ class HostPipeline:
         self._live.append(job)
         return job
 
-    def request(self, p1, astar, atau_star):
-        """Queue the tape of one model evaluation; the buffers exist at once and fill up in the background."""
+    def request(self, p1, astar, atau_star, tentative=False):
+        """Queue the tape of one model evaluation; the buffers exist at once and fill up in the background.
+        tentative: recorded ahead of the decision that the evaluation happens -- the caller owes the job a
+        ``resolve(True / False)`` (False rewinds the stream to where the tape began)."""
         raw = self._take(_capi.NoiseTape.doubles_needed(p1, self.draws))
-        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star)
+        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative)
         job.recycle = [raw]                 # moved to the chain job, which is the last reader of the tape
         return self._track(job)
 
@@ -348,6 +350,9 @@ class HostPipeline:
 
     def close(self):
         """Run everything still queued (every requested tape advances the stream, used or not), stop the threads."""
+        for job in self._live:
+            if job.unresolved:              # only after an exception in the driver: never leave the noise thread waiting
+                job.resolve(False)
         for job in self._live:
             job.wait()
         self._live = []
@@ -411,12 +416,12 @@ class GibbsOutcome:
             self._betas = self.w @ self.Qt
         return self._betas
 
-    def beta_columns(self, cols):
-        """Draws of a few coefficients only: w Q[cols, :]' -- the kill-test statistics look at the new terms and the
-        intercept, never at the whole draws x (P+1) matrix."""
+    def beta_columns(self, cols, first_row=0):
+        """Draws first_row.. of a few coefficients only: w Q[cols, :]' -- the kill-test statistics look at the second
+        half of the draws of the new terms and of the intercept, never at the whole draws x (P+1) matrix."""
         if self._betas is not None:
-            return self._betas[:, cols]
-        return self.w @ self.Qt[:, cols]
+            return self._betas[first_row:, cols]
+        return self.w[first_row:] @ self.Qt[:, cols]
 
 
 class EagerOutcome:
@@ -433,10 +438,10 @@ class EagerOutcome:
             self._betas = self.w @ self.Q.T
         return self._betas
 
-    def beta_columns(self, cols):
+    def beta_columns(self, cols, first_row=0):
         if self._betas is not None:
-            return self._betas[:, cols]
-        return self.w @ self.Q[cols, :].T
+            return self._betas[first_row:, cols]
+        return self.w[first_row:] @ self.Q[cols, :].T
 
 
 class ForwardSelection:
@@ -476,6 +481,11 @@ class ForwardSelection:
         self.host = None                    # HostPipeline while run() is active (b > 0 only)
         self._async_resid = hasattr(backend, 'bic_resid_launch')
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
+        # next test's tape requested before the decision that the test is run (rewound when it is not; data-driven, so
+        # replicated drivers of a row-sharded fit stay in step) -- FOKL_TENTATIVE_TAPES=0 disables, =test forces rewinds
+        mode = os.environ.get('FOKL_TENTATIVE_TAPES', '1')
+        self.tentative_tapes = mode != '0'
+        self._test_rewinds = mode == 'test'
         # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model
         # (it runs in the shadow of the noise tape, so it costs the search nothing); 'gram' = residual moments from the
         # sub-stage's Gram (no device work per candidate; agrees with the device pass to about 1e-12
@@ -486,7 +496,7 @@ class ForwardSelection:
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0)
+                          bic_gram_max_rel=0.0, tapes_rewound=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _ev_from_moments(self, s1, s2, p1):
@@ -527,10 +537,10 @@ class ForwardSelection:
         ycol = gram.shape[0] - 1
         return spec, idx, cand_slots, gram[ycol, ycol]
 
-    def _request_noise(self, p1):
+    def _request_noise(self, p1, tentative=False):
         astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        return self.host.request(p1, astar, atau_star)
+        return self.host.request(p1, astar, atau_star, tentative)
 
     def _commit(self, pending, noise_job=None):
         """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
@@ -610,7 +620,7 @@ class ForwardSelection:
         """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
         if outcome.intercept_scale is None:
             outcome.intercept_scale = np.mean(np.abs(np.mean(
-                outcome.beta_columns(np.array([0]))[half0:self.draws, 0])))
+                outcome.beta_columns(np.array([0]), half0)[:, 0])))
         return outcome.intercept_scale
 
     def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0):
@@ -633,38 +643,76 @@ class ForwardSelection:
         evmin = best.ev
         ahead = {}                                                    # trial set -> spectral job submitted ahead
         last_accepted = True                                          # predictor: proposals go the way the last went
-        for pos, i in enumerate(proposal):
-            decided = clause1[i]
-            if not decided and best.intercept_scale is not None:      # second clause without waiting for a chain
-                if not mean_abs[i] < self.threshav * best.intercept_scale:
-                    continue
-                decided = True
-            # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
-            cur = killed
-            upcoming = itertools.islice((j for j in proposal[pos + 1:] if clause1[j] or
-                                         mean_abs[j] < self.threshav * scale_guess), self.lookahead)
-            for j in itertools.chain((i,), upcoming):
-                key = cur | {cols[j]}
-                if key not in ahead:
-                    ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
+        # The tape of the NEXT test, requested as soon as this one's BIC is known (its size needs the kill set) instead
+        # of after the chain that decides whether that test is run: the noise thread then goes from one tape to the
+        # next without a pause.  (proposal index, model size, job); rewound if the guess was wrong.
+        pending_tape = None
+        likely = lambda j: clause1[j] or mean_abs[j] < self.threshav * scale_guess
+
+        def drop_pending():
+            nonlocal pending_tape
+            if pending_tape is not None:
+                pending_tape[2].resolve(False)
+                self.stats['tapes_rewound'] += 1
+                pending_tape = None
+
+        try:
+            for pos, i in enumerate(proposal):
+                decided = clause1[i]
+                if not decided and best.intercept_scale is not None:      # second clause without waiting for a chain
+                    if not mean_abs[i] < self.threshav * best.intercept_scale:
+                        if pending_tape is not None and pending_tape[0] == i:
+                            drop_pending()
+                        continue
+                    decided = True
+                # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
+                cur = killed
+                upcoming = itertools.islice((j for j in proposal[pos + 1:] if likely(j)), self.lookahead)
+                for j in itertools.chain((i,), upcoming):
+                    key = cur | {cols[j]}
+                    if key not in ahead:
+                        ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
+                    if last_accepted:
+                        cur = key
+                trial = killed | {cols[i]}
+                idx = self._columns_without(A, trial)
+                pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=self.kill_bic != 'gram')
+                if not decided:
+                    scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
+                    if not mean_abs[i] < self.threshav * scale_guess:
+                        if self._async_resid and pending[2] is not None:
+                            self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
+                        if pending_tape is not None and pending_tape[0] == i:
+                            drop_pending()
+                        continue
+                noise_job = None
+                if pending_tape is not None:
+                    if pending_tape[0] == i and pending_tape[1] == idx.shape[0]:
+                        noise_job = pending_tape[2]
+                        noise_job.resolve(True)
+                        pending_tape = None
+                    else:
+                        drop_pending()                                    # recorded for a test that is not the next one
+                jobs = self._commit(pending, noise_job)
+                ev = self._score(pending)
+                self._record(idx.shape[0], n_prev, ev, True)
+                last_accepted = bool(ev < evmin)
                 if last_accepted:
-                    cur = key
-            trial = killed | {cols[i]}
-            idx = self._columns_without(A, trial)
-            pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=self.kill_bic != 'gram')
-            if not decided:
-                scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
-                if not mean_abs[i] < self.threshav * scale_guess:
-                    if self._async_resid and pending[2] is not None:
-                        self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
-                    continue
-            jobs = self._commit(pending)
-            ev = self._score(pending)
-            self._record(idx.shape[0], n_prev, ev, True)
-            last_accepted = bool(ev < evmin)
-            if last_accepted:
-                killed, evmin = trial, ev
-                best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                    killed, evmin = trial, ev
+                    best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                if self.tentative_tapes:
+                    nxt = next((j for j in proposal[pos + 1:] if likely(j)), None)
+                    if nxt is not None:
+                        p1_next = A - len(killed) - 1
+                        if self._test_rewinds:                            # tests: a recorded tape that is then discarded
+                            bogus = self._request_noise(p1_next + 1, tentative=True)
+                            while bogus.result.progress[0] < self.draws:
+                                time.sleep(0)
+                            bogus.resolve(False)
+                            self.stats['tapes_rewound'] += 1
+                        pending_tape = (nxt, p1_next, self._request_noise(p1_next, tentative=True))
+        finally:
+            drop_pending()                                            # also on an exception: the noise thread must not wait
         return sorted(killed), evmin, best
 
     # -- the search ---------------------------------------------------------------------------------------
@@ -737,10 +785,9 @@ class ForwardSelection:
                 ev = full.ev
 
                 # statistics of the new terms (FR:1656-1664)
-                beters_new = full.beta_columns(np.arange(dam - vm + 1, dam + 1))
-                mean_abs = np.abs(np.mean(beters_new[half1:draws], axis=0))
-                rel_std = np.divide(np.std(beters_new[half1:draws], axis=0),
-                                    np.abs(np.mean(beters_new[half0:draws], axis=0)))
+                tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
+                mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
+                rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
                 order = np.argsort(mean_abs)
                 cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
                 mean_abs, rel_std = mean_abs[order], rel_std[order]

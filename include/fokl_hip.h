@@ -266,10 +266,17 @@ int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads
                      uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      fokl_host_pool **out);
 void fokl_pool_destroy(fokl_host_pool *pool);
-/* fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0). */
+/*
+ * fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0).
+ * tentative != 0: the tape is recorded ahead of the decision that it is needed; the noise thread then holds the stream
+ * until fokl_pool_resolve(job, commit) -- commit keeps the tape (identical to a plain submission at that point of the
+ * stream), otherwise the stream is rewound to where the tape began and `progress` is set to -1.  Every tentative
+ * job MUST be resolved, or the noise thread (and fokl_pool_destroy) waits for ever.
+ */
 int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, double *normals,
                            double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau, int32_t *progress,
-                           fokl_host_job **out);
+                           int tentative, fokl_host_job **out);
+int fokl_pool_resolve(fokl_host_job *job, int commit);
 /*
  * The draws of one candidate from its tape (whose noise job must have been submitted): with finish threads and
  * block_done [ceil(draws / block)] (zero-initialised) given, the tape is completed IN PLACE by the finish threads and

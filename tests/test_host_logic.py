@@ -363,3 +363,24 @@ def test_model_saved_by_the_reference_loads_and_evaluates():
     with tempfile.TemporaryDirectory() as tmp:
         again = FoKLRoutines.load(model.save('roundtrip', tmp))
     assert np.array_equal(again.betas, want['betas'])
+
+
+@pytest.mark.parametrize('name', ['bern_m6', 'bern_m4_way3'])
+def test_tentative_tapes_and_rewinds_change_nothing(monkeypatch, name):
+    """The next kill test's noise tape is requested before the decision that the test is run and the stream is rewound
+    when it is not (FOKL_TENTATIVE_TAPES: 0 = off, 1 = on, test = additionally record-and-discard a bogus tape before
+    every request): draws, model, BIC trace and the final numpy RNG state must be identical in all three modes."""
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture not generated')
+    runs = {}
+    for mode in ('0', '1', 'test'):
+        monkeypatch.setenv('FOKL_TENTATIVE_TAPES', mode)
+        g, model, betas, mtx, evs = fit_case(name)
+        runs[mode] = (betas, mtx, evs, rng_fingerprint(), dict(model.fit_stats))
+    assert runs['0'][4]['tapes_rewound'] == 0
+    assert runs['test'][4]['tapes_rewound'] > runs['1'][4]['tapes_rewound'] >= 0
+    for mode in ('1', 'test'):
+        assert np.array_equal(runs[mode][0], runs['0'][0])
+        assert np.array_equal(runs[mode][1], runs['0'][1])
+        assert np.array_equal(runs[mode][2], runs['0'][2])
+        assert runs[mode][3] == runs['0'][3]
