@@ -160,7 +160,7 @@ def main():
         t0 = time.perf_counter()
         logical = physical = calls = 0
         host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
-                    pool_finish_s=0.0, pool_spectral_s=0.0)
+                    pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0)
         for _ in range(args.steps):
             st = one_step()
             logical += st['terms_logical']

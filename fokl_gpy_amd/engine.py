@@ -483,6 +483,9 @@ class ForwardSelection:
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
         # next test's tape requested before the decision that the test is run (rewound when it is not; data-driven, so
         # replicated drivers of a row-sharded fit stay in step) -- FOKL_TENTATIVE_TAPES=0 disables, =test forces rewinds
+        # the next sub-stage's columns and Gram block are built, and G2 of its predicted model started, before this
+        # sub-stage's kill tests are over (once at most `foresight` likely tests remain); FOKL_FORESIGHT=0 disables
+        self.foresight = int(os.environ.get('FOKL_FORESIGHT', '8'))
         mode = os.environ.get('FOKL_TENTATIVE_TAPES', '1')
         self.tentative_tapes = mode != '0'
         self._test_rewinds = mode == 'test'
@@ -496,7 +499,7 @@ class ForwardSelection:
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0, tapes_rewound=0)
+                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _ev_from_moments(self, s1, s2, p1):
@@ -568,18 +571,24 @@ class ForwardSelection:
             self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
         return ev
 
-    def _evaluate(self, gram, slots, idx, n_prev_cols, kill):
+    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None):
         """
         gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
         slots : device slot of each active column
         idx   : active-column indices of this candidate model (idx[0] == 0, the intercept)
+        spectral_job : G2 of exactly this model submitted earlier (pipelined search), if any
+        overlap : called once G2 is under way -- work for the driver thread in its shadow (pipelined search)
         """
         idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
         if self.host is not None:
             # not speculative: the tape is requested first, so that it is recorded while G2 runs
             noise_job = self._request_noise(p1)
-            pending = self._begin(gram, slots, idx)
+            if spectral_job is None:
+                spectral_job = self.host.spectral(gram, idx)
+            if overlap is not None:
+                overlap()
+            pending = self._begin(gram, slots, idx, spectral_job)
             jobs = self._commit(pending, noise_job)
             ev = self._score(pending)
             self._record(p1, n_prev_cols, ev, kill)
@@ -623,12 +632,14 @@ class ForwardSelection:
                 outcome.beta_columns(np.array([0]), half0)[:, 0])))
         return outcome.intercept_scale
 
-    def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0):
+    def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None):
         """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
 
         Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
         what the test computes does not.  So G2 of the models the next few tests will need is submitted ahead, and
         the residual pass of the upcoming one is in flight while this thread waits for that chain.
+        foresee(killed set) is told, towards the end of the loop, which columns the loop will probably have removed
+        when it is done (the caller starts G2 of the next sub-stage's model with it).
         """
         A = len(slots)
         vm = cand_col.shape[0]
@@ -649,6 +660,12 @@ class ForwardSelection:
         pending_tape = None
         likely = lambda j: clause1[j] or mean_abs[j] < self.threshav * scale_guess
 
+        def forecast(pos):
+            # the kill set at the end of the loop if every remaining test that looks likely runs and is accepted
+            rest = [j for j in proposal[pos:] if likely(j)]
+            if foresee is not None and len(rest) <= self.foresight:
+                foresee(killed | {cols[j] for j in rest})
+
         def drop_pending():
             nonlocal pending_tape
             if pending_tape is not None:
@@ -657,6 +674,7 @@ class ForwardSelection:
                 pending_tape = None
 
         try:
+            forecast(0)
             for pos, i in enumerate(proposal):
                 decided = clause1[i]
                 if not decided and best.intercept_scale is not None:      # second clause without waiting for a chain
@@ -700,6 +718,7 @@ class ForwardSelection:
                 if last_accepted:
                     killed, evmin = trial, ev
                     best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                forecast(pos + 1)
                 if self.tentative_tapes:
                     nxt = next((j for j in proposal[pos + 1:] if likely(j)), None)
                     if nxt is not None:
@@ -731,128 +750,183 @@ class ForwardSelection:
                                   pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'])
                 self.host = None
 
+    def _patterns(self):
+        """(stage ind, indvec) of every sub-stage in the reference's order (FR:1602-1613, FR:1722-1747)."""
+        m = self.m
+        sett = 1 if m == 1 else (3 if self.way3 else 2)   # FR:1595-1600
+        ind = 1
+        while True:
+            indvec = deal_indvec(ind, m, sett)
+            while True:
+                yield ind, list(indvec)
+                if not advance_indvec(indvec, m, self.way3):
+                    break
+            ind += 1
+            if ind > self.n_phis:                  # FR:1747
+                return
+
+    def _build_ahead(self, indvec, active_slots):
+        """K1 + K2 of a coming sub-stage while the current one is still being decided: its columns, and their Gram
+        block against every column that can still be in the model then (all of the current sub-stage's) and y."""
+        vecs = distinct_arrangements(indvec)
+        slots = self.pool.take(vecs.shape[0])
+        self.backend.build_terms(vecs.astype(np.int32), slots)
+        self.stats['terms_physical'] += vecs.shape[0]
+        block = self.backend.gram(slots, active_slots + slots + [SLOT_Y], self.allreduce)
+        return dict(indvec=indvec, vecs=vecs, slots=slots, block=block, over=len(active_slots))
+
+    @staticmethod
+    def _extend_gram(gram, keep, block, block_kept, over):
+        """Gram of [columns `keep` of gram's model] + [new columns] + y.  gram: (A + 1)^2 with y last; block: the new
+        columns' rows of the Gram, whose columns block_kept belong to the kept columns, over .. over + vm - 1 to the
+        new columns themselves and over + vm to y (_build_ahead: block_kept = keep, over = A; a K2 call on exactly
+        the kept columns: block_kept = 0 .. len(keep) - 1, over = len(keep))."""
+        A = gram.shape[0] - 1
+        n_prev, vm = len(keep), block.shape[0]
+        A2 = n_prev + vm
+        out = np.empty((A2 + 1, A2 + 1))
+        out[:n_prev, :n_prev] = gram[np.ix_(keep, keep)]
+        out[:n_prev, A2] = out[A2, :n_prev] = gram[keep, A]
+        out[A2, A2] = gram[A, A]
+        cross = block[:, block_kept]
+        out[n_prev:A2, :n_prev] = cross
+        out[:n_prev, n_prev:A2] = cross.T
+        out[n_prev:A2, n_prev:A2] = block[:, over:over + vm]
+        out[n_prev:A2, A2] = out[A2, n_prev:A2] = block[:, over + vm]
+        return out
+
     def _run(self):
         m, n = self.m, self.n
         draws = self.draws
         half1 = int(math.ceil(draws / 2 + 1))      # FR:1656
         half0 = int(math.ceil(draws / 2))          # FR:1658, FR:1671
-        sett = 1 if m == 1 else (3 if self.way3 else 2)   # FR:1595-1600
 
         # Gram of [ones, y] seeds the cache: n, sum y, y'y
         model_slots = []                            # device slots of accepted terms (aligned with damtx rows)
         damtx = np.zeros((0, m))
         base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], self.allreduce)
-        model_gram = np.array([[base[0, 0]]])       # Gram over [ones] + model columns
-        model_xty = np.array([base[0, 1]])
-        dtd = base[1, 1]
+        gram = np.array(base, dtype=np.float64)     # Gram over [ones] + model columns + y
+        keep = [0]
 
         evs = np.array([])
         betas = mtx = None
         last = None
         last_damtx = damtx
-        ind = 1
         greater = 0
-        finished = False
+        patterns = self._patterns()
+        pattern = next(patterns)
+        ahead = None                                # the coming sub-stage, built early (pipelined search only)
+        forecasts = {}                              # survivors' slots -> (G2 job of the coming model, its Gram)
+        look_ahead = self.host is not None and self.foresight > 0
 
-        while True:
-            indvec = deal_indvec(ind, m, sett)
-            while True:
+        while pattern is not None:
+            ind, indvec = pattern
+            pattern = next(patterns, None)
+            n_prev = 1 + len(model_slots)
+            spectral_job = None
+            if ahead is not None:
+                vecs, new_slots = ahead['vecs'], ahead['slots']
+                hit = forecasts.pop(tuple(model_slots), None)
+                if hit is not None:
+                    spectral_job, gram = hit
+                    self.stats['forecasts_used'] += 1
+                else:
+                    gram = self._extend_gram(gram, keep, ahead['block'], keep, ahead['over'])
+                ahead, forecasts = None, {}
+            else:
+                # K1 + K2: build the new columns once, extend the Gram
                 vecs = distinct_arrangements(indvec)
-                vm = vecs.shape[0]
-                damtx = np.append(damtx, vecs, axis=0)
-                dam = damtx.shape[0]
-                n_prev = 1 + len(model_slots)
-
-                # K1 + K2: build the vm new columns once, extend the Gram
-                new_slots = self.pool.take(vm)
+                new_slots = self.pool.take(vecs.shape[0])
                 self.backend.build_terms(vecs.astype(np.int32), new_slots)
-                self.stats['terms_physical'] += vm
-                active_slots = [SLOT_ONES] + model_slots + new_slots
-                A = len(active_slots)
-                block = self.backend.gram(new_slots, active_slots + [SLOT_Y], self.allreduce)   # [vm, A + 1]
-                gram = np.empty((A + 1, A + 1))
-                gram[:n_prev, :n_prev] = model_gram
-                gram[:n_prev, A] = model_xty
-                gram[A, :n_prev] = model_xty
-                gram[A, A] = dtd
-                gram[n_prev:A, :A] = block[:, :A]
-                gram[:n_prev, n_prev:A] = block[:, :n_prev].T
-                gram[n_prev:A, A] = block[:, A]
-                gram[A, n_prev:A] = block[:, A]
+                self.stats['terms_physical'] += vecs.shape[0]
+                block = self.backend.gram(new_slots, [SLOT_ONES] + model_slots + new_slots + [SLOT_Y], self.allreduce)
+                gram = self._extend_gram(gram, keep, block, list(range(n_prev)), n_prev)
+            vm = vecs.shape[0]
+            damtx = np.append(damtx, vecs, axis=0)
+            dam = damtx.shape[0]
+            active_slots = [SLOT_ONES] + model_slots + new_slots
+            A = len(active_slots)
 
-                full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False)
-                best = full
-                ev = full.ev
+            def build_next(coming=pattern, active=active_slots):
+                nonlocal ahead
+                if look_ahead and coming is not None:
+                    ahead = self._build_ahead(coming[1], active)
 
-                # statistics of the new terms (FR:1656-1664)
-                tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
-                mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
-                rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
-                order = np.argsort(mean_abs)
-                cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
-                mean_abs, rel_std = mean_abs[order], rel_std[order]
+            full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False, spectral_job=spectral_job,
+                                  overlap=build_next)
+            best = full
+            ev = full.ev
 
-                # sequential kill tests (FR:1666-1690): proposals in ascending |mean beta|
-                killed = []                                           # active-column indices removed so far
-                evmin = ev
-                if self.host is None:
-                    for i in range(vm):
-                        # FR:1670-1671.  The second clause needs the intercept draws of the model accepted so far
-                        # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
-                        if rel_std[i] > self.threshstdb or (
-                                rel_std[i] > self.threshstda and
-                                mean_abs[i] < self.threshav * self._intercept_scale(best, half0)):
-                            trial = set(killed)
-                            trial.add(int(cand_col[i]))
-                            res = self._evaluate(gram, active_slots, self._columns_without(A, trial), n_prev, kill=True)
-                            if res.ev < evmin:
-                                killed = sorted(trial)
-                                evmin = res.ev
-                                best = res
-                else:
-                    killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
-                                                                     rel_std, best, half0)
-                ev = evmin
+            def foresee(pred_killed, gram=gram, active=active_slots, A=A):
+                # G2 of the coming sub-stage's model if the kill tests end as predicted (at most two guesses)
+                if ahead is None or len(forecasts) >= 2:
+                    return
+                keep_pred = [c for c in range(A) if c not in pred_killed]
+                key = tuple(active[c] for c in keep_pred[1:])
+                if key not in forecasts:
+                    g = self._extend_gram(gram, keep_pred, ahead['block'], keep_pred, ahead['over'])
+                    forecasts[key] = (self.host.spectral(g, np.arange(g.shape[0] - 1, dtype=np.int32)), g)
 
-                # commit the surviving columns (FR:1691-1695)
-                keep = [c for c in range(A) if c not in set(killed)]
-                if killed:
-                    damtx = np.delete(damtx, [c - 1 for c in killed], axis=0)
-                    self.pool.give([active_slots[c] for c in killed])
-                model_slots = [active_slots[c] for c in keep[1:]]
-                model_gram = gram[np.ix_(keep, keep)]
-                model_xty = gram[keep, A]
-                self.stats['substages'] += 1
-                last, last_damtx = best, damtx
+            # statistics of the new terms (FR:1656-1664)
+            tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
+            mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
+            rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
+            order = np.argsort(mean_abs)
+            cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
+            mean_abs, rel_std = mean_abs[order], rel_std[order]
 
-                if self.console:
-                    print([ind, float(ev)])
+            # sequential kill tests (FR:1666-1690): proposals in ascending |mean beta|
+            killed = []                                           # active-column indices removed so far
+            evmin = ev
+            if self.host is None:
+                for i in range(vm):
+                    # FR:1670-1671.  The second clause needs the intercept draws of the model accepted so far
+                    # (Python's short-circuit `or` / `and`, exactly as in the reference's expression).
+                    if rel_std[i] > self.threshstdb or (
+                            rel_std[i] > self.threshstda and
+                            mean_abs[i] < self.threshav * self._intercept_scale(best, half0)):
+                        trial = set(killed)
+                        trial.add(int(cand_col[i]))
+                        res = self._evaluate(gram, active_slots, self._columns_without(A, trial), n_prev, kill=True)
+                        if res.ev < evmin:
+                            killed = sorted(trial)
+                            evmin = res.ev
+                            best = res
+            else:
+                killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
+                                                                 rel_std, best, half0, foresee)
+            ev = evmin
 
-                # best-model bookkeeping and stop rule (FR:1701-1721)
-                if evs.size > 0:
-                    if ev < np.min(evs):
-                        betas, mtx, greater = best, damtx, 1
-                        evs = np.append(evs, ev)
-                    elif greater < self.tolerance:
-                        greater += 1
-                        evs = np.append(evs, ev)
-                    else:
-                        finished = True
-                        evs = np.append(evs, ev)
-                        break
-                else:
-                    greater += 1
-                    betas, mtx = best, damtx
+            # commit the surviving columns (FR:1691-1695)
+            keep = [c for c in range(A) if c not in set(killed)]
+            if killed:
+                damtx = np.delete(damtx, [c - 1 for c in killed], axis=0)
+                self.pool.give([active_slots[c] for c in killed])
+            model_slots = [active_slots[c] for c in keep[1:]]
+            self.stats['substages'] += 1
+            last, last_damtx = best, damtx
+
+            if self.console:
+                print([ind, float(ev)])
+
+            # best-model bookkeeping and stop rule (FR:1701-1721)
+            if evs.size > 0:
+                if ev < np.min(evs):
+                    betas, mtx, greater = best, damtx, 1
                     evs = np.append(evs, ev)
-
-                if not advance_indvec(indvec, m, self.way3):
+                elif greater < self.tolerance:
+                    greater += 1
+                    evs = np.append(evs, ev)
+                else:
+                    evs = np.append(evs, ev)
                     break
+            else:
+                greater += 1
+                betas, mtx = best, damtx
+                evs = np.append(evs, ev)
 
-            if finished:
-                break
-            ind += 1
-            if ind > self.n_phis:                  # FR:1747
-                break
+        if ahead is not None:                      # the search stopped: the columns built ahead are not needed
+            self.pool.give(ahead['slots'])
 
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx

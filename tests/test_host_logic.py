@@ -150,15 +150,37 @@ def test_slot_pool_never_hands_out_reserved_slots():
     assert sorted(pool.take(2)) == sorted(got[:2])
 
 
-def test_kill_tests_reuse_the_substage_gram():
-    """One basis build and one Gram block per sub-stage; every other model evaluation is a sub-matrix lookup."""
-    g, model, *_ = fit_case('bern_m3')
-    be = model._backend_override
-    st = model.fit_stats
-    assert be.calls['build'] == st['substages']
-    assert be.calls['gram'] == st['substages'] + 1               # + the [ones, y] seed block
-    assert st['gibbs_calls'] == st['substages'] + st['kill_tests']
-    assert st['terms_physical'] < st['terms_logical']
+def test_kill_tests_reuse_the_substage_gram(monkeypatch):
+    """One basis build and one Gram block per sub-stage; every other model evaluation is a sub-matrix lookup.
+    The pipelined search builds the coming sub-stage early, so a search ended by the stop rule has built one
+    sub-stage it did not use (FOKL_FORESIGHT=0 switches that off)."""
+    for foresight, spare in (('0', 0), ('8', 1)):
+        monkeypatch.setenv('FOKL_FORESIGHT', foresight)
+        g, model, *_ = fit_case('bern_m3')
+        be = model._backend_override
+        st = model.fit_stats
+        assert be.calls['build'] == st['substages'] + spare
+        assert be.calls['gram'] == st['substages'] + 1 + spare   # + the [ones, y] seed block
+        assert st['gibbs_calls'] == st['substages'] + st['kill_tests']
+        assert st['terms_physical'] < st['terms_logical']
+        if spare:
+            assert st['forecasts_used'] > 0
+
+
+def test_building_the_coming_substage_early_changes_nothing(monkeypatch):
+    """FOKL_FORESIGHT: K1 / K2 of the next sub-stage and G2 of its predicted model run before the current kill tests
+    are over.  Same search, same random stream; the Gram entries may differ in the last bits (a BLAS / K2 call's
+    summation order depends on which other columns share the call)."""
+    runs = []
+    for foresight in ('0', '8', '1000'):
+        monkeypatch.setenv('FOKL_FORESIGHT', foresight)
+        g, model, betas, mtx, evs = fit_case('bern_m6')
+        runs.append((betas, mtx, evs, rng_fingerprint(), model.fit_stats['forecasts_used']))
+    assert runs[0][4] == 0 and runs[1][4] > 0
+    for other in runs[1:]:
+        assert np.array_equal(other[1], runs[0][1]) and other[3] == runs[0][3]
+        np.testing.assert_allclose(other[2], runs[0][2], rtol=1e-12)
+        np.testing.assert_allclose(other[0], runs[0][0], rtol=1e-8, atol=1e-10)
 
 
 # ---------------------------------------------------------------------------------------------------------
