@@ -1,3 +1,4 @@
+"""Development aid: CPU load per L3 domain over one second (are the neighbours on this host busy?)."""
 import time, glob
 def snap():
     out = {}

@@ -1,3 +1,5 @@
+// Development aid: ns per Gibbs iteration of fokl_noise_tape through the built library (usage: tape_bench <path to libfokl_hip.so>;
+// FOKL_SAMPLER_ISA=base forces the portable recorder).  g++ -O2 -std=c++17 tools/tape_bench.cpp -o tape_bench -ldl
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
