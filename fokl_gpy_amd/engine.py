@@ -489,13 +489,14 @@ class ForwardSelection:
         mode = os.environ.get('FOKL_TENTATIVE_TAPES', '1')
         self.tentative_tapes = mode != '0'
         self._test_rewinds = mode == 'test'
-        # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model
-        # (it runs in the shadow of the noise tape, so it costs the search nothing); 'gram' = residual moments from the
-        # sub-stage's Gram (no device work per candidate; agrees with the device pass to about 1e-12
-        # relative); 'check' = device, recording the largest disagreement with 'gram' seen.
-        self.kill_bic = os.environ.get('FOKL_KILL_BIC', 'device')
-        if self.kill_bic not in ('gram', 'device', 'check'):
-            raise ValueError("FOKL_KILL_BIC must be gram, device or check")
+        # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model;
+        # 'gram' = residual moments from the sub-stage's Gram (no device work per candidate; agrees with
+        # the device pass to < 1e-10 relative on the BIC); 'check' = device, recording the largest disagreement with
+        # 'gram' seen; 'auto' (default) = device while a K3 pass fits in the shadow of the candidate's noise tape --
+        # it then costs the search nothing -- and gram once it would not (N = 1e7: 0.37 -> 0.16 s per fit).
+        self.kill_bic = os.environ.get('FOKL_KILL_BIC', 'auto')
+        if self.kill_bic not in ('auto', 'gram', 'device', 'check'):
+            raise ValueError("FOKL_KILL_BIC must be auto, gram, device or check")
         self.trace = []                     # one record per gibbs evaluation
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
@@ -625,6 +626,13 @@ class ForwardSelection:
     def _columns_without(count, removed):
         return np.array([c for c in range(count) if c not in removed], dtype=np.int32)
 
+    def _resid_fits_in_shadow(self, columns):
+        """FOKL_KILL_BIC=auto: does a K3 pass over `columns` columns (about 5.5 TB/s) take clearly less time than
+        recording the noise tape of a model of that size (about 40 ns + 1 ns per column and Gibbs iteration)?"""
+        resid_s = 8.0 * self.n * (columns + 2) / 5.5e12 + 20e-6
+        tape_s = self.draws * (40.0 + columns) * 1e-9
+        return resid_s < 0.6 * tape_s
+
     def _intercept_scale(self, outcome, half0):
         """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
         if outcome.intercept_scale is None:
@@ -650,6 +658,7 @@ class ForwardSelection:
         # Guess at "mean_abs < threshav * |mean intercept draw|" for proposals further down the list: the posterior mean
         # of the intercept is close to its least-squares value, and it barely moves from one accepted model to the next.
         scale_guess = abs(float(best.betahat[0]))
+        on_device = self.kill_bic in ('device', 'check') or (self.kill_bic == 'auto' and self._resid_fits_in_shadow(A))
         killed = frozenset()
         evmin = best.ev
         ahead = {}                                                    # trial set -> spectral job submitted ahead
@@ -694,7 +703,7 @@ class ForwardSelection:
                         cur = key
                 trial = killed | {cols[i]}
                 idx = self._columns_without(A, trial)
-                pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=self.kill_bic != 'gram')
+                pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=on_device)
                 if not decided:
                     scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
                     if not mean_abs[i] < self.threshav * scale_guess:
