@@ -191,3 +191,92 @@ def test_portable_and_wide_tape_recorders_agree():
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(out.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host thread pool (include/fokl_hip.h: fokl_pool_*)
+# ---------------------------------------------------------------------------------------------------------
+
+def _chain_inputs(p, rng):
+    return np.linspace(1.0, 1e4, p), rng.standard_normal(p) * 30
+
+
+@pytest.mark.parametrize('finish_threads', [0, 1, 3])
+def test_pool_draws_equal_the_one_call_chain(finish_threads):
+    """noise -> (finish) -> chain through the pool == fokl_gibbs_chain on one thread: same draws, same stream."""
+    rng = np.random.default_rng(2)
+    np.random.seed(21)
+    s_pool, s_ref = _capi.LegacyStream(), _capi.LegacyStream()
+    pool = _capi.HostPool(s_pool, chain_threads=2, finish_threads=finish_threads, spectral_threads=0)
+    jobs = []
+    for p in (1, 2, 15, 16, 17, 64, 129):
+        lamb, qty = _chain_inputs(p, rng)
+        tape = _capi.NoiseTape(p, 257)                                   # not a multiple of the block size
+        noise = pool.submit_noise(tape, 4e3 + p / 2, 4 + p / 2)
+        jobs.append((lamb, qty, p, noise, pool.submit_chain(lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9, tape)))
+    for lamb, qty, p, noise, chain in jobs:
+        w, flag = chain.wait()
+        noise.wait()
+        want = _capi.gibbs_chain(lamb, qty, 4e3 + p / 2, 4 + p / 2, 900.0, 2.0, 5e5, 0.3, 0.9, 257, s_ref)
+        assert np.array_equal(w, want) and flag[0] == 0
+    busy = pool.busy_seconds()
+    assert busy['noise'] > 0 and busy['chain'] > 0 and (busy['finish'] > 0) == (finish_threads > 0)
+    pool.close()
+    assert np.array_equal(s_pool.key, s_ref.key) and s_pool.pos.value == s_ref.pos.value
+    assert s_pool.has_gauss.value == s_ref.has_gauss.value and s_pool.cache.value == s_ref.cache.value
+
+
+def test_pool_tentative_tape_commit_and_rewind():
+    """A tentative tape that is committed is the tape a plain request would have recorded; an aborted one leaves the
+    stream where it was -- also when the abort arrives only after the tape has been recorded."""
+    import time
+    np.random.seed(8)
+    s_pool, s_ref = _capi.LegacyStream(), _capi.LegacyStream()
+    pool = _capi.HostPool(s_pool, 1, 0, 0)
+    first = pool.submit_noise(_capi.NoiseTape(9, 100), 50.0, 7.0)
+    bogus = pool.submit_noise(_capi.NoiseTape(33, 100), 60.0, 19.0, tentative=True)
+    while bogus.result.progress[0] < 100:                                # recorded, now waiting for its verdict
+        time.sleep(0.001)
+    bogus.resolve(False)
+    early = pool.submit_noise(_capi.NoiseTape(5, 100), 60.0, 19.0, tentative=True)
+    early.resolve(False)                                                 # most likely before it was even started
+    kept = pool.submit_noise(_capi.NoiseTape(12, 100), 55.0, 8.5, tentative=True)
+    kept.resolve(True)
+    for job in (first, bogus, early, kept):
+        job.wait()
+    assert bogus.result.progress[0] == -1 and early.result.progress[0] == -1 and kept.result.progress[0] == 100
+    want_first = _capi.noise_tape(9, 100, 50.0, 7.0, s_ref)
+    want_kept = _capi.noise_tape(12, 100, 55.0, 8.5, s_ref)
+    for got, want in ((first.result, want_first), (kept.result, want_kept)):
+        assert np.array_equal(got.normals, want.normals) and np.array_equal(got.gam_sig, want.gam_sig)
+        assert np.array_equal(got.gam_tau, want.gam_tau) and np.array_equal(got.lead, want.lead)
+    pool.close()
+    assert np.array_equal(s_pool.key, s_ref.key) and s_pool.pos.value == s_ref.pos.value
+    with pytest.raises(_capi.FoklNativeError):                           # only tentative jobs take a verdict
+        _capi._check(_capi.load().fokl_pool_resolve(None, 1))
+
+
+def test_pool_spectral_job_is_scipy_eigh_and_rejects_bad_indices():
+    import scipy.linalg
+    rng = np.random.default_rng(5)
+    np.random.seed(1)
+    pool = _capi.HostPool(_capi.LegacyStream(), 1, 0, 2)
+    x = rng.standard_normal((400, 41))
+    x[:, 0] = 1.0
+    y = rng.standard_normal(400)
+    full = np.column_stack([x, y])
+    gram = np.ascontiguousarray(full.T @ full)
+    idx = np.array([0, 3, 4, 9, 17, 18, 40], dtype=np.int32)
+    res = pool.submit_spectral(gram, idx, 41).wait()
+    lam, q = scipy.linalg.eigh(gram[np.ix_(idx, idx)])
+    sgn = np.sign(q[np.argmax(np.abs(q), axis=0), np.arange(len(idx))])
+    assert np.array_equal(res.lamb, lam) and np.array_equal(res.Qt, (q * sgn).T)
+    b = np.linalg.lstsq(x[:, idx], y, rcond=None)[0]
+    np.testing.assert_allclose(res.betahat, b, rtol=1e-9)
+    r = y - x[:, idx] @ b
+    np.testing.assert_allclose(res.moments, [r.sum(), (r * r).sum()], rtol=1e-9, atol=1e-9)
+    with pytest.raises(_capi.FoklNativeError):
+        pool.submit_spectral(gram, np.array([0, 99], dtype=np.int32), 41)
+    with pytest.raises(_capi.FoklNativeError):
+        pool.submit_spectral(gram, idx, 42)
+    pool.close()
