@@ -222,11 +222,9 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
                              pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead, job->gam_sig,
                              job->gam_tau, job->progress);
         if (rc != FOKL_OK) err = "noise tape: invalid arguments or gamma shape";
-        busy = &pool->noise_busy_ns;
         pool->noise_busy_ns.fetch_add(
             std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
-            std::memory_order_relaxed);
-        busy = nullptr;                                     // the wait for the verdict below is not work
+            std::memory_order_relaxed);                     // the wait for the verdict below is not work
         if (job->tentative) {
             for (int spins = 0; job->verdict.load(std::memory_order_acquire) == 0;) {
                 if (++spins < 4000) {
@@ -272,8 +270,10 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
         busy = &pool->spectral_busy_ns;
         break;
     }
-    const auto dt = std::chrono::steady_clock::now() - t0;
-    if (busy) busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
+    if (busy) {
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
+    }
     if (job->self_owned) {
         delete job;                                         // failures reach the chain job through block_done
         return;

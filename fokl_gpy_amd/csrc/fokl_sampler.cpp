@@ -38,6 +38,7 @@ extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 // clones of the element-wise loops picked at load time) and once, as fokl_sampler_wide.o, for AVX-512 F/DQ/VL/BW,
 // where only the tape recorder is exported (fokl_record_tape_wide) and chosen at run time -- measured on Zen 5:
 // 151 -> 120 ns per Gibbs iteration at 60 columns.  Same IEEE operations per element either way: identical numbers.
+#define FOKL_INTERNAL extern "C" __attribute__((visibility("hidden")))
 #ifdef FOKL_SAMPLER_WIDE
 #define FOKL_CLONES
 #else
@@ -479,10 +480,10 @@ void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star
 #ifdef FOKL_SAMPLER_WIDE
 
 // The only entry of the AVX-512 build (library-internal); arguments were validated by fokl_noise_tape.
-extern "C" __attribute__((visibility("hidden"))) void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
-                                      int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache, double *normals_out,
-                                      double *pair_r2_out, int32_t *lead_out, double *gam_sig_out,
-                                      double *gam_tau_out, int32_t *progress)
+FOKL_INTERNAL void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
+                                         int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                                         double *normals_out, double *pair_r2_out, int32_t *lead_out,
+                                         double *gam_sig_out, double *gam_tau_out, int32_t *progress)
 {
     LegacyRng r;
     bind_rng(r, mt_key, mt_pos, has_gauss, gauss_cache);
@@ -493,10 +494,10 @@ extern "C" __attribute__((visibility("hidden"))) void fokl_record_tape_wide(int 
 
 #else
 
-extern "C" __attribute__((visibility("hidden"))) void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
-                                      int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache, double *normals_out,
-                                      double *pair_r2_out, int32_t *lead_out, double *gam_sig_out,
-                                      double *gam_tau_out, int32_t *progress);   // fokl_sampler_wide.o
+FOKL_INTERNAL void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
+                                         int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                                         double *normals_out, double *pair_r2_out, int32_t *lead_out,
+                                         double *gam_sig_out, double *gam_tau_out, int32_t *progress);   // fokl_sampler_wide.o
 
 namespace {
 
