@@ -227,6 +227,8 @@ def main():
         gm = roof('gram', 'mfma')
         kernels['gram']['mfma_achieved_tflops'] = gm['achieved']
         kernels['gram']['mfma_frac'] = gm['frac']
+        # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
+        kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
     # HBM traffic per launch from the committed PMC passes of this same workload (profiles/pmc_r01.json, produced by
     # tools/profile_r01.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note).
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_r01.json')

@@ -42,7 +42,7 @@ SIGNATURES = {
     'fokl_write_slot': (c_int, [c_vp, c_int, c_i64, c_i64, c_vp]),
     'fokl_timing_enable': (c_int, [c_vp, c_int]),
     'fokl_timing_reset': (c_int, [c_vp]),
-    'fokl_timing_get': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_timing_get': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_gibbs_chain': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -553,10 +553,11 @@ class DeviceContext:
         self._ck(self._lib.fokl_timing_reset(self._h))
 
     def timing_get(self, kernel_id):
-        ms, launches, nbytes, flops = c_dbl(0), c_i64(0), c_dbl(0), c_dbl(0)
+        ms, launches, nbytes, flops, ideal = c_dbl(0), c_i64(0), c_dbl(0), c_dbl(0), c_dbl(0)
         self._ck(self._lib.fokl_timing_get(self._h, int(kernel_id), ctypes.byref(ms), ctypes.byref(launches),
-                                           ctypes.byref(nbytes), ctypes.byref(flops)))
-        return dict(ms=ms.value, launches=launches.value, bytes=nbytes.value, flops=flops.value)
+                                           ctypes.byref(nbytes), ctypes.byref(flops), ctypes.byref(ideal)))
+        return dict(ms=ms.value, launches=launches.value, bytes=nbytes.value, flops=flops.value,
+                    ideal_ms=ideal.value)
 
     # -- RCCL ------------------------------------------------------------------------------------------
     @staticmethod

@@ -37,6 +37,7 @@ struct TimingSlot {
     int64_t launches = 0;
     double bytes = 0.0;
     double flops = 0.0;
+    double ideal_ms = 0.0;   // sum over launches of max(bytes / FOKL_PEAK_HBM_BYTES_PER_S, flops / FOKL_PEAK_F64_FLOPS)
 };
 
 struct PendingEvent {
@@ -130,6 +131,7 @@ struct TimedRegion {
         ctx->tslot[id].launches += 1;
         ctx->tslot[id].bytes += bytes;
         ctx->tslot[id].flops += flops;
+        ctx->tslot[id].ideal_ms += 1e3 * std::max(bytes / FOKL_PEAK_HBM_BYTES_PER_S, flops / FOKL_PEAK_F64_FLOPS);
         start = take_event(ctx);
         stop = take_event(ctx);
         if (start && stop) (void)hipEventRecord(start, ctx->stream);
@@ -954,7 +956,7 @@ extern "C" int fokl_timing_reset(fokl_ctx *ctx)
 }
 
 extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
-                               double *flops)
+                               double *flops, double *ideal_ms)
 {
     if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_timing_get: null context");
     if (kernel_id < 0 || kernel_id >= FOKL_K_COUNT) return fail(ctx, FOKL_ERR_ARG, "fokl_timing_get: bad kernel id");
@@ -964,6 +966,7 @@ extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, i
     if (launches) *launches = ctx->tslot[kernel_id].launches;
     if (bytes) *bytes = ctx->tslot[kernel_id].bytes;
     if (flops) *flops = ctx->tslot[kernel_id].flops;
+    if (ideal_ms) *ideal_ms = ctx->tslot[kernel_id].ideal_ms;
     return FOKL_OK;
 }
 

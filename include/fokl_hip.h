@@ -168,9 +168,15 @@ int fokl_write_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, const 
 
 int fokl_timing_enable(fokl_ctx *ctx, int on);
 int fokl_timing_reset(fokl_ctx *ctx);
-/* Accumulated device time (ms), launch count and algorithmic bytes / flops of kernel family `kernel_id`. */
+/*
+ * Accumulated device time (ms), launch count and algorithmic bytes / flops of kernel family `kernel_id`, and
+ * ideal_ms = the sum over its launches of the roofline time max(bytes / HBM peak, flops / fp64 MFMA peak): a family
+ * whose launches sit on both sides of the ridge (the Gram blocks) is priced launch by launch.
+ */
+#define FOKL_PEAK_HBM_BYTES_PER_S 8.0e12  /* MI355X HBM3E, spec */
+#define FOKL_PEAK_F64_FLOPS 78.6e12       /* MI355X dense fp64 (vector = matrix), spec */
 int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
-                    double *flops);
+                    double *flops, double *ideal_ms);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* G2/G3: the Gibbs chain (host C++, N-independent).  Replaces the D-iteration loop FR:1519-1548.           */
