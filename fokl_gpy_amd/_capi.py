@@ -192,7 +192,7 @@ class NoiseTape:
         # int32 area: progress (a line of its own: polled by other threads) | block_done [nblocks] | lead [d]
         ints = (16, 16 + -(-nblocks // 16) * 16)
         off = [0]
-        for count in (d * p1, d * half, d, d):
+        for count in (d * p1 + 16, d * half + 8, d, d):     # slack: the recorder stores whole vectors (see the header)
             off.append(off[-1] + pad(count))
         return tuple(off), ints, off[4] + pad((ints[1] + d + 1) // 2) + 8
 

@@ -258,11 +258,19 @@ struct LegacyRng {
             const __m512i even = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14);
             const __m512i odd = _mm512_setr_epi64(1, 3, 5, 7, 9, 11, 13, 15);
             const __m512d one = _mm512_set1_pd(1.0), zero = _mm512_setzero_pd();
-            while (have + 8 <= count && j + 16 <= dcount) {
+            while (have < count && j + 16 <= dcount) {
                 const __m512d s0 = _mm512_loadu_pd(sq + j), s1 = _mm512_loadu_pd(sq + j + 8);
                 const __m512d rr = _mm512_add_pd(_mm512_permutex2var_pd(s0, even, s1),
                                                  _mm512_permutex2var_pd(s0, odd, s1));      // sq[j+2a] + sq[j+2a+1]
-                const unsigned m = _mm512_cmp_pd_mask(rr, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(rr, zero, _CMP_NEQ_OQ);
+                unsigned m = _mm512_cmp_pd_mask(rr, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(rr, zero, _CMP_NEQ_OQ);
+                int used = 16;                              // doubles consumed by this step
+                const int need = count - have;
+                if (__builtin_popcount(m) > need) {
+                    // the last step of a call: keep the first `need` accepted attempts, stop right after the last of
+                    // them (the stores below still write full vectors: see the slack fokl_noise_tape asks for)
+                    m = _pdep_u32((1u << need) - 1u, m);
+                    used = 2 * (32 - __builtin_clz(m));
+                }
                 _mm512_storeu_pd(r2 + have, _mm512_maskz_compress_pd((__mmask8)m, rr));
                 // (x2, x1) of attempt a = elements 2a+1, 2a: swap within pairs, keep the pairs of accepted attempts
                 const __m512d x0 = _mm512_permute_pd(_mm512_loadu_pd(x + j), 0x55);
@@ -272,7 +280,7 @@ struct LegacyRng {
                 _mm512_storeu_pd(out + 2 * have, _mm512_maskz_compress_pd((__mmask8)PAIR_MASK[lo], x0));
                 _mm512_storeu_pd(out + 2 * (have + c0), _mm512_maskz_compress_pd((__mmask8)PAIR_MASK[hi], x1));
                 have += c0 + __builtin_popcount(hi);
-                j += 16;
+                j += used;
             }
 #endif
             while (j < last && have < count) {              // branch-free compaction of the accepted attempts
@@ -297,9 +305,17 @@ struct LegacyRng {
         }
         double f, x1, x2, r2;
         do {
-            x1 = 2.0 * next_double() - 1.0;
-            x2 = 2.0 * next_double() - 1.0;
-            r2 = x1 * x1 + x2 * x2;
+            const int j = dbase >= 0 ? (pos - dbase) >> 1 : dcount;
+            if (dbase >= 0 && dcount - j >= 2) {            // both doubles in the converted block: coordinates are there
+                x1 = xbuf[j];
+                x2 = xbuf[j + 1];
+                r2 = sbuf[j] + sbuf[j + 1];
+                pos += 4;
+            } else {
+                x1 = 2.0 * next_double() - 1.0;
+                x2 = 2.0 * next_double() - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+            }
         } while (r2 >= 1.0 || r2 == 0.0);
         f = std::sqrt(-2.0 * std::log(r2) / r2);
         gauss = f * x1;
@@ -507,7 +523,8 @@ bool use_wide_build()
         const char *isa = std::getenv("FOKL_SAMPLER_ISA");            // "base" forces the portable build (tests)
         if (isa && std::strcmp(isa, "base") == 0) return false;
         return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&
-               __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw");
+               __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
+               __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
     }();
     return wide;
 }

@@ -208,8 +208,10 @@ int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar
  * to the consumer (which can run on any thread): row k of normals_out [draws, p1] holds, after lead_out[k] (0 or 1)
  * finished values, (p1 - lead) / 2 accepted pairs as (x2, x1) with r2 = x1^2 + x2^2 in row k of pair_r2_out
  * [draws, p1 / 2 + 1] -- the normals are sqrt(-2 log(r2) / r2) * (x2, x1) -- and, if p1 - lead is odd, one more
- * finished value.  fokl_gibbs_chain_from_tape completes the normals and replays the arithmetic: identical
- * w / sigs / taus, bit for bit.
+ * finished value.  normals_out and pair_r2_out need 16 and 8 doubles of slack after their last row (the recorder
+ * stores whole vectors; what it writes past a row is overwritten when the next row is recorded).
+ * fokl_gibbs_chain_from_tape completes the normals and replays the arithmetic: identical w / sigs / taus, bit for
+ * bit.
  * The split is exact unless some iteration has bstar < 0, where the reference skips a gamma draw (FR:1538-1539;
  * impossible for b > 0): *bstar_negative is then set to 1 and the caller must redo the candidate with
  * fokl_gibbs_chain from the stream state it saved before the tape.
