@@ -89,6 +89,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--rows', type=int, default=1_000_000)
     ap.add_argument('--inputs', type=int, default=8)
+    ap.add_argument('--mode', choices=('fits', 'rows'), default='fits',
+                    help="N > 1: 'fits' = every rank fits its own dataset (weak scaling, the default and the driver's "
+                         "contract); 'rows' = ONE dataset of --rows rows sharded over the ranks, Gram blocks and residual "
+                         "moments all-reduced over RCCL inside the library (strong scaling; for fits that are device "
+                         "bound, N >= 5e7)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-microbench', action='store_true',
                     help='skip the back-to-back basis-build launches after the timed region (used for profiler runs)')
@@ -134,19 +139,36 @@ def main():
     comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
 
     n, m = args.rows, args.inputs
-    x, y = make_workload(12 + rank, n, m)
-    seed_fit = 1000 + rank
+    rows_mode = args.mode == 'rows'
+    if rows_mode:
+        # one dataset, rank r holds rows [lo, hi): the concatenation of the ranks' shards (seed 12, shard r).  The
+        # data-driven defaults of b / btau (FR:1322-1348) need the global mean and variance of y: one all-gather.
+        lo, hi = dist.shard_range(n, rank, world)
+        x, y = make_workload((12, rank), hi - lo, m)
+        mom = comm.allgather([hi - lo, float(np.sum(y)), float(np.sum(y * y))])
+        mean = float(np.sum(mom[:, 1]) / n)
+        var = float(np.sum(mom[:, 2]) / n - mean * mean)
+        hypers = dict(b=var * (4 + 1), btau=abs(mean) / var * (4 + 1))
+        seed_fit = 1000                                     # the sampler is replicated: same stream on every rank
+    else:
+        x, y = make_workload(12 + rank, n, m)
+        hypers = {}
+        seed_fit = 1000 + rank
 
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model = FoKLRoutines.FoKL(kernel='Bernoulli Polynomials', UserWarnings=False, ConsoleOutput=False)
+        model = FoKLRoutines.FoKL(kernel='Bernoulli Polynomials', UserWarnings=False, ConsoleOutput=False, **hypers)
         t0 = time.perf_counter()
-        model._prepare_fit(x, y, dict(clean=True))         # format, normalise, defaults, H2D upload (untimed)
+        # format, normalise, defaults, H2D upload (untimed); a shard must not be rescaled by its own min / max
+        model._prepare_fit(x, y, dict(clean=True, normalize=False) if rows_mode else dict(clean=True))
         prep_s = time.perf_counter() - t0
 
         def one_step():
             np.random.seed(seed_fit)
-            model._search(backend, n, m)
+            if rows_mode:
+                model._search(backend, x.shape[0], m, n_global=n, row_sharded=True)
+            else:
+                model._search(backend, n, m)
             ctx.sync()
             return model.fit_stats
 
@@ -203,8 +225,11 @@ def main():
         comm.close()
         return
     t_max = float(np.max(gathered[:, 0]))
-    tot_logical = float(np.sum(gathered[:, 1]))
-    tot_physical = float(np.sum(gathered[:, 2]))
+    if rows_mode:                                           # every rank ran the same search on its rows: count it once
+        tot_logical, tot_physical = float(gathered[0, 1]), float(gathered[0, 2])
+    else:
+        tot_logical = float(np.sum(gathered[:, 1]))
+        tot_physical = float(np.sum(gathered[:, 2]))
 
     def roof(name, bound):
         k = kern[name]
@@ -252,16 +277,17 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * t_max / max(args.steps, 1),
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if rows_mode else 'weak',
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
         'config': {'workload': f'configs[2]: synthetic N={n}, M={m}, Bernoulli Polynomials, 2-way interactions, '
                                f'burnin 1000 + draws 1000, one full forward-selection fit per step',
-                   'rows': n, 'inputs': m, 'parallelism': f'independent fits x{world}' if world > 1 else 'single GPU',
+                   'rows': n, 'inputs': m, 'parallelism': (f'rows sharded x{world}, RCCL all-reduce of Gram blocks' if rows_mode else
+                                   f'independent fits x{world}') if world > 1 else 'single GPU',
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
-        'terms_logical_per_step': tot_logical / world / max(args.steps, 1),
-        'terms_physical_per_step': tot_physical / world / max(args.steps, 1),
+        'terms_logical_per_step': tot_logical / (1 if rows_mode else world) / max(args.steps, 1),
+        'terms_physical_per_step': tot_physical / (1 if rows_mode else world) / max(args.steps, 1),
         'gibbs_calls_per_step': float(np.sum(gathered[:, 3])) / world / max(args.steps, 1),
         'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
         'host_prepare_s': prep_s,

@@ -463,6 +463,7 @@ class ForwardSelection:
         self.backend = backend
         self.n_local = int(n)
         self.n = int(n_global) if n_global is not None else int(n)
+        self.n_local = int(n)               # rows resident on this rank's device
         self.m = int(m)
         self.n_phis = int(n_phis)
         self.a, self.b, self.atau, self.btau = a, b, atau, btau
@@ -629,7 +630,7 @@ class ForwardSelection:
     def _resid_fits_in_shadow(self, columns):
         """FOKL_KILL_BIC=auto: does a K3 pass over `columns` columns (about 5.5 TB/s) take clearly less time than
         recording the noise tape of a model of that size (about 40 ns + 1 ns per column and Gibbs iteration)?"""
-        resid_s = 8.0 * self.n * (columns + 2) / 5.5e12 + 20e-6
+        resid_s = 8.0 * self.n_local * (columns + 2) / 5.5e12 + 20e-6
         tape_s = self.draws * (40.0 + columns) * 1e-9
         return resid_s < 0.6 * tape_s
 
