@@ -661,7 +661,9 @@ class FoKL:
             cut = int(np.floor(draws * 0.025) + 1)
             mean, bounds = backend.predict(slots, chosen, cut)
             return mean, bounds
-        return backend.predict(slots, chosen)
+        # the mean over the draws of X beta' (FR:958, 978) is X times the mean draw: one pass over the columns instead
+        # of one per draw (N = 1e6, 1000 draws: 19 ms -> 0.1 ms on the device); rounding differs in the last bits only
+        return backend.predict(slots, np.mean(chosen, axis=0, keepdims=True))
 
     def coverage3(self, **kwargs):
         """
@@ -931,7 +933,8 @@ class FoKL:
                     cols = np.stack([backend.read_slot(s) for s in slots], axis=1)
                     dy[:, m, di, :] = cols @ coef.T
                 else:
-                    dy[:, m, di, 0] = backend.predict(slots, coef)       # mean over the draws (FR:793-794)
+                    # mean over the draws (FR:793-794) = the columns times the mean draw
+                    dy[:, m, di, 0] = backend.predict(slots, np.mean(coef, axis=0, keepdims=True))
                 pool.give(slots)
 
         if not current['ReturnFullArray']:
