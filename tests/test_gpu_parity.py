@@ -235,7 +235,7 @@ def test_predict_mean_and_order_statistics(device_ctx):
         srt = np.sort(mod, axis=1)
         assert np.max(np.abs(mean - mod.mean(1))) < 1e-12
         assert np.max(np.abs(bounds[:, 0] - srt[:, cut])) < 1e-12 and np.max(np.abs(bounds[:, 1] - srt[:, draws - cut])) < 1e-12
-        assert np.max(np.abs(device_ctx.predict(sl, betas) - mean)) == 0.0
+        assert np.max(np.abs(device_ctx.predict(sl, betas) - mean)) < 1e-13        # two kernels, same numbers
 
 
 # ---------------------------------------------------------------------------------------------------------
