@@ -238,6 +238,33 @@ def test_predict_mean_and_order_statistics(device_ctx):
         assert np.max(np.abs(device_ctx.predict(sl, betas) - mean)) < 1e-13        # two kernels, same numbers
 
 
+def test_predict_bounds_when_the_draws_are_far_from_gaussian(device_ctx):
+    """The matrix-pipe predict kernel looks for the bounds among the predictions beyond mean -/+ z sigma of the row;
+    draws with a few wild outliers inflate sigma until hardly anything passes, equal draws leave sigma = 0: both must
+    end in the exact fallback and give numpy's order statistics."""
+    rng = np.random.default_rng(17)
+    n = 1237
+    upload(device_ctx, rng.random((n, 1)), np.zeros(n), O.KERNEL_BERNOULLI)
+    cols = rng.standard_normal((n, 6))
+    load_columns(device_ctx, cols)
+    sl = np.concatenate([[0], np.arange(2, 8)]).astype(np.int32)
+    X = np.concatenate([np.ones((n, 1)), cols], axis=1)
+    draws = 333
+    cut = int(np.floor(draws * 0.025) + 1)
+    wild = 0.01 * rng.standard_normal((draws, 7))
+    wild[::41] *= 1e4
+    same = np.tile(rng.standard_normal((1, 7)), (draws, 1))
+    skew = np.exp(2.0 * rng.standard_normal((draws, 7)))
+    for betas in (wild, same, skew):
+        mean, bounds = device_ctx.predict(sl, betas, cut)
+        mod = X @ betas.T
+        srt = np.sort(mod, axis=1)
+        scale = np.abs(mod).max(axis=1) + 1e-300
+        assert np.max(np.abs(mean - mod.mean(1)) / scale) < 1e-12
+        assert np.max(np.abs(bounds[:, 0] - srt[:, cut]) / scale) < 1e-12
+        assert np.max(np.abs(bounds[:, 1] - srt[:, draws - cut]) / scale) < 1e-12
+
+
 # ---------------------------------------------------------------------------------------------------------
 # whole fits through the HIP backend vs the reference fixtures
 # ---------------------------------------------------------------------------------------------------------
