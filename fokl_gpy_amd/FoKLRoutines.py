@@ -915,7 +915,11 @@ class FoKL:
         pool = _engine.SlotPool(backend, initial=max(64, B + 2))
 
         individual = current['IndividualDraws'] or not draws > 1
-        dy = np.zeros([N, M, 2, draws if individual else 1])
+        # mean over the draws and the compact output: the columns are kept as they come and assembled once (the
+        # general [N, M, 2, draws] array costs more host time than all the device work)
+        compact = not individual and not current['ReturnFullArray']
+        columns = {}
+        dy = None if compact else np.zeros([N, M, 2, draws if individual else 1])
         coef_all = np.asarray(betas)[-draws:, :]
         for m in range(M):
             rows = [b for b in range(B) if int(mtx[b, m]) != 0]         # other terms do not depend on x_m (FR:785-787)
@@ -934,10 +938,18 @@ class FoKL:
                     dy[:, m, di, :] = cols @ coef.T
                 else:
                     # mean over the draws (FR:793-794) = the columns times the mean draw
-                    dy[:, m, di, 0] = backend.predict(slots, np.mean(coef, axis=0, keepdims=True))
+                    vec = backend.predict(slots, np.mean(coef, axis=0, keepdims=True))
+                    if compact:
+                        columns[(di, m)] = vec
+                    else:
+                        dy[:, m, di, 0] = vec
                 pool.give(slots)
 
-        if not current['ReturnFullArray']:
+        if compact:
+            # first derivatives of inputs 0 .. M-1, then second derivatives, all-zero columns dropped (FR:797-800)
+            kept = [columns[key] for key in sorted(columns) if np.any(columns[key] != 0)]
+            dy = np.stack(kept, axis=1) if kept else np.zeros((N, 0))
+        elif not current['ReturnFullArray']:
             dy = np.concatenate([dy[:, :, 0, :], dy[:, :, 1, :]], axis=1)
             dy = dy[:, ~np.all(dy == 0, axis=0)]
         dy = np.squeeze(dy)
