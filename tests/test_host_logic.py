@@ -406,3 +406,30 @@ def test_tentative_tapes_and_rewinds_change_nothing(monkeypatch, name):
         assert np.array_equal(runs[mode][1], runs['0'][1])
         assert np.array_equal(runs[mode][2], runs['0'][2])
         assert runs[mode][3] == runs['0'][3]
+
+
+def test_thread_plan_follows_the_cpu_budget(monkeypatch):
+    """The host pipeline's thread counts come from the CPUs the process may keep busy: affinity mask, cgroup quota,
+    ranks per node; explicit FOKL_*_THREADS win."""
+    monkeypatch.delenv('FOKL_CHAIN_THREADS', raising=False)
+    monkeypatch.delenv('FOKL_FINISH_THREADS', raising=False)
+    monkeypatch.delenv('FOKL_SPECTRAL_THREADS', raising=False)
+    cases = ((16, (2, 3, 3)), (8, (2, 3, 3)), (7.5, (1, 2, 2)), (4, (1, 1, 1)), (2, (1, 0, 1)), (1, (1, 0, 1)))
+    for budget, plan in cases:
+        monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
+        assert engine._thread_plan() == plan
+    monkeypatch.setenv('FOKL_FINISH_THREADS', '5')
+    assert engine._thread_plan() == (1, 5, 1)
+    monkeypatch.undo()
+    assert engine._cpu_budget() >= 1
+
+
+def test_kill_bic_auto_switches_with_the_size_of_the_residual_pass():
+    """FOKL_KILL_BIC=auto keeps the K3 pass for kill-test candidates while it is clearly shorter than recording the
+    candidate's noise tape, i.e. for the benchmark's N = 1e6 with 2000 iterations but not for N = 1e7."""
+    def search(n, iterations):
+        return engine.ForwardSelection(OracleBackend(), n, 8, 20, 4, 1.0, 4, 1.0, 3, iterations, iterations // 2,
+                                       False, False, 0.05, 0.5, 2, False, None)
+    assert search(1_000_000, 2000)._resid_fits_in_shadow(60)
+    assert not search(10_000_000, 2000)._resid_fits_in_shadow(60)
+    assert not search(1_000_000, 200)._resid_fits_in_shadow(60)
