@@ -1,0 +1,354 @@
+/*
+ * fokl_hip.h -- C ABI of libfokl_hip.so, the MI355X (gfx950) implementation of FoKL-GPy's
+ * forward-variable-selection hot path (FoKLRoutines.FoKL.fit: basis build -> Gram / X'y -> Gibbs -> BIC).
+ *
+ * The reference is pure Python and has no FFI seam of its own: the hot path is closure code inside
+ * FoKL.fit (/root/reference/src/FoKL/FoKLRoutines.py:1350-1760, "FR" below).  This header is the seam a
+ * maintainer binds with ctypes directly under that method (INTEGRATION.md shows the stub); each entry
+ * point names the reference lines whose work it replaces.  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 (FOKL_OK) or a negative FOKL_ERR_* code; fokl_last_error() gives the text;
+ *   - a context owns one HIP stream on one device; use one context per host thread;
+ *   - the design matrix lives on the device as column "slots" (one basis column of N fp64 values each).
+ *     Slot 0 is the intercept column of ones and slot 1 holds the observations y; both are filled by
+ *     fokl_upload().  All other slots are handed out by the caller (the host driver keeps the free list);
+ *   - matrices crossing the ABI are dense row-major fp64 in host memory.
+ */
+#ifndef FOKL_HIP_H
+#define FOKL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOKL_OK             0
+#define FOKL_ERR_HIP       -1   /* a HIP runtime call failed (no device, out of memory, launch failure ...) */
+#define FOKL_ERR_ARG       -2   /* invalid argument (null pointer, slot out of range, size mismatch ...)      */
+#define FOKL_ERR_STATE     -3   /* call out of order (e.g. build before upload)                               */
+#define FOKL_ERR_COMM      -4   /* RCCL failure                                                               */
+#define FOKL_ERR_NUMERIC   -5   /* sampler received non-finite spectrum / hyper-parameters                    */
+
+#define FOKL_KERNEL_SPLINES   0 /* 'Cubic Splines'          (FR:199, FR:834-836) */
+#define FOKL_KERNEL_BERNOULLI 1 /* 'Bernoulli Polynomials'  (FR:199, FR:841-843) */
+
+#define FOKL_SLOT_ONES 0
+#define FOKL_SLOT_Y    1
+#define FOKL_SLOT_FIRST_FREE 2
+
+/* ids for fokl_timing_get() */
+#define FOKL_K_BASIS   0        /* K1 basis-build kernel                */
+#define FOKL_K_GRAM    1        /* K2 Gram kernels (+ slab reduction)   */
+#define FOKL_K_RESID   2        /* K3 residual / BIC kernel             */
+#define FOKL_K_PREDICT 3        /* evaluate(): X * beta^T + order stats */
+#define FOKL_K_COUNT   4
+
+typedef struct fokl_ctx fokl_ctx;
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* library / context                                                                                      */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_version(void);
+/* Number of visible HIP devices (0 and FOKL_ERR_HIP when the runtime finds none). */
+int fokl_device_count(int *count);
+int fokl_ctx_create(int device, fokl_ctx **out);
+void fokl_ctx_destroy(fokl_ctx *ctx);
+/* Text of the last error raised on `ctx` (or, with ctx == NULL, by fokl_ctx_create / pure host functions). */
+const char *fokl_last_error(const fokl_ctx *ctx);
+int fokl_sync(fokl_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* dataset: replaces the per-fit constants of FR:1357-1361 (_inputs_to_phind, FR:544-592) and FR:1374     */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Copy one (shard of a) normalised dataset to the device and lay it out for the kernels:
+ *   x      [n, m] row-major, already normalised to [0, 1] (what FoKL.clean produces, FR:441-507);
+ *   y      [n];
+ *   kernel FOKL_KERNEL_*;
+ *   phis   dense coefficient table: splines [n_basis, 4, width] (width = 499 pieces, coefficient k of
+ *          piece p of basis i at (i*4 + k)*width + p); Bernoulli [n_basis, width] zero padded, basis i
+ *          (order i + 1) uses its first i + 2 entries (the reference's tuple-of-lists, GK:221-267, GK:308-326).
+ * Inputs are transposed to structure-of-arrays on the device; the spline piece index / local coordinate
+ * (FR:570-589) are recomputed inside the basis kernel from x instead of being stored.
+ * Invalidates every slot; slots 0 (ones) and 1 (y) are rebuilt.
+ */
+int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
+                const double *phis, int n_basis, int width);
+
+/* Make sure slots [0, n_slots) exist (grows in chunks; existing slot contents are preserved). */
+int fokl_reserve_slots(fokl_ctx *ctx, int n_slots);
+int fokl_slot_capacity(const fokl_ctx *ctx);
+int64_t fokl_rows(const fokl_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K1: basis-matrix columns.  Replaces the X-build triple loop of gibbs(), FR:1446-1485, with              */
+/* evaluate_basis (FR:807-849, d = 0) and _inputs_to_phind (FR:570-589) fused in.                          */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * terms [T, m] int32 row-major: entry = basis order (1-based) of that input in the term, 0 = input absent
+ *       (a row of the reference's interaction matrix `discmtx`, FR:1473);
+ * slots [T]: destination slot of each term's column.
+ * Column j = prod_{k: terms[j,k] != 0} basis_{terms[j,k]}(x[:, k]), factors multiplied in ascending k and
+ * every operation rounded separately exactly like the reference's scalar code (no FMA contraction,
+ * x**k correctly rounded).  Asynchronous on the context's stream.
+ */
+int fokl_build_terms(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots);
+
+/*
+ * The same columns with the factor of input `wrt_input` replaced by its `order`-th derivative (1 or 2) divided
+ * by `divisor`: replaces the per-term product of bss_derivatives (FR:764-787; evaluate_basis d = 1, 2, FR:837-847).
+ * As in the reference every factor is evaluated at the twice-normalised coordinate X of FR:584-586 (splines), the
+ * caller passes divisor = (span_m / l) ** order (FR:758-759) and leaves out terms that do not contain `wrt_input`
+ * (their derivative is zero, FR:785-787).
+ */
+int fokl_build_terms_deriv(fokl_ctx *ctx, const int32_t *terms, int T, const int32_t *slots, int wrt_input,
+                           int order, double divisor);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K2: Gram blocks.  Replaces XtX = X'X, Xty = X'y (FR:1492-1494) and dtd = y'y (FR:1374).                 */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * out[a, b] = sum_i col(row_slots[a])[i] * col(col_slots[b])[i]   (nr x nc, row-major, host memory).
+ * Passing FOKL_SLOT_Y among the column slots yields X'y, FOKL_SLOT_ONES yields column sums.
+ * `path`: 0 = choose automatically, 1 = force the wavefront-reduction (VALU) kernel, 2 = force the fp64
+ * MFMA tile kernel.  Partial sums are combined in a fixed order, so results are bitwise reproducible.
+ * If a communicator is attached (fokl_comm_init) and `allreduce` != 0 the block is summed over ranks
+ * (row-sharded data) before it is returned.  Blocking.
+ */
+int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
+              double *out, int path, int allreduce);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* K3: residual moments for the BIC.  Replaces siglik = var(y - X betahat), FR:1551 (and FR:1505).         */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * out[0] = sum_i r_i, out[1] = sum_i r_i^2 with r = y - sum_j betahat[j] * col(slots[j]); the caller forms
+ * the population variance out[1]/n - (out[0]/n)^2 and the BIC (FR:1553-1554).  Blocking; optional all-reduce.
+ */
+int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat, double *out,
+                   int allreduce);
+/*
+ * The same in two halves so that the host can run the (N-independent) Gibbs chain of a candidate while the
+ * device streams its residuals: _launch enqueues kernel + copy-back on the context's stream and returns,
+ * _fetch waits and delivers.  At most one launch may be outstanding, and no other blocking call
+ * (fokl_gram, fokl_bic_resid, fokl_predict) may be issued on the context in between.
+ */
+int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat);
+int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* evaluate(): posterior-mean prediction and 95 % bounds on the device.  Replaces FR:966-978.              */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * For the rows currently uploaded: modells[i, d] = sum_j betas[d, j] * col(slots[j])[i] (FR:966-968),
+ * mean[i] = mean_d modells[i, d] (FR:969) and, when `bounds` != NULL, bounds[i] = (sorted[cut],
+ * sorted[draws - cut]) of row i's draws (FR:973-977).  betas is [draws, nc] row-major in host memory.
+ */
+int fokl_predict(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betas, int draws, int cut,
+                 double *mean, double *bounds);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* test / debug access to slots                                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_read_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, double *host);
+int fokl_write_slot(fokl_ctx *ctx, int slot, int64_t row0, int64_t nrows, const double *host);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* per-kernel timing with HIP events on the context's stream (bench.py's roofline figures)                 */
+/* ------------------------------------------------------------------------------------------------------ */
+
+int fokl_timing_enable(fokl_ctx *ctx, int on);
+int fokl_timing_reset(fokl_ctx *ctx);
+/*
+ * Accumulated device time (ms), launch count and algorithmic bytes / flops of kernel family `kernel_id`, and
+ * ideal_ms = the sum over its launches of the roofline time max(bytes / HBM peak, flops / fp64 MFMA peak): a family
+ * whose launches sit on both sides of the ridge (the Gram blocks) is priced launch by launch.
+ */
+#define FOKL_PEAK_HBM_BYTES_PER_S 8.0e12  /* MI355X HBM3E, spec */
+#define FOKL_PEAK_F64_FLOPS 78.6e12       /* MI355X dense fp64 (vector = matrix), spec */
+int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
+                    double *flops, double *ideal_ms);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* G2/G3: the Gibbs chain (host C++, N-independent).  Replaces the D-iteration loop FR:1519-1548.           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Runs `draws` iterations in the eigenbasis of XtX = Q diag(lamb) Q':
+ *     d   = 1 / (lamb + 1/tausqd)                                   (FR:1521-1522)
+ *     w   = d * qty + sqrt(sigsqd) * sqrt(d) * vec,  vec ~ N(0, I)  (FR:1524-1528; beta = Q w)
+ *     bstar = b + (w'diag(lamb)w - 2 w'qty + dtd + w'w / tausqd)/2  (FR:1532-1533)
+ *     sigsqd = 1 / Gamma(astar, 1/bstar)   (NaN, and no draw, if bstar < 0; FR:1538-1541)
+ *     tausqd = 1 / Gamma(atau_star, 1/(w'w/(2 sigsqd) + btau))      (FR:1545-1547)
+ * with qty = Q'Xty.  Random numbers come from numpy's legacy global stream, continued bit for bit:
+ * mt_key[624] / mt_pos / has_gauss / gauss_cache are the fields of np.random.get_state() and are updated
+ * in place (MT19937 -> 53-bit doubles -> polar Gaussian with one cached value -> Marsaglia-Tsang gamma).
+ * w_out [draws, p1] receives w per iteration (the caller forms betas = w_out Q'); sigs_out / taus_out
+ * [draws] may be NULL.
+ */
+int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, double astar, double atau_star,
+                     double b, double btau, double dtd, double sigsqd0, double tausqd0, int draws,
+                     uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     double *w_out, double *sigs_out, double *taus_out);
+
+/*
+ * The same chain in two halves, so that the serial random stream can run on a worker thread ahead of the
+ * data-dependent arithmetic.  fokl_noise_tape advances the stream exactly as `draws` iterations of
+ * fokl_gibbs_chain would and records, per iteration, the p1 standard normals and the two standard gamma variates
+ * of shapes astar / atau_star (gam_sig_out, gam_tau_out [draws]).  The expensive half of the polar method is left
+ * to the consumer (which can run on any thread): row k of normals_out [draws, p1] holds, after lead_out[k] (0 or 1)
+ * finished values, (p1 - lead) / 2 accepted pairs as (x2, x1) with r2 = x1^2 + x2^2 in row k of pair_r2_out
+ * [draws, p1 / 2 + 1] -- the normals are sqrt(-2 log(r2) / r2) * (x2, x1) -- and, if p1 - lead is odd, one more
+ * finished value.  normals_out and pair_r2_out need 16 and 8 doubles of slack after their last row (the recorder
+ * stores whole vectors; what it writes past a row is overwritten when the next row is recorded).
+ * fokl_gibbs_chain_from_tape completes the normals and replays the arithmetic: identical w / sigs / taus, bit for
+ * bit.
+ * The split is exact unless some iteration has bstar < 0, where the reference skips a gamma draw (FR:1538-1539;
+ * impossible for b > 0): *bstar_negative is then set to 1 and the caller must redo the candidate with
+ * fokl_gibbs_chain from the stream state it saved before the tape.
+ * `progress` (may be NULL) lets the consumer follow a tape that is still being recorded on another thread: the
+ * producer stores the number of complete iterations (release) after every FOKL_TAPE_BLOCK of them and at the end, or
+ * -1 on failure; the consumer waits (acquire) until iteration k is there.  Both sides must be given the same int32,
+ * initialised to 0 before the producer starts; keep it on a cache line the producer does not otherwise write.
+ */
+#define FOKL_TAPE_BLOCK 16
+int fokl_noise_tape(int p1, int draws, double astar, double atau_star, uint32_t *mt_key, int32_t *mt_pos,
+                    int32_t *has_gauss, double *gauss_cache, double *normals_out, double *pair_r2_out,
+                    int32_t *lead_out, double *gam_sig_out, double *gam_tau_out, int32_t *progress);
+int fokl_gibbs_chain_from_tape(const double *lamb, const double *qty, int p1, double b, double btau, double dtd,
+                               double sigsqd0, double tausqd0, int draws, const double *normals,
+                               const double *pair_r2, const int32_t *lead, const double *gam_sig,
+                               const double *gam_tau, double *w_out, double *sigs_out, double *taus_out,
+                               int32_t *bstar_negative, const int32_t *progress);
+
+/*
+ * The consumer side split once more, so that several threads can share the log / sqrt work of ONE tape:
+ * fokl_finish_tape_blocks completes, in place, the normals of iteration blocks part, part + parts, ... (`block`
+ * iterations each), waiting on `progress` as above, and stores block_done[blk] = 1 (release) after each, -1 on failure;
+ * fokl_gibbs_chain_from_finished_tape runs the recursion on finished normals, waiting on block_done (NULL: the whole
+ * tape is finished).  Results are those of fokl_gibbs_chain_from_tape bit for bit.
+ */
+int fokl_finish_tape_blocks(int p1, int draws, double *normals, const double *pair_r2, const int32_t *lead,
+                            const int32_t *progress, int part, int parts, int block, int32_t *block_done);
+int fokl_gibbs_chain_from_finished_tape(const double *lamb, const double *qty, int p1, double b, double btau,
+                                        double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
+                                        const double *gam_sig, const double *gam_tau, const int32_t *block_done,
+                                        int block, double *w_out, double *sigs_out, double *taus_out,
+                                        int32_t *bstar_negative);
+
+/* Raw access to the same generator (parity tests against numpy): n standard normals / n std gammas. */
+int fokl_rng_normals(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     int64_t n, double *out);
+int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                    double shape, double scale, int64_t n, double *out);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Host threads of one fit: the work of G2/G3 that must not sit on the Python driver thread.                */
+/* ------------------------------------------------------------------------------------------------------ */
+
+typedef struct fokl_host_pool fokl_host_pool;
+typedef struct fokl_host_job fokl_host_job;
+
+/*
+ * One noise thread (owns the random stream mt_key / mt_pos / has_gauss / gauss_cache -- caller storage, updated in
+ * place -- and records tapes strictly in submission order), `finish_threads` threads that complete the normals of
+ * each tape (all of them on every tape; 0 = the chain threads do it), `chain_threads` threads that run the chain
+ * recursions and `spectral_threads` threads that diagonalise XtX sub-blocks.  `dsyevr` is the address of LAPACK's dsyevr with the
+ * Fortran calling convention and 32-bit integers (the Python side passes scipy's own:
+ * scipy.linalg.cython_lapack.__pyx_capi__['dsyevr']), so that eigenpairs are those of the reference's
+ * scipy.linalg.eigh call (FR:1499) bit for bit; NULL is allowed with spectral_threads == 0.
+ * The threads inherit the CPU affinity of the caller, except that the noise thread is pinned to logical CPU
+ * `noise_cpu` if that is >= 0 (the caller then keeps its other threads off that core).  Every buffer handed to a submit call must stay alive until
+ * fokl_pool_wait has returned for that job.  fokl_pool_destroy first runs everything still queued.
+ */
+int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int noise_cpu, void *dsyevr,
+                     uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+                     fokl_host_pool **out);
+void fokl_pool_destroy(fokl_host_pool *pool);
+/*
+ * fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0).
+ * tentative != 0: the tape is recorded ahead of the decision that it is needed; the noise thread then holds the stream
+ * until fokl_pool_resolve(job, commit) -- commit keeps the tape (identical to a plain submission at that point of the
+ * stream), otherwise the stream is rewound to where the tape began and `progress` is set to -1.  Every tentative
+ * job MUST be resolved, or the noise thread (and fokl_pool_destroy) waits for ever.
+ */
+int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, double *normals,
+                           double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau, int32_t *progress,
+                           int tentative, fokl_host_job **out);
+int fokl_pool_resolve(fokl_host_job *job, int commit);
+/*
+ * The draws of one candidate from its tape (whose noise job must have been submitted): with finish threads and
+ * block_done [ceil(draws / block)] (zero-initialised) given, the tape is completed IN PLACE by the finish threads and
+ * the recursion follows them; otherwise fokl_gibbs_chain_from_tape runs on a chain thread, following `progress`.
+ */
+int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b, double btau,
+                           double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
+                           const double *pair_r2, const int32_t *lead, const double *gam_sig, const double *gam_tau,
+                           const int32_t *progress, int32_t *block_done, int block, double *w_out,
+                           int32_t *bstar_negative, fokl_host_job **out);
+/*
+ * G2 for the candidate model made of columns idx[0..p1) of `gram` (row-major, leading dimension ld, y in column
+ * ycol): XtX = gram[idx][:, idx], Xty = gram[idx, ycol].  Outputs: lamb_out [p1] ascending eigenvalues,
+ * qt_out [p1, p1] with ROW j = eigenvector j (largest-magnitude component positive), qty_out = Q'Xty,
+ * betahat_out = Q (qty / lamb) (FR:1499-1504).  moments_out [2] (may be NULL) receives sum r and sum r^2 of the
+ * residual r = y - X betahat, formed from the Gram alone -- sum y - 1'X b and y'y - 2 b'Xty + b'XtX b in extended
+ * precision; column 0 of gram must be the ones column -- the quantities fokl_bic_resid measures on the device
+ * (FR:1551).  No random numbers: may be submitted speculatively.
+ */
+int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
+                              double *lamb_out, double *qt_out, double *qty_out, double *betahat_out,
+                              double *moments_out, fokl_host_job **out);
+/* 1 if the job has run.  fokl_pool_wait blocks until then, frees the job and returns its status. */
+int fokl_pool_poll(const fokl_host_job *job);
+int fokl_pool_wait(fokl_host_job *job);
+/* Accumulated time (s) the kinds of thread spent inside jobs (including their waits on the tape producer). */
+int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *chain, double *finish,
+                           double *spectral);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* N4: the consumer of fitted models, GP_Integrate (reference src/FoKL/GP_Integrate.py:5-282)               */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Fourth-order Runge-Kutta integration of dy_k/dt = model_k(inputs) for n_states cubic-spline BSS-ANOVA models.
+ * Model k: betas[k] [mtx_rows[k] + 1] (constant first), mtx[k] [mtx_rows[k], mtx_cols[k]] basis orders; its input
+ * vector has n_source[k] >= mtx_cols[k] entries, entry i being state source[k][i] (normalised with norms
+ * [2, n_states] = minima, maxima and clamped to [0, 1]) if source[k][i] >= 0, else column -(source[k][i] + 1) of the
+ * current row of forcing [n_steps, n_other] (already normalised; the same row serves the four stages of a step).
+ * spline_table [n_basis, 4, width] as in fokl_upload, width must be 499 (evaluated on 498 intervals, as the
+ * reference does).  y [n_states] holds the initial state and is advanced in place (the reference mutates y0 too);
+ * trajectory [n_states, n_steps + 1] receives the state before the first and after every step.  Host only.
+ */
+int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *const *betas,
+                      const int32_t *const *mtx, const int32_t *mtx_rows, const int32_t *mtx_cols,
+                      const int32_t *const *source, const int32_t *n_source, const double *forcing,
+                      const double *norms, const double *spline_table, int n_basis, int width, double h, double *y,
+                      double *trajectory);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* multi-GPU: one process per GPU, RCCL over xGMI                                                          */
+/* ------------------------------------------------------------------------------------------------------ */
+
+#define FOKL_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id and hands the bytes to the other ranks through any host channel. */
+int fokl_comm_unique_id(char id[FOKL_UNIQUE_ID_BYTES]);
+int fokl_comm_init(fokl_ctx *ctx, const char id[FOKL_UNIQUE_ID_BYTES], int rank, int world);
+int fokl_comm_destroy(fokl_ctx *ctx);
+/* recv[r*count .. (r+1)*count) = send of rank r: the per-candidate BIC gather of the kill-test shard. */
+int fokl_comm_allgather_f64(fokl_ctx *ctx, const double *send, int count, double *recv);
+/* In-place sum over ranks (row-sharded Gram blocks / residual moments). */
+int fokl_comm_allreduce_sum_f64(fokl_ctx *ctx, double *buf, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOKL_HIP_H */
