@@ -433,3 +433,29 @@ def test_kill_bic_auto_switches_with_the_size_of_the_residual_pass():
     assert search(1_000_000, 2000)._resid_fits_in_shadow(60)
     assert not search(10_000_000, 2000)._resid_fits_in_shadow(60)
     assert not search(1_000_000, 200)._resid_fits_in_shadow(60)
+
+
+def _rendezvous_worker(rank, queue):
+    from fokl_gpy_amd import dist as _dist
+    uid, path = _dist._exchange_unique_id(rank, 2, lambda: bytes(range(128)), tag='fokl_test', timeout_s=30.0)
+    queue.put((rank, uid, path))
+
+
+def test_rccl_id_rendezvous_through_the_temp_file(monkeypatch):
+    """Rank 0 publishes the 128-byte RCCL id in a temp file named after MASTER_PORT / the launcher's pid (no torch in a
+    GPU process); the other ranks poll for it -- here rank 1 starts polling first."""
+    import multiprocessing as mp
+    import time
+    monkeypatch.setenv('MASTER_PORT', '45991')
+    ctx = mp.get_context('fork')
+    queue = ctx.Queue()
+    late = ctx.Process(target=_rendezvous_worker, args=(1, queue))
+    late.start()
+    time.sleep(0.3)
+    first = ctx.Process(target=_rendezvous_worker, args=(0, queue))
+    first.start()
+    got = sorted(queue.get(timeout=30) for _ in range(2))
+    late.join(10)
+    first.join(10)
+    assert got[0][1] == got[1][1] == bytes(range(128)) and got[0][2] == got[1][2]
+    os.remove(got[0][2])

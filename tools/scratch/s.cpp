@@ -317,7 +317,11 @@ struct LegacyRng {
                 r2 = x1 * x1 + x2 * x2;
             }
         } while (r2 >= 1.0 || r2 == 0.0);
+#ifdef EXP_NO_MATH
+        f = r2;
+#else
         f = std::sqrt(-2.0 * std::log(r2) / r2);
+#endif
         gauss = f * x1;
         has_gauss = 1;
         return f * x2;
@@ -358,6 +362,12 @@ struct LegacyRng {
             } while (V <= 0.0);
             V = V * V * V;
             double U = next_double();
+#ifdef EXP_ALWAYS_ACCEPT
+            if (U < 2.0) return b * V;
+#endif
+#ifdef EXP_NO_MATH
+            return b + U;
+#endif
             if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return b * V;
             if (std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V))) return b * V;
         }
@@ -482,12 +492,8 @@ void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star
     const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
     for (int k = 0; k < draws; ++k) {
         fill_normals_raw(r, p1, normals_out + (size_t)k * p1, pair_r2_out + (size_t)k * half, lead_out + k);
-#ifdef EXP_NO_GAMMA
-        gam_sig_out[k] = 1.0; gam_tau_out[k] = 1.0;
-#else
         gam_sig_out[k] = fast_sig ? r.marsaglia_tsang(b_sig, c_sig) : r.std_gamma(astar);
         gam_tau_out[k] = fast_tau ? r.marsaglia_tsang(b_tau, c_tau) : r.std_gamma(atau_star);
-#endif
         // iterations up to k are complete and visible.  Published per block, not per iteration: every store to a
         // line that other cores are polling costs this thread a coherence round trip.
         if (progress && ((k + 1) % FOKL_TAPE_BLOCK == 0 || k + 1 == draws))
