@@ -371,14 +371,15 @@ class HostPipeline:
 class GibbsOutcome:
     """One model evaluation.  The BIC is known at once; the draws arrive from a chain thread (chain arithmetic in the
     eigenbasis), betas = w Q' (FR:1528) is formed only for the columns somebody looks at."""
-    __slots__ = ('lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'intercept_scale', '_jobs', '_owner', '_w', '_betas',
-                 '_w_raw', '_chain_job')
+    __slots__ = ('lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'intercept_scale', 'siglik', '_jobs', '_owner', '_w',
+                 '_betas', '_w_raw', '_chain_job')
 
     def __init__(self, owner, spec, ev, idx, noise_job, chain_job, w_raw):
         self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
         self.ev, self.idx = ev, idx
         self._jobs, self._owner = (noise_job, chain_job), owner
         self._w = self._betas = self.intercept_scale = None
+        self.siglik = 0.0
         self._w_raw, self._chain_job = w_raw, chain_job
 
     def __del__(self):
@@ -507,6 +508,7 @@ class ForwardSelection:
     def _ev_from_moments(self, s1, s2, p1):
         n = self.n
         siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
+        self._last_siglik = siglik
         lik = -(n / 2) * math.log(siglik) - (n - 1) / 2 if siglik > 0 else math.nan
         ev = p1 * math.log(n) - 2 * lik                              # FR:1553-1554
         if self.aic:
@@ -594,7 +596,9 @@ class ForwardSelection:
             jobs = self._commit(pending, noise_job)
             ev = self._score(pending)
             self._record(p1, n_prev_cols, ev, kill)
-            return GibbsOutcome(self, pending[0], ev, idx, *jobs)
+            outcome = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+            outcome.siglik = self._last_siglik
+            return outcome
 
         n = self.n
         astar = self.a + 1 + n / 2 + p1 / 2                          # FR:1508
@@ -641,14 +645,16 @@ class ForwardSelection:
                 outcome.beta_columns(np.array([0]), half0)[:, 0])))
         return outcome.intercept_scale
 
-    def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None):
+    def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None,
+                              ahead=None):
         """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
 
         Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
         what the test computes does not.  So G2 of the models the next few tests will need is submitted ahead, and
         the residual pass of the upcoming one is in flight while this thread waits for that chain.
         foresee(killed set) is told, towards the end of the loop, which columns the loop will probably have removed
-        when it is done (the caller starts G2 of the next sub-stage's model with it).
+        when it is done (the caller starts G2 of the next sub-stage's model with it).  `ahead` may bring G2 jobs the
+        caller has already submitted (trial set -> job).
         """
         A = len(slots)
         vm = cand_col.shape[0]
@@ -662,7 +668,7 @@ class ForwardSelection:
         on_device = self.kill_bic in ('device', 'check') or (self.kill_bic == 'auto' and self._resid_fits_in_shadow(A))
         killed = frozenset()
         evmin = best.ev
-        ahead = {}                                                    # trial set -> spectral job submitted ahead
+        ahead = {} if ahead is None else ahead                        # trial set -> spectral job submitted ahead
         last_accepted = True                                          # predictor: proposals go the way the last went
         # The tape of the NEXT test, requested as soon as this one's BIC is known (its size needs the kill set) instead
         # of after the chain that decides whether that test is run: the noise thread then goes from one tape to the
@@ -704,6 +710,11 @@ class ForwardSelection:
                         cur = key
                 trial = killed | {cols[i]}
                 idx = self._columns_without(A, trial)
+                early_tape = None
+                if decided and pending_tape is None:
+                    # the test runs for sure and its tape is not on its way yet (first test of a sub-stage, or after
+                    # a wrong guess): have it recorded while this thread waits for G2
+                    early_tape = self._request_noise(idx.shape[0])
                 pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=on_device)
                 if not decided:
                     scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
@@ -713,7 +724,7 @@ class ForwardSelection:
                         if pending_tape is not None and pending_tape[0] == i:
                             drop_pending()
                         continue
-                noise_job = None
+                noise_job = early_tape
                 if pending_tape is not None:
                     if pending_tape[0] == i and pending_tape[1] == idx.shape[0]:
                         noise_job = pending_tape[2]
@@ -877,6 +888,21 @@ class ForwardSelection:
                     g = self._extend_gram(gram, keep_pred, ahead['block'], keep_pred, ahead['over'])
                     forecasts[key] = (self.host.spectral(g, np.arange(g.shape[0] - 1, dtype=np.int32)), g)
 
+            early = {}
+            if self.host is not None and self.lookahead > 0:
+                # The proposals are ordered by statistics of the chain that is still running; the least-squares fit says
+                # nearly the same: |mean beta| ~ |betahat|, std beta ~ (siglik (XtX)^-1_jj)^1/2.  G2 of the first tests
+                # this predicts starts now (a wrong guess costs a spectral thread a few milliseconds).
+                new = np.arange(dam - vm + 1, dam + 1)
+                guess_mean = np.abs(full.betahat[new])
+                guess_std = np.sqrt(full.siglik * np.sum(full.Qt[:, new] ** 2 / full.lamb[:, None], axis=0))
+                cur = frozenset()
+                likely = [int(c) for c in new[np.argsort(guess_mean)]
+                          if guess_std[c - new[0]] > min(self.threshstda, self.threshstdb) * guess_mean[c - new[0]]]
+                for c in likely[:1 + self.lookahead]:
+                    cur = cur | {c}
+                    early[cur] = self.host.spectral(gram, self._columns_without(A, cur))
+
             # statistics of the new terms (FR:1656-1664)
             tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
             mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
@@ -904,7 +930,7 @@ class ForwardSelection:
                             best = res
             else:
                 killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
-                                                                 rel_std, best, half0, foresee)
+                                                                 rel_std, best, half0, foresee, early)
             ev = evmin
 
             # commit the surviving columns (FR:1691-1695)
