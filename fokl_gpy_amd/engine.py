@@ -638,6 +638,23 @@ class ForwardSelection:
         tape_s = self.draws * (40.0 + columns) * 1e-9
         return resid_s < 0.6 * tape_s
 
+    def _guess_first_tests(self, gram, full, n_new):
+        """G2 jobs for the first kill tests of the sub-stage model `full` (its last n_new columns are new), guessed from
+        the least-squares fit before the model's chain is there: the proposals will be ordered by |mean beta| ~
+        |betahat| and can pass FR:1670 only if std beta / |mean beta| ~ (siglik (XtX)^-1_jj)^1/2 / |betahat_j| exceeds
+        the smaller threshold.  Returns {trial set -> job}; a wrong guess costs a spectral thread a few milliseconds."""
+        A = gram.shape[0] - 1
+        new = np.arange(A - n_new, A)
+        guess_mean = np.abs(full.betahat[new])
+        guess_std = np.sqrt(max(full.siglik, 0.0) * np.sum(full.Qt[:, new] ** 2 / full.lamb[:, None], axis=0))
+        floor = min(self.threshstda, self.threshstdb)
+        likely = [int(new[j]) for j in np.argsort(guess_mean) if guess_std[j] > floor * guess_mean[j]]
+        jobs, cur = {}, frozenset()
+        for c in likely[:1 + self.lookahead]:
+            cur = cur | {c}
+            jobs[cur] = self.host.spectral(gram, self._columns_without(A, cur))
+        return jobs
+
     def _intercept_scale(self, outcome, half0):
         """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
         if outcome.intercept_scale is None:
@@ -890,18 +907,8 @@ class ForwardSelection:
 
             early = {}
             if self.host is not None and self.lookahead > 0:
-                # The proposals are ordered by statistics of the chain that is still running; the least-squares fit says
-                # nearly the same: |mean beta| ~ |betahat|, std beta ~ (siglik (XtX)^-1_jj)^1/2.  G2 of the first tests
-                # this predicts starts now (a wrong guess costs a spectral thread a few milliseconds).
-                new = np.arange(dam - vm + 1, dam + 1)
-                guess_mean = np.abs(full.betahat[new])
-                guess_std = np.sqrt(full.siglik * np.sum(full.Qt[:, new] ** 2 / full.lamb[:, None], axis=0))
-                cur = frozenset()
-                likely = [int(c) for c in new[np.argsort(guess_mean)]
-                          if guess_std[c - new[0]] > min(self.threshstda, self.threshstdb) * guess_mean[c - new[0]]]
-                for c in likely[:1 + self.lookahead]:
-                    cur = cur | {c}
-                    early[cur] = self.host.spectral(gram, self._columns_without(A, cur))
+                # guess the first tests now, while the chain of the sub-stage model is still running
+                early = self._guess_first_tests(gram, full, vm)
 
             # statistics of the new terms (FR:1656-1664)
             tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
