@@ -500,11 +500,21 @@ class ForwardSelection:
         if self.kill_bic not in ('auto', 'gram', 'device', 'check'):
             raise ValueError("FOKL_KILL_BIC must be auto, gram, device or check")
         self.trace = []                     # one record per gibbs evaluation
+        self._ev_cache = {}                 # model (set of terms) -> its BIC, see _same_model_same_ev
+        self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
                           bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
+    def _same_model_same_ev(self, idx, ev):
+        """The reference scores identical models identically (a sub-stage whose new terms are all killed ends on the
+        model of the one before, FR:1691-1721, and `ev < min(evs)` then is an exact tie).  Here a model can be scored
+        along different routes (device residual pass or Gram identity, Gram blocks from different launches), equal to
+        rounding only: the first score of a model is the score of every later evaluation of it."""
+        key = frozenset(self._active_terms[c] for c in idx)
+        return self._ev_cache.setdefault(key, ev)
+
     def _ev_from_moments(self, s1, s2, p1):
         n = self.n
         siglik = s2 / n - (s1 / n) ** 2                              # np.var(y - X betahat), FR:1551
@@ -542,7 +552,7 @@ class ForwardSelection:
             if self._async_resid:
                 self.backend.bic_resid_launch(cand_slots, spec.betahat)
         ycol = gram.shape[0] - 1
-        return spec, idx, cand_slots, gram[ycol, ycol]
+        return spec, idx, cand_slots, gram[ycol, ycol], slots
 
     def _request_noise(self, p1, tentative=False):
         astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
@@ -551,20 +561,25 @@ class ForwardSelection:
 
     def _commit(self, pending, noise_job=None):
         """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
-        spec, idx, _, dtd = pending
+        spec, idx, _, dtd, _ = pending
         if noise_job is None:
             noise_job = self._request_noise(idx.shape[0])
         chain_job, w_raw = self.host.chain(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job)
         return noise_job, chain_job, w_raw
 
     def _score(self, pending):
-        spec, idx, cand_slots, _ = pending
+        spec, idx, cand_slots, dtd, slots = pending
         p1 = idx.shape[0]
-        if cand_slots is None:
-            self.stats['bic_from_gram'] += 1
-            return self._ev_from_moments(spec.moments[0], spec.moments[1], p1)
+        launched = cand_slots is not None
+        if not launched:
+            # y'y - 2 b'Xty + b'XtX b cancels y'y / SSR digits: fine for a noisy fit (1e3 at the benchmark), useless
+            # for a model that (nearly) interpolates the data -- those candidates get the residual pass after all
+            if spec.moments[1] > 1e-6 * dtd:
+                self.stats['bic_from_gram'] += 1
+                return self._same_model_same_ev(idx, self._ev_from_moments(spec.moments[0], spec.moments[1], p1))
+            cand_slots = [slots[i] for i in idx]
         t0 = time.perf_counter()
-        if self._async_resid:
+        if self._async_resid and launched:
             s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
         else:
             s1, s2 = self.backend.bic_resid(cand_slots, spec.betahat, self.allreduce)
@@ -573,7 +588,7 @@ class ForwardSelection:
         if self.kill_bic == 'check':
             other = self._ev_from_moments(spec.moments[0], spec.moments[1], p1)
             self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
-        return ev
+        return self._same_model_same_ev(idx, ev)
 
     def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None):
         """
@@ -623,7 +638,7 @@ class ForwardSelection:
                 s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
         if not self._async_resid:
             s1, s2 = self.backend.bic_resid(cand_slots, betahat, self.allreduce)
-        ev = self._ev_from_moments(s1, s2, p1)
+        ev = self._same_model_same_ev(idx, self._ev_from_moments(s1, s2, p1))
         self._record(p1, n_prev_cols, ev, kill)
         return EagerOutcome(w, Q, betahat, ev, idx)
 
@@ -882,6 +897,7 @@ class ForwardSelection:
             vm = vecs.shape[0]
             damtx = np.append(damtx, vecs, axis=0)
             dam = damtx.shape[0]
+            self._active_terms = [()] + [tuple(int(v) for v in row) for row in damtx]
             active_slots = [SLOT_ONES] + model_slots + new_slots
             A = len(active_slots)
 

@@ -459,3 +459,46 @@ def test_rccl_id_rendezvous_through_the_temp_file(monkeypatch):
     first.join(10)
     assert got[0][1] == got[1][1] == bytes(range(128)) and got[0][2] == got[1][2]
     os.remove(got[0][2])
+
+
+def _random_problem(seed):
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(150, 900)), int(rng.integers(1, 6))
+    x = rng.random((n, m))
+    y = np.sin(3 * x[:, 0]) + (x[:, 1 % m] * x[:, 2 % m] if m > 1 else 0) + 0.1 * rng.standard_normal(n)
+    kw = dict(kernel=1, burnin=int(rng.integers(20, 120)), draws=int(rng.integers(20, 120)),
+              tolerance=int(rng.integers(1, 4)), way3=bool(rng.integers(0, 2)), aic=bool(rng.integers(0, 2)),
+              UserWarnings=False, ConsoleOutput=False)
+    if rng.integers(0, 3) == 0:
+        kw.update(threshstda=0.0, threshstdb=100.0, threshav=float(rng.random()))
+    return x, y, kw
+
+
+@pytest.mark.parametrize('seed', [3, 10, 29, 53, 70])
+def test_pipelined_search_equals_the_inline_search(monkeypatch, seed):
+    """Random small problems (seeds 29 and 53: single-input searches whose sub-stages end on the model of the one
+    before -- the reference scores identical models identically and `ev < min(evs)` is an exact tie there): the
+    threaded search in its default and in its most speculative configuration must select the same model, stop at the
+    same sub-stage and leave numpy's stream where the in-line search leaves it."""
+    x, y, kw = _random_problem(seed)
+
+    def run(**env):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = FoKLRoutines.FoKL(**kw)
+            model._backend_override = OracleBackend()
+            np.random.seed(seed + 7)
+            betas, mtx, evs = model.fit(x, y, clean=True)
+        return betas, mtx, evs, rng_fingerprint()
+
+    ref = run(FOKL_NOISE_PIPELINE='0')
+    for env in (dict(FOKL_NOISE_PIPELINE='1', FOKL_TENTATIVE_TAPES='1', FOKL_FORESIGHT='8', FOKL_KILL_BIC='auto',
+                     FOKL_LOOKAHEAD='3'),
+                dict(FOKL_NOISE_PIPELINE='1', FOKL_TENTATIVE_TAPES='test', FOKL_FORESIGHT='1000', FOKL_KILL_BIC='gram',
+                     FOKL_LOOKAHEAD='1')):
+        got = run(**env)
+        assert np.array_equal(got[1], ref[1]) and got[3] == ref[3] and got[2].shape == ref[2].shape
+        np.testing.assert_allclose(got[2], ref[2], rtol=1e-10)
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-7, atol=1e-9)
