@@ -265,9 +265,11 @@ struct LegacyRng {
                 unsigned m = _mm512_cmp_pd_mask(rr, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(rr, zero, _CMP_NEQ_OQ);
                 int used = 16;                              // doubles consumed by this step
                 const int need = count - have;
-                if (__builtin_popcount(m) > need) {
-                    // the last step of a call: keep the first `need` accepted attempts, stop right after the last of
-                    // them (the stores below still write full vectors: see the slack fokl_noise_tape asks for)
+                if (__builtin_popcount(m) >= need) {
+                    // the last step of a call: keep the first `need` accepted attempts and stop right after the last of
+                    // them -- rejected attempts that follow belong to whoever draws next (a uniform, not necessarily
+                    // another polar attempt).  The stores below still write full vectors: see the slack
+                    // fokl_noise_tape asks for.
                     m = _pdep_u32((1u << need) - 1u, m);
                     used = 2 * (32 - __builtin_clz(m));
                 }

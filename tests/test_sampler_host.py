@@ -280,3 +280,46 @@ def test_pool_spectral_job_is_scipy_eigh_and_rejects_bad_indices():
     with pytest.raises(_capi.FoklNativeError):
         pool.submit_spectral(gram, idx, 42)
     pool.close()
+
+
+def test_random_tapes_through_the_pool_are_numpy_bit_for_bit():
+    """Random word positions (odd ones included), a cached Gaussian or not, model sizes 1 .. 199, gamma shapes on both
+    sides of 1 (shape <= 1 draws a uniform right after the normals, where a recorder that swallowed trailing rejected
+    polar attempts went wrong), tentative tapes kept or rewound: every kept tape, completed, must equal numpy's own
+    normal / standard_gamma calls, and numpy's state must be where the pool leaves the stream."""
+    rng = np.random.default_rng(20261003)
+    checked = 0
+    for trial in range(60):
+        np.random.seed(int(rng.integers(0, 2 ** 32)))
+        burn = int(rng.integers(0, 700))
+        if burn:
+            np.random.randint(0, 2 ** 31, size=burn)
+        if rng.integers(0, 2):
+            np.random.standard_normal(1)                              # leaves a cached Gaussian
+        st = _capi.LegacyStream()
+        pool = _capi.HostPool(st, 1, 0, 0)
+        jobs = []
+        for _ in range(int(rng.integers(1, 6))):
+            p, d = int(rng.integers(1, 200)), int(rng.integers(1, 60))
+            a1 = float(rng.choice([0.3, 1.0, 1.5, 7.0, 300.0, 5e5]))
+            a2 = float(rng.choice([0.5, 1.0, 2.5, 34.0]))
+            tentative = bool(rng.integers(0, 4) == 0)
+            job = pool.submit_noise(_capi.NoiseTape(p, d), a1, a2, tentative=tentative)
+            keep = True
+            if tentative:
+                keep = bool(rng.integers(0, 2))
+                job.resolve(keep)
+            jobs.append((p, d, a1, a2, keep, job))
+        for p, d, a1, a2, keep, job in jobs:
+            tape = job.wait()
+            if not keep:
+                continue
+            _capi.finish_tape_blocks(tape)
+            for k in range(d):
+                assert np.array_equal(tape.normals[k], np.random.normal(0, 1, size=p))
+                assert tape.gam_sig[k] == np.random.standard_gamma(a1) and tape.gam_tau[k] == np.random.standard_gamma(a2)
+            checked += 1
+        pool.close()
+        a, b = np.random.get_state(), st.as_numpy_state()
+        assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    assert checked > 100
