@@ -793,7 +793,14 @@ class ForwardSelection:
         chains and the eigen-decompositions run on native threads (HostPipeline); otherwise every chain runs in line."""
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
         if pipelined:
-            self.host = HostPipeline(self.stream, self.draws)
+            try:
+                self.host = HostPipeline(self.stream, self.draws)
+            except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
+                # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
+                # line, only slower
+                import warnings
+                warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
+                self.host = None
         try:
             return self._run()
         finally:
