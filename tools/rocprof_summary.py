@@ -23,7 +23,7 @@ def find(dirname, suffix):
 def short(name):
     name = name.replace('void ', '')
     for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_mfma_kernel', 'gram_valu_kernel', 'resid_kernel', 'reduce_slabs_kernel',
-                'transpose_inputs_kernel', 'predict_kernel'):
+                'transpose_inputs_kernel', 'predict_mfma_kernel', 'predict_kernel'):
         if key in name:
             tag = ''
             if '<' in name:
