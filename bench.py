@@ -220,6 +220,13 @@ def main():
             hot[label] = dict(avg_us=1e3 * t['ms'] / t['launches'], achieved=gbs, frac=gbs / HBM_PEAK_GBS)
         ctx.timing_enable(False)
 
+    # Also outside the timed region: what this device sustains for the kernels' access mixes (trivial streaming kernels)
+    # and for fp64 MFMA on register operands -- context for the roofline fractions, which stay against the spec peaks.
+    sustained = None
+    if rank == 0 and not args.no_microbench:
+        sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
+                     'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
+
     gathered = comm.allgather([elapsed, logical, physical, calls])
     if rank != 0:
         comm.close()
@@ -296,6 +303,7 @@ def main():
         'roofline': dominant,
         'kernels': kernels,
         'basis_build_sustained': hot,
+        'device_sustains': sustained,
     }
     if not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(x, y)

@@ -43,6 +43,7 @@ SIGNATURES = {
     'fokl_timing_enable': (c_int, [c_vp, c_int]),
     'fokl_timing_reset': (c_int, [c_vp]),
     'fokl_timing_get': (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_probe': (c_int, [c_vp, c_int, c_vp]),
     'fokl_gibbs_chain': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_noise_tape': (c_int, [c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -545,6 +546,13 @@ class DeviceContext:
     def write_slot(self, slot, values, row0=0):
         v = np.ascontiguousarray(values, dtype=np.float64)
         self._ck(self._lib.fokl_write_slot(self._h, int(slot), int(row0), v.shape[0], _ptr(v)))
+
+    def probe(self, what):
+        """Sustained rate of a trivial kernel on this device: what = 0 HBM read, 1 HBM write, 2 one read : seven
+        writes (bytes/s), 3 fp64 MFMA on register operands (flop/s) -- include/fokl_hip.h: fokl_probe."""
+        rate = c_dbl(0)
+        self._ck(self._lib.fokl_probe(self._h, int(what), ctypes.byref(rate)))
+        return rate.value
 
     def timing_enable(self, on=True):
         self._ck(self._lib.fokl_timing_enable(self._h, int(bool(on))))

@@ -178,6 +178,17 @@ int fokl_timing_reset(fokl_ctx *ctx);
 int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, double *bytes,
                     double *flops, double *ideal_ms);
 
+/*
+ * What the device sustains, measured with trivial kernels next to the real ones: HBM read-only / write-only streams,
+ * one read stream feeding seven write streams (K1's 8-input, 56-term shape) in bytes/s, and v_mfma_f64_16x16x4_f64 on
+ * register operands in flop/s.  About 0.1 s and up to 4 GiB of scratch per call; not used by any computation.
+ */
+#define FOKL_PROBE_HBM_READ 0
+#define FOKL_PROBE_HBM_WRITE 1
+#define FOKL_PROBE_HBM_MIX 2
+#define FOKL_PROBE_MFMA_F64 3
+int fokl_probe(fokl_ctx *ctx, int what, double *rate);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* G2/G3: the Gibbs chain (host C++, N-independent).  Replaces the D-iteration loop FR:1519-1548.           */
 /* ------------------------------------------------------------------------------------------------------ */

@@ -470,3 +470,13 @@ def test_model_saved_by_the_reference_evaluates_on_the_device():
         mean, bounds = model.evaluate(want['inputs'], clean=True, ReturnBounds=True)
     np.testing.assert_allclose(mean, want['mean'], rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(bounds, want['bounds'], rtol=1e-11, atol=1e-11)
+
+
+def test_device_probes_report_plausible_rates(device_ctx):
+    """fokl_probe: what the device sustains for trivial streaming kernels and register-only fp64 MFMA (bench.py reports
+    them beside the roofline fractions).  Loose physical bounds only."""
+    read, write, mix, mfma = (device_ctx.probe(k) for k in range(4))
+    assert 2e12 < write < read < 8.5e12 and write < mix < read
+    assert 2e13 < mfma < 8e13
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.probe(9)
