@@ -435,6 +435,7 @@ def test_kill_test_bic_from_gram_agrees_with_the_device_pass(monkeypatch):
     """Kill-test candidates take their residual moments from the sub-stage's Gram instead of a K3 pass.
     FOKL_KILL_BIC=check runs both on every candidate of a full-size fit (N = 1e6: the cancellation in
     y'y - 2 b'Xty + b'XtX b is at its worst there) and records the largest relative disagreement of the BIC."""
+    monkeypatch.setenv('FOKL_NOISE_PIPELINE', '1')                 # these are features of the threaded search
     rng = np.random.default_rng(12)
     n, m = 1_000_000, 8
     x = rng.random((n, m))

@@ -154,6 +154,7 @@ def test_kill_tests_reuse_the_substage_gram(monkeypatch):
     """One basis build and one Gram block per sub-stage; every other model evaluation is a sub-matrix lookup.
     The pipelined search builds the coming sub-stage early, so a search ended by the stop rule has built one
     sub-stage it did not use (FOKL_FORESIGHT=0 switches that off)."""
+    monkeypatch.setenv('FOKL_NOISE_PIPELINE', '1')                 # these are features of the threaded search
     for foresight, spare in (('0', 0), ('8', 1)):
         monkeypatch.setenv('FOKL_FORESIGHT', foresight)
         g, model, *_ = fit_case('bern_m3')
@@ -171,6 +172,7 @@ def test_building_the_coming_substage_early_changes_nothing(monkeypatch):
     """FOKL_FORESIGHT: K1 / K2 of the next sub-stage and G2 of its predicted model run before the current kill tests
     are over.  Same search, same random stream; the Gram entries may differ in the last bits (a BLAS / K2 call's
     summation order depends on which other columns share the call)."""
+    monkeypatch.setenv('FOKL_NOISE_PIPELINE', '1')                 # these are features of the threaded search
     runs = []
     for foresight in ('0', '8', '1000'):
         monkeypatch.setenv('FOKL_FORESIGHT', foresight)
@@ -350,6 +352,7 @@ def test_product_has_no_cpu_fallback():
 def test_kill_test_bic_from_gram_matches_explicit_residuals(monkeypatch):
     """FOKL_KILL_BIC=check: every kill-test candidate's BIC both ways (Gram identity in extended precision vs the
     backend's residual pass); the search itself is unchanged by the choice."""
+    monkeypatch.setenv('FOKL_NOISE_PIPELINE', '1')                 # these are features of the threaded search
     name = 'bern_m6'
     if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
         pytest.skip('fixture not generated')
@@ -392,6 +395,7 @@ def test_tentative_tapes_and_rewinds_change_nothing(monkeypatch, name):
     """The next kill test's noise tape is requested before the decision that the test is run and the stream is rewound
     when it is not (FOKL_TENTATIVE_TAPES: 0 = off, 1 = on, test = additionally record-and-discard a bogus tape before
     every request): draws, model, BIC trace and the final numpy RNG state must be identical in all three modes."""
+    monkeypatch.setenv('FOKL_NOISE_PIPELINE', '1')                 # these are features of the threaded search
     if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
         pytest.skip('fixture not generated')
     runs = {}
