@@ -261,7 +261,8 @@ def _thread_plan():
     else:
         plan = (1, 0, 1)
     names = ('FOKL_CHAIN_THREADS', 'FOKL_FINISH_THREADS', 'FOKL_SPECTRAL_THREADS')
-    return tuple(int(os.environ.get(name, str(default))) for name, default in zip(names, plan))
+    chain, finish, spectral = (int(os.environ.get(name, str(default))) for name, default in zip(names, plan))
+    return max(1, chain), max(0, finish), max(1, spectral)       # the threaded search needs a chain and a spectral thread
 
 
 class HostPipeline:
