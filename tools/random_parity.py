@@ -10,9 +10,12 @@ from helpers import OracleBackend
 warnings.simplefilter('ignore')
 spl = getKernels.table_to_phis(np.load(os.path.join(ROOT, 'tests', 'golden', 'spline_phis.npz'))['table'])
 
+MAX_ROWS = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+
+
 def problem(seed):
     rng = np.random.default_rng(seed)
-    n, m = int(rng.integers(300, 3000)), int(rng.integers(1, 6))
+    n, m = int(rng.integers(300, MAX_ROWS)), int(rng.integers(1, 6))
     x = rng.random((n, m))
     y = np.sin(3 * x[:, 0]) + (x[:, 1 % m] * x[:, 2 % m] if m > 1 else 0) + 0.1 * rng.standard_normal(n)
     kw = dict(burnin=int(rng.integers(20, 100)), draws=int(rng.integers(20, 100)), tolerance=int(rng.integers(1, 4)),
