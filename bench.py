@@ -37,13 +37,53 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
 
 
+# BASELINE.json's configs as concrete synthetic inputs: U[0,1) inputs from default_rng(seed), a smooth
+# low-order response + 0.05 N(0,1); the fit's chain starts from np.random.seed(seed_fit).  `unit` selects one of the
+# independent datasets of configs[4] (dataset seed 100 + unit, chain seed 1000 + unit).
+CONFIGS = {
+    1: dict(rows=100_000, inputs=4, kernel='Cubic Splines', seed=11, seed_fit=1000, fit={},
+            label='configs[1]: synthetic N={rows}, M=4, Cubic Splines, burnin 1000 + draws 1000'),
+    2: dict(rows=1_000_000, inputs=8, kernel='Bernoulli Polynomials', seed=12, seed_fit=1000, fit={},
+            label='configs[2]: synthetic N={rows}, M=8, Bernoulli Polynomials, 2-way interactions, burnin 1000 + '
+                  'draws 1000'),
+    3: dict(rows=1_000_000, inputs=16, kernel='Bernoulli Polynomials', seed=13, seed_fit=1000, fit=dict(way3=True),
+            phis_cap=3,
+            label='configs[3]: synthetic N={rows}, M=16, Bernoulli Polynomials, 3-way interactions, stages capped '
+                  'at 3 (phis[:3]: the uncapped search needs eigen-decompositions of 3 360-column models per kill '
+                  'test), burnin 1000 + draws 1000'),
+    4: dict(rows=100_000, inputs=8, kernel='Bernoulli Polynomials', seed=100, seed_fit=1000, fit={},
+            label='configs[4]: independent fits of synthetic N={rows}, M=8 datasets (Bernoulli Polynomials, 2-way, '
+                  'burnin 1000 + draws 1000), dataset seeds 100 + i, chain seeds 1000 + i'),
+}
+
+
 def make_workload(seed, n, m):
-    """U[0,1) inputs, y = sin(4 x0) + x1 x2 + 0.3 x3^2 + 0.5 x4 x5 + 0.05 N(0,1)."""
+    """U[0,1) inputs; the response uses as many of the structures below as there are inputs.
+    M = 4: sin(4 x0) + x1 x2 + 0.3 x3^2;  M = 8: ... + 0.5 x4 x5;  M = 16 (3-way config): sin(4 x0) + x1 x2 x3 +
+    0.3 x4^2 + 0.5 x5 x6.  Always + 0.05 N(0,1)."""
     rng = np.random.default_rng(seed)
     x = rng.random((n, m))
-    y = np.sin(4.0 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.5 * x[:, 4] * x[:, 5]
+    if m >= 16:
+        y = np.sin(4.0 * x[:, 0]) + x[:, 1] * x[:, 2] * x[:, 3] + 0.3 * x[:, 4] ** 2 + 0.5 * x[:, 5] * x[:, 6]
+    else:
+        y = np.sin(4.0 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2
+        if m >= 6:
+            y = y + 0.5 * x[:, 4] * x[:, 5]
     y = y + 0.05 * rng.standard_normal(n)
     return x, y
+
+
+def config_workload(config, unit=0, rows=None):
+    """-> (x, y, spec): the dataset of BASELINE configs[config] (unit-th dataset for configs[4]) and its description:
+    spec = dict(rows, inputs, kernel, phis_cap, fit keywords, seed, seed_fit, label)."""
+    spec = dict(CONFIGS[config])
+    spec['rows'] = int(rows) if rows else spec['rows']
+    spec['seed'] = spec['seed'] + unit
+    spec['seed_fit'] = spec['seed_fit'] + unit
+    spec['label'] = spec['label'].format(rows=spec['rows'])
+    spec.setdefault('phis_cap', None)
+    x, y = make_workload(spec['seed'], spec['rows'], spec['inputs'])
+    return x, y, spec
 
 
 def cpu_baseline(x, y, n_sample=60000):

@@ -322,11 +322,12 @@ def _scipy_dsyevr_address():
 
 class PoolJob:
     """A job on a HostPool.  Keeps the buffers the job reads / writes alive; ``wait()`` may be called repeatedly."""
-    __slots__ = ('_h', 'keep', 'result', 'recycle', 'unresolved')
+    __slots__ = ('_h', 'keep', 'result', 'recycle', 'held', 'unresolved')
 
     def __init__(self, handle, keep, result=None, tentative=False):
         self._h, self.keep, self.result = handle, keep, result
         self.recycle = None                 # raw buffers the owner of the pool may reuse once the job has run
+        self.held = None                    # raw buffer a LATER job will still read: not reusable when this one is done
         self.unresolved = bool(tentative)   # a tentative noise job that has not been given its verdict yet
 
     def done(self):

@@ -48,39 +48,99 @@ class SingleComm:
         pass
 
 
+def _rendezvous_path(tag='fokl'):
+    """Where rank 0 of THIS launch advertises itself: named after what every rank of one launch shares whatever the
+    launcher (MASTER_PORT -- bound by the launcher's own store, so unique among live launches of the node -- the
+    elastic run id and restart count), never after process ids."""
+    import tempfile
+    port = os.environ.get('MASTER_PORT', '0')
+    launch = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+    restart = os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    safe = ''.join(c if c.isalnum() or c in '-_' else '_' for c in f'{port}_{launch}_{restart}')
+    return os.path.join(tempfile.gettempdir(), f'{tag}_rccl_rdzv_{safe}.txt')
+
+
 def _exchange_unique_id(rank, world, make_id, tag='fokl', timeout_s=300.0):
     """
-    Rank 0 creates the 128-byte RCCL id, the other ranks of the node read it.
+    Rank 0 creates the 128-byte RCCL id and serves it to the other ranks over a loop-back / MASTER_ADDR TCP socket on
+    an OS-assigned port; the port number travels through a small file (_rendezvous_path) that rank 0 creates with
+    O_EXCL and mode 0600 after unlinking whatever an earlier, crashed launch may have left there.  A reader accepts
+    the file only if it belongs to its own uid, and gets the id only from a LIVE rank 0 (a stale file points at a
+    closed port: connection refused, read the file again), so neither a restart of the worker group nor a leftover
+    or planted file can hand out a dead id.  Returns (id, path).
 
-    One node, one process per GPU (the launch contract), so the hand-off is a file in the node's temp directory,
-    written atomically and named after what all ranks of one launch share: MASTER_PORT and the launcher's pid.
     Deliberately NOT torch.distributed's TCPStore: importing torch loads its private copies of the HIP runtime and
     of librccl into the process, and RCCL then initialises against the wrong runtime ("unhandled cuda error").
     """
-    import tempfile
+    import socket
+    import struct
     import time
-    port = os.environ.get('MASTER_PORT', '0')
-    launch = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
-    path = os.path.join(tempfile.gettempdir(), f'{tag}_rccl_id_{port}_{launch}_{os.getppid()}.bin')
+    path = _rendezvous_path(tag)
+    host = os.environ.get('MASTER_ADDR', '127.0.0.1') if world > 1 else '127.0.0.1'
+    deadline = time.monotonic() + timeout_s
     if rank == 0:
         uid = bytes(make_id())
-        tmp = path + f'.{os.getpid()}.tmp'
-        with open(tmp, 'wb') as fh:
-            fh.write(uid)
-        os.replace(tmp, path)
+        if world == 1:
+            return uid, None
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        try:
+            try:
+                srv.bind((host, 0))
+            except OSError:
+                srv.bind(('0.0.0.0', 0))
+            srv.listen(world)
+            try:
+                os.unlink(path)
+            except FileNotFoundError:
+                pass
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, 'w') as fh:
+                fh.write(f'{srv.getsockname()[1]}\n')
+            served = set()
+            while len(served) < world - 1:
+                srv.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError(f"rank 0: only {len(served)} of {world - 1} ranks asked for the RCCL id "
+                                       f"within {timeout_s:.0f} s")
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        hello = conn.recv(8, socket.MSG_WAITALL)
+                        if len(hello) == 8 and hello[:4] == b'FOKL':
+                            conn.sendall(uid)
+                            served.add(struct.unpack('<i', hello[4:])[0])
+                    except OSError:
+                        pass
+        finally:
+            srv.close()
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
         return uid, path
-    deadline = time.monotonic() + timeout_s
     while True:
         try:
-            with open(path, 'rb') as fh:
-                uid = fh.read()
-            if len(uid) == 128:
-                return uid, path
-        except FileNotFoundError:
+            st = os.stat(path)
+            if st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0:
+                with open(path) as fh:
+                    port = int(fh.read().strip() or 0)
+                with socket.create_connection((host, port), timeout=5.0) as conn:
+                    conn.sendall(b'FOKL' + struct.pack('<i', rank))
+                    uid = b''
+                    while len(uid) < 128:
+                        part = conn.recv(128 - len(uid))
+                        if not part:
+                            break
+                        uid += part
+                if len(uid) == 128:
+                    return uid, path
+        except (FileNotFoundError, ValueError, ConnectionError, socket.timeout, OSError):
             pass
         if time.monotonic() > deadline:
-            raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 at {path} after {timeout_s:.0f} s")
-        time.sleep(0.01)
+            raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 via {path} after {timeout_s:.0f} s")
+        time.sleep(0.02)
 
 
 class RcclComm:
@@ -104,11 +164,6 @@ class RcclComm:
         finally:
             os.dup2(saved, 1)
             os.close(saved)
-        if self._id_file is not None and self.rank == 0:
-            try:
-                os.remove(self._id_file)                      # everybody has read it by now
-            except OSError:
-                pass
 
     def allgather(self, values):
         return self.ctx.allgather(np.asarray(values, dtype=np.float64).reshape(-1), self.world)

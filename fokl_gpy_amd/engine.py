@@ -290,7 +290,11 @@ class HostPipeline:
         if os.environ.get('FOKL_PIN_L3', '1') != '0':
             self._saved_affinity, noise_cpu = _place_host_threads()
         chain, finish, spectral = _thread_plan()
-        self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu)
+        try:
+            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu)
+        except BaseException:
+            self._restore_affinity()        # the caller may carry on in line: not pinned to one L3 domain
+            raise
         # Every job names buffers the native threads read and write: they are kept here until the job has run, whether
         # or not the driver still cares about the result (a rejected candidate's tape is recorded all the same).
         self._live = []
@@ -332,8 +336,18 @@ class HostPipeline:
         ``resolve(True / False)`` (False rewinds the stream to where the tape began)."""
         raw = self._take(_capi.NoiseTape.doubles_needed(p1, self.draws))
         job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative)
-        job.recycle = [raw]                 # moved to the chain job, which is the last reader of the tape
+        # The tape's last reader is the chain job, which does not exist yet: until chain() or discard() the buffer is
+        # only `held`, so that a _reap() between request and chain (the recorder may well be done by then) cannot hand
+        # it out again -- chain() would then get the tape's own memory as its output buffer.
+        job.held = raw
         return self._track(job)
+
+    def discard(self, noise_job):
+        """A tentative tape that will not be used: rewind the stream to where it began; its buffer goes back to the
+        pool once the recorder has let go of it."""
+        noise_job.resolve(False)
+        if noise_job.held is not None:
+            noise_job.recycle, noise_job.held = [noise_job.held], None
 
     def spectral(self, gram, idx):
         """Queue G2 for the model made of columns idx of gram; may be called ahead of need (no random numbers)."""
@@ -346,7 +360,7 @@ class HostPipeline:
         tape = noise_job.result
         w_raw = self._take(tape.draws * tape.p1)
         job = self.pool.submit_chain(spec.lamb, spec.qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw)
-        job.recycle, noise_job.recycle = noise_job.recycle, None
+        job.recycle, noise_job.held = [noise_job.held], None       # the chain job is the last reader of the tape
         return self._track(job), w_raw
 
     def close(self):
@@ -360,13 +374,16 @@ class HostPipeline:
         self._spare = {}
         busy = self.pool.busy_seconds()
         self.pool.close()
+        self._restore_affinity()
+        return busy
+
+    def _restore_affinity(self):
         if self._saved_affinity is not None:
             try:
                 os.sched_setaffinity(0, self._saved_affinity)
             except OSError:
                 pass
             self._saved_affinity = None
-        return busy
 
 
 class GibbsOutcome:
@@ -383,14 +400,18 @@ class GibbsOutcome:
         self.siglik = 0.0
         self._w_raw, self._chain_job = w_raw, chain_job
 
-    def __del__(self):
-        # w lives in a buffer of the pipeline's pool: hand it back, directly or through the job that is still writing
+    def release(self):
+        """Hand the buffer of w back to the pipeline's pool (directly, or through the chain job that is still writing
+        it).  Called by the search when no decision can look at this model's draws any more; idempotent."""
+        raw, self._w_raw = self._w_raw, None
         host = self._owner.host
-        if host is not None and self._w_raw is not None:
-            if self._chain_job.done():
-                host.give(self._w_raw)
-            else:
-                self._chain_job.recycle.append(self._w_raw)
+        if raw is None or host is None:
+            return
+        self._w = self._jobs = None
+        if self._chain_job.done():
+            host.give(raw)
+        else:
+            self._chain_job.recycle.append(raw)
 
     @property
     def Q(self):
@@ -501,6 +522,7 @@ class ForwardSelection:
         if self.kill_bic not in ('auto', 'gram', 'device', 'check'):
             raise ValueError("FOKL_KILL_BIC must be auto, gram, device or check")
         self.trace = []                     # one record per gibbs evaluation
+        self._outcomes = []                 # pipelined evaluations whose draws sit in pooled buffers (see _retire)
         self._ev_cache = {}                 # model (set of terms) -> its BIC, see _same_model_same_ev
         self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
@@ -614,6 +636,7 @@ class ForwardSelection:
             self._record(p1, n_prev_cols, ev, kill)
             outcome = GibbsOutcome(self, pending[0], ev, idx, *jobs)
             outcome.siglik = self._last_siglik
+            self._outcomes.append(outcome)
             return outcome
 
         n = self.n
@@ -643,6 +666,14 @@ class ForwardSelection:
         self._record(p1, n_prev_cols, ev, kill)
         return EagerOutcome(w, Q, betahat, ev, idx)
 
+    def _retire(self, *keep):
+        """End of a sub-stage: the draws of every model evaluated so far except `keep` (the best model of the search and
+        the model the next sub-stage starts from) can no longer be looked at -- their buffers go back to the pool."""
+        for outcome in self._outcomes:
+            if not any(outcome is k for k in keep):
+                outcome.release()
+        self._outcomes = [k for k in keep if isinstance(k, GibbsOutcome)]
+
     @staticmethod
     def _columns_without(count, removed):
         return np.array([c for c in range(count) if c not in removed], dtype=np.int32)
@@ -650,7 +681,10 @@ class ForwardSelection:
     def _resid_fits_in_shadow(self, columns):
         """FOKL_KILL_BIC=auto: does a K3 pass over `columns` columns (about 5.5 TB/s) take clearly less time than
         recording the noise tape of a model of that size (about 40 ns + 1 ns per column and Gibbs iteration)?"""
-        resid_s = 8.0 * self.n_local * (columns + 2) / 5.5e12 + 20e-6
+        # rows per rank as every rank computes it alike (shards differ by one row when N % world != 0, and ranks that
+        # decide differently here would disagree on whether the next call is a collective)
+        world = max(1, round(self.n / max(self.n_local, 1)))
+        resid_s = 8.0 * -(-self.n // world) * (columns + 2) / 5.5e12 + 20e-6
         tape_s = self.draws * (40.0 + columns) * 1e-9
         return resid_s < 0.6 * tape_s
 
@@ -718,7 +752,7 @@ class ForwardSelection:
         def drop_pending():
             nonlocal pending_tape
             if pending_tape is not None:
-                pending_tape[2].resolve(False)
+                self.host.discard(pending_tape[2])
                 self.stats['tapes_rewound'] += 1
                 pending_tape = None
 
@@ -771,7 +805,11 @@ class ForwardSelection:
                 last_accepted = bool(ev < evmin)
                 if last_accepted:
                     killed, evmin = trial, ev
+                    best.release()                                        # the model it replaces: its draws are history
                     best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                    self._outcomes.append(best)
+                else:
+                    jobs[1].recycle.append(jobs[2])                       # nobody will read a rejected candidate's draws
                 forecast(pos + 1)
                 if self.tentative_tapes:
                     nxt = next((j for j in proposal[pos + 1:] if likely(j)), None)
@@ -781,7 +819,7 @@ class ForwardSelection:
                             bogus = self._request_noise(p1_next + 1, tentative=True)
                             while bogus.result.progress[0] < self.draws:
                                 time.sleep(0)
-                            bogus.resolve(False)
+                            self.host.discard(bogus)
                             self.stats['tapes_rewound'] += 1
                         pending_tape = (nxt, p1_next, self._request_noise(p1_next, tentative=True))
         finally:
@@ -991,6 +1029,7 @@ class ForwardSelection:
                 greater += 1
                 betas, mtx = best, damtx
                 evs = np.append(evs, ev)
+            self._retire(betas, best)
 
         if ahead is not None:                      # the search stopped: the columns built ahead are not needed
             self.pool.give(ahead['slots'])

@@ -189,8 +189,10 @@ def _lib():
     return _LIB
 
 
-def build_columns_c(xsm, phind, phis, kernel, terms):
-    """F3 through oracle_c.c -- identical arithmetic (libm pow, no FMA) to ``build_columns_scalar``; returns [N, T]."""
+def build_columns_c(xsm, phind, phis, kernel, terms, threads=1):
+    """F3 through oracle_c.c -- identical arithmetic (libm pow, no FMA) to ``build_columns_scalar``; returns [N, T].
+    threads > 1 splits the ROWS over that many native calls (every element is computed by the same scalar code, so
+    the result does not depend on the split); used by the golden generators for the full-size configurations."""
     lib = _lib()
     xsm = np.ascontiguousarray(xsm, dtype=np.float64)
     n, m = xsm.shape
@@ -198,15 +200,23 @@ def build_columns_c(xsm, phind, phis, kernel, terms):
     t = terms.shape[0]
     packed, nb, width = pack_phis(phis, kernel)
     out = np.empty((t, n), dtype=np.float64)
-    if kernel == KERNEL_SPLINES:
-        ph = np.ascontiguousarray(phind, dtype=np.uint16)
-        ph_ptr = ph.ctypes.data_as(ctypes.c_void_p)
+    ph = np.ascontiguousarray(phind, dtype=np.uint16) if kernel == KERNEL_SPLINES else None
+
+    def rows(lo, hi):
+        ph_ptr = ctypes.c_void_p(ph.ctypes.data + 2 * lo * m) if ph is not None else ctypes.c_void_p(0)
+        lib.oracle_build_columns(ctypes.c_void_p(xsm.ctypes.data + 8 * lo * m), ph_ptr, ctypes.c_int64(hi - lo),
+                                 ctypes.c_int(m), ctypes.c_int(kernel), packed.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_int(nb), ctypes.c_int(width), terms.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_int(t), ctypes.c_void_p(out.ctypes.data + 8 * lo), ctypes.c_int64(n))
+
+    threads = max(1, min(int(threads), n // 4096 or 1))
+    if threads == 1:
+        rows(0, n)
     else:
-        ph_ptr = ctypes.c_void_p(0)
-    lib.oracle_build_columns(xsm.ctypes.data_as(ctypes.c_void_p), ph_ptr, ctypes.c_int64(n), ctypes.c_int(m),
-                             ctypes.c_int(kernel), packed.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(nb),
-                             ctypes.c_int(width), terms.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(t),
-                             out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n))
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [n * k // threads for k in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:                      # ctypes releases the GIL during the call
+            list(ex.map(lambda k: rows(cuts[k], cuts[k + 1]), range(threads)))
     return np.ascontiguousarray(out.T)
 
 

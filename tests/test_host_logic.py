@@ -445,24 +445,40 @@ def _rendezvous_worker(rank, queue):
     queue.put((rank, uid, path))
 
 
-def test_rccl_id_rendezvous_through_the_temp_file(monkeypatch):
-    """Rank 0 publishes the 128-byte RCCL id in a temp file named after MASTER_PORT / the launcher's pid (no torch in a
-    GPU process); the other ranks poll for it -- here rank 1 starts polling first."""
+def test_rccl_id_rendezvous_survives_a_stale_file_and_a_late_rank_zero(monkeypatch):
+    """Rank 0 serves the 128-byte RCCL id over a socket whose port it advertises in a 0600 temp file named after
+    MASTER_PORT / run id / restart count (no torch in a GPU process; no process ids in the name).
+    Here rank 1 starts first and finds the leftover of a crashed launch (a port nobody listens on) and a planted file
+    with loose permissions: it must keep polling until the live rank 0 answers."""
     import multiprocessing as mp
+    import socket
     import time
+    from fokl_gpy_amd import dist as _dist
     monkeypatch.setenv('MASTER_PORT', '45991')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    path = _dist._rendezvous_path('fokl_test')
+    assert str(os.getppid()) not in os.path.basename(path) and str(os.getpid()) not in os.path.basename(path)
+    dead = socket.socket()
+    dead.bind(('127.0.0.1', 0))
+    dead_port = dead.getsockname()[1]
+    dead.close()
+    with open(path, 'w') as fh:
+        fh.write(f'{dead_port}\n')
+    os.chmod(path, 0o644)                                  # loose permissions: ignored outright
     ctx = mp.get_context('fork')
     queue = ctx.Queue()
     late = ctx.Process(target=_rendezvous_worker, args=(1, queue))
     late.start()
-    time.sleep(0.3)
+    time.sleep(0.2)
+    os.chmod(path, 0o600)                                  # now a well-formed but stale advertisement
+    time.sleep(0.2)
     first = ctx.Process(target=_rendezvous_worker, args=(0, queue))
     first.start()
     got = sorted(queue.get(timeout=30) for _ in range(2))
     late.join(10)
     first.join(10)
-    assert got[0][1] == got[1][1] == bytes(range(128)) and got[0][2] == got[1][2]
-    os.remove(got[0][2])
+    assert got[0][1] == got[1][1] == bytes(range(128)) and got[0][2] == got[1][2] == path
+    assert not os.path.exists(path)                        # rank 0 cleans up once everybody has been served
 
 
 def _random_problem(seed):
@@ -506,3 +522,40 @@ def test_pipelined_search_equals_the_inline_search(monkeypatch, seed):
         assert np.array_equal(got[1], ref[1]) and got[3] == ref[3] and got[2].shape == ref[2].shape
         np.testing.assert_allclose(got[2], ref[2], rtol=1e-10)
         np.testing.assert_allclose(got[0], ref[0], rtol=1e-7, atol=1e-9)
+
+
+def test_a_reap_between_tape_request_and_chain_cannot_recycle_the_tape(monkeypatch):
+    """the recorder may be done with a tape before the chain that reads it is submitted; a _reap() in
+    between (HostPipeline.spectral -> _track does one whenever 24 jobs are live) must not hand the tape's buffer
+    out again -- chain() takes its output buffer from the same pool."""
+    import time
+    monkeypatch.setenv('FOKL_PIN_L3', '0')
+    np.random.seed(3)
+    stream = _capi.LegacyStream()
+    host = engine.HostPipeline(stream, 40)
+    try:
+        p1 = 5
+        job = host.request(p1, 12.0, 6.0)
+        while job.result.progress[0] < 40:
+            time.sleep(0.001)
+        time.sleep(0.01)
+        host._reap()                                       # the noise job is done and leaves the live list ...
+        assert not any(host._spare.values())               # ... but its buffer is not up for grabs
+        gram = np.eye(p1 + 1) * 50.0
+        gram[:p1, p1] = gram[p1, :p1] = 1.0
+        spec = host.spectral(gram, np.arange(p1)).wait()
+        chain_job, w_raw = host.chain(spec, 1.0, 1.0, 50.0, 0.2, 0.2, job)
+        assert not np.shares_memory(w_raw, job.result.normals)
+        assert job.held is None and len(chain_job.recycle) == 1
+        chain_job.wait()
+        host._reap()
+        assert sum(len(v) for v in host._spare.values()) == 1     # now the tape buffer is back
+        # a discarded tentative tape comes back as well, and the stream is where it was before it
+        before = host.request(p1, 12.0, 6.0, tentative=True)
+        host.discard(before)
+        before.wait()
+        host._reap()
+        assert sum(len(v) for v in host._spare.values()) == 1 and before.held is None
+    finally:
+        host.close()
+        stream.publish()
