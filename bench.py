@@ -4,21 +4,30 @@ Benchmark of the forward-selection hot path on MI355X -- BASELINE.json's metric:
 
     candidate-terms/sec (basis build + Gibbs + BIC), N = 1e6, M = 8
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4}] [--mode fits|rows|candidates]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 One *step* = one complete forward-selection fit (FoKL.fit's search: every sub-stage's basis build, Gram,
-Gibbs chains, BIC and kill tests) over the synthetic configs[2] workload -- N = 1e6 rows, M = 8 inputs,
-Bernoulli-polynomial kernel, 2-way interactions, reference-default hyper-parameters (burnin 1000, draws 1000,
-tolerance 3) -- with the normalised inputs already resident in HBM when the timed region starts.
+Gibbs chains, BIC and kill tests) over a synthetic BASELINE configuration (default configs[2]: N = 1e6 rows,
+M = 8 inputs, Bernoulli-polynomial kernel, 2-way interactions, reference-default hyper-parameters: burnin 1000,
+draws 1000, tolerance 3) with the normalised inputs already resident in HBM when the timed region starts.
+--config 4: a step is --fits-per-step independent fits (N = 1e5, M = 8 each) on resident datasets.
 
 `value` = candidate terms / second, where the numerator is the reference-equivalent (logical) count: the sum
 over all gibbs evaluations of the columns the reference builds for that evaluation (FoKLRoutines.py:1461),
-tallied per call by the search driver.  `terms_physical` is what the GPU really built.
+tallied per call by the search driver.  `value_physical` counts what the GPU really built.
 
-N > 1: every rank fits its own dataset of the same shape (independent fits are the unit that shards without a
-data-path collective, BASELINE configs[4]); per-rank time and term counts are exchanged with one RCCL
-all-gather; value = all ranks' terms / max-over-ranks time ("weak" scaling).
+After the timed region the last fit of rank 0 is compared with the oracle-generated golden of the same workload
+(tests/golden/cfg*.npz: interaction matrix and gibbs-call sequence exact, BIC trace 1e-9, draws 1e-9 of the column
+scale, numpy stream equal): `parity_checked` / `parity` in the JSON line, exit code 3 on a mismatch.
+
+N > 1 (--mode):
+  fits        every rank fits its own dataset(s) (independent fits are the unit that shards without a data-path
+              collective, BASELINE configs[4]); one RCCL all-gather of the per-rank counters; "weak" scaling.
+  candidates  ONE fit; the RNG-free half of every model evaluation (eigen-decomposition + BIC of the speculative
+              kill-test candidates) is dealt over the ranks and gathered with RCCL all-gathers (north_star's split;
+              default for --config 3); "strong" scaling.
+  rows        ONE dataset, rows sharded, Gram blocks / residual moments all-reduced on the device; "strong" scaling.
 """
 import argparse
 import json
@@ -86,40 +95,152 @@ def config_workload(config, unit=0, rows=None):
     return x, y, spec
 
 
-def cpu_baseline(x, y, n_sample=60000):
+GOLDENS = {  # (config, unit, rows, fit overrides) -> fixture made by tests/golden/make_config_golden.py
+    (2, 0, 1_000_000): ('cfg2_n1e6_m8', {}),
+    (4, 0, 100_000): ('cfg4_unit0_n1e5_m8', {}),
+    (4, 5, 100_000): ('cfg4_unit5_n1e5_m8', {}),
+    (1, 0, 100_000): ('cfg1_n1e5_m4_splines', {}),
+    (3, 0, 100_000): ('cfg3_n1e5_m16_way3', dict(burnin=30, draws=30)),
+}
+
+
+def kernel_and_phis(spec):
+    """-> (kernel name, phis or None, oracle kernel id) of a workload spec."""
+    from fokl_gpy_amd import getKernels
+    if spec['kernel'] == 'Cubic Splines':
+        tab = np.load(os.path.join(ROOT, 'tests', 'golden', 'spline_phis.npz'))['table']
+        return spec['kernel'], getKernels.table_to_phis(tab), 0
+    phis = getKernels.bernoulli()
+    if spec['phis_cap']:
+        phis = phis[:spec['phis_cap']]
+    return spec['kernel'], phis, 1
+
+
+def compare_with_golden(name, model, betas, mtx, evs, state):
+    """The tolerances of tests/test_config_goldens.py.  -> dict(ok, ...)"""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'), allow_pickle=False)
+    out = dict(golden=name + '.npz')
+    trace = model.fit_trace
+    out['mtx_equal'] = bool(mtx.shape == g['mtx'].shape and np.array_equal(mtx, g['mtx']))
+    out['gibbs_calls_equal'] = bool([t['cols'] for t in trace] == g['call_cols'].tolist() and
+                                    [t['built'] for t in trace] == g['call_built'].tolist())
+    out['terms_logical'] = int(np.sum(g['call_built']))
+    if out['mtx_equal'] and out['gibbs_calls_equal']:
+        out['max_rel_bic'] = float(np.max(np.abs(np.array([t['ev'] for t in trace]) - g['call_ev']) / np.abs(g['call_ev'])))
+        scale = np.max(np.abs(g['betas']), axis=0)
+        out['max_draw_err_over_scale'] = float(np.max(np.abs(betas - g['betas']) / scale))
+        out['numpy_stream_equal'] = bool(np.array_equal(state[1], g['rng_key']) and state[2] == int(g['rng_pos']) and
+                                         state[3] == int(g['rng_has_gauss']) and state[4] == float(g['rng_cached']))
+        out['ok'] = bool(out['max_rel_bic'] < 1e-9 and out['max_draw_err_over_scale'] < 1e-9 and
+                         out['numpy_stream_equal'] and len(evs) == len(g['evs']))
+    else:
+        out['ok'] = False
+    return out
+
+
+def cpu_baselines(x, y, spec, seconds_target=15.0, which=('scalar', 'vectorised')):
     """
-    The reference's algorithm on the host (oracle, kind "port"): the first two gibbs evaluations of the same
-    workload (T = 8 main effects, then + 28 two-way terms) on the first `n_sample` rows with the reference's own
-    per-element Python loop structure (FoKLRoutines.py:1446-1485), one core.  The reference's cost at this N is
-    its O(N * T * M) X-build, so the rate is extrapolated linearly in N to the benchmark's row count.
+    The reference's algorithm on the host cores of this box (oracle, kind "port"), on a bounded sample of the same
+    workload: its first two gibbs evaluations (FoKLRoutines.py:1396-1558 for the first two sub-stage models, e.g.
+    8 main effects and then + 28 two-way terms at M = 8) with the configuration's own number of Gibbs iterations.
+
+      scalar      the reference's own per-element Python loop structure for the basis matrix (FR:1446-1485), one core,
+                  on the first n_sample rows; the X-build is what the reference's time goes to at this N and it is
+                  linear in N, so the rate is scaled by n_sample / N;
+      vectorised  the same two evaluations at FULL N with the basis matrix built by whole-column numpy expressions
+                  (oracle.build_columns_numpy) and numpy's multi-threaded BLAS for XtX -- the fair NumPy baseline of
+                  SURVEY 8(d)(ii).
+    Both are baselines, not targets.
     """
     from oracle import fokl_oracle as O
-    from fokl_gpy_amd import getKernels
-    phis = getKernels.bernoulli()
+    kernel, phis, kid = kernel_and_phis(spec)
+    hp = dict(O.DEFAULT_HYPERS)
+    hp.update(spec['fit'])
+    a, atau = hp['a'], hp['atau']
+    draws = hp['burnin'] + hp['draws']
     n_full, m = x.shape
-    xs = np.ascontiguousarray(x[:n_sample])
-    ys = np.ascontiguousarray(y[:n_sample])[:, None]
-    a = atau = 4
-    b, btau = O.default_b_btau(ys, a, atau)
-    dtd = ys.T.dot(ys)
-    t1 = O.distinct_arrangements(O.deal_indvec(1, m, 2))
-    t2 = O.distinct_arrangements(O.deal_indvec(2, m, 2))
-    state = np.random.get_state()
-    np.random.seed(12345)
-    t0 = time.perf_counter()
-    r1 = O.gibbs(xs, ys, phis, O.KERNEL_BERNOULLI, [], t1, a, b, atau, btau, 2000, None, xs, b / (1 + a),
-                 btau / (1 + atau), dtd, build=O.build_columns_scalar)
-    O.gibbs(xs, ys, phis, O.KERNEL_BERNOULLI, r1.X, np.vstack([t1, t2]), a, b, atau, btau, 2000, None, xs,
-            b / (1 + a), btau / (1 + atau), dtd, build=O.build_columns_scalar)
-    dt = time.perf_counter() - t0
-    np.random.set_state(state)
+    sett = 1 if m == 1 else (3 if hp['way3'] else 2)
+    t1 = O.distinct_arrangements(O.deal_indvec(1, m, sett))
+    t2 = O.distinct_arrangements(O.deal_indvec(2, m, sett)) if len(phis) >= 2 and m > 1 else t1[:0]
+    if t1.shape[0] + t2.shape[0] > 64:                  # M = 16: the 137-column chain alone (O(P^3) numpy products per
+        t2 = t1[:0]                                     # Gibbs iteration, FR:1521-1528) would take a minute
+    n_calls = 2 if t2.shape[0] else 1
     terms = t1.shape[0] + t2.shape[0]
-    rate_sample = terms / dt
-    return dict(value=rate_sample * n_sample / n_full, unit='candidate-terms/s', cores=1, kind='port',
-                sample=f'oracle scalar path (reference loop structure), first 2 gibbs evaluations ({terms} terms, '
-                       f'2000 draws each) on the first {n_sample} of {n_full} rows in {dt:.1f} s; '
-                       f'rate scaled by {n_sample}/{n_full} (X-build is linear in N)',
-                seconds=dt, terms=terms)
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    xn_full = (x - lo) / (hi - lo)                      # clean()'s min-max normalisation (FR:420-470)
+    state = np.random.get_state()
+    out = {}
+
+    def two_calls(xs, ys, build):
+        b, btau = O.default_b_btau(ys, a, atau)
+        dtd = ys.T.dot(ys)
+        if kid == O.KERNEL_SPLINES:
+            phind, xsm = O.inputs_to_phind(xs, len(phis[0][0]))
+        else:
+            phind, xsm = None, xs
+        np.random.seed(12345)
+        t0 = time.perf_counter()
+        r1 = O.gibbs(xs, ys, phis, kid, [], t1, a, b, atau, btau, draws, phind, xsm, b / (1 + a), btau / (1 + atau),
+                     dtd, build=build)
+        if t2.shape[0]:
+            O.gibbs(xs, ys, phis, kid, r1.X, np.vstack([t1, t2]), a, b, atau, btau, draws, phind, xsm, b / (1 + a),
+                    btau / (1 + atau), dtd, build=build)
+        return time.perf_counter() - t0
+
+    if 'scalar' in which:
+        # ~8 us per (row, term) for the reference's loop; the two chains add ~1 s
+        n_sample = int(min(n_full, max(2000, seconds_target / (terms * 8e-6))))
+        xs = np.ascontiguousarray(xn_full[:n_sample])
+        ys = np.ascontiguousarray(y[:n_sample])[:, None]
+        dt = two_calls(xs, ys, O.build_columns_scalar)
+        out['cpu_baseline'] = dict(
+            value=terms / dt * n_sample / n_full, unit='candidate-terms/s', cores=1, kind='port',
+            sample=f'oracle scalar path (reference loop structure, FR:1446-1485), first {n_calls} gibbs evaluation(s) ({terms} '
+                   f'terms, {draws} Gibbs iterations each) on the first {n_sample} of {n_full} rows in {dt:.1f} s; rate '
+                   f'scaled by {n_sample}/{n_full} (the X-build is linear in N)',
+            seconds=dt, terms=terms)
+    if 'vectorised' in which:
+        try:
+            from threadpoolctl import threadpool_info
+            blas_threads = max([lib.get('num_threads', 1) for lib in threadpool_info() if lib.get('user_api') == 'blas']
+                               or [1])
+        except Exception:
+            blas_threads = 1
+        dt = two_calls(xn_full, y[:, None], O.build_columns_numpy)
+        out['cpu_baseline_vectorised'] = dict(
+            value=terms / dt, unit='candidate-terms/s', cores=int(blas_threads), kind='port',
+            sample=f'oracle with whole-column numpy expressions for the basis matrix and numpy BLAS ({blas_threads} '
+                   f'threads) for XtX: first {n_calls} gibbs evaluation(s) ({terms} terms, {draws} Gibbs iterations each) at '
+                   f'the full N = {n_full} in {dt:.1f} s; no extrapolation',
+            seconds=dt, terms=terms)
+    np.random.set_state(state)
+    return out
+
+
+def pin_to_l3_domain(local):
+    """Keep this rank's host threads (search driver + the native noise / chain / spectral threads, about ten) on the
+    logical CPUs of ONE L3 domain: noise tapes (about 1 MB each) are handed from thread to thread.  Rank r takes the
+    domain of CPU 8 r (8 cores x 2 SMT threads on the EPYC hosts of this pool)."""
+    if os.environ.get('FOKL_BENCH_PIN', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        want = set(range(8 * local, 8 * local + 8))
+        try:
+            with open(f'/sys/devices/system/cpu/cpu{8 * local}/cache/index3/shared_cpu_list') as fh:
+                want = set()
+                for part in fh.read().strip().split(','):
+                    lo, _, hi = part.partition('-')
+                    want.update(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            pass
+        want = sorted(want & allowed)
+        if len(want) >= 2:
+            os.sched_setaffinity(0, want)
+            return want
+    except OSError:
+        pass
+    return None
 
 
 def main():
@@ -127,16 +248,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--rows', type=int, default=1_000_000)
-    ap.add_argument('--inputs', type=int, default=8)
-    ap.add_argument('--mode', choices=('fits', 'rows'), default='fits',
-                    help="N > 1: 'fits' = every rank fits its own dataset (weak scaling, the default and the driver's "
-                         "contract); 'rows' = ONE dataset of --rows rows sharded over the ranks, Gram blocks and residual "
-                         "moments all-reduced over RCCL inside the library (strong scaling; for fits that are device "
-                         "bound, N >= 5e7)")
+    ap.add_argument('--config', type=int, choices=sorted(CONFIGS), default=2,
+                    help='BASELINE.json configs[i]; the metric is quoted on configs[2] (default)')
+    ap.add_argument('--rows', type=int, default=None, help='override the configuration\'s row count')
+    ap.add_argument('--inputs', type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--fits-per-step', type=int, default=None,
+                    help='--config 4: independent fits per rank and step (default 8 = 64 fits over 8 GPUs)')
+    ap.add_argument('--mode', choices=('fits', 'rows', 'candidates'), default=None,
+                    help="N > 1, see the module docstring; default: candidates for --config 3, fits otherwise")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-microbench', action='store_true',
-                    help='skip the back-to-back basis-build launches after the timed region (used for profiler runs)')
+                    help='skip the back-to-back kernel launches after the timed region (used for profiler runs)')
+    ap.add_argument('--no-parity', action='store_true')
     args = ap.parse_args()
 
     from fokl_gpy_amd import dist
@@ -147,106 +270,160 @@ def main():
                   file=sys.stderr)
             sys.exit(2)
     os.environ['FOKL_DEVICE'] = str(local)
+    pinned = pin_to_l3_domain(local)
 
-    # Keep this rank's host threads (search driver + the native noise / chain / spectral threads, about ten) on the
-    # logical CPUs of ONE L3 domain: noise tapes (about 1 MB each) are handed from thread to thread.  Rank r takes the
-    # domain of CPU 8 r (8 cores x 2 SMT threads on the EPYC hosts of this pool).
-    pinned = None
-    if os.environ.get('FOKL_BENCH_PIN', '1') != '0' and hasattr(os, 'sched_setaffinity'):
-        try:
-            allowed = set(os.sched_getaffinity(0))
-            want = set(range(8 * local, 8 * local + 8))
-            try:
-                with open(f'/sys/devices/system/cpu/cpu{8 * local}/cache/index3/shared_cpu_list') as fh:
-                    want = set()
-                    for part in fh.read().strip().split(','):
-                        lo, _, hi = part.partition('-')
-                        want.update(range(int(lo), int(hi or lo) + 1))
-            except (OSError, ValueError):
-                pass
-            want = sorted(want & allowed)
-            if len(want) >= 2:
-                os.sched_setaffinity(0, want)
-                pinned = want
-        except OSError:
-            pinned = None
+    from fokl_gpy_amd import FoKLRoutines, _capi, engine
+    cfg = args.config
+    mode = args.mode or ('candidates' if cfg == 3 else 'fits')
+    one_fit_for_all = mode in ('rows', 'candidates')
+    fits_per_step = (args.fits_per_step or 8) if cfg == 4 else 1
+    if one_fit_for_all and fits_per_step != 1:
+        print("bench.py: --config 4 runs in --mode fits", file=sys.stderr)
+        sys.exit(2)
 
-    from fokl_gpy_amd import FoKLRoutines, _capi
-    backend = FoKLRoutines.device_backend(local)          # raises without libfokl_hip.so / a gfx950 device
-    ctx = backend.ctx
     # FOKL_BENCH_FORCE_RCCL=1 takes the RCCL bootstrap + collectives also in a world of one (launcher smoke test)
     use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
+    backends = [FoKLRoutines.device_backend(local)]          # raises without libfokl_hip.so / a gfx950 device
+    for _ in range(fits_per_step - 1):                        # one resident dataset (and stream) per fit of a step
+        backends.append(engine.HipBackend(_capi.DeviceContext(local)))
+    ctx = backends[0].ctx
     comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
 
-    n, m = args.rows, args.inputs
-    rows_mode = args.mode == 'rows'
-    if rows_mode:
-        # one dataset, rank r holds rows [lo, hi): the concatenation of the ranks' shards (seed 12, shard r).  The
-        # data-driven defaults of b / btau (FR:1322-1348) need the global mean and variance of y: one all-gather.
-        lo, hi = dist.shard_range(n, rank, world)
-        x, y = make_workload((12, rank), hi - lo, m)
-        mom = comm.allgather([hi - lo, float(np.sum(y)), float(np.sum(y * y))])
-        mean = float(np.sum(mom[:, 1]) / n)
-        var = float(np.sum(mom[:, 2]) / n - mean * mean)
-        hypers = dict(b=var * (4 + 1), btau=abs(mean) / var * (4 + 1))
-        seed_fit = 1000                                     # the sampler is replicated: same stream on every rank
-    else:
-        x, y = make_workload(12 + rank, n, m)
-        hypers = {}
-        seed_fit = 1000 + rank
+    units = [0] if one_fit_for_all else [rank * fits_per_step + i for i in range(fits_per_step)]
+    fits = []                                                 # (model, backend, x, y, spec, n_local)
+    prep_s = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for unit, backend in zip(units, backends):
+            x, y, spec = config_workload(cfg, unit, args.rows)
+            if args.inputs and args.inputs != spec['inputs']:
+                x, y = make_workload(spec['seed'], spec['rows'], args.inputs)
+                spec['inputs'] = args.inputs
+            kernel, phis, _ = kernel_and_phis(spec)
+            hypers = {}
+            clean_kw = dict(clean=True)
+            n_local = spec['rows']
+            if mode == 'rows':
+                # rank r holds rows [lo, hi) of the one dataset; the data-driven defaults of b / btau (FR:1322-1348)
+                # need the global mean and variance of y: one all-gather.  A shard must not be rescaled by its own
+                # min / max: the synthetic inputs are U[0,1) already.
+                lo, hi = dist.shard_range(spec['rows'], rank, world)
+                x, y = x[lo:hi], y[lo:hi]
+                n_local = hi - lo
+                mom = comm.allgather([n_local, float(np.sum(y)), float(np.sum(y * y))])
+                mean = float(np.sum(mom[:, 1]) / spec['rows'])
+                var = float(np.sum(mom[:, 2]) / spec['rows'] - mean * mean)
+                hypers = dict(b=var * (4 + 1), btau=abs(mean) / var * (4 + 1))
+                clean_kw = dict(clean=True, normalize=False)
+            model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **hypers,
+                                      **spec['fit'])
+            model._backend_override = backend
+            t0 = time.perf_counter()
+            model._prepare_fit(x, y, clean_kw)                # format, normalise, defaults, H2D upload (untimed)
+            prep_s += time.perf_counter() - t0
+            fits.append((model, backend, x, y, spec, n_local))
+    spec0 = fits[0][4]
+    n, m = spec0['rows'], spec0['inputs']
+
+    def one_step():
+        stats = []
+        for model, backend, _, _, spec, n_local in fits:
+            np.random.seed(spec['seed_fit'])
+            if mode == 'rows':
+                model._search(backend, n_local, m, n_global=spec['rows'], row_sharded=True)
+            elif mode == 'candidates' and use_rccl:
+                model._search(backend, n_local, m, comm=comm, candidate_sharded=True)
+            else:
+                model._search(backend, n_local, m)
+            backend.ctx.sync()
+            stats.append(model.fit_stats)
+        return stats
 
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model = FoKLRoutines.FoKL(kernel='Bernoulli Polynomials', UserWarnings=False, ConsoleOutput=False, **hypers)
-        t0 = time.perf_counter()
-        # format, normalise, defaults, H2D upload (untimed); a shard must not be rescaled by its own min / max
-        model._prepare_fit(x, y, dict(clean=True, normalize=False) if rows_mode else dict(clean=True))
-        prep_s = time.perf_counter() - t0
-
-        def one_step():
-            np.random.seed(seed_fit)
-            if rows_mode:
-                model._search(backend, x.shape[0], m, n_global=n, row_sharded=True)
-            else:
-                model._search(backend, n, m)
-            ctx.sync()
-            return model.fit_stats
-
         for _ in range(args.warmup):
             one_step()
-
-        ctx.timing_enable(True)
-        ctx.timing_reset()
+        for _, backend, *_ in fits:
+            backend.ctx.timing_enable(True)
+            backend.ctx.timing_reset()
         comm.barrier()
         ctx.sync()
         t0 = time.perf_counter()
         logical = physical = calls = 0
         host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
-                    pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0)
+                    pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0, spectral_remote=0,
+                    exchanges=0)
         for _ in range(args.steps):
-            st = one_step()
-            logical += st['terms_logical']
-            physical += st['terms_physical']
-            calls += st['gibbs_calls']
-            for key in host:
-                host[key] += st.get(key, 0)
+            for st in one_step():
+                logical += st['terms_logical']
+                physical += st['terms_physical']
+                calls += st['gibbs_calls']
+                for key in host:
+                    host[key] += st.get(key, 0)
         ctx.sync()
         comm.barrier()
         elapsed = time.perf_counter() - t0
-        ctx.timing_enable(False)
+        end_state = np.random.get_state()
+        for _, backend, *_ in fits:
+            backend.ctx.timing_enable(False)
 
-    kern = {name: ctx.timing_get(kid) for name, kid in
-            (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID))}
+    kern = {}
+    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID),
+                      ('resid_matrix_free', _capi.K_RESID_MF)):
+        tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
+        for _, backend, *_ in fits:
+            t = backend.ctx.timing_get(kid)
+            for key in tot:
+                tot[key] += t[key]
+        kern[name] = tot
+
+    # ---- parity of what was just timed (rank 0, first fit of the step) against the oracle's golden ----------------
+    parity_checked, parity = False, None
+    if rank == 0 and not args.no_parity and mode != 'rows':
+        model0 = fits[0][0]
+        key = (cfg, units[0], n)
+        if key in GOLDENS and not GOLDENS[key][1] and not args.inputs and \
+                os.path.exists(os.path.join(ROOT, 'tests', 'golden', GOLDENS[key][0] + '.npz')):
+            state = end_state if fits_per_step == 1 else None
+            if state is None:                                  # several fits per step: rerun the first one on its own
+                np.random.seed(spec0['seed_fit'])
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    model0._search(fits[0][1], n, m)
+                state = np.random.get_state()
+            parity = compare_with_golden(GOLDENS[key][0], model0, model0.betas, model0.mtx, model0.evs, state)
+            parity['workload'] = 'the timed fit itself (last step)'
+            parity_checked = True
+        elif cfg == 3 and not args.inputs and world == 1:
+            # no oracle can run configs[3] at N = 1e6 with 2000 Gibbs iterations on 585-column models: the golden is
+            # the same family at the largest size it finishes (N = 1e5, burnin 30 + draws 30) -- fitted here, untimed
+            name, over = GOLDENS[(3, 0, 100_000)]
+            if os.path.exists(os.path.join(ROOT, 'tests', 'golden', name + '.npz')):
+                xs, ys, sp = config_workload(3, 0, 100_000)
+                kernel, phis, _ = kernel_and_phis(sp)
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    side = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False)
+                    side._backend_override = engine.HipBackend(_capi.DeviceContext(local))
+                    np.random.seed(sp['seed_fit'])
+                    sb, sm, se = side.fit(xs, ys, clean=True, **sp['fit'], **over)
+                parity = compare_with_golden(name, side, sb, sm, se, np.random.get_state())
+                parity['workload'] = 'configs[3] family at N=1e5, burnin 30 + draws 30 (largest the oracle finishes), ' \
+                                     'fitted after the timed region'
+                parity_checked = True
+                side._backend_override.ctx.close()
 
     # Outside the timed region: the basis-build kernel back to back on the workload's three sub-stage shapes.
     # Inside a fit the GPU idles between launches (the fit is bound by the serial random stream on the host), so the
     # in-situ average above is taken at idle clocks; this is the same kernel at sustained clocks.
     hot = {}
-    if rank == 0 and not args.no_microbench:
-        from fokl_gpy_amd import engine
+    if rank == 0 and not args.no_microbench and m >= 2:
         ctx.timing_enable(True)
-        ctx.reserve_slots(2 + 56)
-        for label, pattern in (('T=8 (1)', [1, 0]), ('T=28 (1,1)', [1, 1]), ('T=56 (2,1)', [2, 1])):
+        ctx.reserve_slots(2 + 2 * m * (m - 1))
+        for label, pattern in ((f'T={m} (1)', [1, 0]), (f'T={m * (m - 1) // 2} (1,1)', [1, 1]),
+                               (f'T={m * (m - 1)} (2,1)', [2, 1])):
+            if max(pattern) > len(fits[0][0].phis):
+                continue
             terms = engine.distinct_arrangements(pattern + [0] * (m - 2)).astype(np.int32)
             slots = np.arange(2, 2 + terms.shape[0], dtype=np.int32)
             for _ in range(3):
@@ -272,11 +449,12 @@ def main():
         comm.close()
         return
     t_max = float(np.max(gathered[:, 0]))
-    if rows_mode:                                           # every rank ran the same search on its rows: count it once
+    if one_fit_for_all:                                     # every rank ran the same search: count it once
         tot_logical, tot_physical = float(gathered[0, 1]), float(gathered[0, 2])
     else:
         tot_logical = float(np.sum(gathered[:, 1]))
         tot_physical = float(np.sum(gathered[:, 2]))
+    fits_total = (1 if one_fit_for_all else world) * fits_per_step * max(args.steps, 1)
 
     def roof(name, bound):
         k = kern[name]
@@ -287,13 +465,26 @@ def main():
             achieved = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
             return dict(kernel=name, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=achieved / HBM_PEAK_GBS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
-                        total_ms=k['ms'])
+                        total_ms=k['ms'], algorithmic_bytes_per_launch=k['bytes'] / k['launches'])
         achieved = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
         return dict(kernel=name, bound='mfma', achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                     frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
                     total_ms=k['ms'])
 
-    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm')}
+    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm'),
+               'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
+    mf = kernels['resid_matrix_free']
+    if mf:
+        # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns
+        # costs more time at the fp64 peak (FMA = 2 flops; most of its operations are separately-rounded multiplies
+        # and adds, i.e. half of that at best) than its 8 N (M_used + 1) bytes cost at the HBM peak
+        k = kern['resid_matrix_free']
+        tf = k['flops'] / k['launches'] / (mf['avg_ms'] * 1e-3) / 1e12
+        mf.update(fp64_valu_tflops=tf, fp64_valu_frac=tf / FP64_MFMA_PEAK_TFLOPS,
+                  roofline_frac=k['ideal_ms'] / k['ms'])
+        if k['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > k['bytes'] / (HBM_PEAK_GBS * 1e9):
+            mf.update(bound='valu-fp64', achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                      frac=tf / FP64_MFMA_PEAK_TFLOPS, hbm_achieved_gbs=mf['achieved'], hbm_frac=mf['frac'])
     if kernels['gram']:
         # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings
         gm = roof('gram', 'mfma')
@@ -301,20 +492,33 @@ def main():
         kernels['gram']['mfma_frac'] = gm['frac']
         # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
         kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
-    # HBM traffic per launch from the committed PMC passes of this same workload (profiles/pmc_r01.json, produced by
-    # tools/profile_r01.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note).
-    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_r01.json')
-    if os.path.exists(pmc_path):
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
+    # rocprofv3 --pmc passes over this same command (profiles/pmc_r02.json, produced by tools/profile_r02.sh: separate
+    # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
+    # was recorded for exactly this workload.
+    traffic_source = None
+    for cand in ('pmc_r02.json', 'pmc_r01.json'):
+        pmc_path = os.path.join(ROOT, 'profiles', cand)
+        if not os.path.exists(pmc_path):
+            continue
         with open(pmc_path) as fh:
             pmc = json.load(fh)
-        if pmc.get('workload') == {'rows': n, 'inputs': m}:
+        if pmc.get('workload') in ({'rows': n, 'inputs': m}, {'rows': n, 'inputs': m, 'config': cfg}) and cfg == 2:
             for name, k in kernels.items():
                 if k and name in pmc['kernels']:
                     k['traffic'] = pmc['kernels'][name]['hbm_bytes_per_launch']
-                    k['algorithmic_bytes_per_launch'] = kern[name]['bytes'] / kern[name]['launches']
+            traffic_source = f'profiles/{cand}: rocprofv3 --pmc passes over this command, committed with the sources; ' \
+                             f'not re-measured in this run'
+            break
     dominant = max((k for k in kernels.values() if k), key=lambda k: k['total_ms'])
+    dominant = dict(dominant, traffic_source=traffic_source)
     gpu_ms = sum(k['total_ms'] for k in kernels.values() if k)
 
+    parallelism = 'single GPU'
+    if world > 1:
+        parallelism = {'fits': f'independent fits x{world}', 'rows': f'rows sharded x{world}, RCCL all-reduce of Gram '
+                       f'blocks', 'candidates': f'candidate models sharded x{world}, RCCL all-gather of per-candidate '
+                       f'BIC + spectral factors'}[mode]
     line = {
         'metric': 'candidate-terms/sec (basis build + Gibbs + BIC)',
         'value': tot_logical / t_max,
@@ -324,18 +528,21 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * t_max / max(args.steps, 1),
         'higher_is_better': True,
-        'scaling': 'strong' if rows_mode else 'weak',
+        'scaling': 'strong' if one_fit_for_all else 'weak',
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': f'configs[2]: synthetic N={n}, M={m}, Bernoulli Polynomials, 2-way interactions, '
-                               f'burnin 1000 + draws 1000, one full forward-selection fit per step',
-                   'rows': n, 'inputs': m, 'parallelism': (f'rows sharded x{world}, RCCL all-reduce of Gram blocks' if rows_mode else
-                                   f'independent fits x{world}') if world > 1 else 'single GPU',
+        'config': {'workload': spec0['label'] + (f', {fits_per_step} fits per rank and step' if cfg == 4 else
+                                                 ', one full forward-selection fit per step'),
+                   'config_index': cfg, 'rows': n, 'inputs': m, 'parallelism': parallelism,
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
-        'terms_logical_per_step': tot_logical / (1 if rows_mode else world) / max(args.steps, 1),
-        'terms_physical_per_step': tot_physical / (1 if rows_mode else world) / max(args.steps, 1),
-        'gibbs_calls_per_step': float(np.sum(gathered[:, 3])) / world / max(args.steps, 1),
+        'value_physical': tot_physical / t_max,
+        'parity_checked': parity_checked,
+        'parity': parity,
+        'fits_per_s': fits_total / t_max,
+        'terms_logical_per_fit': tot_logical / fits_total,
+        'terms_physical_per_fit': tot_physical / fits_total,
+        'gibbs_calls_per_fit': float(np.sum(gathered[:, 3])) / world / (fits_per_step * max(args.steps, 1)),
         'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
         'host_prepare_s': prep_s,
         'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
@@ -346,11 +553,14 @@ def main():
         'device_sustains': sustained,
     }
     if not args.no_cpu_baseline:
-        line['cpu_baseline'] = cpu_baseline(x, y)
+        line.update(cpu_baselines(fits[0][2], fits[0][3], spec0))
     comm.close()
     dist.flush_c_streams()
     sys.stderr.flush()
     print(json.dumps(line), flush=True)          # the ONE JSON line, last thing on stdout
+    if parity_checked and not parity['ok']:
+        print(f"bench.py: PARITY MISMATCH against {parity['golden']}: {parity}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -546,14 +546,17 @@ class FoKL:
         self._upload(backend, inputs, data)
         return backend, np.shape(inputs)[0], np.shape(inputs)[1]
 
-    def _search(self, backend, n, m, n_global=None, row_sharded=False):
-        """Forward selection on the dataset currently resident on ``backend`` (the timed region of bench.py)."""
+    def _search(self, backend, n, m, n_global=None, row_sharded=False, comm=None, candidate_sharded=False):
+        """Forward selection on the dataset currently resident on ``backend`` (the timed region of bench.py).
+        ``comm`` + ``candidate_sharded``: every rank of the communicator calls this on the same dataset with the same
+        numpy stream; candidate models are dealt over the ranks (engine.ForwardSelection)."""
         stream = _capi.LegacyStream()
         search = _engine.ForwardSelection(
             backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
             self.burnin + self.draws, self.draws, self.gimmie, self.way3, self.threshav, self.threshstda,
-            self.threshstdb, self.aic, stream, console=self.ConsoleOutput, comm=getattr(self, '_comm', None),
-            row_sharded=row_sharded, n_global=n_global)
+            self.threshstdb, self.aic, stream, console=self.ConsoleOutput,
+            comm=comm if comm is not None else getattr(self, '_comm', None),
+            row_sharded=row_sharded, n_global=n_global, candidate_sharded=candidate_sharded)
         t0 = time.perf_counter()
         try:
             with _host_blas_threads():

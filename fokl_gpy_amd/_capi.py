@@ -14,7 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.so'))   # override: A/B builds
 
 UNIQUE_ID_BYTES = 128
-K_BASIS, K_GRAM, K_RESID, K_PREDICT = 0, 1, 2, 3
+K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF = 0, 1, 2, 3, 4
+RESID_TERMS_MAX_FACTORS = 48
+RESID_TERMS_MAX_ORDER = 8
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
 
 c_int, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
@@ -37,6 +39,7 @@ SIGNATURES = {
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
     'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_bic_resid_fetch': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_bic_resid_terms_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_predict': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     'fokl_read_slot': (c_int, [c_vp, c_int, c_i64, c_i64, c_vp]),
     'fokl_write_slot': (c_int, [c_vp, c_int, c_i64, c_i64, c_vp]),
@@ -354,8 +357,13 @@ class SpectralResult:
     moments (sum r, sum r^2) of y - X betahat formed from the Gram."""
     __slots__ = ('lamb', 'Qt', 'qty', 'betahat', 'moments', '_buf', '_addr')
 
-    def __init__(self, p1):
-        buf = self._buf = np.empty(p1 * (p1 + 3) + 2, dtype=np.float64)
+    @staticmethod
+    def doubles(p1):
+        return p1 * (p1 + 3) + 2
+
+    def __init__(self, p1, buf=None):
+        """buf: an existing float64 buffer of doubles(p1) values holding a result computed elsewhere (another rank)."""
+        buf = self._buf = np.empty(p1 * (p1 + 3) + 2, dtype=np.float64) if buf is None else buf
         self._addr = buf.__array_interface__['data'][0]
         self.lamb, self.qty, self.betahat = buf[:p1], buf[p1:2 * p1], buf[2 * p1:3 * p1]
         self.Qt = buf[3 * p1:3 * p1 + p1 * p1].reshape(p1, p1)
@@ -520,6 +528,15 @@ class DeviceContext:
         if s.shape[0] != bh.shape[0]:
             raise ValueError("one coefficient per column")
         self._ck(self._lib.fokl_bic_resid_launch(self._h, _ptr(s), s.shape[0], _ptr(bh)))
+
+    def bic_resid_terms_launch(self, terms, betahat):
+        """Matrix-free residual pass of the model [intercept] + terms (rows of the interaction matrix)."""
+        terms = np.ascontiguousarray(terms, dtype=np.int32)
+        beta = np.ascontiguousarray(np.reshape(betahat, -1), dtype=np.float64)
+        n_terms = terms.shape[0] if terms.size else 0
+        if beta.shape[0] != n_terms + 1:
+            raise ValueError("betahat needs one coefficient for the intercept and one per term")
+        self._ck(self._lib.fokl_bic_resid_terms_launch(self._h, _ptr(terms), n_terms, _ptr(beta)))
 
     def bic_resid_fetch(self, allreduce=False):
         out = np.empty(2, dtype=np.float64)

@@ -57,6 +57,7 @@ struct fokl_ctx {
     double *d_x = nullptr;      // [m][ld]
     double *d_zero = nullptr;   // [ld] zeros: stands in for padding columns of Gram panels
     double *d_phis = nullptr;
+    std::vector<double> h_phis;  // host copy of the coefficient table (launch planning of the matrix-free K3)
     size_t phis_doubles = 0;
 
     // slots
@@ -415,6 +416,7 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_zero, (size_t)ctx->ld * sizeof(double)));
     HIP_TRY(ctx, hipMemset(ctx->d_zero, 0, (size_t)ctx->ld * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_phis, phis, ctx->phis_doubles * sizeof(double), hipMemcpyHostToDevice));
+    ctx->h_phis.assign(phis, phis + ctx->phis_doubles);
 
     ctx->have_data = true;
     int rc = fokl_reserve_slots(ctx, fokl_ctx::CHUNK_SLOTS);
@@ -664,6 +666,7 @@ static int build_terms_impl(fokl_ctx *ctx, const int32_t *terms, int T, const in
 // ---------------------------------------------------------------------------------------------------------
 
 extern "C" int fokl_comm_allreduce_sum_f64(fokl_ctx *ctx, double *buf, int count);
+static int comm_allreduce_device(fokl_ctx *ctx, double *d_buf, size_t count);   // fokl_comm.inc: in place, on the stream
 
 // Output elements handled by one 256-thread block of the slab reduction: few elements -> many parts per element.
 static int reduce_elements_per_block(int total)
@@ -818,14 +821,16 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
                            ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, ctx->d_out);
         HIP_TRY(ctx, hipGetLastError());
     }
+    // row-sharded fit: the block is summed over the ranks where it lies -- RCCL on d_out, stream-ordered behind the
+    // reduction kernel -- and crosses PCIe once
+    if (allreduce && ctx->comm) {
+        rc = comm_allreduce_device(ctx, ctx->d_out, (size_t)nr * nc);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nr * nc * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(out, ctx->h_out, (size_t)nr * nc * sizeof(double));
-    if (allreduce && ctx->comm) {
-        rc = fokl_comm_allreduce_sum_f64(ctx, out, nr * nc);
-        if (rc) return rc;
-    }
     return FOKL_OK;
 }
 
@@ -876,19 +881,164 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
     return FOKL_OK;
 }
 
+typedef void (*resid_terms_fn)(const double *, int64_t, int64_t, const double *, int, const ResidTermsHeader *,
+                               const d2 *, int, const double *, double *);
+
+static resid_terms_fn pick_resid_terms(bool splines, int U)
+{
+    if (splines) {
+        if (U <= 16) return resid_terms_kernel<true, 1, 2>;
+        if (U <= 32) return resid_terms_kernel<true, 2, 1>;
+        return resid_terms_kernel<true, 3, 1>;
+    }
+    if (U <= 16) return resid_terms_kernel<false, 1, 2>;
+    if (U <= 32) return resid_terms_kernel<false, 2, 1>;
+    return resid_terms_kernel<false, 3, 1>;
+}
+
+extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: null context");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_terms_launch: call fokl_upload first");
+    if (n_terms < 0 || !betahat || (n_terms > 0 && !terms))
+        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: null pointer");
+    if (ctx->resid_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_terms_launch: previous launch not fetched");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int m = ctx->m;
+    const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
+
+    // distinct (input, order) factors, ordered by input then order (std::map order, as in launch_basis)
+    std::map<std::pair<int, int>, int> fac_id;
+    for (int j = 0; j < n_terms; ++j) {
+        int nz = 0;
+        for (int k = 0; k < m; ++k) {
+            const int o = terms[(size_t)j * m + k];
+            if (o < 0 || o > ctx->n_basis)
+                return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: basis order " + std::to_string(o) +
+                                                   " outside [0, " + std::to_string(ctx->n_basis) + "]");
+            if (o != 0) {
+                if (!splines && o > RT_MAX_ORDER)
+                    return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: Bernoulli order " + std::to_string(o) +
+                                                       " beyond " + std::to_string(RT_MAX_ORDER) +
+                                                       " (FOKL_RESID_TERMS_MAX_ORDER)");
+                fac_id.emplace(std::make_pair(k, o), 0);
+                ++nz;
+            }
+        }
+        if (nz == 0) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: term with no input (all-zero row)");
+        if (nz > 3)
+            return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: a term has more than three factors");
+    }
+    int U = 0;
+    for (auto &kv : fac_id) kv.second = U++;
+    if (U > FOKL_RESID_TERMS_MAX_FACTORS)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: model has " + std::to_string(U) +
+                                           " distinct (input, order) factors, limit " +
+                                           std::to_string(FOKL_RESID_TERMS_MAX_FACTORS));
+    int G = 0;
+    {
+        int last = -1;
+        for (auto &kv : fac_id)
+            if (kv.first.first != last) {
+                last = kv.first.first;
+                ++G;
+            }
+    }
+    const int T = n_terms + 1;
+    const size_t table_bytes = (size_t)T * sizeof(ResidTerm) + (size_t)std::max(G, 1) * sizeof(ResidGroup) +
+                               (size_t)U * RT_COEF_STRIDE * sizeof(double);
+    if (table_bytes > 60 * 1024)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: model too large for the tables in LDS");
+
+    const size_t tables_off = (sizeof(ResidTermsHeader) + 15) & ~(size_t)15;
+    const size_t arg_bytes = tables_off + table_bytes;
+    int rc = begin_args(ctx, arg_bytes);
+    if (rc) return rc;
+    ResidTermsHeader *hdr = reinterpret_cast<ResidTermsHeader *>(ctx->h_args);
+    hdr->n_fac = U;
+    hdr->n_terms = T;
+    hdr->n_groups = G;
+    hdr->pad = 0;
+    ResidTerm *recs = reinterpret_cast<ResidTerm *>(ctx->h_args + tables_off);
+    ResidGroup *groups = reinterpret_cast<ResidGroup *>(recs + T);
+    double *coef = reinterpret_cast<double *>(groups + std::max(G, 1));
+    double flops_per_row = 5.0;
+    {
+        int g = -1;
+        for (auto &kv : fac_id) {
+            const int k = kv.first.first, o = kv.first.second, u = kv.second;
+            if (g < 0 || groups[g].input != k) {
+                if (g >= 0) flops_per_row += 8.0 * std::max(0, groups[g].omax - 1);   // the double-double power chain
+                ++g;
+                groups[g] = ResidGroup{k, u, 0, 0};
+            }
+            groups[g].count += 1;
+            groups[g].omax = std::max(groups[g].omax, o);
+            double *row = coef + (size_t)u * RT_COEF_STRIDE;
+            for (int q = 0; q <= RT_MAX_ORDER; ++q) row[q] = 0.0;
+            if (!splines)
+                for (int q = 0; q <= o; ++q) row[q] = ctx->h_phis[(size_t)(o - 1) * ctx->width + q];
+            row[9] = (double)o;
+            flops_per_row += splines ? 14.0 : 2.0 * o;
+        }
+        if (g >= 0) flops_per_row += 8.0 * std::max(0, groups[g].omax - 1);
+        if (G == 0) groups[0] = ResidGroup{0, 0, 0, 0};
+    }
+    recs[0] = ResidTerm{betahat[0], 0u, 0};
+    for (int j = 0; j < n_terms; ++j) {
+        uint32_t packed = 0;
+        int cnt = 0;
+        for (int k = 0; k < m; ++k) {
+            const int o = terms[(size_t)j * m + k];
+            if (o != 0) packed |= (uint32_t)fac_id[std::make_pair(k, o)] << (8 * cnt++);
+        }
+        recs[j + 1] = ResidTerm{betahat[j + 1], packed, cnt};
+        flops_per_row += cnt + 1;
+    }
+    rc = push_args(ctx, arg_bytes);
+    if (rc) return rc;
+
+    const int64_t n_row_blocks = (ctx->n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, (int64_t)cu_count(ctx) * 8));
+    rc = ensure_slab(ctx, (size_t)S * 2);
+    if (rc) return rc;
+    rc = ensure_out(ctx, 2);
+    if (rc) return rc;
+    resid_terms_fn fn = pick_resid_terms(splines, U);
+    {
+        {
+            TimedRegion timed(ctx, FOKL_K_RESID_MF, 8.0 * (double)ctx->n * (double)(G + 1),
+                              (double)ctx->n * flops_per_row);
+            hipLaunchKernelGGL(fn, dim3(S), dim3(RS_THREADS), table_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n,
+                               ctx->d_phis, ctx->width, reinterpret_cast<const ResidTermsHeader *>(ctx->d_args),
+                               reinterpret_cast<const d2 *>(ctx->d_args + tables_off), (int)(table_bytes / sizeof(d2)),
+                               ctx->slot_ptr[FOKL_SLOT_Y], ctx->d_slab);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
+                           2, ctx->d_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->resid_pending = true;
+    return FOKL_OK;
+}
+
 extern "C" int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce)
 {
     if (!ctx || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_fetch: null pointer");
     if (!ctx->resid_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_bic_resid_fetch: nothing was launched");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->resid_pending = false;
+    if (allreduce && ctx->comm) {
+        // the launch left this rank's two moments in d_out: sum them over the ranks there, copy again
+        int rc = comm_allreduce_device(ctx, ctx->d_out, 2);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_out[0];
     out[1] = ctx->h_out[1];
-    if (allreduce && ctx->comm) {
-        int rc = fokl_comm_allreduce_sum_f64(ctx, out, 2);
-        if (rc) return rc;
-    }
     return FOKL_OK;
 }
 

@@ -699,4 +699,271 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// K3, matrix-free: the same residual moments without reading the basis columns back
+// ---------------------------------------------------------------------------------------------------------
+//
+// A residual pass over stored columns reads 8 N (P + 2) bytes; the columns are products of a handful of basis
+// functions of the inputs, and the inputs (8 N M_used bytes, often resident in the 256 MB Infinity Cache) are all it
+// takes to form them again.  Every lane owns the same two consecutive rows as in resid_kernel, evaluates the U distinct
+// (input, order) factors of the model once -- same separately-rounded operations as K1, so the column values are the
+// stored columns' bit for bit -- keeps them in VGPRs (wave-uniform indices -> s_set_gpr_idx, no scratch), and
+// accumulates fit = fma(beta_j, column_j, fit) in column order exactly like resid_kernel: the two kernels return the
+// same bits (tests/test_gpu_parity.py).  The power chain RN(x**j) of an input is shared by all its orders.
+//
+// Per-term records and the flattened factor lists sit in LDS (wave-uniform broadcast reads).
+
+// Everything the kernel needs to know about the model sits in LDS in fixed-size records, so that no step of the
+// per-row work waits on a dependent chain of scalar loads:
+struct ResidTerm {           // one model column (16 bytes: one broadcast ds_read_b128)
+    double beta;
+    uint32_t fac;            // up to three factor indices, 8 bits each, in ascending input order
+    int cnt;                 // number of factors (0 = the intercept column of ones)
+};
+
+struct ResidGroup {          // the factors of one input: first .. first + count - 1, orders ascending
+    int input;
+    int first;
+    int count;
+    int omax;                // largest order of the group
+};
+
+constexpr int RT_MAX_ORDER = 8;            // Bernoulli orders the matrix-free pass handles (coefficient row: 9 doubles)
+constexpr int RT_COEF_STRIDE = 10;         // doubles per factor: c[0 .. 8] + the order (as a double), 16-byte aligned rows
+
+struct ResidTermsHeader {
+    int n_fac;       // U distinct (input, order) factors, sorted by input then order
+    int n_terms;     // model columns, intercept included
+    int n_groups;    // inputs used
+    int pad;
+    // followed, each 16-byte aligned, by ResidTerm[n_terms], ResidGroup[n_groups], double coef[U][RT_COEF_STRIDE]
+    // (splines: coef[v][9] = order only)
+};
+
+// The per-lane factor table: banks of 16 doubles, each small enough for hipcc to keep in VGPRs and index with
+// s_set_gpr_idx (one 32- or 48-entry array goes to scratch instead); the bank is picked by a wave-uniform branch.
+// (Each arm carries its own empty volatile asm: arms that differ and cannot be speculated stay branches.  Merged into
+// a select between the banks' addresses -- which is what the optimiser makes of a plain if / else -- the arrays can no
+// longer be promoted to registers and land in scratch memory.)
+// R = rows a lane works on at once.  Every lane owns two consecutive rows, as in resid_kernel; with one bank it takes
+// both together (R = 2: every table read serves two rows), with two or three banks one after the other (R = 1: half
+// the registers, twice the wavefronts per SIMD -- this kernel lives on latency hiding, not on VALU throughput).
+#define FOKL_FAC_GET(u, out)                                                                                \
+    do {                                                                                                    \
+        const int b_ = (u) >> 4;                                                                            \
+        if (NB == 1 || b_ == 0) {                                                                           \
+            out[0] = fx0[(u) & 15];                                                                         \
+            if (R == 2) out[R - 1] = fy0[(u) & 15];                                                         \
+            asm volatile("; bank 0" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
+        } else if (NB == 2 || b_ == 1) {                                                                    \
+            out[0] = fx1[(u) & 15];                                                                         \
+            if (R == 2) out[R - 1] = fy1[(u) & 15];                                                         \
+            asm volatile("; bank 1" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
+        } else {                                                                                            \
+            out[0] = fx2[(u) & 15];                                                                         \
+            if (R == 2) out[R - 1] = fy2[(u) & 15];                                                         \
+            asm volatile("; bank 2" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
+        }                                                                                                   \
+    } while (0)
+#define FOKL_FAC_SET(u, val)                                                                                \
+    do {                                                                                                    \
+        const int b_ = (u) >> 4;                                                                            \
+        if (NB == 1 || b_ == 0) {                                                                           \
+            fx0[(u) & 15] = val[0];                                                                         \
+            if (R == 2) fy0[(u) & 15] = val[R - 1];                                                         \
+            asm volatile("; bank 0");                                                                       \
+        } else if (NB == 2 || b_ == 1) {                                                                    \
+            fx1[(u) & 15] = val[0];                                                                         \
+            if (R == 2) fy1[(u) & 15] = val[R - 1];                                                         \
+            asm volatile("; bank 1");                                                                       \
+        } else {                                                                                            \
+            fx2[(u) & 15] = val[0];                                                                         \
+            if (R == 2) fy2[(u) & 15] = val[R - 1];                                                         \
+            asm volatile("; bank 2");                                                                       \
+        }                                                                                                   \
+    } while (0)
+
+template <int R>
+__device__ __forceinline__ void load_rows(const double *p, double (&out)[R])
+{
+    if (R == 2) {
+        const d2 v = load_d2(p);
+        out[0] = v.x;
+        out[R - 1] = v.y;
+    } else {
+        out[0] = *(global_d_ptr)(p);
+    }
+}
+
+template <bool SPLINES, int NB, int R>
+__global__ __launch_bounds__(RS_THREADS) void resid_terms_kernel(
+    const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
+    const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
+    const double *__restrict__ y, double *__restrict__ slab)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    __shared__ double red[RS_THREADS / WAVE][2];
+    const int T = hdr->n_terms, G = hdr->n_groups;
+    const int tid = threadIdx.x;
+    {
+        d2 *dst = reinterpret_cast<d2 *>(lds_raw);
+        for (int i = tid; i < table_d2s; i += RS_THREADS) dst[i] = tables[i];
+    }
+    const ResidTerm *terms = reinterpret_cast<const ResidTerm *>(lds_raw);
+    const ResidGroup *groups = reinterpret_cast<const ResidGroup *>(terms + T);
+    const double *coef = reinterpret_cast<const double *>(groups + G);
+    __syncthreads();
+
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t n_tiles = (n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r = (tile * RS_THREADS + tid) * 2;
+        const bool in0 = r < n, in1 = r + 1 < n;
+        if (!in0) continue;                                     // ld is a multiple of 64 rows: the pair stays in bounds
+        double resid[2] = {0.0, 0.0};
+#pragma unroll 1
+        for (int pass = 0; pass < 2 / R; ++pass) {
+            const int64_t rr = r + pass;                        // first row of this pass
+            double fx0[16], fy0[R == 2 ? 16 : 1], fx1[NB > 1 ? 16 : 1], fy1[NB > 1 && R == 2 ? 16 : 1];
+            double fx2[NB > 2 ? 16 : 1], fy2[NB > 2 && R == 2 ? 16 : 1];
+            double x_next[R];
+            load_rows<R>(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[0].input) * ld + rr, x_next);
+            for (int g = 0; g < G; ++g) {
+                const ResidGroup gr = groups[g];
+                const int first = __builtin_amdgcn_readfirstlane(gr.first);
+                const int count = __builtin_amdgcn_readfirstlane(gr.count);
+                const int omax = __builtin_amdgcn_readfirstlane(gr.omax);
+                double x[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) x[q] = x_next[q];
+                if (g + 1 < G)                                  // the next input is on its way while this one is worked on
+                    load_rows<R>(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[g + 1].input) * ld + rr, x_next);
+                if (SPLINES) {
+                    int piece[R];
+                    double t[R];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) spline_locate(x[q], width, false, piece[q], t[q]);
+                    for (int v = first; v < first + count; ++v) {
+                        const int order = __builtin_amdgcn_readfirstlane((int)coef[(size_t)v * RT_COEF_STRIDE + 9]);
+                        const global_d_ptr sl = (global_d_ptr)(phis + (size_t)(order - 1) * 4 * width);
+                        double c[R][4];
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) c[q][e] = sl[e * width + piece[q]];
+                        double val[R];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) val[q] = cubic_basis(c[q][0], c[q][1], c[q][2], c[q][3], t[q]);
+                        FOKL_FAC_SET(v, val);
+                    }
+                } else {
+                    // RN(x**j), j = 1 .. omax, once per input (double-double chain, as bernoulli_basis forms them)
+                    double pw[RT_MAX_ORDER + 1][R];
+                    {
+                        double ph[R], pl[R];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) {
+                            pw[1][q] = ph[q] = x[q];
+                            pl[q] = 0.0;
+                        }
+#pragma unroll
+                        for (int j = 2; j <= RT_MAX_ORDER; ++j) {
+                            if (j <= omax) {
+#pragma unroll
+                                for (int q = 0; q < R; ++q) dd_mul_d(ph[q], pl[q], x[q]);
+                            }
+#pragma unroll
+                            for (int q = 0; q < R; ++q) pw[j][q] = ph[q];
+                        }
+                    }
+                    // c0 + sum_{j>=1} c_j RN(x**j), the sum taken from 0 in ascending j with every product and addition
+                    // rounded (bernoulli_basis); the coefficient row of a factor is five broadcast 16-byte LDS reads
+                    for (int v = first; v < first + count; ++v) {
+                        const d2 *row = reinterpret_cast<const d2 *>(coef + (size_t)v * RT_COEF_STRIDE);
+                        const d2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3], c8o = row[4];
+                        const int order = __builtin_amdgcn_readfirstlane((int)c8o.y);
+                        const double c[RT_MAX_ORDER + 1] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y, c8o.x};
+                        double val[R];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) val[q] = c[1] * pw[1][q];
+#pragma unroll
+                        for (int j = 2; j <= RT_MAX_ORDER; ++j)
+                            if (j <= order) {
+#pragma unroll
+                                for (int q = 0; q < R; ++q) val[q] = val[q] + c[j] * pw[j][q];
+                            }
+#pragma unroll
+                        for (int q = 0; q < R; ++q) val[q] = c[0] + val[q];
+                        FOKL_FAC_SET(v, val);
+                    }
+                }
+            }
+
+            double fit[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) fit[q] = 0.0;
+#define FOKL_APPLY_TERM(t)                                                                   \
+    do {                                                                                     \
+        const int cnt_ = __builtin_amdgcn_readfirstlane((t).cnt);                            \
+        const uint32_t fac_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t).fac);        \
+        double p_[R], g_[R];                                                                 \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = 1.0;                           \
+        if (cnt_ > 0) {                                                                      \
+            const int a_ = fac_ & 255;                                                       \
+            FOKL_FAC_GET(a_, p_);                    /* 1 * first factor */                   \
+            if (cnt_ > 1) {                                                                  \
+                const int b2_ = (fac_ >> 8) & 255;                                           \
+                FOKL_FAC_GET(b2_, g_);                                                       \
+                _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = p_[q] * g_[q];         \
+                if (cnt_ > 2) {                                                              \
+                    const int c2_ = (fac_ >> 16) & 255;                                      \
+                    FOKL_FAC_GET(c2_, g_);                                                   \
+                    _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = p_[q] * g_[q];     \
+                }                                                                            \
+            }                                                                                \
+        }                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) fit[q] = __builtin_fma((t).beta, p_[q], fit[q]);  \
+    } while (0)
+            int j = 0;
+            for (; j + 4 <= T; j += 4) {                        // four records in flight per wait
+                const ResidTerm ta = terms[j], tb = terms[j + 1], tc = terms[j + 2], td = terms[j + 3];
+                FOKL_APPLY_TERM(ta);
+                FOKL_APPLY_TERM(tb);
+                FOKL_APPLY_TERM(tc);
+                FOKL_APPLY_TERM(td);
+            }
+            for (; j < T; ++j) {
+                const ResidTerm ta = terms[j];
+                FOKL_APPLY_TERM(ta);
+            }
+#undef FOKL_APPLY_TERM
+            double yv[R];
+            load_rows<R>(y + rr, yv);
+#pragma unroll
+            for (int q = 0; q < R; ++q) resid[pass * R + q] = yv[q] - fit[q];
+        }
+        const double r0 = resid[0];
+        const double r1 = in1 ? resid[1] : 0.0;
+        s1 += r0 + r1;
+        s2 += r0 * r0 + r1 * r1;
+    }
+    const int wave = tid / WAVE, lane = tid % WAVE;
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < RS_THREADS / WAVE; ++w) s += red[w][tid];
+        slab[(size_t)blockIdx.x * 2 + tid] = s;
+    }
+}
+#undef FOKL_FAC_GET
+#undef FOKL_FAC_SET
+
 }  // namespace fokl

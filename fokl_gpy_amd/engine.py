@@ -120,6 +120,7 @@ class HipBackend:
 
     def upload(self, inputs, data, kernel_id, packed, n_basis, width):
         self.ctx.upload(inputs, data, kernel_id, packed, n_basis, width)
+        self.kernel_id = kernel_id
 
     def reserve_slots(self, count):
         self.ctx.reserve_slots(count)
@@ -144,6 +145,27 @@ class HipBackend:
 
     def bic_resid_fetch(self, allreduce=False):
         return self.ctx.bic_resid_fetch(allreduce)
+
+    def bic_resid_terms_launch(self, terms, betahat):
+        self.ctx.bic_resid_terms_launch(terms, betahat)
+
+    def resid_terms_supported(self, terms):
+        """Can a model made of (a subset of) these terms take the matrix-free residual pass?  (The limits of
+        fokl_bic_resid_terms_launch, include/fokl_hip.h.)"""
+        nz = terms != 0
+        if not nz.any() or int(nz.sum(axis=1).max()) > 3:
+            return False
+        if getattr(self, 'kernel_id', 1) != 0 and int(terms.max()) > _capi.RESID_TERMS_MAX_ORDER:
+            return False
+        k = np.nonzero(terms)[1]
+        n_factors = np.unique(k.astype(np.int64) * 65536 + terms[nz]).shape[0]
+        table = 16 * (terms.shape[0] + 1) + 16 * terms.shape[1] + 80 * n_factors
+        # Measured on MI355X (tools/k3_probe.py, N = 1e6): with at most 16 distinct factors -- one register bank, two rows
+        # per lane -- the matrix-free pass beats the stored-column pass by 1.2 x (37 columns) to 2.5 x (101 columns);
+        # with two banks it breaks even, with three it loses (481 vs 296 us at 201 columns): bank selection and the
+        # one-row-at-a-time passes cost more than the column reads they save.  FOKL_K3_MAX_FACTORS overrides.
+        limit = min(int(os.environ.get('FOKL_K3_MAX_FACTORS', '16')), _capi.RESID_TERMS_MAX_FACTORS)
+        return n_factors <= limit and table <= 60 * 1024
 
     def predict(self, slots, betas, cut=None):
         return self.ctx.predict(slots, betas, cut)
@@ -280,8 +302,15 @@ class HostPipeline:
     The driver thread keeps what needs Python or the device: the sequential decisions, the K1 / K2 / K3 launches.
     """
 
-    def __init__(self, stream, draws):
+    def __init__(self, stream, draws, comm=None):
         self.stream, self.draws = stream, int(draws)
+        # candidate sharding (see ShardedSpectralJob): G2 jobs are dealt over the ranks of `comm` in submission order
+        # (FOKL_CANDIDATE_SHARD_FORCE=1: also in a world of one, so that a 1-GPU box takes the exchange path)
+        forced = os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1'
+        self.comm = comm if comm is not None and (comm.world > 1 or forced) else None
+        self._seq = 0
+        self._windows = {}                  # window (seq // world) -> its jobs whose results have not travelled yet
+        self.remote_results = self.exchanges = 0
         # Tapes (about 1 MB each) are produced by one thread and consumed by others: keep all of them on cores that
         # share an L3 for the duration of the fit, and give the noise thread -- the serial resource -- a physical core
         # to itself (measured on a 2 x 64-core EPYC host).  The native threads inherit the affinity set here; the
@@ -350,9 +379,40 @@ class HostPipeline:
             noise_job.recycle, noise_job.held = [noise_job.held], None
 
     def spectral(self, gram, idx):
-        """Queue G2 for the model made of columns idx of gram; may be called ahead of need (no random numbers)."""
+        """Queue G2 for the model made of columns idx of gram; may be called ahead of need (no random numbers).
+        With a communicator the job runs on ONE rank -- every rank drives the same search and therefore submits the same
+        jobs in the same order, job number s belongs to rank s % world -- and wait() brings the result to all."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
-        return self._track(self.pool.submit_spectral(gram, idx, gram.shape[0] - 1))
+        if self.comm is None:
+            return self._track(self.pool.submit_spectral(gram, idx, gram.shape[0] - 1))
+        seq, self._seq = self._seq, self._seq + 1
+        local = None
+        if seq % self.comm.world == self.comm.rank:
+            local = self._track(self.pool.submit_spectral(gram, idx, gram.shape[0] - 1))
+        job = ShardedSpectralJob(self, seq, idx.shape[0], local)
+        self._windows.setdefault(seq // self.comm.world, []).append(job)
+        return job
+
+    def _exchange(self, window):
+        """One all-gather for the jobs of `window` (world consecutive job numbers: one job per rank) that have been
+        submitted and not exchanged yet: every rank contributes the result it owns -- lamb, Q'Xty, betahat, Q' and the
+        residual moments behind the candidate's BIC, SpectralResult's buffer as it is -- padded to the largest model
+        of the exchange.  Every rank calls this for the same window at the same point of the (replicated) search."""
+        jobs = self._windows.pop(window)
+        length = max(_capi.SpectralResult.doubles(job.p1) for job in jobs)
+        send = np.zeros(length)
+        for job in jobs:
+            if job.local is not None:
+                res = job.local.wait()
+                send[:res._buf.shape[0]] = res._buf
+                job.result = res
+        gathered = self.comm.allgather(send)
+        self.exchanges += 1
+        for job in jobs:
+            if job.result is None:
+                need = _capi.SpectralResult.doubles(job.p1)
+                job.result = _capi.SpectralResult(job.p1, np.array(gathered[job.seq % self.comm.world, :need]))
+                self.remote_results += 1
 
     def chain(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job):
         """Queue the draws of the model whose tape is noise_job's.  Returns (job, raw buffer holding w): the caller
@@ -384,6 +444,20 @@ class HostPipeline:
             except OSError:
                 pass
             self._saved_affinity = None
+
+
+class ShardedSpectralJob:
+    """G2 of one candidate model in a candidate-sharded search: computed by rank seq % world (`local` is that rank's
+    pool job, None elsewhere); wait() returns the SpectralResult on every rank."""
+    __slots__ = ('owner', 'seq', 'p1', 'local', 'result')
+
+    def __init__(self, owner, seq, p1, local):
+        self.owner, self.seq, self.p1, self.local, self.result = owner, seq, p1, local, None
+
+    def wait(self):
+        if self.result is None:
+            self.owner._exchange(self.seq // self.owner.comm.world)
+        return self.result
 
 
 class GibbsOutcome:
@@ -482,7 +556,7 @@ class ForwardSelection:
 
     def __init__(self, backend, n, m, n_phis, a, b, atau, btau, tolerance, draws_total, draws_keep, gimmie, way3,
                  threshav, threshstda, threshstdb, aic, stream, console=False, comm=None, row_sharded=False,
-                 n_global=None):
+                 n_global=None, candidate_sharded=False):
         self.backend = backend
         self.n_local = int(n)
         self.n = int(n_global) if n_global is not None else int(n)
@@ -499,11 +573,24 @@ class ForwardSelection:
         self.console = console
         self.comm = comm
         self.allreduce = bool(row_sharded)
+        # candidate sharding (north_star): every rank holds all rows and drives the same search from the
+        # same random stream; the RNG-free half of every model evaluation -- G2 and the BIC of the speculative kill-test
+        # candidates -- is computed by one rank each and all-gathered (HostPipeline._exchange)
+        self.candidate_sharded = bool(candidate_sharded) and comm is not None and (
+            comm.world > 1 or os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1')
+        if self.candidate_sharded and row_sharded:
+            raise ValueError("a search shards either its rows or its candidates over the ranks, not both")
         self.sigsqd0 = b / (1 + a)          # FR:1371
         self.tausqd0 = btau / (1 + atau)    # FR:1372
         self.pool = SlotPool(backend)
         self.host = None                    # HostPipeline while run() is active (b > 0 only)
         self._async_resid = hasattr(backend, 'bic_resid_launch')
+        # K3 without the stored columns (fokl_bic_resid_terms_launch): the residual pass re-forms the basis columns from
+        # the inputs, 8 N (M_used + 1) bytes instead of 8 N (P + 2).  Decided per sub-stage (every model evaluated in a
+        # sub-stage is a column subset of its full model): FOKL_K3=columns keeps the stored-column pass for A/B runs.
+        self._matrix_free = (hasattr(backend, 'bic_resid_terms_launch') and
+                             os.environ.get('FOKL_K3', 'matrixfree') != 'columns')
+        self._terms_arr = None              # [A, m] int32 terms of the active columns (row 0 = intercept) or None
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
         # next test's tape requested before the decision that the test is run (rewound when it is not; data-driven, so
         # replicated drivers of a row-sharded fit stay in step) -- FOKL_TENTATIVE_TAPES=0 disables, =test forces rewinds
@@ -521,13 +608,19 @@ class ForwardSelection:
         self.kill_bic = os.environ.get('FOKL_KILL_BIC', 'auto')
         if self.kill_bic not in ('auto', 'gram', 'device', 'check'):
             raise ValueError("FOKL_KILL_BIC must be auto, gram, device or check")
+        if self.candidate_sharded:
+            # the candidate's BIC travels with its spectral factors (moments from the Gram, computed by the owner): a
+            # K3 pass per candidate would be replicated on every GPU; and enough G2 jobs must be in flight ahead of the
+            # tests to keep the spectral threads of all ranks busy
+            self.kill_bic = 'gram'
+            self.lookahead = max(self.lookahead, 3 * comm.world)
         self.trace = []                     # one record per gibbs evaluation
         self._outcomes = []                 # pipelined evaluations whose draws sit in pooled buffers (see _retire)
         self._ev_cache = {}                 # model (set of terms) -> its BIC, see _same_model_same_ev
         self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0)
+                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0, resid_matrix_free=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _same_model_same_ev(self, idx, ev):
@@ -573,9 +666,25 @@ class ForwardSelection:
         if on_device:
             cand_slots = [slots[i] for i in idx]
             if self._async_resid:
-                self.backend.bic_resid_launch(cand_slots, spec.betahat)
+                self._launch_resid(cand_slots, idx, spec.betahat)
         ycol = gram.shape[0] - 1
         return spec, idx, cand_slots, gram[ycol, ycol], slots
+
+    def _launch_resid(self, cand_slots, idx, betahat):
+        if self._terms_arr is not None:
+            self.backend.bic_resid_terms_launch(self._terms_arr[idx[1:]], betahat)
+            self.stats['resid_matrix_free'] += 1
+        else:
+            self.backend.bic_resid_launch(cand_slots, betahat)
+
+    def _set_active_terms(self, damtx):
+        """Terms of the active columns of the sub-stage that begins (column 0 = intercept)."""
+        self._active_terms = [()] + [tuple(int(v) for v in row) for row in damtx]
+        self._terms_arr = None
+        if self._matrix_free and damtx.shape[0]:
+            arr = np.ascontiguousarray(damtx, dtype=np.int32)
+            if self.backend.resid_terms_supported(arr):
+                self._terms_arr = np.vstack([np.zeros((1, arr.shape[1]), dtype=np.int32), arr])
 
     def _request_noise(self, p1, tentative=False):
         astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
@@ -653,7 +762,7 @@ class ForwardSelection:
         betahat = Q @ (qty / lamb)                                  # FR:1502-1504
         self.stats['t_eigh'] += time.perf_counter() - t0
         if self._async_resid:
-            self.backend.bic_resid_launch(cand_slots, betahat)
+            self._launch_resid(cand_slots, idx, betahat)
         try:
             w = _capi.gibbs_chain(lamb, qty, astar, atau_star, self.b, self.btau, dtd, self.sigsqd0,
                                   self.tausqd0, self.draws, self.stream)
@@ -833,7 +942,7 @@ class ForwardSelection:
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
         if pipelined:
             try:
-                self.host = HostPipeline(self.stream, self.draws)
+                self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None)
             except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
                 # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
                 # line, only slower
@@ -846,7 +955,8 @@ class ForwardSelection:
             if self.host is not None:
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
-                                  pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'])
+                                  pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'],
+                                  spectral_remote=self.host.remote_results, exchanges=self.host.exchanges)
                 self.host = None
 
     def _patterns(self):
@@ -943,7 +1053,7 @@ class ForwardSelection:
             vm = vecs.shape[0]
             damtx = np.append(damtx, vecs, axis=0)
             dam = damtx.shape[0]
-            self._active_terms = [()] + [tuple(int(v) for v in row) for row in damtx]
+            self._set_active_terms(damtx)
             active_slots = [SLOT_ONES] + model_slots + new_slots
             A = len(active_slots)
 

@@ -43,7 +43,8 @@ extern "C" {
 #define FOKL_K_GRAM    1        /* K2 Gram kernels (+ slab reduction)   */
 #define FOKL_K_RESID   2        /* K3 residual / BIC kernel             */
 #define FOKL_K_PREDICT 3        /* evaluate(): X * beta^T + order stats */
-#define FOKL_K_COUNT   4
+#define FOKL_K_RESID_MF 4       /* K3 without the stored columns (fokl_bic_resid_terms_launch) */
+#define FOKL_K_COUNT   5
 
 typedef struct fokl_ctx fokl_ctx;
 
@@ -142,6 +143,20 @@ int fokl_bic_resid(fokl_ctx *ctx, const int32_t *slots, int nc, const double *be
  */
 int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc, const double *betahat);
 int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce);
+
+/*
+ * Matrix-free form of fokl_bic_resid_launch: the model is given by its terms (rows of the interaction matrix,
+ * [n_terms, M] int32 as for fokl_build_terms; betahat[0] belongs to the intercept, betahat[1 + j] to terms[j]) and the
+ * kernel forms X betahat (FR:1551: `np.matmul(X, betahat)`) from the resident inputs, recomputing every basis column
+ * with the operations of fokl_build_terms instead of reading it back: 8 N (M_used + 1) bytes of HBM traffic instead
+ * of 8 N (P + 2), and no column needs to exist.  Same moments, bit for bit, as the stored-column pass over columns
+ * built by fokl_build_terms.  Limits: at most FOKL_RESID_TERMS_MAX_FACTORS distinct (input, order) pairs in the model,
+ * at most three inputs per term, Bernoulli orders up to FOKL_RESID_TERMS_MAX_ORDER (FOKL_ERR_ARG beyond; callers
+ * fall back to the stored-column pass).  Fetch with fokl_bic_resid_fetch.
+ */
+#define FOKL_RESID_TERMS_MAX_FACTORS 48
+#define FOKL_RESID_TERMS_MAX_ORDER 8
+int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* evaluate(): posterior-mean prediction and 95 % bounds on the device.  Replaces FR:966-978.              */

@@ -220,6 +220,38 @@ def build_columns_c(xsm, phind, phis, kernel, terms, threads=1):
     return np.ascontiguousarray(out.T)
 
 
+def build_columns_numpy(xsm, phind, phis, kernel, terms):
+    """F3 vectorised over the rows: the same expressions as ``evaluate_basis`` (FR:836, FR:843) applied to whole input
+    columns with numpy ufuncs (``x ** k`` -> np.power), factors multiplied in ascending input order starting from 1
+    (FR:1466-1483).  This is the "fair" CPU baseline of SURVEY 8(d)(ii): what a NumPy user would write instead of the
+    reference's per-element Python loops; values agree with the scalar path to the last bit or two of np.power."""
+    xsm = np.asarray(xsm, dtype=np.float64)
+    n, m = xsm.shape
+    terms = np.atleast_2d(terms)
+    out = np.empty((n, terms.shape[0]))
+    cache = {}
+    for j in range(terms.shape[0]):
+        phi = None
+        for k in range(m):
+            num = int(terms[j][k])
+            if num == 0:
+                continue
+            fac = cache.get((k, num))
+            if fac is None:
+                x = xsm[:, k]
+                if kernel == KERNEL_SPLINES:
+                    p = phind[:, k]
+                    c = [np.asarray(phis[num - 1][order])[p] for order in range(4)]
+                    fac = c[0] + c[1] * x + c[2] * (x ** 2) + c[3] * (x ** 3)
+                else:
+                    c = phis[num - 1]
+                    fac = c[0] + sum(c[q] * (x ** q) for q in range(1, len(c)))
+                cache[(k, num)] = fac
+            phi = fac if phi is None else phi * fac
+        out[:, j] = phi
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # G1-G4: one gibbs() call
 # ---------------------------------------------------------------------------------------------------------

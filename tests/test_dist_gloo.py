@@ -28,6 +28,13 @@ def test_two_rank_collectives_rowshard_and_replicas(tmp_path):
         # row-sharded fit: same model on every rank as the single-process fit (sums differ only in association)
         assert res['rowshard_mtx_equal']
         assert res['rowshard_evs_err'] < 1e-10 and res['rowshard_betas_err'] < 1e-8
+        # candidate-sharded fit: the same model, call sequence, stream and (to rounding: the kill tests' BIC comes
+        # from the Gram identity in this mode) numbers as the single-process fit; about half of the spectral results
+        # arrived from the other rank
+        assert res['cand_mtx_equal'] and res['cand_calls_equal'] and res['cand_stream_equal']
+        assert res['cand_evs_err'] < 1e-10 and res['cand_betas_err'] < 1e-8
+        assert res['cand_ranks_bitwise_equal']
+        assert res['cand_exchanges'] > 0 and res['cand_remote'] >= res['cand_gibbs_calls'] // 2 - 2
     # throughput mode: every rank sees all ranks' counters after the single all-gather
     assert results[0]['replica_terms'] == results[1]['replica_terms']
     assert results[0]['replica_terms'][0] == results[0]['replica_own_terms']

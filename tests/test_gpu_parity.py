@@ -219,6 +219,48 @@ def test_k3_residual_moments(device_ctx):
         assert abs(s1z - y.sum()) <= 1e-12 * np.abs(y).sum() and abs(s2z - y @ y) <= 1e-12 * (y @ y)
 
 
+@pytest.mark.parametrize('kid', [O.KERNEL_BERNOULLI, O.KERNEL_SPLINES])
+def test_k3_matrix_free_returns_the_bits_of_the_stored_column_pass(device_ctx, kid):
+    """fokl_bic_resid_terms_launch re-forms every basis column from the inputs with the operations of
+    fokl_build_terms and accumulates in the column order of resid_kernel: the two residual passes must agree bit for
+    bit -- for models whose factor table takes one, two and three register banks (<= 16 / 32 / 48 distinct
+    (input, order) pairs), ragged row counts, 1-, 2- and 3-way terms, and against the oracle's columns to rounding."""
+    rng = np.random.default_rng(14)
+    m = 8
+    for n, orders, n_terms in ((1, 2, 5), (777, 2, 12), (20001, 4, 60), (65536 + 3, 6, 140), (5000, 3, 300),
+                               (3001, 8, 25)):
+        x = rng.random((n, m))
+        y = rng.standard_normal(n)
+        phis = upload(device_ctx, x, y, kid)
+        terms = np.zeros((n_terms, m), dtype=np.int32)
+        for j in range(n_terms):
+            ways = int(rng.integers(1, 4))
+            for k in rng.choice(m, size=ways, replace=False):
+                terms[j, k] = int(rng.integers(1, orders + 1))
+        n_factors = len({(k, int(o)) for row in terms for k, o in enumerate(row) if o})
+        assert n_factors <= _capi.RESID_TERMS_MAX_FACTORS
+        device_ctx.reserve_slots(2 + n_terms)
+        slots = np.arange(2, 2 + n_terms, dtype=np.int32)
+        device_ctx.build_terms(terms, slots)
+        beta = rng.standard_normal(n_terms + 1)
+        want = device_ctx.bic_resid(np.concatenate([[0], slots]).astype(np.int32), beta)
+        device_ctx.bic_resid_terms_launch(terms, beta)
+        got = device_ctx.bic_resid_fetch()
+        assert got == want, (n, n_factors, got, want)
+        cols = oracle_columns(x, kid, phis, terms)
+        r = y - (beta[0] + cols @ beta[1:])
+        assert abs(got[0] - r.sum()) <= 1e-11 * np.abs(r).sum() + 1e-300 and abs(got[1] - r @ r) <= 1e-11 * (r @ r)
+    # intercept-only model, and the limits are reported, not overrun
+    device_ctx.bic_resid_terms_launch(np.zeros((0, m), dtype=np.int32), [0.25])
+    s1, s2 = device_ctx.bic_resid_fetch()
+    assert abs(s1 - (y - 0.25).sum()) <= 1e-12 * np.abs(y - 0.25).sum()
+    too_many = np.zeros((56, m), dtype=np.int32)
+    for j in range(56):
+        too_many[j, j % m] = 1 + j // m
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.bic_resid_terms_launch(too_many, np.zeros(57))
+
+
 def test_predict_mean_and_order_statistics(device_ctx):
     rng = np.random.default_rng(11)
     n = 3000
