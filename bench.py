@@ -352,7 +352,7 @@ def main():
         logical = physical = calls = 0
         host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
                     pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0, spectral_remote=0,
-                    exchanges=0)
+                    exchanges=0, chains_skipped=0, spectral_submitted=0, resid_matrix_free=0, bic_from_gram=0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']

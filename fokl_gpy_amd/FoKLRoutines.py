@@ -458,6 +458,9 @@ class FoKL:
         ``ConsoleOutput``.
         """
         backend, n, m = self._prepare_fit(inputs, data, kwargs)
+        if self.update == True:  # noqa: E712  (sequential updating, FR:1365-1367)
+            self.betas, self.mtx, self.evs = self._update_search(backend, n, m)
+            return self.betas, self.mtx, self.evs
         return self._search(backend, n, m)
 
     def _prepare_fit(self, inputs, data, kwargs):
@@ -516,8 +519,6 @@ class FoKL:
         self.inputs = inputs
         self.data = data
 
-        if self.update == True:  # noqa: E712  (sequential updating, FR:1365-1367)
-            raise NotImplementedError("update=True (fitupdate, FR:1850-2583) is outside the scope of this build")
 
         # data-driven defaults of the inverse-gamma scales (FR:1322-1348)
         a, atau = self.a, self.atau
@@ -540,7 +541,8 @@ class FoKL:
                 btau = (np.abs(data_mean) / sigmasq) * (atau + 1)
                 self.btau = btau
 
-        self._check_relats(np.shape(inputs)[1])
+        if self.update != True:  # noqa: E712  (fitupdate has its own handling of relats_in, FR:2449-2468)
+            self._check_relats(np.shape(inputs)[1])
 
         backend = self._backend()
         self._upload(backend, inputs, data)
@@ -984,7 +986,44 @@ class FoKL:
         return dy
 
     def fitupdate(self, inputs, data):
-        raise NotImplementedError("fitupdate (FR:1850-2583) is outside the scope of this build")
+        """Sequential-updating fit on already cleaned ``inputs`` / ``data`` (FR:1850-2583; ``fit`` calls it when
+        ``update=True``, FR:1365-1367).  Built here: the first call, i.e. a model without a prior (``built`` False --
+        gibbs_Xin_update "case 1" under the driver loop of FR:2473-2583): 2-way sub-stages (ind - i, i) without kill
+        tests, every model scored by the best log-likelihood among its draws.  Returns ``(betas, mtx, evs)`` with ALL
+        burnin + draws rows of the best model's draws, as the reference does; sets ``built`` when the search ends by the
+        tolerance rule (FR:2565).  ``relats_in`` excludes nothing in any variant the reference can run (FR:2449-2466,
+        2505-2510: arrays with one row or lists of non-zero ints leave `mrel` at 0; the others raise TypeError)."""
+        self.inputs, self.data = inputs, data
+        backend = self._backend()
+        self._upload(backend, inputs, data)
+        return self._update_search(backend, np.shape(inputs)[0], np.shape(inputs)[1])
+
+    def _update_search(self, backend, n, m):
+        if self.built:
+            raise NotImplementedError(
+                "fitupdate on a model that has been built (gibbs_Xin_update cases 2 and 3, FR:2153-2431: priors from "
+                "the previous posterior) is not part of this build; the first update call (case 1) is")
+        relats_in = self.relats_in
+        if not all(isinstance(v, int) for v in relats_in):                # FR:2449-2466
+            if np.all(np.sum(np.logical_not(relats_in), axis=0)):
+                raise TypeError("only integer scalar arrays can be converted to a scalar index")
+        elif sum(np.logical_not(relats_in)) != 0:                          # FR:2468, 2505-2507: relats_in[t, :] on a list
+            raise TypeError("list indices must be integers or slices, not tuple")
+        stream = _capi.LegacyStream()
+        t0 = time.perf_counter()
+        try:
+            with _host_blas_threads():
+                betas, mtx, evs, built, stats, trace = _engine.fit_update_first(
+                    backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
+                    self.burnin + self.draws, self.gimmie, self.aic, self.sigsqd0, stream,
+                    console=self.ConsoleOutput)
+        finally:
+            stream.publish()
+        self.built = bool(built)
+        self.fit_stats = dict(stats, seconds=time.perf_counter() - t0)
+        self.fit_trace = trace
+        self.avg_betas = np.mean(betas, axis=0)
+        return betas, mtx, evs
 
     def to_pyomo(self, *args, **kwargs):
         raise NotImplementedError("to_pyomo (FR:1796-1805) is outside the scope of this build")

@@ -30,6 +30,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const d2 *global_cd2_ptr;
 typedef __attribute__((address_space(1))) d2 *global_d2_ptr;
 typedef __attribute__((address_space(1))) double *global_d_ptr;
+typedef __attribute__((address_space(1))) const double *global_cd_ptr;
 
 __device__ __forceinline__ d2 load_d2(const double *p) { return *(global_cd2_ptr)(p); }
 // Basis columns are written once and are far larger than L2 before anybody reads them: non-temporal stores
@@ -152,8 +153,11 @@ struct DerivSpec {
 };
 
 // One (input, order) factor for the two rows of a lane.  `sl` = the spline slab of this order (LDS or global).
-template <bool SPLINES>
-__device__ __forceinline__ void evaluate_factor(const double *__restrict__ sl, const double *__restrict__ bern, int order,
+// `sl` is either a pointer into the LDS slabs or an address-space-1 pointer into the global table: the two cases are
+// separate instantiations so that the gathers are ds_read / global_load (a generic pointer would make them flat_load,
+// which also counts on lgkmcnt and serialises against every LDS wait).
+template <bool SPLINES, typename SlabPtr>
+__device__ __forceinline__ void evaluate_factor(SlabPtr sl, const double *__restrict__ bern, int order,
                                                 int width, d2 x, int p0, int p1, double t0, double t1, int deriv,
                                                 double div, double &vx, double &vy)
 {
@@ -238,12 +242,15 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
             d2 v;
             {
                 const int s = SPLINES ? fac_slab[u] : -1;
-                const double *sl = SPLINES ? (s >= 0 ? slabs + s * 4 * width : phis + (size_t)(order - 1) * 4 * width)
-                                           : nullptr;
                 const double *bern = SPLINES ? nullptr : phis + (size_t)(order - 1) * width;
+                const int dv = k == deriv.input ? deriv.order : 0;
                 double vx, vy;
-                evaluate_factor<SPLINES>(sl, bern, order, width, x, p0, p1, t0, t1, k == deriv.input ? deriv.order : 0,
-                                         deriv.div, vx, vy);
+                if (SPLINES && s < 0)                                  // wave-uniform: slab not staged, gather from L2
+                    evaluate_factor<SPLINES>((global_cd_ptr)(phis + (size_t)(order - 1) * 4 * width), bern, order, width,
+                                             x, p0, p1, t0, t1, dv, deriv.div, vx, vy);
+                else
+                    evaluate_factor<SPLINES>((const double *)(slabs + (SPLINES ? s : 0) * 4 * width), bern, order, width,
+                                             x, p0, p1, t0, t1, dv, deriv.div, vx, vy);
                 v.x = vx;
                 v.y = vy;
             }
@@ -326,11 +333,14 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
             double vx, vy;
             {
                 const int s = SPLINES ? fac_slab[u] : -1;
-                const double *sl = SPLINES ? (s >= 0 ? slabs + s * 4 * width : phis + (size_t)(order - 1) * 4 * width)
-                                           : nullptr;
                 const double *bern = SPLINES ? nullptr : phis + (size_t)(order - 1) * width;
-                evaluate_factor<SPLINES>(sl, bern, order, width, x, p0, p1, t0, t1, k == deriv.input ? deriv.order : 0,
-                                         deriv.div, vx, vy);
+                const int dv = k == deriv.input ? deriv.order : 0;
+                if (SPLINES && s < 0)                                  // wave-uniform: slab not staged, gather from L2
+                    evaluate_factor<SPLINES>((global_cd_ptr)(phis + (size_t)(order - 1) * 4 * width), bern, order, width,
+                                             x, p0, p1, t0, t1, dv, deriv.div, vx, vy);
+                else
+                    evaluate_factor<SPLINES>((const double *)(slabs + (SPLINES ? s : 0) * 4 * width), bern, order, width,
+                                             x, p0, p1, t0, t1, dv, deriv.div, vx, vy);
             }
             fx[u] = vx;
             fy[u] = vy;
@@ -545,16 +555,25 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
     const int spair = tid & 15, scol = tid >> 4;
     const int64_t n_chunks = (n + GM_R - 1) / GM_R;
     const double *cp[PCHUNK];
-#pragma unroll
-    for (int p = 0; p < PCHUNK; ++p) {
+    uint32_t padding = 0;                                  // bit p: pass p of this thread is a padding column, which re-reads
+#pragma unroll                                             // the first 16 bytes of the zero column (a cache hit) instead
+    for (int p = 0; p < PCHUNK; ++p) {                     // of streaming 8 N bytes of zeros per padded column
         const int c = scol + 16 * p;                       // NCOL is a multiple of 16: always a valid panel column
         const double *ptr = zero_col;
+        bool real = false;
         if (c < BI) {
-            if (i0 + c < nr) ptr = slot_ptr[row_slots[i0 + c]];
+            if (i0 + c < nr) {
+                ptr = slot_ptr[row_slots[i0 + c]];
+                real = true;
+            }
         } else {
-            if (j0 + (c - BI) < nc) ptr = slot_ptr[col_slots[j0 + (c - BI)]];
+            if (j0 + (c - BI) < nc) {
+                ptr = slot_ptr[col_slots[j0 + (c - BI)]];
+                real = true;
+            }
         }
         cp[p] = ptr;
+        if (!real) padding |= 1u << p;
     }
     d2 stage[PASSES];
     int64_t staged_row = 0;
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
         staged_row = r;
         const int64_t rc = r < n ? r : 0;                  // rows past the end are masked at commit time
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) stage[p] = load_d2(cp[p] + rc);
+        for (int p = 0; p < PASSES; ++p) stage[p] = load_d2(cp[p] + ((padding >> p) & 1u ? 0 : rc));
     };
     auto commit = [&]() {
         const bool ok0 = staged_row < n, ok1 = staged_row + 1 < n;

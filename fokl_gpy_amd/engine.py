@@ -310,7 +310,7 @@ class HostPipeline:
         self.comm = comm if comm is not None and (comm.world > 1 or forced) else None
         self._seq = 0
         self._windows = {}                  # window (seq // world) -> its jobs whose results have not travelled yet
-        self.remote_results = self.exchanges = 0
+        self.remote_results = self.exchanges = self.spectral_submitted = 0
         # Tapes (about 1 MB each) are produced by one thread and consumed by others: keep all of them on cores that
         # share an L3 for the duration of the fit, and give the noise thread -- the serial resource -- a physical core
         # to itself (measured on a 2 x 64-core EPYC host).  The native threads inherit the affinity set here; the
@@ -371,6 +371,12 @@ class HostPipeline:
         job.held = raw
         return self._track(job)
 
+    def abandon(self, noise_job):
+        """A tape that is recorded (the stream must advance exactly as if the model had been sampled) but that no chain
+        will read: its buffer goes back to the pool once the recorder is done with it."""
+        if noise_job.held is not None:
+            noise_job.recycle, noise_job.held = [noise_job.held], None
+
     def discard(self, noise_job):
         """A tentative tape that will not be used: rewind the stream to where it began; its buffer goes back to the
         pool once the recorder has let go of it."""
@@ -383,6 +389,7 @@ class HostPipeline:
         With a communicator the job runs on ONE rank -- every rank drives the same search and therefore submits the same
         jobs in the same order, job number s belongs to rank s % world -- and wait() brings the result to all."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.spectral_submitted += 1
         if self.comm is None:
             return self._track(self.pool.submit_spectral(gram, idx, gram.shape[0] - 1))
         seq, self._seq = self._seq, self._seq + 1
@@ -620,7 +627,8 @@ class ForwardSelection:
         self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0, resid_matrix_free=0)
+                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
+                          spectral_submitted=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _same_model_same_ev(self, idx, ev):
@@ -908,8 +916,22 @@ class ForwardSelection:
                         pending_tape = None
                     else:
                         drop_pending()                                    # recorded for a test that is not the next one
-                jobs = self._commit(pending, noise_job)
-                ev = self._score(pending)
+                if pending[2] is None:
+                    # the BIC comes from the Gram and is known now, before anything is spent on the candidate's draws:
+                    # a rejected candidate only has to advance the random stream (its tape is recorded, never finished
+                    # nor chained -- nobody reads the draws of a model that loses, FR:1686-1690)
+                    ev = self._score(pending)
+                    if ev < evmin:
+                        jobs = self._commit(pending, noise_job)
+                    else:
+                        if noise_job is None:
+                            noise_job = self._request_noise(idx.shape[0])
+                        self.host.abandon(noise_job)
+                        self.stats['chains_skipped'] += 1
+                        jobs = None
+                else:
+                    jobs = self._commit(pending, noise_job)
+                    ev = self._score(pending)
                 self._record(idx.shape[0], n_prev, ev, True)
                 last_accepted = bool(ev < evmin)
                 if last_accepted:
@@ -917,7 +939,7 @@ class ForwardSelection:
                     best.release()                                        # the model it replaces: its draws are history
                     best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
                     self._outcomes.append(best)
-                else:
+                elif jobs is not None:
                     jobs[1].recycle.append(jobs[2])                       # nobody will read a rejected candidate's draws
                 forecast(pos + 1)
                 if self.tentative_tapes:
@@ -956,7 +978,8 @@ class ForwardSelection:
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
                                   pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'],
-                                  spectral_remote=self.host.remote_results, exchanges=self.host.exchanges)
+                                  spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
+                                  spectral_submitted=self.host.spectral_submitted)
                 self.host = None
 
     def _patterns(self):
@@ -1148,3 +1171,92 @@ class ForwardSelection:
             betas, mtx = last, last_damtx
         out_betas = betas.betas[-self.draws_keep::, :]
         return out_betas, np.array(mtx, dtype=np.float64), evs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N3: sequential updating, first call (fitupdate without a prior model)
+# ---------------------------------------------------------------------------------------------------------
+
+def update_substage_patterns(m, n_phis):
+    """(ind, indvec) of the sub-stages of fitupdate in the reference's order (FR:2480-2496, 2574-2578): for every total
+    order ind the 2-way patterns (ind - i, i), i = floor(ind / 2) .. 0."""
+    ind = 1
+    while ind <= n_phis:
+        for i in ([0] if ind == 1 else range(ind // 2, -1, -1)):
+            vec = [0] * m
+            vec[0], vec[1] = ind - i, i
+            yield ind, vec
+        ind += 1
+
+
+def fit_update_first(backend, n, m, n_phis, a, b, atau, btau, tolerance, draws_total, gimmie, aic, sigsqd0, stream,
+                     console=False):
+    """
+    ``fit(update=True)`` on a model that has not been built (FR:1850-2583 with `mu_old` empty: gibbs_Xin_update
+    "case 1", FR:2060-2152, under the driver loop FR:2473-2583) on the device backend.
+
+    Every sub-stage appends all distinct arrangements of its pattern (no kill tests), so the design only grows:
+    K1 builds the new columns once, K2 extends the Gram by the new block, K3 gives the squared error of the
+    least-squares fit (`squerr`, FR:2083), and the sampler -- same recursion and same use of the random stream as
+    FR:1519-1548, started from sigsqd0 and tausqd = 1 / sigsqd0 -- runs in the eigenbasis (fokl_gibbs_chain).  The
+    model is scored with the best log-likelihood among its draws (FR:2113-2118, 2146): in the eigenbasis
+    (betahat - beta_k)' XtX (betahat - beta_k) = sum_i lamb_i (qty_i / lamb_i - w_ki)^2.
+    Returns (betas [draws_total, P + 1] of the best model, mtx, evs, built, stats).
+    """
+    if m == 1:
+        raise ValueError("not enough values to unpack (expected 2, got 0)")     # as the reference, FR:2528
+    pool = SlotPool(backend)
+    gram = np.array(backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y]), dtype=np.float64)
+    model_slots = []
+    damtx = np.zeros((0, m))
+    evs = np.array([])
+    greater = 0
+    built = False
+    best = mtx = last = None
+    stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0)
+    trace = []
+    for ind, indvec in update_substage_patterns(m, n_phis):
+        vecs = distinct_arrangements(indvec)
+        new_slots = pool.take(vecs.shape[0])
+        backend.build_terms(vecs.astype(np.int32), new_slots)
+        n_prev = 1 + len(model_slots)
+        block = backend.gram(new_slots, [SLOT_ONES] + model_slots + new_slots + [SLOT_Y])
+        gram = ForwardSelection._extend_gram(gram, list(range(n_prev)), block, list(range(n_prev)), n_prev)
+        model_slots = model_slots + new_slots
+        damtx = np.append(damtx, vecs, axis=0)
+        p1 = 1 + len(model_slots)
+        XtX, Xty, dtd = gram[:p1, :p1], gram[:p1, p1], gram[p1, p1]
+        lamb, Q = eigh_canonical(XtX)
+        qty = Q.T @ Xty
+        betahat = Q @ (qty / lamb)                                   # FR:2079-2081
+        _, squerr = backend.bic_resid([SLOT_ONES] + model_slots, betahat)   # ||y - X betahat||^2, FR:2083
+        astar = a + 1 + n / 2 + p1 / 2                               # FR:2085
+        atau_star = atau + (p1 - 1) / 2                              # FR:2086
+        w, sigs, _ = _capi.gibbs_chain(lamb, qty, astar, atau_star, b, btau, dtd, sigsqd0, 1 / sigsqd0, draws_total,
+                                       stream, want_sig_tau=True)
+        sig_used = np.concatenate([[sigsqd0], sigs[:-1]])            # iteration k looks at the sigsqd it starts with
+        quad = np.sum(lamb * (qty / lamb - w) ** 2, axis=1)
+        lik = -(n / 2) * np.log(sig_used) - (squerr + quad) / (2 * sig_used)     # FR:2113-2118
+        ev = p1 * math.log(n) - 2 * np.max(lik)                      # FR:2146
+        if aic:
+            ev = ev + (2 - math.log(n)) * damtx.shape[0]             # FR:2541-2547 (dam, not dam + 1)
+        stats['gibbs_calls'] += 1
+        stats['terms_logical'] += vecs.shape[0]
+        stats['terms_physical'] += vecs.shape[0]
+        stats['substages'] += 1
+        trace.append(dict(cols=p1, built=vecs.shape[0], ev=float(ev), kill=False))
+        if console:
+            print(ind, ev)
+        last = (w, Q, damtx)
+        evs = np.append(evs, ev)
+        if ev == np.min(evs):                                        # FR:2556-2566
+            best, mtx, greater = (w, Q), damtx, 1
+        elif greater <= tolerance:
+            greater += 1
+        else:
+            built = True
+            break
+    if gimmie:
+        best, mtx = last[:2], last[2]
+    betas = best[0] @ best[1].T
+    return betas, np.array(mtx, dtype=np.float64), evs, built, stats, trace

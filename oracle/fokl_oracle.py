@@ -487,6 +487,134 @@ def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, 
 
 
 # ---------------------------------------------------------------------------------------------------------
+# N3: fitupdate, first call (no prior model): gibbs_Xin_update "case 1" + its driver loop
+# ---------------------------------------------------------------------------------------------------------
+
+def gibbs_update_case1(sigsqd0, inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, phind, xsm, draws,
+                       eigh=eigh_reference, build=build_columns_c):
+    """gibbs_Xin_update without a prior model (FR:2010-2152): X-build as in gibbs(), then a sampler that starts from
+    sigsqd0 / tausqd = 1 / sigsqd0, evaluates the log-likelihood of every draw and scores the model with the best one:
+    ev = (mmtx + 1) log n - 2 max(lik).  Returns (betas, X, ev)."""
+    n_obs = inputs.shape[0]
+    discmtx = np.atleast_2d(discmtx)
+    mmtx = discmtx.shape[0]
+    if np.size(Xin) == 0:
+        Xin = np.ones((n_obs, 1))
+    nxin = Xin.shape[1]
+    if mmtx + 1 > nxin:
+        X = np.concatenate([Xin, build(xsm, phind, phis, kernel, discmtx[nxin - 1:mmtx])], axis=1)
+    else:
+        X = Xin
+
+    tausqd = 1 / sigsqd0
+    XtX = np.transpose(X).dot(X)
+    Xty = np.transpose(X).dot(data)
+    lamb, Q = eigh(XtX)
+    betahat = Q.dot(np.diag(1 / lamb)).dot(np.transpose(Q)).dot(Xty)
+    squerr = np.linalg.norm(data - X.dot(betahat)) ** 2
+    astar = a + 1 + len(data) / 2 + (mmtx + 1) / 2
+    atau_star = atau + mmtx / 2
+    dtd = np.transpose(data).dot(data)
+
+    betas = np.zeros((draws, mmtx + 1))
+    sigsqd = sigsqd0
+    lik = np.zeros((draws, 1))
+    n = len(data)
+    eye = np.identity(mmtx + 1)
+    for k in range(draws):
+        shifted_inv = np.diag(1 / np.diag(np.diag(lamb) + (1 / tausqd) * eye))
+        mun = Q.dot(shifted_inv).dot(np.transpose(Q)).dot(Xty)
+        S = Q.dot(np.diag(np.diag(shifted_inv) ** (1 / 2)))
+        vec = np.random.normal(loc=0, scale=1, size=(mmtx + 1, 1))
+        betas[k][:] = np.transpose(mun + sigsqd ** (1 / 2) * S.dot(vec))
+
+        comp1 = -(n / 2) * np.log(sigsqd)
+        comp2 = np.transpose(betahat) - betas[k][:]
+        comp3 = betahat - np.reshape(betas[k][:], (len(betas[k][:]), 1))
+        lik[k] = comp1 - (squerr + comp2.dot(XtX).dot(comp3)) / (2 * sigsqd)
+
+        vecc = mun - np.reshape(betas[k][:], (len(betas[k][:]), 1))
+        bstar = b + (0.5 * np.transpose(vecc)).dot((XtX + (1 / tausqd) * eye).dot(vecc)) + 0.5 * dtd \
+            - 0.5 * np.transpose(mun).dot(Xty)
+        if bstar < 0:
+            sigsqd = math.nan
+        else:
+            sigsqd = 1 / np.random.gamma(astar, 1 / bstar)
+        btau_star = (1 / (2 * sigsqd)) * (betas[k][:].dot(np.reshape(betas[k][:], (len(betas[k][:]), 1)))) + btau
+        tausqd = 1 / np.random.gamma(atau_star, 1 / btau_star)
+
+    ev = (mmtx + 1) * np.log(n) - 2 * np.max(lik)
+    return betas, X[:, 0:mmtx + 1], ev
+
+
+def fitupdate_first(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, trace=None, sigsqd0=0.5,
+                    **hypers):
+    """
+    ``FoKL.fit`` with ``update=True`` on a model that has not been built yet (FR:1365-1367 -> fitupdate, FR:1850-2583):
+    sub-stages (ind - i, i), i = floor(ind / 2) .. 0, of 2-way terms only, every sub-stage adds all its terms (no kill
+    tests), one gibbs_Xin_update per sub-stage, `ev == min(evs)` / `greater <= tolerance` stop rule (FR:2551-2566).
+    ``relats_in`` never excludes anything in the variants the reference can run (probed: arrays with one row, lists of
+    non-zero ints).  Returns (betas of the best model -- all burnin + draws rows --, mtx, evs, built).
+    """
+    hp = dict(DEFAULT_HYPERS)
+    for key, val in hypers.items():
+        if key not in hp:
+            raise ValueError(f"Unexpected keyword argument: '{key}'")
+        hp[key] = val
+    a, atau = hp['a'], hp['atau']
+    b, btau = default_b_btau(data, a, atau, hp['b'], hp['btau'])
+    tolerance, aic = hp['tolerance'], hp['aic']
+    draws = hp['burnin'] + hp['draws']
+    if kernel == KERNEL_SPLINES:
+        phind, xsm = inputs_to_phind(inputs, len(phis[0][0]))
+    else:
+        phind, xsm = None, inputs
+    n, m = inputs.shape
+    if m == 1:
+        raise ValueError("not enough values to unpack (expected 2, got 0)")      # FR:2528 on the scalar damtx
+    damtx = np.zeros((0, m))
+    evs = []
+    ind = 1
+    greater = 0
+    finished = False
+    built = False
+    X = []
+    betas_best = mtx = betas = None
+    while True:
+        i_list = [0] if ind == 1 else np.arange(0, math.floor(ind / 2) + 0.1, 1)[::-1]
+        for i in i_list:
+            vecs = np.zeros(m)
+            vecs[0] = ind - i
+            vecs[1] = i
+            vecs = distinct_arrangements(vecs)
+            damtx = np.concatenate((damtx, vecs), axis=0)
+            nxin = 1 if np.size(X) == 0 else X.shape[1]
+            betas, X, ev = gibbs_update_case1(sigsqd0, inputs, data, phis, kernel, X, damtx, a, b, atau, btau, phind,
+                                              xsm, draws, eigh=eigh, build=build)
+            if aic:
+                ev = ev + (2 - np.log(n)) * damtx.shape[0]
+            if trace is not None:
+                trace.append(dict(cols=damtx.shape[0] + 1, built=damtx.shape[0] + 1 - nxin, ev=float(ev), kill=False))
+            evs = np.concatenate((evs, [ev])) if np.size(evs) else np.array([ev])
+            if ev == np.min(evs):
+                betas_best, mtx, greater = betas, damtx, 1
+            elif greater <= tolerance:
+                greater = greater + 1
+            else:
+                finished = True
+                built = True
+                break
+        if finished:
+            break
+        ind = ind + 1
+        if ind > len(phis):
+            break
+    if hp['gimmie']:
+        betas_best, mtx = betas, damtx
+    return betas_best, mtx, evs, built
+
+
+# ---------------------------------------------------------------------------------------------------------
 # evaluate / coverage3 numerics (kept class surface; FR:929-978, FR:1193)
 # ---------------------------------------------------------------------------------------------------------
 

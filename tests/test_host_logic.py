@@ -258,16 +258,16 @@ def test_relats_in_behaviour_matches_reference_quirks():
 
 
 def test_out_of_scope_entry_points_say_so():
-    model = FoKLRoutines.FoKL(kernel=1, update=True, UserWarnings=False, ConsoleOutput=False)
+    """to_pyomo (out of scope) and sequential updating of a model that HAS a prior (gibbs_Xin_update
+    cases 2 / 3; the first update call is built, tests/test_fitupdate.py) refuse loudly."""
+    model = FoKLRoutines.FoKL(kernel=1, update=True, built=True, UserWarnings=False, ConsoleOutput=False)
     model._backend_override = OracleBackend()
     with pytest.raises(NotImplementedError):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            model.fit(np.random.default_rng(0).random((20, 1)), np.zeros(20), clean=True)
+            model.fit(np.random.default_rng(0).random((20, 2)), np.zeros(20), clean=True)
     with pytest.raises(NotImplementedError):
         model.to_pyomo()
-    with pytest.raises(NotImplementedError):
-        model.fitupdate(None, None)
 
 
 def test_evaluate_requires_minmax_and_validates_draws():
