@@ -17,6 +17,7 @@ unknown keywords must keep raising ``ValueError`` exactly like the reference (FR
 import copy
 import os
 import pickle
+import threading
 import time
 import warnings
 
@@ -120,16 +121,39 @@ def device_backend(device=None):
     return _CONTEXTS[device]
 
 
-def _host_blas_threads():
+_BLAS_LIMIT_LOCK = threading.Lock()
+_BLAS_LIMIT_USERS = 0
+_BLAS_LIMIT_CTX = None
+
+
+class _host_blas_threads:
     """The per-candidate host algebra is tiny ((P+1)^2 eigenproblems, draws x (P+1) products): a BLAS pool sized for
     a 256-thread host spends more time waking threads than computing, and its spinning workers compete with the
-    noise-tape thread.  Cap it (FOKL_HOST_THREADS, default 1: measured best on a 2 x 64-core EPYC host)."""
-    import contextlib
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        return contextlib.nullcontext()
-    return threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '1')), user_api='blas')
+    noise-tape thread.  Cap it (FOKL_HOST_THREADS, default 1: measured best on a 2 x 64-core EPYC host) for as long as
+    any fit of this process is running -- fits may run side by side on threads (bench.py --config 4 --concurrent), so
+    the cap is taken by the first and released by the last."""
+
+    def __enter__(self):
+        global _BLAS_LIMIT_USERS, _BLAS_LIMIT_CTX
+        with _BLAS_LIMIT_LOCK:
+            _BLAS_LIMIT_USERS += 1
+            if _BLAS_LIMIT_USERS == 1:
+                try:
+                    from threadpoolctl import threadpool_limits
+                    _BLAS_LIMIT_CTX = threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '1')),
+                                                        user_api='blas')
+                except Exception:
+                    _BLAS_LIMIT_CTX = None
+        return self
+
+    def __exit__(self, *exc):
+        global _BLAS_LIMIT_USERS, _BLAS_LIMIT_CTX
+        with _BLAS_LIMIT_LOCK:
+            _BLAS_LIMIT_USERS -= 1
+            if _BLAS_LIMIT_USERS == 0 and _BLAS_LIMIT_CTX is not None:
+                _BLAS_LIMIT_CTX.restore_original_limits()
+                _BLAS_LIMIT_CTX = None
+        return False
 
 
 _CLEAN_DEFAULTS = {'train': 1, 'AutoTranspose': True, 'SingleInstance': False, 'bit': 64,
@@ -548,11 +572,15 @@ class FoKL:
         self._upload(backend, inputs, data)
         return backend, np.shape(inputs)[0], np.shape(inputs)[1]
 
-    def _search(self, backend, n, m, n_global=None, row_sharded=False, comm=None, candidate_sharded=False):
+    def _search(self, backend, n, m, n_global=None, row_sharded=False, comm=None, candidate_sharded=False,
+                rng_state=None):
         """Forward selection on the dataset currently resident on ``backend`` (the timed region of bench.py).
         ``comm`` + ``candidate_sharded``: every rank of the communicator calls this on the same dataset with the same
-        numpy stream; candidate models are dealt over the ranks (engine.ForwardSelection)."""
-        stream = _capi.LegacyStream()
+        numpy stream; candidate models are dealt over the ranks (engine.ForwardSelection).
+        ``rng_state``: a numpy legacy state (``np.random.RandomState(seed).get_state()``) to run the chain from instead
+        of numpy's global generator -- fits running side by side on threads cannot share the global one; the state
+        after the fit is left in ``self._rng_state_after`` and the global generator is not touched."""
+        stream = _capi.LegacyStream(rng_state)
         search = _engine.ForwardSelection(
             backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
             self.burnin + self.draws, self.draws, self.gimmie, self.way3, self.threshav, self.threshstda,
@@ -564,7 +592,9 @@ class FoKL:
             with _host_blas_threads():
                 betas, mtx, evs = search.run()
         finally:
-            stream.publish()           # numpy's global stream ends where the reference's would
+            if rng_state is None:
+                stream.publish()       # numpy's global stream ends where the reference's would
+            self._rng_state_after = stream.as_numpy_state()
         self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0)
         self.fit_trace = search.trace
 
@@ -822,7 +852,7 @@ class FoKL:
             filename = filename + '.fokl'
         path = os.path.join(directory, filename) if directory is not None else filename
         state = copy.copy(self)
-        for transient in ('_backend_override', '_comm'):
+        for transient in ('_backend_override', '_comm', '_rng_state_after'):
             if hasattr(state, transient):
                 delattr(state, transient)
         with open(path, 'wb') as fh:

@@ -65,6 +65,7 @@ SIGNATURES = {
     'fokl_pool_poll': (c_int, [c_vp]),
     'fokl_pool_wait': (c_int, [c_vp]),
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_noise_waits': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_finish_tape_blocks': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'fokl_gibbs_chain_from_finished_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp,
                                                     c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -439,7 +440,10 @@ class HostPool:
     def busy_seconds(self):
         v = [c_dbl(0) for _ in range(4)]
         _check(self._lib.fokl_pool_busy_seconds(self._h, *[ctypes.byref(x) for x in v]))
-        return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value)
+        w = [c_dbl(0), c_dbl(0)]
+        _check(self._lib.fokl_pool_noise_waits(self._h, ctypes.byref(w[0]), ctypes.byref(w[1])))
+        return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value,
+                    noise_queue_wait=w[0].value, noise_verdict_wait=w[1].value)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -92,6 +92,8 @@ struct fokl_host_pool {
     int32_t *mt_pos = nullptr, *has_gauss = nullptr;
     double *gauss_cache = nullptr;
     std::atomic<int64_t> noise_busy_ns{0}, chain_busy_ns{0}, finish_busy_ns{0}, spectral_busy_ns{0};
+    // where the serial resource waits: for the next request (empty queue) and for the verdict on a tentative tape
+    std::atomic<int64_t> noise_queue_wait_ns{0}, noise_verdict_wait_ns{0};
     // completion of any job (fokl_pool_wait spins briefly, then sleeps here: a fit must not burn a core per waiter --
     // eight ranks may share a CPU quota far below eight times the thread count)
     std::mutex done_m;
@@ -226,6 +228,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
             std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
             std::memory_order_relaxed);                     // the wait for the verdict below is not work
         if (job->tentative) {
+            const auto w0 = std::chrono::steady_clock::now();
             for (int spins = 0; job->verdict.load(std::memory_order_acquire) == 0;) {
                 if (++spins < 4000) {
                     _mm_pause();
@@ -233,6 +236,9 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
                     std::this_thread::sleep_for(std::chrono::microseconds(10));
                 }
             }
+            pool->noise_verdict_wait_ns.fetch_add(
+                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
+                std::memory_order_relaxed);
             if (job->verdict.load(std::memory_order_acquire) < 0) {
                 std::memcpy(pool->mt_key, saved_key, sizeof(saved_key));
                 *pool->mt_pos = saved_pos;
@@ -287,8 +293,13 @@ void worker(fokl_host_pool *pool, Queue *queue)
     for (;;) {
         fokl_host_job *job;
         {
+            const auto w0 = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lock(queue->m);
             queue->cv.wait(lock, [&] { return queue->stop || !queue->q.empty(); });
+            if (queue == &pool->noise_q)
+                pool->noise_queue_wait_ns.fetch_add(
+                    std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
+                    std::memory_order_relaxed);
             if (queue->q.empty()) return;                   // stop requested and the queue is drained
             job = queue->q.front();
             queue->q.pop_front();
@@ -549,5 +560,18 @@ extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise,
     if (chain) *chain = 1e-9 * (double)pool->chain_busy_ns.load();
     if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
     if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
+    return FOKL_OK;
+}
+
+// Where the noise thread -- the serial resource of a fit -- was not recording: waiting for the next request with an
+// empty queue, and holding the stream until the driver's verdict on a tentative tape.
+extern "C" int fokl_pool_noise_waits(const fokl_host_pool *pool, double *queue_wait, double *verdict_wait)
+{
+    if (!pool) {
+        fokl_set_global_error("fokl_pool_noise_waits: null pool");
+        return FOKL_ERR_ARG;
+    }
+    if (queue_wait) *queue_wait = 1e-9 * (double)pool->noise_queue_wait_ns.load();
+    if (verdict_wait) *verdict_wait = 1e-9 * (double)pool->noise_verdict_wait_ns.load();
     return FOKL_OK;
 }

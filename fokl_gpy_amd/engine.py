@@ -830,7 +830,7 @@ class ForwardSelection:
         return outcome.intercept_scale
 
     def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None,
-                              ahead=None):
+                              ahead=None, first_tape=None):
         """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
 
         Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
@@ -857,7 +857,10 @@ class ForwardSelection:
         # The tape of the NEXT test, requested as soon as this one's BIC is known (its size needs the kill set) instead
         # of after the chain that decides whether that test is run: the noise thread then goes from one tape to the
         # next without a pause.  (proposal index, model size, job); rewound if the guess was wrong.
-        pending_tape = None
+        # first_tape: recorded straight after the sub-stage model's own tape, before the statistics that order the
+        # proposals exist -- every first test has A - 1 columns whichever proposal it removes, so the tape fits any of
+        # them (proposal index None); rewound if no proposal is tested at all
+        pending_tape = None if first_tape is None else (None, A - 1, first_tape)
         likely = lambda j: clause1[j] or mean_abs[j] < self.threshav * scale_guess
 
         def forecast(pos):
@@ -910,7 +913,7 @@ class ForwardSelection:
                         continue
                 noise_job = early_tape
                 if pending_tape is not None:
-                    if pending_tape[0] == i and pending_tape[1] == idx.shape[0]:
+                    if pending_tape[0] in (i, None) and pending_tape[1] == idx.shape[0]:
                         noise_job = pending_tape[2]
                         noise_job.resolve(True)
                         pending_tape = None
@@ -978,6 +981,8 @@ class ForwardSelection:
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
                                   pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'],
+                                  noise_queue_wait_s=busy['noise_queue_wait'],
+                                  noise_verdict_wait_s=busy['noise_verdict_wait'],
                                   spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
                                   spectral_submitted=self.host.spectral_submitted)
                 self.host = None
@@ -1089,6 +1094,12 @@ class ForwardSelection:
                                   overlap=build_next)
             best = full
             ev = full.ev
+            # the tape of the first kill test, whichever proposal that will be (see _kill_tests_pipelined): the noise
+            # thread goes straight on after the sub-stage model's tape instead of idling until that model's chain has
+            # finished and its statistics have ordered the proposals
+            first_tape = None
+            if self.host is not None and self.tentative_tapes and vm > 0 and A > 1:
+                first_tape = self._request_noise(A - 1, tentative=True)
 
             def foresee(pred_killed, gram=gram, active=active_slots, A=A):
                 # G2 of the coming sub-stage's model if the kill tests end as predicted (at most two guesses)
@@ -1132,7 +1143,7 @@ class ForwardSelection:
                             best = res
             else:
                 killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
-                                                                 rel_std, best, half0, foresee, early)
+                                                                 rel_std, best, half0, foresee, early, first_tape)
             ev = evmin
 
             # commit the surviving columns (FR:1691-1695)

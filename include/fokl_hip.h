@@ -339,6 +339,8 @@ int fokl_pool_wait(fokl_host_job *job);
 /* Accumulated time (s) the kinds of thread spent inside jobs (including their waits on the tape producer). */
 int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *chain, double *finish,
                            double *spectral);
+/* Seconds the noise thread spent waiting: with an empty queue, and for the verdict on tentative tapes. */
+int fokl_pool_noise_waits(const fokl_host_pool *pool, double *queue_wait, double *verdict_wait);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* N4: the consumer of fitted models, GP_Integrate (reference src/FoKL/GP_Integrate.py:5-282)               */
