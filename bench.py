@@ -547,10 +547,15 @@ def main():
             mf.update(bound='valu-fp64', achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                       frac=tf / FP64_MFMA_PEAK_TFLOPS, hbm_achieved_gbs=mf['achieved'], hbm_frac=mf['frac'])
     if kernels['gram']:
-        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings
+        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings,
+        # `bound` = the roof that binds the launches of this run taken together ...
         gm = roof('gram', 'mfma')
-        kernels['gram']['mfma_achieved_tflops'] = gm['achieved']
-        kernels['gram']['mfma_frac'] = gm['frac']
+        hb = kernels['gram']
+        if kern['gram']['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > kern['gram']['bytes'] / (HBM_PEAK_GBS * 1e9):
+            kernels['gram'] = dict(gm, hbm_achieved_gbs=hb['achieved'], hbm_frac=hb['frac'],
+                                   algorithmic_bytes_per_launch=hb['algorithmic_bytes_per_launch'])
+        else:
+            kernels['gram'].update(mfma_achieved_tflops=gm['achieved'], mfma_frac=gm['frac'])
         # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
         kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed

@@ -886,12 +886,18 @@ typedef void (*resid_terms_fn)(const double *, int64_t, int64_t, const double *,
 
 static resid_terms_fn pick_resid_terms(bool splines, int U)
 {
+    // up to 16 factors: table in one VGPR bank, two rows per lane; beyond: table in LDS, one row at a time (measured on
+    // MI355X, tools/k3_probe.py; the two- and three-bank register variants lose to it and are kept for A/B runs only,
+    // FOKL_K3_REGISTER_BANKS=1)
+    static const bool banks = getenv("FOKL_K3_REGISTER_BANKS") && atoi(getenv("FOKL_K3_REGISTER_BANKS")) != 0;
     if (splines) {
         if (U <= 16) return resid_terms_kernel<true, 1, 2>;
+        if (!banks) return resid_terms_lds_kernel<true>;
         if (U <= 32) return resid_terms_kernel<true, 2, 1>;
         return resid_terms_kernel<true, 3, 1>;
     }
     if (U <= 16) return resid_terms_kernel<false, 1, 2>;
+    if (!banks) return resid_terms_lds_kernel<false>;
     if (U <= 32) return resid_terms_kernel<false, 2, 1>;
     return resid_terms_kernel<false, 3, 1>;
 }
@@ -1005,11 +1011,18 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     rc = ensure_out(ctx, 2);
     if (rc) return rc;
     resid_terms_fn fn = pick_resid_terms(splines, U);
+    size_t lds_bytes = table_bytes;
+    if (fn == (resid_terms_fn)resid_terms_lds_kernel<true> || fn == (resid_terms_fn)resid_terms_lds_kernel<false>) {
+        lds_bytes += (size_t)U * RS_THREADS * sizeof(double);          // + the factor table [U][lane]
+        if (lds_bytes > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    }
     {
         {
             TimedRegion timed(ctx, FOKL_K_RESID_MF, 8.0 * (double)ctx->n * (double)(G + 1),
                               (double)ctx->n * flops_per_row);
-            hipLaunchKernelGGL(fn, dim3(S), dim3(RS_THREADS), table_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n,
+            hipLaunchKernelGGL(fn, dim3(S), dim3(RS_THREADS), lds_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n,
                                ctx->d_phis, ctx->width, reinterpret_cast<const ResidTermsHeader *>(ctx->d_args),
                                reinterpret_cast<const d2 *>(ctx->d_args + tables_off), (int)(table_bytes / sizeof(d2)),
                                ctx->slot_ptr[FOKL_SLOT_Y], ctx->d_slab);

@@ -985,4 +985,144 @@ __global__ __launch_bounds__(RS_THREADS) void resid_terms_kernel(
 #undef FOKL_FAC_GET
 #undef FOKL_FAC_SET
 
+// The same pass for models with more than 16 distinct factors: the per-row factor table lives in LDS as
+// [factor][lane] (8 bytes per lane and factor, the lane's own column: conflict-free ds_read_b64 / ds_write_b64, no
+// register indexing, no bank branches).  A lane takes its two rows one after the other so that 48 factors fit
+// (96 KB + the records); rows, accumulation order and the block reduction are those of resid_kernel, so the bits are too.
+template <bool SPLINES>
+__global__ __launch_bounds__(RS_THREADS) void resid_terms_lds_kernel(
+    const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
+    const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
+    const double *__restrict__ y, double *__restrict__ slab)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    __shared__ double red[RS_THREADS / WAVE][2];
+    const int U = hdr->n_fac, T = hdr->n_terms, G = hdr->n_groups;
+    const int tid = threadIdx.x;
+    {
+        d2 *dst = reinterpret_cast<d2 *>(lds_raw);
+        for (int i = tid; i < table_d2s; i += RS_THREADS) dst[i] = tables[i];
+    }
+    const ResidTerm *terms = reinterpret_cast<const ResidTerm *>(lds_raw);
+    const ResidGroup *groups = reinterpret_cast<const ResidGroup *>(terms + T);
+    const double *coef = reinterpret_cast<const double *>(groups + G);
+    double *fac = reinterpret_cast<double *>(lds_raw) + 2 * (size_t)table_d2s + tid;     // fac[u * RS_THREADS]: this lane's column
+    (void)U;
+    __syncthreads();
+
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t n_tiles = (n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r = (tile * RS_THREADS + tid) * 2;
+        const bool in0 = r < n, in1 = r + 1 < n;
+        double resid[2] = {0.0, 0.0};
+        if (in0) {                                              // no barrier below: every lane reads only its own column
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int64_t rr = r + pass;                    // ld is a multiple of 64 rows: stays in bounds
+                double x_next = *(global_cd_ptr)(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[0].input) * ld + rr);
+                for (int g = 0; g < G; ++g) {
+                    const ResidGroup gr = groups[g];
+                    const int first = __builtin_amdgcn_readfirstlane(gr.first);
+                    const int count = __builtin_amdgcn_readfirstlane(gr.count);
+                    const int omax = __builtin_amdgcn_readfirstlane(gr.omax);
+                    const double x = x_next;
+                    if (g + 1 < G)
+                        x_next = *(global_cd_ptr)(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[g + 1].input) * ld + rr);
+                    if (SPLINES) {
+                        int piece;
+                        double t;
+                        spline_locate(x, width, false, piece, t);
+                        for (int v = first; v < first + count; ++v) {
+                            const int order = __builtin_amdgcn_readfirstlane((int)coef[(size_t)v * RT_COEF_STRIDE + 9]);
+                            const global_cd_ptr sl = (global_cd_ptr)(phis + (size_t)(order - 1) * 4 * width);
+                            const double c0 = sl[piece], c1 = sl[width + piece], c2 = sl[2 * width + piece],
+                                         c3 = sl[3 * width + piece];
+                            fac[(size_t)v * RS_THREADS] = cubic_basis(c0, c1, c2, c3, t);
+                        }
+                    } else {
+                        double pw[RT_MAX_ORDER + 1];
+                        {
+                            double ph = x, pl = 0.0;
+                            pw[1] = x;
+#pragma unroll
+                            for (int j = 2; j <= RT_MAX_ORDER; ++j) {
+                                if (j <= omax) dd_mul_d(ph, pl, x);
+                                pw[j] = ph;
+                            }
+                        }
+                        for (int v = first; v < first + count; ++v) {
+                            const d2 *row = reinterpret_cast<const d2 *>(coef + (size_t)v * RT_COEF_STRIDE);
+                            const d2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3], c8o = row[4];
+                            const int order = __builtin_amdgcn_readfirstlane((int)c8o.y);
+                            const double c[RT_MAX_ORDER + 1] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y, c8o.x};
+                            double val = c[1] * pw[1];
+#pragma unroll
+                            for (int j = 2; j <= RT_MAX_ORDER; ++j)
+                                if (j <= order) val = val + c[j] * pw[j];
+                            fac[(size_t)v * RS_THREADS] = c[0] + val;
+                        }
+                    }
+                }
+
+                double fit = 0.0;
+                // four records, then their (up to twelve) factor reads, in flight per wait; absent factors read factor 0
+                // and multiply by one instead (a select, no branch)
+#define FOKL_LOAD_TERM(t, fa, fb, fc)                                                        \
+    const uint32_t w_##t = (t).fac;                                                          \
+    const double fa = fac[(size_t)(w_##t & 255u) * RS_THREADS];                              \
+    const double fb = fac[(size_t)((w_##t >> 8) & 255u) * RS_THREADS];                       \
+    const double fc = fac[(size_t)((w_##t >> 16) & 255u) * RS_THREADS];
+#define FOKL_USE_TERM(t, fa, fb, fc)                                                         \
+    {                                                                                        \
+        double p_ = (t).cnt > 0 ? fa : 1.0;                                                  \
+        if ((t).cnt > 1) p_ = p_ * fb;                                                       \
+        if ((t).cnt > 2) p_ = p_ * fc;                                                       \
+        fit = __builtin_fma((t).beta, p_, fit);                                              \
+    }
+                int j = 0;
+                for (; j + 4 <= T; j += 4) {
+                    const ResidTerm ta = terms[j], tb = terms[j + 1], tc = terms[j + 2], td = terms[j + 3];
+                    FOKL_LOAD_TERM(ta, a0, a1, a2)
+                    FOKL_LOAD_TERM(tb, b0, b1, b2)
+                    FOKL_LOAD_TERM(tc, c0, c1, c2)
+                    FOKL_LOAD_TERM(td, d0, d1, d2)
+                    FOKL_USE_TERM(ta, a0, a1, a2)
+                    FOKL_USE_TERM(tb, b0, b1, b2)
+                    FOKL_USE_TERM(tc, c0, c1, c2)
+                    FOKL_USE_TERM(td, d0, d1, d2)
+                }
+                for (; j < T; ++j) {
+                    const ResidTerm ta = terms[j];
+                    FOKL_LOAD_TERM(ta, a0, a1, a2)
+                    FOKL_USE_TERM(ta, a0, a1, a2)
+                }
+#undef FOKL_LOAD_TERM
+#undef FOKL_USE_TERM
+                resid[pass] = *(global_cd_ptr)(y + rr) - fit;
+            }
+        }
+        if (in0) {
+            const double r0 = resid[0];
+            const double r1 = in1 ? resid[1] : 0.0;
+            s1 += r0 + r1;
+            s2 += r0 * r0 + r1 * r1;
+        }
+    }
+    const int wave = tid / WAVE, lane = tid % WAVE;
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[wave][0] = s1;
+        red[wave][1] = s2;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < RS_THREADS / WAVE; ++w) s += red[w][tid];
+        slab[(size_t)blockIdx.x * 2 + tid] = s;
+    }
+}
+
 }  // namespace fokl
