@@ -1017,11 +1017,12 @@ class FoKL:
 
     def fitupdate(self, inputs, data):
         """Sequential-updating fit on already cleaned ``inputs`` / ``data`` (FR:1850-2583; ``fit`` calls it when
-        ``update=True``, FR:1365-1367).  Built here: the first call, i.e. a model without a prior (``built`` False --
-        gibbs_Xin_update "case 1" under the driver loop of FR:2473-2583): 2-way sub-stages (ind - i, i) without kill
-        tests, every model scored by the best log-likelihood among its draws.  Returns ``(betas, mtx, evs)`` with ALL
-        burnin + draws rows of the best model's draws, as the reference does; sets ``built`` when the search ends by the
-        tolerance rule (FR:2565).  ``relats_in`` excludes nothing in any variant the reference can run (FR:2449-2466,
+        ``update=True``, FR:1365-1367): 2-way sub-stages (ind - i, i) without kill tests, every model scored by the best
+        log-likelihood among its draws.  A model without a prior (``built`` False) takes gibbs_Xin_update "case 1"
+        (device K1 / K2 / K3 + the native eigenbasis chain); a built model takes its priors from ``betas[burn:-1]`` of
+        the previous fit and cases 2 / 3 (device K1 / K2, host samplers on the Gram).  Returns ``(betas, mtx, evs)``
+        with ALL burnin + draws rows of the best model's draws, as the reference does; sets ``built`` when the first
+        search ends by the tolerance rule (FR:2565).  ``relats_in`` excludes nothing in any variant the reference can run (FR:2449-2466,
         2505-2510: arrays with one row or lists of non-zero ints leave `mrel` at 0; the others raise TypeError)."""
         self.inputs, self.data = inputs, data
         backend = self._backend()
@@ -1029,18 +1030,26 @@ class FoKL:
         return self._update_search(backend, np.shape(inputs)[0], np.shape(inputs)[1])
 
     def _update_search(self, backend, n, m):
-        if self.built:
-            raise NotImplementedError(
-                "fitupdate on a model that has been built (gibbs_Xin_update cases 2 and 3, FR:2153-2431: priors from "
-                "the previous posterior) is not part of this build; the first update call (case 1) is")
         relats_in = self.relats_in
         if not all(isinstance(v, int) for v in relats_in):                # FR:2449-2466
             if np.all(np.sum(np.logical_not(relats_in), axis=0)):
                 raise TypeError("only integer scalar arrays can be converted to a scalar index")
         elif sum(np.logical_not(relats_in)) != 0:                          # FR:2468, 2505-2507: relats_in[t, :] on a list
             raise TypeError("list indices must be integers or slices, not tuple")
-        stream = _capi.LegacyStream()
         t0 = time.perf_counter()
+        if self.built:
+            # priors from the previous posterior (gibbs_Xin_update cases 2 / 3): host samplers on device-built Grams,
+            # drawing from numpy's global generator call for call as the reference does
+            with _host_blas_threads():
+                betas, mtx, evs, stats, trace = _engine.fit_update_next(
+                    backend, n, m, len(self.phis), self.betas, self.burn, self.a, self.b, self.atau, self.btau,
+                    self.tolerance, self.burnin + self.draws, self.gimmie, self.aic, self.sigsqd0,
+                    console=self.ConsoleOutput)
+            self.fit_stats = dict(stats, seconds=time.perf_counter() - t0)
+            self.fit_trace = trace
+            self.avg_betas = np.mean(betas, axis=0)
+            return betas, mtx, evs
+        stream = _capi.LegacyStream()
         try:
             with _host_blas_threads():
                 betas, mtx, evs, built, stats, trace = _engine.fit_update_first(

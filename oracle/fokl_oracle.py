@@ -615,6 +615,202 @@ def fitupdate_first(inputs, data, phis, kernel, eigh=eigh_reference, build=build
 
 
 # ---------------------------------------------------------------------------------------------------------
+# N3: fitupdate on a built model: priors from the previous posterior (gibbs_Xin_update cases 2 and 3)
+# ---------------------------------------------------------------------------------------------------------
+# The reference mixes np.matrix and ndarray operands; the statements below keep its operand types (np.asmatrix where it
+# has them) so that every product dispatches to the same BLAS call and every `*` means what it means there.
+
+def gibbs_update_case2(sigsqd0, data, X, mu_old, Sigma_old, a, b, atau, btau, draws, eigh=eigh_reference):
+    """Same number of terms as the prior model (FR:2153-2264): all coefficients keep the Gaussian prior
+    N(mu_old, sigsqd tausqd Sigma_old); eigh and two inverses per Gibbs iteration."""
+    mmtx = X.shape[1] - 1
+    num_old_terms = np.shape(mu_old)[1]
+    X_old = X
+    tausqd = 1 / sigsqd0
+    XotXo = np.asmatrix(np.transpose(X_old).dot(X_old))
+    Xoty = np.transpose(X_old).dot(data)
+    Sigma_old_inverse = np.linalg.inv(Sigma_old)
+    astar = a + len(data) / 2 + (mmtx + 1) / 2
+    atau_star = atau + (mmtx + 1) / 2
+    yty = np.transpose(data).dot(data)
+    ytXo = np.transpose(data).dot(X_old)
+    betas_old = np.asmatrix(np.zeros((draws, num_old_terms)))
+    sigsqd = sigsqd0
+    lik = np.zeros((draws, 1))
+    n = len(data)
+    mu_old = mu_old.transpose()
+    for k in range(draws):
+        Sigma_old_post = np.linalg.inv(XotXo + (1 / tausqd) * Sigma_old_inverse)
+        Lamb_old, Q_old = eigh(XotXo + (1 / tausqd) * Sigma_old_inverse)
+        Lamb_tausqd_inv_old = 1 / Lamb_old
+        mu_old_post = Sigma_old_post.dot(Xoty + (1 / tausqd * Sigma_old_inverse).dot(mu_old))
+        S_old = Q_old.dot(np.diag(Lamb_tausqd_inv_old) ** (1 / 2))
+        vec_old = np.random.normal(loc=0, scale=1, size=(num_old_terms, 1))
+        betas_old[k][:] = np.transpose(mu_old_post + sigsqd ** (1 / 2) * S_old.dot(vec_old))
+        bk = betas_old[k][:]
+        comp1 = 0.5 * (yty - ytXo.dot(bk.transpose()))
+        comp2 = 0.5 * (-bk.dot(Xoty) + bk.dot(XotXo).dot(bk.transpose()))
+        comp3 = 0.5 * (1 / tausqd) * (bk.dot(Sigma_old_inverse).dot(bk.transpose())
+                                      - bk.dot(Sigma_old_inverse).dot(mu_old))
+        comp4 = 0.5 * (1 / tausqd) * (-np.transpose(mu_old).dot(Sigma_old_inverse).dot(bk.transpose())
+                                      + np.transpose(mu_old).dot(Sigma_old_inverse).dot(mu_old))
+        bstar = comp1 + comp2 + comp3 + comp4 + b
+        if bstar < 0:
+            sigsqd = math.nan
+        else:
+            sigsqd = 1 / np.random.gamma(astar, 1 / bstar)
+        comp1 = 0.5 * (1 / sigsqd) * (bk.dot(Sigma_old_inverse).dot(bk.transpose())
+                                      - bk.dot(Sigma_old_inverse).dot(mu_old))
+        comp2 = 0.5 * (1 / sigsqd) * (-np.transpose(mu_old).dot(Sigma_old_inverse).dot(bk.transpose())
+                                      + np.transpose(mu_old).dot(Sigma_old_inverse).dot(mu_old))
+        btau_star = comp1 + comp2 + btau
+        tausqd = 1 / np.random.gamma(atau_star, 1 / btau_star)
+        comp1 = -(n / 2) * np.log(sigsqd)
+        comp2 = yty - ytXo.dot(bk.transpose())
+        comp3 = -bk.dot(Xoty) + bk.dot(XotXo).dot(bk.transpose())
+        lik[k] = comp1 - 0.5 / sigsqd * (comp2 + comp3)
+    ev = (mmtx + 1) * np.log(n) - 2 * max(lik)
+    return betas_old, X[:, 0:mmtx + 1], ev
+
+
+def gibbs_update_case3(sigsqd0, data, X, mu_old, Sigma_old, a, b, atau, btau, draws, eigh=eigh_reference):
+    """More terms than the prior model (FR:2266-2425): the first `num_old_terms` coefficients keep the prior
+    N(mu_old, sigsqd Sigma_old) (no tausqd there), the new ones the usual N(0, sigsqd tausqd); blocked Gibbs."""
+    mmtx = X.shape[1] - 1
+    num_old_terms = np.shape(mu_old)[1]
+    length_old = num_old_terms
+    length_new = mmtx - num_old_terms + 1
+    X_old = X[:, 0:length_old]
+    X_new = X[:, length_old:length_old + length_new]
+    tausqd = 1 / sigsqd0
+    XotXo = np.asmatrix(np.transpose(X_old).dot(X_old))
+    Xoty = np.transpose(X_old).dot(data)
+    Sigma_old_inverse = np.linalg.inv(Sigma_old)
+    Sigma_old_post = np.linalg.inv(XotXo + Sigma_old_inverse)
+    Lamb_old, Q_old = eigh(XotXo + Sigma_old_inverse)
+    XntXn = np.transpose(X_new).dot(X_new)
+    Xnty = np.transpose(X_new).dot(data)
+    Lamb_new, Q_new = eigh(XntXn)
+    XotXn = np.transpose(X_old).dot(X_new)
+    XntXo = np.transpose(X_new).dot(X_old)
+    Lamb_tausqd_inv_old = np.diag(np.linalg.inv(np.diag(Lamb_old)))
+    astar = a + len(data) / 2 + (mmtx + 1) / 2
+    atau_star = atau + length_new / 2
+    yty = np.transpose(data).dot(data)
+    ytXo = np.transpose(data).dot(X_old)
+    ytXn = np.transpose(data).dot(X_new)
+    betas_old = np.asmatrix(np.zeros((draws, num_old_terms)))
+    betas_new = np.asmatrix(np.zeros((draws, mmtx - num_old_terms + 1)))
+    sigsqd = sigsqd0
+    lik = np.zeros((draws, 1))
+    n = len(data)
+    mu_old = mu_old.transpose()
+    for k in range(draws):
+        mu_old_post = Sigma_old_post.dot(Xoty - XotXn.dot(betas_new[k - 1].transpose()) + Sigma_old_inverse.dot(mu_old))
+        S_old = Q_old.dot(np.diag(Lamb_tausqd_inv_old) ** (1 / 2))
+        vec_old = np.random.normal(loc=0, scale=1, size=(length_old, 1))
+        betas_old[k][:] = np.transpose(mu_old_post + sigsqd ** (1 / 2) * S_old.dot(vec_old))
+        bo = betas_old[k][:]
+        Lamb_tausqd_inv_new = np.diag(np.linalg.inv(np.diag(Lamb_new) + (1 / tausqd) * np.identity(length_new)))
+        mu_new_post = np.linalg.inv(XntXn + (1 / tausqd) * np.identity(length_new)).dot(
+            Xnty - XntXo.dot(betas_old[k].transpose()))
+        S_new = Q_new.dot(np.diag(Lamb_tausqd_inv_new) ** (1 / 2))
+        vec_new = np.random.normal(loc=0, scale=1, size=(length_new, 1))
+        betas_new[k][:] = np.transpose(mu_new_post + sigsqd ** (1 / 2) * S_new.dot(vec_new))
+        bn = betas_new[k][:]
+        comp1 = 0.5 * (yty - ytXo.dot(bo.transpose()) - ytXn.dot(bn.transpose()))
+        comp2 = 0.5 * (-bo.dot(Xoty) + bo.dot(XotXo).dot(bo.transpose()) + bo.dot(XotXn).dot(bn.transpose()))
+        comp3 = 0.5 * (-bn.dot(Xnty) + bn.dot(XntXo).dot(bo.transpose()) + bn.dot(XntXn).dot(bn.transpose()))
+        comp4 = 0.5 / tausqd * (bn.dot(bn.transpose()))
+        comp5 = 0.5 * (bo.dot(Sigma_old_inverse).dot(bo.transpose()) - bo.dot(Sigma_old_inverse).dot(mu_old))
+        comp6 = 0.5 * (-np.transpose(mu_old).dot(Sigma_old_inverse).dot(bo.transpose())
+                       + np.transpose(mu_old).dot(Sigma_old_inverse).dot(mu_old))
+        bstar = comp1 + comp2 + comp3 + comp4 + comp5 + comp6 + b
+        if bstar < 0:
+            sigsqd = math.nan
+        else:
+            sigsqd = 1 / np.random.gamma(astar, 1 / bstar)
+        btau_star = (1 / (2 * sigsqd)) * (bn.dot(bn.transpose())) + btau
+        tausqd = 1 / np.random.gamma(atau_star, 1 / btau_star)
+        comp1 = -(n / 2) * np.log(sigsqd)
+        comp2 = yty - ytXo.dot(bo.transpose()) - ytXn.dot(bn.transpose())
+        comp3 = -bo.dot(Xoty) + bo.dot(XotXo).dot(bo.transpose()) + bo.dot(XotXn).dot(bn.transpose())
+        comp4 = -bn.dot(Xnty) + bn.dot(XntXo).dot(bo.transpose()) + bn.dot(XntXn).dot(bn.transpose())
+        lik[k] = comp1 - 0.5 / sigsqd * (comp2 + comp3 + comp4)
+    ev = (mmtx + 1) * np.log(n) - 2 * max(lik)
+    return np.concatenate((betas_old, betas_new), axis=1), X[:, 0:mmtx + 1], ev
+
+
+def fitupdate_next(inputs, data, phis, kernel, betas_prev, burn=500, eigh=eigh_reference, build=build_columns_c,
+                   sigsqd0=0.5, **hypers):
+    """``fit(update=True)`` on a model that HAS been built (FR:1939-1943, 2473-2583): prior mean / covariance from the
+    previous draws ``betas_prev[burn:-1]``; sub-stages are skipped until the interaction matrix is as long as the prior
+    model (FR:2530), then case 2 ("same") once and case 3 ("new") for every longer model.  Returns (betas, mtx, evs,
+    built) with evs as the reference leaves it: a [k, 1] array."""
+    hp = dict(DEFAULT_HYPERS)
+    for key, val in hypers.items():
+        if key not in hp:
+            raise ValueError(f"Unexpected keyword argument: '{key}'")
+        hp[key] = val
+    a, atau = hp['a'], hp['atau']
+    b, btau = default_b_btau(data, a, atau, hp['b'], hp['btau'])
+    tolerance, aic = hp['tolerance'], hp['aic']
+    draws = hp['burnin'] + hp['draws']
+    mu_old = np.asmatrix(np.mean(betas_prev[burn:-1], axis=0))
+    sigma_old = np.cov(betas_prev[burn:-1].transpose())
+    num_old_terms = np.shape(mu_old)[1]
+    if kernel == KERNEL_SPLINES:
+        phind, xsm = inputs_to_phind(inputs, len(phis[0][0]))
+    else:
+        phind, xsm = None, inputs
+    n, m = inputs.shape
+    damtx = np.zeros((0, m))
+    evs = []
+    ind = 1
+    greater = 0
+    finished = False
+    built = True
+    X = None
+    betas_best = mtx = betas = None
+    while True:
+        i_list = [0] if ind == 1 else np.arange(0, math.floor(ind / 2) + 0.1, 1)[::-1]
+        for i in i_list:
+            vecs = np.zeros(m)
+            vecs[0] = ind - i
+            vecs[1] = i
+            damtx = np.concatenate((damtx, distinct_arrangements(vecs)), axis=0)
+            if num_old_terms - 1 <= damtx.shape[0]:
+                have = 1 if X is None else X.shape[1]
+                Xin = np.ones((n, 1)) if X is None else X
+                if damtx.shape[0] + 1 > have:
+                    Xin = np.concatenate([Xin, build(xsm, phind, phis, kernel, damtx[have - 1:])], axis=1)
+                if num_old_terms == damtx.shape[0] + 1:
+                    betas, X, ev = gibbs_update_case2(sigsqd0, data, Xin, mu_old, sigma_old, a, b, atau, btau, draws,
+                                                      eigh=eigh)
+                else:
+                    betas, X, ev = gibbs_update_case3(sigsqd0, data, Xin, mu_old, sigma_old, a, b, atau, btau, draws,
+                                                      eigh=eigh)
+                if aic:
+                    ev = ev + (2 - np.log(n)) * damtx.shape[0]
+                evs = np.concatenate((evs, [ev])) if np.size(evs) else [ev]
+                if ev == np.min(evs):
+                    betas_best, mtx, greater = betas, damtx, 1
+                elif greater <= tolerance:
+                    greater = greater + 1
+                else:
+                    finished = True
+                    break
+        if finished:
+            break
+        ind = ind + 1
+        if ind > len(phis):
+            break
+    if hp['gimmie']:
+        betas_best, mtx = betas, damtx
+    return betas_best, mtx, np.array(evs), built
+
+
+# ---------------------------------------------------------------------------------------------------------
 # evaluate / coverage3 numerics (kept class surface; FR:929-978, FR:1193)
 # ---------------------------------------------------------------------------------------------------------
 

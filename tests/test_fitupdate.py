@@ -97,7 +97,7 @@ def test_first_update_call_on_the_checker_backend(tag):
 
 def test_update_quirks_of_the_reference():
     """One input dies in the reference's shape handling (FR:2528); relats_in excludes nothing in the variants that run
-    and raises TypeError in the others; a built model is refused (cases 2 / 3 are not part of this build)."""
+    and raises TypeError in the others."""
     rng = np.random.default_rng(0)
     x, y = rng.random((80, 3)), rng.random(80)
     kw = dict(kernel=1, update=True, burnin=10, draws=10, UserWarnings=False, ConsoleOutput=False)
@@ -120,13 +120,105 @@ def test_update_quirks_of_the_reference():
             model._backend_override = OracleBackend()
             with pytest.raises(TypeError):
                 model.fit(x, y, clean=True)
-        built = FoKLRoutines.FoKL(built=True, **kw)
-        built._backend_override = OracleBackend()
-        with pytest.raises(NotImplementedError):
-            built.fit(x, y, clean=True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', CASES)
 def test_first_update_call_on_gpu(tag):
     check_against_reference(tag, *fit_product(tag))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# second call: priors from the first fit's posterior (gibbs_Xin_update cases 2 and 3)
+# ---------------------------------------------------------------------------------------------------------
+
+S = np.load(os.path.join(GOLDEN, 'fitupdate_sequence.npz'), allow_pickle=False)
+SEQ = [str(c) for c in S['cases']]
+
+
+def seq_setup(tag):
+    kern = str(S[f'{tag}_kernel'])
+    hy = {str(k): float(v) for k, v in zip(S[f'{tag}_hyper_keys'], S[f'{tag}_hyper_vals'])}
+    for k in ('burnin', 'draws', 'tolerance', 'burn'):
+        if k in hy:
+            hy[k] = int(hy[k])
+    for k in ('gimmie', 'aic'):
+        if k in hy:
+            hy[k] = bool(hy[k])
+    if kern == 'Cubic Splines':
+        phis, kid = getKernels.table_to_phis(np.load(os.path.join(GOLDEN, 'spline_phis.npz'))['table']), O.KERNEL_SPLINES
+    else:
+        phis, kid = getKernels.bernoulli(), O.KERNEL_BERNOULLI
+    return kern, phis, kid, hy
+
+
+@pytest.mark.parametrize('tag', SEQ)
+@pytest.mark.parametrize('variant', ['ref', 'canon'])
+def test_oracle_restates_the_second_update_call_bit_for_bit(tag, variant):
+    """From the reference's own first-call draws and the stream position it left: cases 2 / 3 of the oracle return the
+    reference's second-call numbers exactly (b / btau persist from the first call, FR:1322-1348 only fill None)."""
+    kern, phis, kid, hy = seq_setup(tag)
+    pre = f'{tag}_{variant}_'
+    burn, sig0 = hy.pop('burn'), hy.pop('sigsqd0', 0.5)
+    # replay the first call to put numpy's stream where the second call starts
+    x1, y1 = S[f'{tag}_raw_inputs1'], S[f'{tag}_raw_data1']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        first = FoKLRoutines.FoKL(kernel=kern, phis=phis, UserWarnings=False, ConsoleOutput=False)
+        first.clean(x1, y1, _setattr=True)
+    eigh = O.eigh_canonical if variant == 'canon' else O.eigh_reference
+    np.random.seed(int(S[f'{tag}_seed']))
+    b1, m1, e1, built = O.fitupdate_first(first.inputs, first.data, phis, kid, eigh=eigh, sigsqd0=sig0, **hy)
+    assert np.array_equal(b1, S[pre + 'betas1']) and built == bool(S[pre + 'built1'])
+    assert np.array_equal(rng_fingerprint()[0], S[pre + 'rng_mid'])
+    b2, m2, e2, _ = O.fitupdate_next(S[f'{tag}_norm_inputs2'], S[f'{tag}_norm_data2'], phis, kid, b1, burn=burn, eigh=eigh,
+                                     sigsqd0=sig0, **dict(hy, b=float(S[f'{tag}_b']), btau=float(S[f'{tag}_btau'])))
+    fp, cache = rng_fingerprint()
+    assert np.array_equal(m2, S[pre + 'mtx2']) and np.array_equal(e2, S[pre + 'evs2'])
+    assert np.array_equal(np.asarray(b2), S[pre + 'betas2'])
+    assert np.array_equal(fp, S[pre + 'rng']) and cache == float(S[pre + 'rng_cache'])
+
+
+def update_twice(tag, backend_factory=None):
+    kern, phis, kid, hy = seq_setup(tag)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = FoKLRoutines.FoKL(kernel=kern, phis=phis, update=True, UserWarnings=False, ConsoleOutput=False, **hy)
+        if backend_factory is not None:
+            model._backend_override = backend_factory()
+        np.random.seed(int(S[f'{tag}_seed']))
+        b1, m1, e1 = model.fit(S[f'{tag}_raw_inputs1'], S[f'{tag}_raw_data1'], clean=True)
+        mid = rng_fingerprint()
+        b2, m2, e2 = model.fit(S[f'{tag}_raw_inputs2'], S[f'{tag}_raw_data2'], clean=True)
+    return model, (b1, m1, e1, mid), (b2, m2, e2, rng_fingerprint())
+
+
+def check_sequence(tag, model, first, second):
+    """Same tolerances as everywhere: models, shapes and numpy's stream exact, BIC 1e-9 relative, draws 1e-9 of the
+    column scale -- although the second call inverts the covariance of the first call's draws (condition numbers
+    5e3 .. 9e4 in these fixtures) the measured differences stay at 1e-12 / 6e-11."""
+    pre = f'{tag}_canon_'
+    b1, m1, e1, mid = first
+    b2, m2, e2, end = second
+    assert np.array_equal(m1, S[pre + 'mtx1']) and model.built == bool(S[pre + 'built1'])
+    assert np.max(np.abs(b1 - S[pre + 'betas1']) / np.max(np.abs(S[pre + 'betas1']), axis=0)) < 1e-9
+    assert np.array_equal(mid[0], S[pre + 'rng_mid']) and mid[1] == float(S[pre + 'rng_mid_cache'])
+    assert np.array_equal(model.inputs, S[f'{tag}_norm_inputs2'])        # second batch normalised with the first's min / max
+    assert abs(model.b - float(S[f'{tag}_b'])) <= 1e-15 * abs(float(S[f'{tag}_b']))
+    assert np.array_equal(m2, S[pre + 'mtx2']) and np.array_equal(m2, S[f'{tag}_ref_mtx2'])
+    assert e2.shape == S[pre + 'evs2'].shape                              # [k, 1], as the reference leaves it
+    assert np.max(np.abs(e2 - S[pre + 'evs2']) / np.abs(S[pre + 'evs2'])) < 1e-9
+    scale = np.max(np.abs(S[pre + 'betas2']), axis=0)
+    assert b2.shape == S[pre + 'betas2'].shape and np.max(np.abs(b2 - S[pre + 'betas2']) / scale) < 1e-9
+    assert np.array_equal(end[0], S[pre + 'rng']) and end[1] == float(S[pre + 'rng_cache'])
+
+
+@pytest.mark.parametrize('tag', SEQ)
+def test_second_update_call_on_the_checker_backend(tag):
+    check_sequence(tag, *update_twice(tag, OracleBackend))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', SEQ)
+def test_second_update_call_on_gpu(tag):
+    check_sequence(tag, *update_twice(tag))
