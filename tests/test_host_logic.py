@@ -258,14 +258,8 @@ def test_relats_in_behaviour_matches_reference_quirks():
 
 
 def test_out_of_scope_entry_points_say_so():
-    """to_pyomo (out of scope) and sequential updating of a model that HAS a prior (gibbs_Xin_update
-    cases 2 / 3; the first update call is built, tests/test_fitupdate.py) refuse loudly."""
-    model = FoKLRoutines.FoKL(kernel=1, update=True, built=True, UserWarnings=False, ConsoleOutput=False)
-    model._backend_override = OracleBackend()
-    with pytest.raises(NotImplementedError):
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            model.fit(np.random.default_rng(0).random((20, 2)), np.zeros(20), clean=True)
+    """to_pyomo (out of scope) refuses loudly; sequential updating is built (tests/test_fitupdate.py)."""
+    model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False, ConsoleOutput=False)
     with pytest.raises(NotImplementedError):
         model.to_pyomo()
 
