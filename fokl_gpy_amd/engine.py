@@ -274,12 +274,22 @@ def _thread_plan():
     """(chain, finish, spectral) thread counts of the host pipeline for the CPU budget of this process; the driver and
     the noise thread come on top.  FOKL_CHAIN_THREADS / FOKL_FINISH_THREADS / FOKL_SPECTRAL_THREADS override."""
     budget = _cpu_budget()
-    if budget >= 8:
-        plan = (2, 3, 3)
-    elif budget >= 6:
-        plan = (1, 2, 2)
+    # Finishing threads follow the recorder block by block and spin while they wait for it, so each of them costs about
+    # the recorder's own busy time in CPU whatever it computes.  With the vector log (default, fokl_vlog.cpp) one thread
+    # finishes a tape in a third of the time it takes to record; with libm's scalar log (FOKL_FINISH_LOG=exact) it takes
+    # three.  Measured on the GPU boxes (tools/thread_plan_sweep.sh, tools/cpu_budget_sweep.sh; chain + finish + spectral:
+    # ms per configs[2] fit / pool CPU-seconds per fit).  16 CPUs: 2+3+3 107.8 / 0.51, 2+1+3 107.8 / 0.40, 1+1+3 106.9 /
+    # 0.37, 2+0+3 121 / 0.34, 1+0+3 132 / 0.32;  8 CPUs: 1+1+3 115.6, 2+1+3 119.7, 2+1+4 120.0;  6 CPUs: 1+1+3 113.0,
+    # 1+1+2 161.6;  5 CPUs: 1+1+3 118.9;  4 CPUs: 1+1+2 146.6, 1+0+2 149.7, 1+1+1 179.6, 1+1+3 208.6;  3 CPUs: 1+1+2
+    # 189.8, 1+0+2 199.5, 1+1+1 201.6;  2 CPUs: 1+0+1 239.5, 1+0+2 245.7.  The eigen-decompositions are the throughput
+    # item (0.13 CPU-seconds per fit): three spectral threads as soon as five CPUs are there.
+    exact_log = os.environ.get('FOKL_FINISH_LOG', 'fast') == 'exact'
+    if budget >= 12:
+        plan = (2, 3 if exact_log else 1, 3)                # second chain thread: models of hundreds of columns (configs[3])
+    elif budget >= 5:
+        plan = (1, 2 if exact_log else 1, 3)
     elif budget >= 3:
-        plan = (1, 1, 1)
+        plan = (1, 1, 2)
     else:
         plan = (1, 0, 1)
     names = ('FOKL_CHAIN_THREADS', 'FOKL_FINISH_THREADS', 'FOKL_SPECTRAL_THREADS')

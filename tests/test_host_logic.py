@@ -412,10 +412,17 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     monkeypatch.delenv('FOKL_CHAIN_THREADS', raising=False)
     monkeypatch.delenv('FOKL_FINISH_THREADS', raising=False)
     monkeypatch.delenv('FOKL_SPECTRAL_THREADS', raising=False)
-    cases = ((16, (2, 3, 3)), (8, (2, 3, 3)), (7.5, (1, 2, 2)), (4, (1, 1, 1)), (2, (1, 0, 1)), (1, (1, 0, 1)))
+    monkeypatch.delenv('FOKL_FINISH_LOG', raising=False)
+    cases = ((16, (2, 1, 3)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 1, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
     for budget, plan in cases:
         monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
         assert engine._thread_plan() == plan
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')                  # libm's scalar log: finishing needs three threads
+    for budget, plan in ((16, (2, 3, 3)), (7.5, (1, 2, 3))):
+        monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
+        assert engine._thread_plan() == plan
+    monkeypatch.delenv('FOKL_FINISH_LOG')
+    monkeypatch.setattr(engine, '_cpu_budget', lambda: 2)
     monkeypatch.setenv('FOKL_FINISH_THREADS', '5')
     assert engine._thread_plan() == (1, 5, 1)
     monkeypatch.undo()

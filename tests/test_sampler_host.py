@@ -6,6 +6,15 @@ from fokl_gpy_amd import _capi
 from oracle import fokl_oracle as O
 
 
+@pytest.fixture(autouse=True)
+def exact_finishing_log(monkeypatch, request):
+    """The bit-for-bit statements of this file hold with libm's scalar log in the finishing half of the polar method
+    (FOKL_FINISH_LOG=exact); the default of the tape path is glibc's vector log (libmvec), which differs from it in the
+    last bit of one argument in four -- pinned by test_fast_finishing_log_is_within_an_ulp_and_leaves_the_stream_alone."""
+    if 'fast_finishing' not in request.node.name:
+        monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+
+
 @pytest.mark.parametrize('seed', [0, 7, 102823, 102923, 2 ** 32 - 1])
 def test_stream_is_bit_identical_to_numpy(seed):
     np.random.seed(seed)
@@ -323,3 +332,29 @@ def test_random_tapes_through_the_pool_are_numpy_bit_for_bit():
         a, b = np.random.get_state(), st.as_numpy_state()
         assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
     assert checked > 100
+
+
+def test_fast_finishing_log_is_within_an_ulp_and_leaves_the_stream_alone(monkeypatch):
+    """Default finishing (vector log): same tape, same stream position as numpy; normals within 4 ulp of numpy's (measured: 3; the
+    log is within 1 ulp, then a divide, a square root and a product), draws of a chain within 1e-13 of the exact ones."""
+    p1, draws = 37, 300
+    np.random.seed(11)
+    want = np.stack([np.random.normal(size=p1) for _ in range(1)])       # first iteration's normals, numpy's bits
+    np.random.seed(11)
+    out = {}
+    for mode in ('exact', 'fast'):
+        monkeypatch.setenv('FOKL_FINISH_LOG', mode)
+        np.random.seed(11)
+        stream = _capi.LegacyStream()
+        tape = _capi.noise_tape(p1, draws, 40.0, 22.5, stream)
+        lamb = np.linspace(5.0, 900.0, p1)
+        qty = np.cos(np.arange(p1))
+        w, neg = _capi.gibbs_chain_from_tape(lamb, qty, 1.3, 2.1, 50.0, 0.4, 0.6, tape)
+        _capi.finish_tape_blocks(tape)
+        out[mode] = (np.array(tape.normals), w, stream.as_numpy_state())
+    assert np.array_equal(out['exact'][0][0], want[0])
+    a, b = out['exact'][0], out['fast'][0]
+    assert np.max(np.abs(a - b) / np.spacing(np.abs(a))) <= 4.0 and not np.array_equal(a, b)
+    assert np.max(np.abs(out['exact'][1] - out['fast'][1])) < 1e-13 * np.max(np.abs(out['exact'][1]))
+    sa, sb = out['exact'][2], out['fast'][2]
+    assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
