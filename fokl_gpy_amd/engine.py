@@ -418,17 +418,28 @@ class HostPipeline:
         jobs = self._windows.pop(window)
         length = max(_capi.SpectralResult.doubles(job.p1) for job in jobs)
         send = np.zeros(length)
+        failure = None
         for job in jobs:
             if job.local is not None:
-                res = job.local.wait()
-                send[:res._buf.shape[0]] = res._buf
-                job.result = res
+                try:
+                    res = job.local.wait()
+                    send[:res._buf.shape[0]] = res._buf
+                    job.result = res
+                except _capi.FoklNativeError as exc:
+                    # a rank that raised here alone would leave the others waiting in the collective for ever: ship
+                    # NaNs, let every rank see them and fail together
+                    failure = exc
+                    send[:] = np.nan
         gathered = self.comm.allgather(send)
         self.exchanges += 1
         for job in jobs:
+            owner = job.seq % self.comm.world
+            if np.isnan(gathered[owner, 0]):
+                raise RuntimeError(f"candidate-sharded search: rank {owner} could not diagonalise model {job.seq} "
+                                   f"({job.p1} columns)") from failure
             if job.result is None:
                 need = _capi.SpectralResult.doubles(job.p1)
-                job.result = _capi.SpectralResult(job.p1, np.array(gathered[job.seq % self.comm.world, :need]))
+                job.result = _capi.SpectralResult(job.p1, np.array(gathered[owner, :need]))
                 self.remote_results += 1
 
     def chain(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job):
