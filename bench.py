@@ -232,25 +232,56 @@ def l3_domain_of(cpu):
         return None
 
 
-def pin_to_l3_domain(local):
-    """Keep this rank's host threads (search driver + the native noise / chain / spectral threads, about ten) on the
-    logical CPUs of ONE L3 domain: noise tapes (about 1 MB each) are handed from thread to thread.  Rank r takes the
-    domain of CPU 8 r (8 cores x 2 SMT threads on the EPYC hosts of this pool)."""
+def quietest_l3_domain(local, ranks, sample_s=0.25):
+    """The hosts of the pool are shared: other tenants' load on the cores a fit's threads sit on shows up one to one in
+    the (host-bound) fit time.  Sample /proc/stat for a moment and take the least busy L3 domain among those this rank
+    may claim (domains d with d % ranks == local, so that the ranks of a node never pick the same one)."""
+    def snap():
+        out = {}
+        with open('/proc/stat') as fh:
+            for line in fh:
+                if line.startswith('cpu') and line[3].isdigit():
+                    p = line.split()
+                    out[int(p[0][3:])] = (sum(map(int, p[1:9])), int(p[4]) + int(p[5]))
+        return out
+    try:
+        allowed = set(os.sched_getaffinity(0))
+        a = snap()
+        time.sleep(sample_s)
+        b = snap()
+        domains, seen = [], set()
+        for cpu in sorted(allowed):
+            if cpu in seen:
+                continue
+            dom = l3_domain_of(cpu)
+            if not dom:
+                continue
+            seen.update(dom)
+            busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
+            domains.append((sum(busy) / max(1, len(busy)), dom))
+        mine = [d for i, d in enumerate(domains) if i % max(1, ranks) == local % max(1, ranks)]
+        if not mine:
+            return None
+        return min(mine, key=lambda d: d[0])[1]
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+def pin_to_l3_domain(local, ranks=1):
+    """Keep this rank's host threads (search driver + the native noise / chain / spectral threads, about eight) on the
+    logical CPUs of ONE L3 domain: noise tapes (about 1 MB each) are handed from thread to thread.  The domain is the
+    quietest one this rank may claim (quietest_l3_domain); failing that, the domain of CPU 8 r (8 cores x 2 SMT threads
+    on the EPYC hosts of this pool)."""
     if os.environ.get('FOKL_BENCH_PIN', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
         return None
     try:
-        allowed = set(os.sched_getaffinity(0))
-        want = set(range(8 * local, 8 * local + 8))
-        try:
-            with open(f'/sys/devices/system/cpu/cpu{8 * local}/cache/index3/shared_cpu_list') as fh:
-                want = set()
-                for part in fh.read().strip().split(','):
-                    lo, _, hi = part.partition('-')
-                    want.update(range(int(lo), int(hi or lo) + 1))
-        except (OSError, ValueError):
-            pass
-        want = sorted(want & allowed)
-        if len(want) >= 2:
+        want = None
+        if os.environ.get('FOKL_BENCH_PIN', '1') != 'fixed':
+            want = quietest_l3_domain(local, ranks)
+        if not want:
+            allowed = set(os.sched_getaffinity(0))
+            want = l3_domain_of(8 * local) or sorted(set(range(8 * local, 8 * local + 8)) & allowed)
+        if want and len(want) >= 2:
             os.sched_setaffinity(0, want)
             return want
     except OSError:
@@ -307,7 +338,7 @@ def main():
         for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '2'), ('FOKL_SPECTRAL_THREADS', '2')):
             os.environ.setdefault(name, val)
     else:
-        pinned = pin_to_l3_domain(local)
+        pinned = pin_to_l3_domain(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     mode = args.mode or ('candidates' if cfg == 3 else 'fits')
     one_fit_for_all = mode in ('rows', 'candidates')
     fits_per_step = (args.fits_per_step or 8) if cfg == 4 else 1
