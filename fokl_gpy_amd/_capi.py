@@ -15,7 +15,6 @@ LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.s
 
 UNIQUE_ID_BYTES = 128
 K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF = 0, 1, 2, 3, 4
-PREDICT_MAX_ORDER_STAT = 128     # fokl_predict.inc: PR_MAX_K
 RESID_TERMS_MAX_FACTORS = 48
 RESID_TERMS_MAX_ORDER = 8
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
@@ -554,12 +553,6 @@ class DeviceContext:
         draws, nc = betas.shape
         if nc != s.shape[0]:
             raise ValueError("betas columns must match the slot list")
-        if cut is not None and cut + 1 > PREDICT_MAX_ORDER_STAT:
-            raise ValueError(
-                f"95 % bounds over {draws} draws need the {cut + 1}-th smallest prediction of every row; the on-chip "
-                f"order statistics of fokl_predict hold {PREDICT_MAX_ORDER_STAT} per row (bounds over up to "
-                f"{int((PREDICT_MAX_ORDER_STAT - 1) / 0.025) - 1} draws).  Evaluate with fewer draws "
-                f"(evaluate(..., draws=...), coverage3(draws=...)) or without bounds (ReturnBounds=False).")
         mean = np.empty(self.n, dtype=np.float64)
         bounds = np.empty((self.n, 2), dtype=np.float64) if cut is not None else None
         self._ck(self._lib.fokl_predict(self._h, _ptr(s), nc, _ptr(betas), draws, int(cut or 0), _ptr(mean),

@@ -280,6 +280,30 @@ def test_predict_mean_and_order_statistics(device_ctx):
         assert np.max(np.abs(device_ctx.predict(sl, betas) - mean)) < 1e-13        # two kernels, same numbers
 
 
+def test_predict_bounds_over_thousands_of_draws(device_ctx):
+    """evaluate(ReturnBounds=True) / coverage3 over >= 5 080 draws need the 128-th and later order
+    statistics per row, more than the on-chip lists hold; the reference sorts any number of draws (FR:971-977).  The
+    lists then live in device memory: same result as numpy's sort, here with 6 200 and 12 000 draws."""
+    rng = np.random.default_rng(23)
+    n, nc = 700, 9
+    upload(device_ctx, rng.random((n, 1)), np.zeros(n), O.KERNEL_BERNOULLI)
+    cols = rng.standard_normal((n, nc - 1))
+    load_columns(device_ctx, cols)
+    X = np.concatenate([np.ones((n, 1)), cols], axis=1)
+    sl = np.concatenate([[0], np.arange(2, 2 + nc - 1)]).astype(np.int32)
+    for draws in (6200, 12000):
+        betas = rng.standard_normal((draws, nc)) * np.linspace(1.0, 0.1, nc)
+        cut = int(np.floor(draws * 0.025) + 1)
+        assert cut + 1 > 128
+        mean, bounds = device_ctx.predict(sl, betas, cut)
+        mod = X @ betas.T
+        srt = np.sort(mod, axis=1)
+        scale = np.max(np.abs(mod))
+        assert np.max(np.abs(mean - mod.mean(axis=1))) < 1e-12 * scale
+        assert np.max(np.abs(bounds[:, 0] - srt[:, cut])) < 1e-12 * scale
+        assert np.max(np.abs(bounds[:, 1] - srt[:, draws - cut])) < 1e-12 * scale
+
+
 def test_predict_bounds_when_the_draws_are_far_from_gaussian(device_ctx):
     """The matrix-pipe predict kernel looks for the bounds among the predictions beyond mean -/+ z sigma of the row;
     draws with a few wild outliers inflate sigma until hardly anything passes, equal draws leave sigma = 0: both must
