@@ -88,10 +88,12 @@ def test_config_datasets_regenerate_bit_for_bit():
     assert seen >= 1
 
 
-def test_host_logic_reproduces_the_config4_unit_on_the_checker_backend():
+@pytest.mark.parametrize('name', ['cfg4_unit0_n1e5_m8', 'cfg1_n1e5_m4_splines'])
+def test_host_logic_reproduces_full_size_configs_on_the_checker_backend(name):
     """The search driver + native sampler on the CPU stand-in backend (tests/helpers.OracleBackend) against the
-    golden of one configs[4] unit at its full size (N = 1e5, M = 8, 2000 Gibbs iterations per evaluation)."""
-    g = load_golden('cfg4_unit0_n1e5_m8')
+    goldens of one configs[4] unit (N = 1e5, M = 8, Bernoulli) and of configs[1] (N = 1e5, M = 4, Cubic Splines) at
+    their full size and 2000 Gibbs iterations per evaluation."""
+    g = load_golden(name)
     assert_matches_golden(g, *fit_like_golden(g, OracleBackend()))
 
 
