@@ -11,7 +11,8 @@ One *step* = one complete forward-selection fit (FoKL.fit's search: every sub-st
 Gibbs chains, BIC and kill tests) over a synthetic BASELINE configuration (default configs[2]: N = 1e6 rows,
 M = 8 inputs, Bernoulli-polynomial kernel, 2-way interactions, reference-default hyper-parameters: burnin 1000,
 draws 1000, tolerance 3) with the normalised inputs already resident in HBM when the timed region starts.
---config 4: a step is --fits-per-step independent fits (N = 1e5, M = 8 each) on resident datasets.
+--config 4: a step is --fits-per-step independent fits (N = 1e5, M = 8 each) on resident datasets, dealt over --procs
+worker processes that share the GPU (throughput mode).
 
 `value` = candidate terms / second, where the numerator is the reference-equivalent (logical) count: the sum
 over all gibbs evaluations of the columns the reference builds for that evaluation (FoKLRoutines.py:1461),
@@ -289,6 +290,255 @@ def pin_to_l3_domain(local, ranks=1):
     return None
 
 
+def kernel_report(kern, n, m, cfg):
+    """Per-kernel roofline readings from the HIP-event totals `kern` (name -> ms, launches, bytes, flops, ideal_ms).
+    -> (kernels, dominant kernel's `roofline` object, device milliseconds)"""
+    def roof(name, bound):
+        k = kern[name]
+        if k['launches'] == 0 or k['ms'] <= 0:
+            return None
+        avg_ms = k['ms'] / k['launches']
+        if bound == 'hbm':
+            achieved = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
+            return dict(kernel=name, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
+                        total_ms=k['ms'], algorithmic_bytes_per_launch=k['bytes'] / k['launches'])
+        achieved = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
+        return dict(kernel=name, bound='mfma', achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
+                    total_ms=k['ms'])
+
+    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm'),
+               'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
+    mf = kernels['resid_matrix_free']
+    if mf:
+        # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns
+        # costs more time at the fp64 peak (FMA = 2 flops; most of its operations are separately-rounded multiplies
+        # and adds, i.e. half of that at best) than its 8 N (M_used + 1) bytes cost at the HBM peak
+        k = kern['resid_matrix_free']
+        tf = k['flops'] / k['launches'] / (mf['avg_ms'] * 1e-3) / 1e12
+        mf.update(fp64_valu_tflops=tf, fp64_valu_frac=tf / FP64_MFMA_PEAK_TFLOPS,
+                  roofline_frac=k['ideal_ms'] / k['ms'])
+        if k['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > k['bytes'] / (HBM_PEAK_GBS * 1e9):
+            mf.update(bound='valu-fp64', achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                      frac=tf / FP64_MFMA_PEAK_TFLOPS, hbm_achieved_gbs=mf['achieved'], hbm_frac=mf['frac'])
+    if kernels['gram']:
+        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings,
+        # `bound` = the roof that binds the launches of this run taken together ...
+        gm = roof('gram', 'mfma')
+        hb = kernels['gram']
+        if kern['gram']['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > kern['gram']['bytes'] / (HBM_PEAK_GBS * 1e9):
+            kernels['gram'] = dict(gm, hbm_achieved_gbs=hb['achieved'], hbm_frac=hb['frac'],
+                                   algorithmic_bytes_per_launch=hb['algorithmic_bytes_per_launch'])
+        else:
+            kernels['gram'].update(mfma_achieved_tflops=gm['achieved'], mfma_frac=gm['frac'])
+        # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
+        kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
+    # rocprofv3 --pmc passes over this same command (profiles/pmc_r02.json, produced by tools/profile_r02.sh: separate
+    # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
+    # was recorded for exactly this workload.
+    traffic_source = None
+    for cand in ('pmc_r02.json', 'pmc_r01.json'):
+        pmc_path = os.path.join(ROOT, 'profiles', cand)
+        if not os.path.exists(pmc_path):
+            continue
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        if pmc.get('workload') in ({'rows': n, 'inputs': m}, {'rows': n, 'inputs': m, 'config': cfg}) and cfg == 2:
+            for name, k in kernels.items():
+                if k and name in pmc['kernels']:
+                    k['traffic'] = pmc['kernels'][name]['hbm_bytes_per_launch']
+            traffic_source = f'profiles/{cand}: rocprofv3 --pmc passes over this command, committed with the sources; ' \
+                             f'not re-measured in this run'
+            break
+    dominant = max((k for k in kernels.values() if k), key=lambda k: k['total_ms'])
+    dominant = dict(dominant, traffic_source=traffic_source)
+    gpu_ms = sum(k['total_ms'] for k in kernels.values() if k)
+    return kernels, dominant, gpu_ms
+
+
+def config4_worker(k, procs, local, unit_ids, rows, steps, warmup, start, done):
+    """One of the worker PROCESSES of `--config 4 --procs P`: its own device context(s), host threads and L3 domain; fits
+    its share of the rank's datasets back to back.  (Threads of one process share the interpreter lock of the Python
+    drivers; processes do not: 13.7 / 21.9 / 32.8 / 40.6 fits/s with 1 / 2 / 3 / 4 of them on one MI355X.)"""
+    try:
+        dom = l3_domain_of(8 * (local * procs + k))
+        if dom:
+            os.sched_setaffinity(0, dom)
+    except OSError:
+        pass
+    for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
+                      ('FOKL_SPECTRAL_THREADS', '2' if procs > 2 else '3')):
+        os.environ.setdefault(name, val)
+    os.environ['FOKL_DEVICE'] = str(local)
+    from fokl_gpy_amd import FoKLRoutines, _capi, engine
+    fits = []
+    prep_s = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for unit in unit_ids:
+            x, y, spec = config_workload(4, unit, rows)
+            kernel, phis, _ = kernel_and_phis(spec)
+            model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **spec['fit'])
+            model._backend_override = engine.HipBackend(_capi.DeviceContext(local))
+            t0 = time.perf_counter()
+            model._prepare_fit(x, y, dict(clean=True))
+            prep_s += time.perf_counter() - t0
+            fits.append((model, spec))
+
+        def one_pass(acc=None):
+            for model, spec in fits:
+                np.random.seed(spec['seed_fit'])
+                model._search(model._backend_override, spec['rows'], spec['inputs'])
+                model._backend_override.ctx.sync()
+                if acc is not None:
+                    for key in acc:
+                        acc[key] += model.fit_stats.get(key, 0)
+
+        for _ in range(warmup):
+            one_pass()
+        for model, _ in fits:
+            model._backend_override.ctx.timing_enable(True)
+            model._backend_override.ctx.timing_reset()
+        acc = dict(terms_logical=0, terms_physical=0, gibbs_calls=0, pool_noise_s=0.0, pool_chain_s=0.0,
+                   pool_finish_s=0.0, pool_spectral_s=0.0, t_eigh=0.0, t_resid=0.0, t_chain=0.0)
+        start.wait()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass(acc)
+        elapsed = time.perf_counter() - t0
+    kern = {}
+    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID),
+                      ('resid_matrix_free', _capi.K_RESID_MF)):
+        tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
+        for model, _ in fits:
+            t = model._backend_override.ctx.timing_get(kid)
+            for key in tot:
+                tot[key] += t[key]
+        kern[name] = tot
+    done.put(dict(worker=k, elapsed=elapsed, prep_s=prep_s, stats=acc, kern=kern))
+
+
+def config4_with_worker_processes(args, rank, world, local, procs):
+    """`--config 4` with `procs` worker processes per rank (throughput mode: many independent host-bound fits share one
+    GPU).  This process only launches, synchronises and reports; it touches the GPU after the workers have been started
+    (RCCL barrier / gather at N > 1, parity check and probes on rank 0)."""
+    import multiprocessing as mp
+    from fokl_gpy_amd import dist
+    fits_per_step = args.fits_per_step or 8
+    units = [rank * fits_per_step + i for i in range(fits_per_step)]
+    rows = args.rows or CONFIGS[4]['rows']
+    ctx_mp = mp.get_context('spawn')                        # before this process has initialised the GPU
+    start, done = ctx_mp.Barrier(procs + 1), ctx_mp.Queue()
+    workers = [ctx_mp.Process(target=config4_worker, args=(k, procs, local, units[k::procs], rows, args.steps,
+                                                            args.warmup, start, done)) for k in range(procs)]
+    for w in workers:
+        w.start()
+
+    from fokl_gpy_amd import FoKLRoutines, _capi, engine
+    use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
+    backend = FoKLRoutines.device_backend(local)
+    ctx = backend.ctx
+    comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
+    comm.barrier()
+    start.wait(timeout=1800)                                # every worker has prepared and warmed up: go
+    t0 = time.perf_counter()
+    results = [done.get(timeout=3600) for _ in workers]
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    for w in workers:
+        w.join(60)
+
+    kern = {}
+    for name in ('basis_build', 'gram', 'resid', 'resid_matrix_free'):
+        tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
+        for r in results:
+            for key in tot:
+                tot[key] += r['kern'][name][key]
+        kern[name] = tot
+    host = {}
+    for r in results:
+        for key, val in r['stats'].items():
+            host[key] = host.get(key, 0) + val
+    logical, physical, calls = host.pop('terms_logical'), host.pop('terms_physical'), host.pop('gibbs_calls')
+
+    # parity of the same fit this process can repeat on its own: unit `units[0]` against its golden
+    parity_checked, parity = False, None
+    x0, y0, spec0 = config_workload(4, units[0], rows)
+    if rank == 0 and not args.no_parity:
+        key = (4, units[0], rows)
+        if key in GOLDENS and os.path.exists(os.path.join(ROOT, 'tests', 'golden', GOLDENS[key][0] + '.npz')):
+            kernel, phis, _ = kernel_and_phis(spec0)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False)
+                model._backend_override = backend
+                np.random.seed(spec0['seed_fit'])
+                b0, m0, e0 = model.fit(x0, y0, clean=True)
+            parity = compare_with_golden(GOLDENS[key][0], model, b0, m0, e0, np.random.get_state())
+            parity['workload'] = 'unit 0 of the timed fits, repeated by the reporting process after the timed region'
+            parity_checked = True
+
+    sustained = None
+    if rank == 0 and not args.no_microbench:
+        ctx.upload(np.zeros((64, 1)), np.zeros(64), 1, np.zeros(2), 1, 2)
+        sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
+                     'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
+
+    gathered = comm.allgather([elapsed, logical, physical, calls])
+    if rank != 0:
+        comm.close()
+        return
+    t_max = float(np.max(gathered[:, 0]))
+    tot_logical, tot_physical = float(np.sum(gathered[:, 1])), float(np.sum(gathered[:, 2]))
+    fits_total = world * fits_per_step * max(args.steps, 1)
+    kernels, dominant, gpu_ms = kernel_report(kern, rows, spec0['inputs'], 4)
+    line = {
+        'metric': 'candidate-terms/sec (basis build + Gibbs + BIC)',
+        'value': tot_logical / t_max,
+        'unit': 'candidate-terms/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * t_max / max(args.steps, 1),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': spec0['label'] + f', {fits_per_step} fits per rank and step dealt over {procs} worker '
+                                                f'processes per GPU',
+                   'config_index': 4, 'rows': rows, 'inputs': spec0['inputs'],
+                   'parallelism': (f'independent fits x{world} GPUs, ' if world > 1 else 'single GPU, ') +
+                                  f'{procs} worker processes per GPU',
+                   'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
+        'value_physical': tot_physical / t_max,
+        'parity_checked': parity_checked,
+        'parity': parity,
+        'fits_per_s': fits_total / t_max,
+        'terms_logical_per_fit': tot_logical / fits_total,
+        'terms_physical_per_fit': tot_physical / fits_total,
+        'gibbs_calls_per_fit': float(np.sum(gathered[:, 3])) / fits_total,
+        'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
+        'host_prepare_s': sum(r['prep_s'] for r in results),
+        'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
+        'worker_seconds': sorted(r['elapsed'] for r in results),
+        'roofline': dominant,
+        'kernels': kernels,
+        'device_sustains': sustained,
+    }
+    if not args.no_cpu_baseline:
+        line.update(cpu_baselines(x0, y0, spec0))
+    comm.close()
+    dist.flush_c_streams()
+    sys.stderr.flush()
+    print(json.dumps(line), flush=True)
+    if parity_checked and not parity['ok']:
+        print(f"bench.py: PARITY MISMATCH against {parity['golden']}: {parity}", file=sys.stderr)
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -306,6 +556,10 @@ def main():
                          'of the time; measured on a 16-CPU quota: 15.4 / 16.4 / 18.5 / 17.1 fits/s at 1 / 2 / 3 / 4 -- the driver '
                          'threads share one Python interpreter lock); default 3 with a budget of 16 or more CPUs, 2 from 12, '
                          'else 1')
+    ap.add_argument('--procs', type=int, default=None,
+                    help='--config 4: worker PROCESSES per rank, each fitting its share of the rank\'s datasets on its own '
+                         'device context, host threads and L3 domain (default: one per 4 CPUs of the budget, at most 4; '
+                         '1 = everything in this process, see --concurrent)')
     ap.add_argument('--mode', choices=('fits', 'rows', 'candidates'), default=None,
                     help="N > 1, see the module docstring; default: candidates for --config 3, fits otherwise")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -324,6 +578,11 @@ def main():
     os.environ['FOKL_DEVICE'] = str(local)
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     cfg = args.config
+    if cfg == 4:
+        procs = args.procs if args.procs else max(1, min(4, int(engine._cpu_budget() // 4)))
+        procs = max(1, min(procs, args.fits_per_step or 8))
+        if procs > 1 and not args.concurrent:
+            return config4_with_worker_processes(args, rank, world, local, procs)
     concurrent = 1
     if cfg == 4:
         budget = engine._cpu_budget()
@@ -548,68 +807,7 @@ def main():
         tot_physical = float(np.sum(gathered[:, 2]))
     fits_total = (1 if one_fit_for_all else world) * fits_per_step * max(args.steps, 1)
 
-    def roof(name, bound):
-        k = kern[name]
-        if k['launches'] == 0 or k['ms'] <= 0:
-            return None
-        avg_ms = k['ms'] / k['launches']
-        if bound == 'hbm':
-            achieved = k['bytes'] / k['launches'] / (avg_ms * 1e-3) / 1e9
-            return dict(kernel=name, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
-                        total_ms=k['ms'], algorithmic_bytes_per_launch=k['bytes'] / k['launches'])
-        achieved = k['flops'] / k['launches'] / (avg_ms * 1e-3) / 1e12
-        return dict(kernel=name, bound='mfma', achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
-                    total_ms=k['ms'])
-
-    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm'),
-               'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
-    mf = kernels['resid_matrix_free']
-    if mf:
-        # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns
-        # costs more time at the fp64 peak (FMA = 2 flops; most of its operations are separately-rounded multiplies
-        # and adds, i.e. half of that at best) than its 8 N (M_used + 1) bytes cost at the HBM peak
-        k = kern['resid_matrix_free']
-        tf = k['flops'] / k['launches'] / (mf['avg_ms'] * 1e-3) / 1e12
-        mf.update(fp64_valu_tflops=tf, fp64_valu_frac=tf / FP64_MFMA_PEAK_TFLOPS,
-                  roofline_frac=k['ideal_ms'] / k['ms'])
-        if k['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > k['bytes'] / (HBM_PEAK_GBS * 1e9):
-            mf.update(bound='valu-fp64', achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                      frac=tf / FP64_MFMA_PEAK_TFLOPS, hbm_achieved_gbs=mf['achieved'], hbm_frac=mf['frac'])
-    if kernels['gram']:
-        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings,
-        # `bound` = the roof that binds the launches of this run taken together ...
-        gm = roof('gram', 'mfma')
-        hb = kernels['gram']
-        if kern['gram']['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > kern['gram']['bytes'] / (HBM_PEAK_GBS * 1e9):
-            kernels['gram'] = dict(gm, hbm_achieved_gbs=hb['achieved'], hbm_frac=hb['frac'],
-                                   algorithmic_bytes_per_launch=hb['algorithmic_bytes_per_launch'])
-        else:
-            kernels['gram'].update(mfma_achieved_tflops=gm['achieved'], mfma_frac=gm['frac'])
-        # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
-        kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/pmc_r02.json, produced by tools/profile_r02.sh: separate
-    # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
-    # was recorded for exactly this workload.
-    traffic_source = None
-    for cand in ('pmc_r02.json', 'pmc_r01.json'):
-        pmc_path = os.path.join(ROOT, 'profiles', cand)
-        if not os.path.exists(pmc_path):
-            continue
-        with open(pmc_path) as fh:
-            pmc = json.load(fh)
-        if pmc.get('workload') in ({'rows': n, 'inputs': m}, {'rows': n, 'inputs': m, 'config': cfg}) and cfg == 2:
-            for name, k in kernels.items():
-                if k and name in pmc['kernels']:
-                    k['traffic'] = pmc['kernels'][name]['hbm_bytes_per_launch']
-            traffic_source = f'profiles/{cand}: rocprofv3 --pmc passes over this command, committed with the sources; ' \
-                             f'not re-measured in this run'
-            break
-    dominant = max((k for k in kernels.values() if k), key=lambda k: k['total_ms'])
-    dominant = dict(dominant, traffic_source=traffic_source)
-    gpu_ms = sum(k['total_ms'] for k in kernels.values() if k)
+    kernels, dominant, gpu_ms = kernel_report(kern, n, m, cfg)
 
     parallelism = 'single GPU'
     if world > 1:
