@@ -358,10 +358,12 @@ def kernel_report(kern, n, m, cfg):
     return kernels, dominant, gpu_ms
 
 
-def config4_worker(k, procs, local, unit_ids, rows, steps, warmup, start, done):
+def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done, gate=None):
     """One of the worker PROCESSES of `--config 4 --procs P`: its own device context(s), host threads and L3 domain; fits
     its share of the rank's datasets back to back.  (Threads of one process share the interpreter lock of the Python
     drivers; processes do not: 13.7 / 21.9 / 32.8 / 40.6 fits/s with 1 / 2 / 3 / 4 of them on one MI355X.)"""
+    if gate is not None and not gate.wait(timeout=900):     # started early, used late (or never: then just leave)
+        return
     try:
         dom = l3_domain_of(8 * (local * procs + k))
         if dom:
@@ -378,7 +380,7 @@ def config4_worker(k, procs, local, unit_ids, rows, steps, warmup, start, done):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         for unit in unit_ids:
-            x, y, spec = config_workload(4, unit, rows)
+            x, y, spec = config_workload(cfg, unit, rows)
             kernel, phis, _ = kernel_and_phis(spec)
             model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **spec['fit'])
             model._backend_override = engine.HipBackend(_capi.DeviceContext(local))
@@ -420,18 +422,18 @@ def config4_worker(k, procs, local, unit_ids, rows, steps, warmup, start, done):
     done.put(dict(worker=k, elapsed=elapsed, prep_s=prep_s, stats=acc, kern=kern))
 
 
-def config4_with_worker_processes(args, rank, world, local, procs):
+def fits_with_worker_processes(args, cfg, rank, world, local, procs):
     """`--config 4` with `procs` worker processes per rank (throughput mode: many independent host-bound fits share one
     GPU).  This process only launches, synchronises and reports; it touches the GPU after the workers have been started
     (RCCL barrier / gather at N > 1, parity check and probes on rank 0)."""
     import multiprocessing as mp
     from fokl_gpy_amd import dist
-    fits_per_step = args.fits_per_step or 8
+    fits_per_step = args.fits_per_step or (8 if cfg == 4 else procs)
     units = [rank * fits_per_step + i for i in range(fits_per_step)]
-    rows = args.rows or CONFIGS[4]['rows']
+    rows = args.rows or CONFIGS[cfg]['rows']
     ctx_mp = mp.get_context('spawn')                        # before this process has initialised the GPU
     start, done = ctx_mp.Barrier(procs + 1), ctx_mp.Queue()
-    workers = [ctx_mp.Process(target=config4_worker, args=(k, procs, local, units[k::procs], rows, args.steps,
+    workers = [ctx_mp.Process(target=fits_worker, args=(cfg, k, procs, local, units[k::procs], rows, args.steps,
                                                             args.warmup, start, done)) for k in range(procs)]
     for w in workers:
         w.start()
@@ -465,9 +467,9 @@ def config4_with_worker_processes(args, rank, world, local, procs):
 
     # parity of the same fit this process can repeat on its own: unit `units[0]` against its golden
     parity_checked, parity = False, None
-    x0, y0, spec0 = config_workload(4, units[0], rows)
+    x0, y0, spec0 = config_workload(cfg, units[0], rows)
     if rank == 0 and not args.no_parity:
-        key = (4, units[0], rows)
+        key = (cfg, units[0], rows)
         if key in GOLDENS and os.path.exists(os.path.join(ROOT, 'tests', 'golden', GOLDENS[key][0] + '.npz')):
             kernel, phis, _ = kernel_and_phis(spec0)
             with warnings.catch_warnings():
@@ -475,7 +477,7 @@ def config4_with_worker_processes(args, rank, world, local, procs):
                 model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False)
                 model._backend_override = backend
                 np.random.seed(spec0['seed_fit'])
-                b0, m0, e0 = model.fit(x0, y0, clean=True)
+                b0, m0, e0 = model.fit(x0, y0, clean=True, **spec0['fit'])
             parity = compare_with_golden(GOLDENS[key][0], model, b0, m0, e0, np.random.get_state())
             parity['workload'] = 'unit 0 of the timed fits, repeated by the reporting process after the timed region'
             parity_checked = True
@@ -493,7 +495,7 @@ def config4_with_worker_processes(args, rank, world, local, procs):
     t_max = float(np.max(gathered[:, 0]))
     tot_logical, tot_physical = float(np.sum(gathered[:, 1])), float(np.sum(gathered[:, 2]))
     fits_total = world * fits_per_step * max(args.steps, 1)
-    kernels, dominant, gpu_ms = kernel_report(kern, rows, spec0['inputs'], 4)
+    kernels, dominant, gpu_ms = kernel_report(kern, rows, spec0['inputs'], cfg)
     line = {
         'metric': 'candidate-terms/sec (basis build + Gibbs + BIC)',
         'value': tot_logical / t_max,
@@ -509,7 +511,7 @@ def config4_with_worker_processes(args, rank, world, local, procs):
         'data': 'synthetic',
         'config': {'workload': spec0['label'] + f', {fits_per_step} fits per rank and step dealt over {procs} worker '
                                                 f'processes per GPU',
-                   'config_index': 4, 'rows': rows, 'inputs': spec0['inputs'],
+                   'config_index': cfg, 'rows': rows, 'inputs': spec0['inputs'],
                    'parallelism': (f'independent fits x{world} GPUs, ' if world > 1 else 'single GPU, ') +
                                   f'{procs} worker processes per GPU',
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
@@ -557,15 +559,17 @@ def main():
                          'threads share one Python interpreter lock); default 3 with a budget of 16 or more CPUs, 2 from 12, '
                          'else 1')
     ap.add_argument('--procs', type=int, default=None,
-                    help='--config 4: worker PROCESSES per rank, each fitting its share of the rank\'s datasets on its own '
-                         'device context, host threads and L3 domain (default: one per 4 CPUs of the budget, at most 4; '
-                         '1 = everything in this process, see --concurrent)')
+                    help='worker PROCESSES per rank, each fitting its share of the rank\'s datasets of a step on its own '
+                         'device context, host threads and L3 domain (--config 4 default: one per 4 CPUs of the budget, at most '
+                         '4; other configurations: opt-in, a step is then that many independent fits)')
     ap.add_argument('--mode', choices=('fits', 'rows', 'candidates'), default=None,
                     help="N > 1, see the module docstring; default: candidates for --config 3, fits otherwise")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-microbench', action='store_true',
                     help='skip the back-to-back kernel launches after the timed region (used for profiler runs)')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-throughput', action='store_true',
+                    help='skip the secondary measurement of the default run (several fits sharing the GPU)')
     args = ap.parse_args()
 
     from fokl_gpy_amd import dist
@@ -578,11 +582,37 @@ def main():
     os.environ['FOKL_DEVICE'] = str(local)
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     cfg = args.config
+    # Secondary measurement of the default run (one GPU, configs[2]): how many candidate terms per second the same GPU
+    # delivers when several independent fits of the configuration share it (a fit leaves it idle three quarters of the
+    # time).  The worker processes have to be started before this process initialises the GPU; they sleep until the
+    # main measurement is over.  `value` stays the one-fit-at-a-time figure.
+    side = None
+    if (cfg == 2 and world == 1 and rank == 0 and not args.procs and not args.no_throughput and not args.mode
+            and os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') != '1'):
+        side_procs = max(1, min(4, int(engine._cpu_budget() // 4)))
+        if side_procs > 1:
+            try:
+                import multiprocessing as mp
+                ctx_mp = mp.get_context('spawn')
+                gate, start_b, done_q = ctx_mp.Event(), ctx_mp.Barrier(side_procs + 1), ctx_mp.Queue()
+                side_workers = [ctx_mp.Process(target=fits_worker, daemon=True,
+                                               args=(cfg, k, side_procs, local, [k], args.rows or CONFIGS[cfg]['rows'], 2, 1,
+                                                     start_b, done_q, gate)) for k in range(side_procs)]
+                for w in side_workers:
+                    w.start()
+                side = (side_procs, gate, start_b, done_q, side_workers)
+            except Exception as exc:                          # never let the extra cost the main measurement
+                print(f"bench.py: throughput side measurement not started: {exc}", file=sys.stderr)
+                side = None
     if cfg == 4:
         procs = args.procs if args.procs else max(1, min(4, int(engine._cpu_budget() // 4)))
         procs = max(1, min(procs, args.fits_per_step or 8))
         if procs > 1 and not args.concurrent:
-            return config4_with_worker_processes(args, rank, world, local, procs)
+            return fits_with_worker_processes(args, cfg, rank, world, local, procs)
+    elif args.procs and args.procs > 1 and (args.mode or 'fits') == 'fits':
+        # opt-in for the other configurations: a step is then `procs` independent fits of the configuration (datasets
+        # unit 0 .. procs - 1 of the rank) side by side on the GPU
+        return fits_with_worker_processes(args, cfg, rank, world, local, args.procs)
     concurrent = 1
     if cfg == 4:
         budget = engine._cpu_budget()
@@ -795,6 +825,30 @@ def main():
         sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
                      'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
 
+    throughput_mode = None
+    if side is not None:
+        side_procs, gate, start_b, done_q, side_workers = side
+        try:
+            gate.set()
+            start_b.wait(timeout=300)                       # all of them have uploaded and warmed up
+            t_side = time.perf_counter()
+            side_res = [done_q.get(timeout=300) for _ in side_workers]
+            t_side = time.perf_counter() - t_side
+            side_terms = sum(r['stats']['terms_logical'] for r in side_res)
+            side_fits = side_procs * 2
+            throughput_mode = dict(
+                workload=f'{side_procs} worker processes, each fitting its own configs[2] dataset (dataset seeds 12 .. '
+                         f'{11 + side_procs}) twice, back to back, on this one GPU',
+                procs=side_procs, value=side_terms / t_side, unit='candidate-terms/s', fits_per_s=side_fits / t_side,
+                seconds=t_side, ms_per_fit_per_worker=1e3 * t_side / 2)
+        except Exception as exc:
+            print(f"bench.py: throughput side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
+        finally:
+            for w in side_workers:
+                w.join(5)
+                if w.is_alive():
+                    w.terminate()
+
     gathered = comm.allgather([elapsed, logical, physical, calls])
     if rank != 0:
         comm.close()
@@ -846,6 +900,7 @@ def main():
         'kernels': kernels,
         'basis_build_sustained': hot,
         'device_sustains': sustained,
+        'throughput_mode': throughput_mode,
     }
     if not args.no_cpu_baseline:
         line.update(cpu_baselines(fits[0][2], fits[0][3], spec0))
