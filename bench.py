@@ -586,7 +586,7 @@ def main():
     # delivers when several independent fits of the configuration share it (a fit leaves it idle three quarters of the
     # time).  The worker processes have to be started before this process initialises the GPU; they sleep until the
     # main measurement is over.  `value` stays the one-fit-at-a-time figure.
-    side = None
+    side_job = None
     if (cfg == 2 and world == 1 and rank == 0 and not args.procs and not args.no_throughput and not args.mode
             and os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') != '1'):
         side_procs = max(1, min(4, int(engine._cpu_budget() // 4)))
@@ -600,10 +600,10 @@ def main():
                                                      start_b, done_q, gate)) for k in range(side_procs)]
                 for w in side_workers:
                     w.start()
-                side = (side_procs, gate, start_b, done_q, side_workers)
+                side_job = (side_procs, gate, start_b, done_q, side_workers)
             except Exception as exc:                          # never let the extra cost the main measurement
                 print(f"bench.py: throughput side measurement not started: {exc}", file=sys.stderr)
-                side = None
+                side_job = None
     if cfg == 4:
         procs = args.procs if args.procs else max(1, min(4, int(engine._cpu_budget() // 4)))
         procs = max(1, min(procs, args.fits_per_step or 8))
@@ -826,8 +826,8 @@ def main():
                      'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
 
     throughput_mode = None
-    if side is not None:
-        side_procs, gate, start_b, done_q, side_workers = side
+    if side_job is not None:
+        side_procs, gate, start_b, done_q, side_workers = side_job
         try:
             gate.set()
             start_b.wait(timeout=300)                       # all of them have uploaded and warmed up
