@@ -36,6 +36,8 @@ SIGNATURES = {
     'fokl_build_terms': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_build_terms_deriv': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl]),
     'fokl_gram': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
+    'fokl_gram_launch': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int]),
+    'fokl_gram_fetch': (c_int, [c_vp, c_vp, c_i64]),
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
     'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_bic_resid_fetch': (c_int, [c_vp, c_vp, c_int]),
@@ -56,10 +58,10 @@ SIGNATURES = {
     'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_destroy': (None, [c_vp]),
     'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
-                                       c_vp]),
+                                       c_vp, c_int, c_vp]),
     'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
-                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp]),
     'fokl_pool_poll': (c_int, [c_vp]),
@@ -186,7 +188,7 @@ class NoiseTape:
     ``progress[0]`` counts the iterations recorded so far (-1 = the producer failed); ``block_done`` are the flags of
     fokl_finish_tape_blocks (blocks of BLOCK iterations).
     One allocation, carved up by address: a tape is made for every model evaluation on the search's critical thread."""
-    __slots__ = ('p1', 'draws', '_buf', '_addr', '_off', '_ints')
+    __slots__ = ('p1', 'draws', 'finishing_requested', '_buf', '_addr', '_off', '_ints')
     BLOCK = 16                                                # = FOKL_TAPE_BLOCK
 
     @classmethod
@@ -219,6 +221,7 @@ class NoiseTape:
         self._buf = raw[shift:]
         self._addr = self._buf.__array_interface__['data'][0]
         self._buf[off[4]:off[4] + ints[1] // 2] = 0.0         # progress and block flags start at zero
+        self.finishing_requested = False                      # HostPool.submit_noise(..., finish=True) was given this tape
 
     def _int_area(self):
         return self._buf[self._off[4]:].view(np.int32)
@@ -401,12 +404,16 @@ class HostPool:
 
     __del__ = close
 
-    def submit_noise(self, tape, astar, atau_star, tentative=False):
-        """tentative: record ahead of the decision; the job must then get ``resolve(commit)`` (see the header)."""
+    def submit_noise(self, tape, astar, atau_star, tentative=False, finish=False):
+        """tentative: record ahead of the decision; the job must then get ``resolve(commit)`` (see the header).
+        finish: the finish threads complete the tape while it is recorded, before a chain is asked for."""
         h = c_vp(0)
+        finish = bool(finish) and self.finish_threads > 0
         _check(self._lib.fokl_pool_submit_noise(self._h, tape.p1, tape.draws, float(astar), float(atau_star),
                                                 *tape.pointers(), tape.progress_pointer(), int(bool(tentative)),
+                                                tape.block_done_pointer() if finish else None, tape.BLOCK,
                                                 ctypes.byref(h)))
+        tape.finishing_requested = finish
         return PoolJob(h, (tape,), tape, tentative)
 
     def submit_chain(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw=None):
@@ -425,7 +432,8 @@ class HostPool:
                                                 float(sigsqd0), float(tausqd0), tape.draws, *tape.pointers(),
                                                 tape.progress_pointer(),
                                                 tape.block_done_pointer() if self.finish_threads else None,
-                                                tape.BLOCK, _ptr(w), _ptr(flag), ctypes.byref(h)))
+                                                tape.BLOCK, int(tape.finishing_requested), _ptr(w), _ptr(flag),
+                                                ctypes.byref(h)))
         return PoolJob(h, (lamb, qty, tape, w, flag), (w, flag))
 
     def submit_spectral(self, gram, idx, ycol):
@@ -515,6 +523,19 @@ class DeviceContext:
         out = np.empty((rs.shape[0], cs.shape[0]), dtype=np.float64)
         self._ck(self._lib.fokl_gram(self._h, _ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], _ptr(out), int(path),
                                      int(bool(allreduce))))
+        return out
+
+    def gram_launch(self, row_slots, col_slots, allreduce=False):
+        """fokl_gram_launch: -> shape of the block gram_fetch will return."""
+        rs = np.ascontiguousarray(row_slots, dtype=np.int32)
+        cs = np.ascontiguousarray(col_slots, dtype=np.int32)
+        self._ck(self._lib.fokl_gram_launch(self._h, _ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0],
+                                            int(bool(allreduce))))
+        return rs.shape[0], cs.shape[0]
+
+    def gram_fetch(self, shape):
+        out = np.empty(shape, dtype=np.float64)
+        self._ck(self._lib.fokl_gram_fetch(self._h, _ptr(out), out.size))
         return out
 
     def bic_resid(self, slots, betahat, allreduce=False):

@@ -78,6 +78,15 @@ struct fokl_ctx {
     size_t out_doubles = 0;
     hipEvent_t args_free = nullptr;     // recorded after the last H2D copy out of h_args
     bool resid_pending = false;         // fokl_bic_resid_launch issued, result not fetched yet
+    // residual moments of a launched pass (a pair of their own: Gram blocks may be computed before they are fetched)
+    double *d_rout = nullptr;
+    double *h_rout = nullptr;           // pinned
+    // fokl_gram_launch: a Gram block on its way while other launches (which use d_out / h_out) go on
+    double *d_gout = nullptr;
+    double *h_gout = nullptr;           // pinned
+    size_t gout_doubles = 0;
+    size_t gram_pending = 0;            // doubles of the block fokl_gram_fetch will return; 0 = none on its way
+    hipEvent_t gram_done = nullptr;
 
     // timing
     bool timing = false;
@@ -206,6 +215,30 @@ static int ensure_out(fokl_ctx *ctx, size_t doubles)
     return FOKL_OK;
 }
 
+static int ensure_rout(fokl_ctx *ctx)
+{
+    if (ctx->d_rout) return FOKL_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rout, 2 * sizeof(double)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_rout, 2 * sizeof(double), hipHostMallocDefault));
+    return FOKL_OK;
+}
+
+static int ensure_gout(fokl_ctx *ctx, size_t doubles)
+{
+    if (doubles <= ctx->gout_doubles) return FOKL_OK;
+    size_t cap = std::max<size_t>(doubles * 2, 1 << 12);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_gout) HIP_TRY(ctx, hipFree(ctx->d_gout));
+    if (ctx->h_gout) HIP_TRY(ctx, hipHostFree(ctx->h_gout));
+    ctx->d_gout = nullptr;
+    ctx->h_gout = nullptr;
+    ctx->gout_doubles = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gout, cap * sizeof(double)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_gout, cap * sizeof(double), hipHostMallocDefault));
+    ctx->gout_doubles = cap;
+    return FOKL_OK;
+}
+
 // Stage `bytes` of launch arguments: wait until the previous copy out of the pinned buffer has finished,
 // let the caller fill it, then copy asynchronously.
 static int begin_args(fokl_ctx *ctx, size_t bytes)
@@ -291,7 +324,8 @@ extern "C" int fokl_ctx_create(int device, fokl_ctx **out)
         return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: device is " + arch + ", this library is built for gfx950 only");
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->args_free, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->args_free, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->gram_done, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: cannot create stream / event");
     }
@@ -320,8 +354,13 @@ extern "C" void fokl_ctx_destroy(fokl_ctx *ctx)
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+    if (ctx->h_gout) (void)hipHostFree(ctx->h_gout);
+    if (ctx->d_rout) (void)hipFree(ctx->d_rout);
+    if (ctx->h_rout) (void)hipHostFree(ctx->h_rout);
     if (ctx->d_comm) (void)hipFree(ctx->d_comm);
     if (ctx->args_free) (void)hipEventDestroy(ctx->args_free);
+    if (ctx->gram_done) (void)hipEventDestroy(ctx->gram_done);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -725,12 +764,13 @@ static gram_mfma_fn jsplit_kernel(int ti, int tj)
     return gram_mfma_kernel<2, 3, false>;
 }
 
-extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
-                         double *out, int path, int allreduce)
+// Everything of a Gram block up to the copy into pinned host memory, enqueued on the context's stream.  aside: the
+// result goes to the d_gout / h_gout pair (fokl_gram_launch) instead of d_out / h_out.
+static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int path,
+                        int allreduce, bool aside)
 {
-    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram: null context");
     if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_gram: call fokl_upload first");
-    if (nr <= 0 || nc <= 0 || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: empty block or null output");
+    if (nr <= 0 || nc <= 0) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: empty block");
     if (path < 0 || path > 2) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: path must be 0, 1 or 2");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_slots(ctx, row_slots, nr, "fokl_gram");
@@ -793,8 +833,10 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
     }
     rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
     if (rc) return rc;
-    rc = ensure_out(ctx, (size_t)nr * nc);
+    rc = aside ? ensure_gout(ctx, (size_t)nr * nc) : ensure_out(ctx, (size_t)nr * nc);
     if (rc) return rc;
+    double *d_dst = aside ? ctx->d_gout : ctx->d_out;
+    double *h_dst = aside ? ctx->h_gout : ctx->h_out;
 
     {
         {
@@ -818,19 +860,56 @@ extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const 
         const int total = nr * nc;
         const int epb = reduce_elements_per_block(total);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
-                           ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, ctx->d_out);
+                           ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, d_dst);
         HIP_TRY(ctx, hipGetLastError());
     }
-    // row-sharded fit: the block is summed over the ranks where it lies -- RCCL on d_out, stream-ordered behind the
-    // reduction kernel -- and crosses PCIe once
+    // row-sharded fit: the block is summed over the ranks where it lies -- RCCL on the device, stream-ordered behind
+    // the reduction kernel -- and crosses PCIe once
     if (allreduce && ctx->comm) {
-        rc = comm_allreduce_device(ctx, ctx->d_out, (size_t)nr * nc);
+        rc = comm_allreduce_device(ctx, d_dst, (size_t)nr * nc);
         if (rc) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nr * nc * sizeof(double), hipMemcpyDeviceToHost,
-                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_dst, (size_t)nr * nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return FOKL_OK;
+}
+
+extern "C" int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
+                         double *out, int path, int allreduce)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram: null context");
+    if (!out) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: null output");
+    int rc = gram_enqueue(ctx, row_slots, nr, col_slots, nc, path, allreduce, false);
+    if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(out, ctx->h_out, (size_t)nr * nc * sizeof(double));
+    return FOKL_OK;
+}
+
+// fokl_gram in two halves: the launch returns at once, other work may be launched behind it (residual passes, basis
+// builds), fokl_gram_fetch waits for the block only.  One block can be on its way at a time: a launch drops a block
+// that was not fetched.
+extern "C" int fokl_gram_launch(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
+                                int allreduce)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_launch: null context");
+    ctx->gram_pending = 0;                  // a block nobody fetched is dropped (the stream orders the overwrite)
+    int rc = gram_enqueue(ctx, row_slots, nr, col_slots, nc, 0, allreduce, true);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->gram_done, ctx->stream));
+    ctx->gram_pending = (size_t)nr * nc;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count)
+{
+    if (!ctx || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_gram_fetch: null pointer");
+    if (!ctx->gram_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_gram_fetch: nothing launched");
+    if (count != (int64_t)ctx->gram_pending)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_gram_fetch: the launched block has a different size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->gram_done));
+    std::memcpy(out, ctx->h_gout, ctx->gram_pending * sizeof(double));
+    ctx->gram_pending = 0;
     return FOKL_OK;
 }
 
@@ -861,7 +940,7 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, (int64_t)cu_count(ctx) * 8));
     rc = ensure_slab(ctx, (size_t)S * 2);
     if (rc) return rc;
-    rc = ensure_out(ctx, 2);
+    rc = ensure_rout(ctx);
     if (rc) return rc;
     {
         {
@@ -873,10 +952,10 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
         }
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
-                           2, ctx->d_out);
+                           2, ctx->d_rout);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ctx->resid_pending = true;
     return FOKL_OK;
 }
@@ -1008,7 +1087,7 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, (int64_t)cu_count(ctx) * 8));
     rc = ensure_slab(ctx, (size_t)S * 2);
     if (rc) return rc;
-    rc = ensure_out(ctx, 2);
+    rc = ensure_rout(ctx);
     if (rc) return rc;
     resid_terms_fn fn = pick_resid_terms(splines, U);
     size_t lds_bytes = table_bytes;
@@ -1029,10 +1108,10 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
         }
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,
-                           2, ctx->d_out);
+                           2, ctx->d_rout);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ctx->resid_pending = true;
     return FOKL_OK;
 }
@@ -1044,14 +1123,14 @@ extern "C" int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->resid_pending = false;
     if (allreduce && ctx->comm) {
-        // the launch left this rank's two moments in d_out: sum them over the ranks there, copy again
-        int rc = comm_allreduce_device(ctx, ctx->d_out, 2);
+        // the launch left this rank's two moments in d_rout: sum them over the ranks there, copy again
+        int rc = comm_allreduce_device(ctx, ctx->d_rout, 2);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    out[0] = ctx->h_out[0];
-    out[1] = ctx->h_out[1];
+    out[0] = ctx->h_rout[0];
+    out[1] = ctx->h_rout[1];
     return FOKL_OK;
 }
 

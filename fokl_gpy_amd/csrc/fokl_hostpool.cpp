@@ -13,11 +13,14 @@
 //            so the driver may submit them speculatively for models it might evaluate next.
 //
 // Buffers named in a job belong to the caller and must stay alive until fokl_pool_wait returned for that job.
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -61,6 +64,10 @@ struct fokl_host_job {
     // aborts it (-1: the stream is put back where the tape started)
     bool tentative = false;
     std::atomic<int> verdict{0};
+    int64_t t_submit = 0, t_start = 0, t_recorded = 0;      // FOKL_POOL_TRACE
+    // a noise job is done when the stream is through with it AND the finish jobs submitted with it have left the tape
+    std::atomic<int> pending{1};
+    fokl_host_job *parent = nullptr;        // finish job submitted with a noise job: that job
     // noise / chain
     int p1 = 0, draws = 0;
     double astar = 0, atau_star = 0;
@@ -98,9 +105,19 @@ struct fokl_host_pool {
     // eight ranks may share a CPU quota far below eight times the thread count)
     std::mutex done_m;
     std::condition_variable done_cv;
+    // FOKL_POOL_TRACE=<file>: one line per noise job (steady-clock ns: submitted, started, recorded, verdict seen; p1;
+    // tentative; verdict), appended when the pool is destroyed -- tools/pool_trace.py lines it up with the driver's log
+    std::string trace_path;
+    std::vector<std::array<int64_t, 7>> trace;
 };
 
 namespace {
+
+inline int64_t now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
 
 void finish(fokl_host_job *job, int status, const char *what)
 {
@@ -199,6 +216,8 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     return FOKL_OK;
 }
 
+void settle(fokl_host_job *job);
+
 void run(fokl_host_pool *pool, fokl_host_job *job)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -206,49 +225,8 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
     std::string err;
     std::atomic<int64_t> *busy = nullptr;
     switch (job->kind) {
-    case Kind::noise: {
-        uint32_t saved_key[624];
-        int32_t saved_pos = 0, saved_has = 0;
-        double saved_cache = 0.0;
-        if (job->tentative && job->verdict.load(std::memory_order_acquire) < 0) {
-            __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);       // aborted before it was started
-            break;
-        }
-        if (job->tentative) {
-            std::memcpy(saved_key, pool->mt_key, sizeof(saved_key));
-            saved_pos = *pool->mt_pos;
-            saved_has = *pool->has_gauss;
-            saved_cache = *pool->gauss_cache;
-        }
-        rc = fokl_noise_tape(job->p1, job->draws, job->astar, job->atau_star, pool->mt_key, pool->mt_pos,
-                             pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead, job->gam_sig,
-                             job->gam_tau, job->progress);
-        if (rc != FOKL_OK) err = "noise tape: invalid arguments or gamma shape";
-        pool->noise_busy_ns.fetch_add(
-            std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
-            std::memory_order_relaxed);                     // the wait for the verdict below is not work
-        if (job->tentative) {
-            const auto w0 = std::chrono::steady_clock::now();
-            for (int spins = 0; job->verdict.load(std::memory_order_acquire) == 0;) {
-                if (++spins < 4000) {
-                    _mm_pause();
-                } else {
-                    std::this_thread::sleep_for(std::chrono::microseconds(10));
-                }
-            }
-            pool->noise_verdict_wait_ns.fetch_add(
-                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
-                std::memory_order_relaxed);
-            if (job->verdict.load(std::memory_order_acquire) < 0) {
-                std::memcpy(pool->mt_key, saved_key, sizeof(saved_key));
-                *pool->mt_pos = saved_pos;
-                *pool->has_gauss = saved_has;
-                *pool->gauss_cache = saved_cache;
-                __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);   // nobody may follow this tape
-            }
-        }
-        break;
-    }
+    case Kind::noise:
+        break;                                              // the noise thread has its own loop (noise_worker)
     case Kind::finish:
         rc = fokl_finish_tape_blocks(job->p1, job->draws, job->normals, job->pair_r2, job->lead, job->progress,
                                      job->part, job->parts, job->block, job->block_done);
@@ -281,6 +259,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
         busy->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(dt).count(), std::memory_order_relaxed);
     }
     if (job->self_owned) {
+        if (job->parent) settle(job->parent);
         delete job;                                         // failures reach the chain job through block_done
         return;
     }
@@ -293,18 +272,183 @@ void worker(fokl_host_pool *pool, Queue *queue)
     for (;;) {
         fokl_host_job *job;
         {
-            const auto w0 = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lock(queue->m);
             queue->cv.wait(lock, [&] { return queue->stop || !queue->q.empty(); });
-            if (queue == &pool->noise_q)
-                pool->noise_queue_wait_ns.fetch_add(
-                    std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
-                    std::memory_order_relaxed);
             if (queue->q.empty()) return;                   // stop requested and the queue is drained
             job = queue->q.front();
             queue->q.pop_front();
         }
         run(pool, job);
+    }
+}
+
+// The noise thread.  Tapes are recorded strictly in submission order.  Tentative tapes -- recorded ahead of the decision
+// that they are needed -- may be NESTED: up to kMaxSpeculation of them can be on record without a verdict, each with
+// the state of the stream at its beginning.  Verdicts settle from both ends of that list: a commit of the oldest makes
+// it final; an abort of the oldest puts the stream back where it began and takes every younger one with it (the caller
+// resolves those to "abort" as well: their content no longer is what the stream serves there); an abort of the youngest
+// rewinds just that one.  A plain (non-tentative) request waits until nothing speculative is left.
+struct StreamState {
+    uint32_t key[624];
+    int32_t pos, has_gauss;
+    double cache;
+};
+
+struct Speculation {
+    fokl_host_job *job;
+    StreamState at_start;
+};
+
+constexpr size_t kMaxSpeculation = 16;
+
+void save_stream(const fokl_host_pool *pool, StreamState &s)
+{
+    std::memcpy(s.key, pool->mt_key, sizeof(s.key));
+    s.pos = *pool->mt_pos;
+    s.has_gauss = *pool->has_gauss;
+    s.cache = *pool->gauss_cache;
+}
+
+void restore_stream(fokl_host_pool *pool, const StreamState &s)
+{
+    std::memcpy(pool->mt_key, s.key, sizeof(s.key));
+    *pool->mt_pos = s.pos;
+    *pool->has_gauss = s.has_gauss;
+    *pool->gauss_cache = s.cache;
+}
+
+void trace_noise(fokl_host_pool *pool, fokl_host_job *job, int64_t verdict_seen)
+{
+    if (!pool->trace_path.empty())
+        pool->trace.push_back({job->t_submit, job->t_start, job->t_recorded, verdict_seen, job->p1,
+                               job->tentative ? 1 : 0, job->verdict.load(std::memory_order_acquire)});
+}
+
+void settle(fokl_host_job *job)                            // status / error were set when the tape was recorded
+{
+    if (job->pending.fetch_sub(1, std::memory_order_acq_rel) != 1) return;      // somebody is still on the tape
+    fokl_host_pool *pool = job->pool;                       // the job may be freed by its waiter right after `done`
+    {
+        std::lock_guard<std::mutex> lock(pool->done_m);
+        job->done.store(1, std::memory_order_release);
+    }
+    pool->done_cv.notify_all();
+}
+
+void record_tape(fokl_host_pool *pool, fokl_host_job *job)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    job->t_start = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
+    const int rc = fokl_noise_tape(job->p1, job->draws, job->astar, job->atau_star, pool->mt_key, pool->mt_pos,
+                                   pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead,
+                                   job->gam_sig, job->gam_tau, job->progress);
+    if (rc != FOKL_OK) {
+        job->status = rc;
+        job->error = "noise tape: invalid arguments or gamma shape";
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    job->t_recorded = std::chrono::duration_cast<std::chrono::nanoseconds>(t1.time_since_epoch()).count();
+    pool->noise_busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(),
+                                  std::memory_order_relaxed);
+}
+
+void noise_worker(fokl_host_pool *pool)
+{
+    prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
+    Queue *queue = &pool->noise_q;
+    std::deque<Speculation> open;                           // recorded, no verdict yet; oldest first
+    auto aborted = [&](fokl_host_job *job) {
+        __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);          // nobody may follow this tape
+        trace_noise(pool, job, now_ns());
+        settle(job);
+    };
+    for (;;) {
+        // verdicts that can be acted on
+        while (!open.empty()) {
+            const int oldest = open.front().job->verdict.load(std::memory_order_acquire);
+            if (oldest > 0) {
+                fokl_host_job *job = open.front().job;
+                open.pop_front();
+                trace_noise(pool, job, now_ns());
+                settle(job);
+                continue;
+            }
+            if (oldest < 0) {
+                restore_stream(pool, open.front().at_start);
+                for (auto &sp : open) aborted(sp.job);
+                open.clear();
+                break;
+            }
+            if (open.back().job->verdict.load(std::memory_order_acquire) < 0) {
+                restore_stream(pool, open.back().at_start);
+                aborted(open.back().job);
+                open.pop_back();
+                continue;
+            }
+            break;
+        }
+        // the next request, if it can be served now
+        fokl_host_job *job = nullptr;
+        bool stopping = false;
+        {
+            std::unique_lock<std::mutex> lock(queue->m);
+            if (open.empty()) {
+                const auto w0 = std::chrono::steady_clock::now();
+                queue->cv.wait(lock, [&] { return queue->stop || !queue->q.empty(); });
+                pool->noise_queue_wait_ns.fetch_add(
+                    std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
+                    std::memory_order_relaxed);
+                if (queue->q.empty()) return;               // stop requested and the queue is drained
+            }
+            stopping = queue->stop;
+            if (!queue->q.empty()) {
+                fokl_host_job *next = queue->q.front();
+                if (open.empty() || (next->tentative && open.size() < kMaxSpeculation)) {
+                    job = next;
+                    queue->q.pop_front();
+                }
+            }
+        }
+        if (!job) {
+            // something speculative is open and nothing can be recorded behind it: its verdict is what comes next
+            (void)stopping;
+            const auto w0 = std::chrono::steady_clock::now();
+            auto settled = [&] {
+                return open.front().job->verdict.load(std::memory_order_acquire) != 0 ||
+                       open.back().job->verdict.load(std::memory_order_acquire) < 0;
+            };
+            auto more = [&] {
+                if (open.size() >= kMaxSpeculation) return false;
+                std::lock_guard<std::mutex> lock(queue->m);
+                return !queue->q.empty() && queue->q.front()->tentative;
+            };
+            for (int spins = 0; !settled(); ++spins) {
+                if (spins < 4000) {
+                    _mm_pause();
+                    if ((spins & 63) == 63 && more()) break;
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(10));
+                    if (more()) break;
+                }
+            }
+            pool->noise_verdict_wait_ns.fetch_add(
+                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count(),
+                std::memory_order_relaxed);
+            continue;
+        }
+        if (job->tentative) {
+            if (job->verdict.load(std::memory_order_acquire) < 0) {     // aborted before it was started
+                aborted(job);
+                continue;
+            }
+            open.push_back({job, {}});
+            save_stream(pool, open.back().at_start);
+            record_tape(pool, job);
+        } else {
+            record_tape(pool, job);
+            trace_noise(pool, job, job->t_recorded);
+            settle(job);
+        }
     }
 }
 
@@ -348,8 +492,9 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
     pool->mt_pos = mt_pos;
     pool->has_gauss = has_gauss;
     pool->gauss_cache = gauss_cache;
+    if (const char *path = std::getenv("FOKL_POOL_TRACE")) pool->trace_path = path;
     try {
-        pool->threads.emplace_back(worker, pool, &pool->noise_q);
+        pool->threads.emplace_back(noise_worker, pool);
         if (noise_cpu >= 0 && noise_cpu < CPU_SETSIZE) {
             // the random stream is the serial resource of a fit: its thread gets a logical CPU of its own (the caller
             // keeps every other thread of the process off that core); failure to pin is not an error
@@ -385,14 +530,48 @@ extern "C" void fokl_pool_destroy(fokl_host_pool *pool)
     stop(pool->spectral_q);
     for (auto &q : pool->finish_q) stop(q);
     for (auto &t : pool->threads) t.join();
+    if (!pool->trace_path.empty()) {
+        if (FILE *f = std::fopen(pool->trace_path.c_str(), "a")) {
+            for (const auto &r : pool->trace)
+                std::fprintf(f, "noise %lld %lld %lld %lld %lld %lld %lld\n", (long long)r[0], (long long)r[1],
+                             (long long)r[2], (long long)r[3], (long long)r[4], (long long)r[5], (long long)r[6]);
+            std::fclose(f);
+        }
+    }
     delete pool;
+}
+
+static void submit_finish_jobs(fokl_host_pool *pool, fokl_host_job *parent, int p1, int draws, double *normals,
+                               double *pair_r2, int32_t *lead, int32_t *progress, int32_t *block_done, int block)
+{
+    const int parts = (int)pool->finish_q.size();
+    for (int part = 0; part < parts; ++part) {             // the tape is completed in place by all finish threads
+        auto *fin = new fokl_host_job();
+        fin->pool = pool;
+        fin->kind = Kind::finish;
+        fin->self_owned = true;
+        fin->parent = parent;
+        fin->p1 = p1;
+        fin->draws = draws;
+        fin->normals = normals;
+        fin->pair_r2 = pair_r2;
+        fin->lead = lead;
+        fin->progress = progress;
+        fin->block_done = block_done;
+        fin->block = block;
+        fin->part = part;
+        fin->parts = parts;
+        submit(pool->finish_q[(size_t)part], fin);
+    }
 }
 
 extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star,
                                       double *normals, double *pair_r2, int32_t *lead, double *gam_sig,
-                                      double *gam_tau, int32_t *progress, int tentative, fokl_host_job **out)
+                                      double *gam_tau, int32_t *progress, int tentative, int32_t *block_done,
+                                      int block, fokl_host_job **out)
 {
-    if (!pool || !out || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !progress) {
+    if (!pool || !out || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !progress ||
+        (block_done && block < 1)) {
         fokl_set_global_error("fokl_pool_submit_noise: null pointer or empty model");
         return FOKL_ERR_ARG;
     }
@@ -410,7 +589,14 @@ extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, d
     job->gam_tau = gam_tau;
     job->progress = progress;
     job->tentative = tentative != 0;
+    if (!pool->trace_path.empty()) job->t_submit = now_ns();
     *out = job;
+    if (block_done && !pool->finish_q.empty()) {
+        // the finishing half follows the recorder whether or not a chain has been asked for yet (a tape recorded ahead
+        // of the decision that it is needed is complete when its chain comes); an aborted tape ends these jobs too
+        job->pending.store(1 + (int)pool->finish_q.size(), std::memory_order_relaxed);
+        submit_finish_jobs(pool, job, p1, draws, normals, pair_r2, lead, progress, block_done, block);
+    }
     submit(pool->noise_q, job);
     return FOKL_OK;
 }
@@ -419,8 +605,8 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
                                       double btau, double dtd, double sigsqd0, double tausqd0, int draws,
                                       const double *normals, const double *pair_r2, const int32_t *lead,
                                       const double *gam_sig, const double *gam_tau, const int32_t *progress,
-                                      int32_t *block_done, int block, double *w_out, int32_t *bstar_negative,
-                                      fokl_host_job **out)
+                                      int32_t *block_done, int block, int finishing_requested, double *w_out,
+                                      int32_t *bstar_negative, fokl_host_job **out)
 {
     if (!pool || !out || !lamb || !qty || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig ||
         !gam_tau || !progress || !w_out || !bstar_negative || (block_done && block < 1)) {
@@ -428,23 +614,9 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
         return FOKL_ERR_ARG;
     }
     const int parts = block_done ? (int)pool->finish_q.size() : 0;
-    for (int part = 0; part < parts; ++part) {             // the tape is completed in place by all finish threads
-        auto *fin = new fokl_host_job();
-        fin->pool = pool;
-        fin->kind = Kind::finish;
-        fin->self_owned = true;
-        fin->p1 = p1;
-        fin->draws = draws;
-        fin->normals = const_cast<double *>(normals);
-        fin->pair_r2 = const_cast<double *>(pair_r2);
-        fin->lead = const_cast<int32_t *>(lead);
-        fin->progress = const_cast<int32_t *>(progress);
-        fin->block_done = block_done;
-        fin->block = block;
-        fin->part = part;
-        fin->parts = parts;
-        submit(pool->finish_q[(size_t)part], fin);
-    }
+    if (parts > 0 && !finishing_requested)
+        submit_finish_jobs(pool, nullptr, p1, draws, const_cast<double *>(normals), const_cast<double *>(pair_r2),
+                           const_cast<int32_t *>(lead), const_cast<int32_t *>(progress), block_done, block);
     auto *job = new fokl_host_job();
     job->pool = pool;
     job->kind = Kind::chain;

@@ -480,17 +480,63 @@ inline void release_rng(const LegacyRng &r, int32_t *pos, int32_t *has_gauss, do
 
 thread_local Scratch t_scratch;
 
-// w = d * qty + sig * sqrt(d) * vec with d = 1 / (lamb + 1/tau2): element-wise, so SIMD lanes change nothing
-// in the results (IEEE div / sqrt / mul / add per element, no contraction); an AVX2 clone is picked at load time.
-FOKL_CLONES
-void draw_in_eigenbasis(const double *__restrict__ lamb, const double *__restrict__ qty, const double *__restrict__ v,
-                        int p1, double inv_tau, double sig, double *__restrict__ w)
+// One Gibbs iteration's vector half: w = d * qty + sig * (sqrt(d) * v) with d = 1 / (lamb + 1 / tau2), element-wise,
+// and the three quadratic forms sum lamb w^2, sum qty w, sum w^2.  Eight partial sums each (element i goes to lane i mod 8), combined in a fixed order: a dependency chain an
+// eighth as long as a plain ascending sum's, and the same numbers from this portable loop and from the AVX2 / AVX-512
+// statements of it (fokl_vlog.cpp, the wide build below), which are what runs where the CPU has them: IEEE add / mul /
+// div / sqrt per element, no contraction.  FOKL_CHAIN_ISA = base | avx2 | avx512 forces one (tests, A/B runs).
+extern "C" __attribute__((visibility("hidden"))) void fokl_chain_vector_avx2(const double *lamb, const double *qty,
+                                                                             const double *v, int p1, double inv_tau,
+                                                                             double sig, double *w, double *out);
+extern "C" __attribute__((visibility("hidden"))) void fokl_chain_vector_wide(const double *lamb, const double *qty,
+                                                                             const double *v, int p1, double inv_tau,
+                                                                             double sig, double *w, double *out);
+
+void chain_vector_portable(const double *__restrict__ lamb, const double *__restrict__ qty, const double *__restrict__ v,
+                           int p1, double inv_tau, double sig, double *__restrict__ w, double *__restrict__ out)
 {
+    double a_lam[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a_ty[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a_ww[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < p1; ++i) {
+        const int l = i & 7;
         const double d = 1.0 / (lamb[i] + inv_tau);
-        w[i] = d * qty[i] + sig * (std::sqrt(d) * v[i]);
+        const double wi = d * qty[i] + sig * (std::sqrt(d) * v[i]);
+        w[i] = wi;
+        const double ww = wi * wi;
+        a_lam[l] += lamb[i] * ww;
+        a_ty[l] += wi * qty[i];
+        a_ww[l] += ww;
+    }
+    out[0] = ((a_lam[0] + a_lam[4]) + (a_lam[2] + a_lam[6])) + ((a_lam[1] + a_lam[5]) + (a_lam[3] + a_lam[7]));
+    out[1] = ((a_ty[0] + a_ty[4]) + (a_ty[2] + a_ty[6])) + ((a_ty[1] + a_ty[5]) + (a_ty[3] + a_ty[7]));
+    out[2] = ((a_ww[0] + a_ww[4]) + (a_ww[2] + a_ww[6])) + ((a_ww[1] + a_ww[5]) + (a_ww[3] + a_ww[7]));
+}
+
+#ifndef FOKL_SAMPLER_WIDE
+inline int chain_vector_isa()                              // 0 portable, 1 AVX2, 2 AVX-512
+{
+    static const int isa = [] {
+        const bool avx2 = __builtin_cpu_supports("avx2");
+        const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&
+                          __builtin_cpu_supports("avx512vl");
+        const char *want = std::getenv("FOKL_CHAIN_ISA");
+        if (want && std::strcmp(want, "base") == 0) return 0;
+        if (want && std::strcmp(want, "avx2") == 0) return avx2 ? 1 : 0;
+        if (want && std::strcmp(want, "avx512") == 0) return wide ? 2 : (avx2 ? 1 : 0);
+        return wide ? 2 : (avx2 ? 1 : 0);
+    }();
+    return isa;
+}
+
+inline void chain_vector_part(const double *lamb, const double *qty, const double *v, int p1, double inv_tau, double sig,
+                              double *w, double *out)
+{
+    switch (chain_vector_isa()) {
+    case 2: fokl_chain_vector_wide(lamb, qty, v, p1, inv_tau, sig, w, out); break;
+    case 1: fokl_chain_vector_avx2(lamb, qty, v, p1, inv_tau, sig, w, out); break;
+    default: chain_vector_portable(lamb, qty, v, p1, inv_tau, sig, w, out);
     }
 }
+#endif
 
 // fokl_noise_tape's loop (see there).
 void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star, double *normals_out,
@@ -515,7 +561,44 @@ void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star
 
 #ifdef FOKL_SAMPLER_WIDE
 
-// The only entry of the AVX-512 build (library-internal); arguments were validated by fokl_noise_tape.
+// chain_vector_portable with one 512-bit register per set of eight lanes (library-internal).
+FOKL_INTERNAL void fokl_chain_vector_wide(const double *__restrict__ lamb, const double *__restrict__ qty,
+                                          const double *__restrict__ v, int p1, double inv_tau, double sig,
+                                          double *__restrict__ w, double *__restrict__ out)
+{
+    const __m512d it = _mm512_set1_pd(inv_tau), sg = _mm512_set1_pd(sig), one = _mm512_set1_pd(1.0);
+    __m512d lam = _mm512_setzero_pd(), ty = lam, sq = lam;
+    int i = 0;
+    for (; i + 8 <= p1; i += 8) {
+        const __m512d l8 = _mm512_loadu_pd(lamb + i), q8 = _mm512_loadu_pd(qty + i);
+        const __m512d d = _mm512_div_pd(one, _mm512_add_pd(l8, it));
+        const __m512d w8 = _mm512_add_pd(_mm512_mul_pd(d, q8),
+                                         _mm512_mul_pd(sg, _mm512_mul_pd(_mm512_sqrt_pd(d), _mm512_loadu_pd(v + i))));
+        _mm512_storeu_pd(w + i, w8);
+        const __m512d ww = _mm512_mul_pd(w8, w8);
+        lam = _mm512_add_pd(lam, _mm512_mul_pd(l8, ww));
+        ty = _mm512_add_pd(ty, _mm512_mul_pd(w8, q8));
+        sq = _mm512_add_pd(sq, ww);
+    }
+    double a_lam[8], a_ty[8], a_ww[8];
+    _mm512_storeu_pd(a_lam, lam);
+    _mm512_storeu_pd(a_ty, ty);
+    _mm512_storeu_pd(a_ww, sq);
+    for (int l = 0; i < p1; ++i, ++l) {
+        const double d = 1.0 / (lamb[i] + inv_tau);
+        const double wi = d * qty[i] + sig * (std::sqrt(d) * v[i]);
+        w[i] = wi;
+        const double ww = wi * wi;
+        a_lam[l] += lamb[i] * ww;
+        a_ty[l] += wi * qty[i];
+        a_ww[l] += ww;
+    }
+    out[0] = ((a_lam[0] + a_lam[4]) + (a_lam[2] + a_lam[6])) + ((a_lam[1] + a_lam[5]) + (a_lam[3] + a_lam[7]));
+    out[1] = ((a_ty[0] + a_ty[4]) + (a_ty[2] + a_ty[6])) + ((a_ty[1] + a_ty[5]) + (a_ty[3] + a_ty[7]));
+    out[2] = ((a_ww[0] + a_ww[4]) + (a_ww[2] + a_ww[6])) + ((a_ww[1] + a_ww[5]) + (a_ww[3] + a_ww[7]));
+}
+
+// The recorder of the AVX-512 build (library-internal); arguments were validated by fokl_noise_tape.
 FOKL_INTERNAL void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
                                          int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                                          double *normals_out, double *pair_r2_out, int32_t *lead_out,
@@ -604,14 +687,9 @@ extern "C" int fokl_gibbs_chain(const double *lamb, const double *qty, int p1, d
         double *__restrict__ w = w_out + (size_t)k * p1;
         const double *__restrict__ v = vec.data();
         fill_normals(r, scratch, p1, vec.data());      // np.random.normal(0, 1, (p1, 1)), C order
-        draw_in_eigenbasis(lamb, qty, v, p1, inv_tau, sig, w);
-        double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
-        for (int i = 0; i < p1; ++i) {                 // quadratic forms, ascending i
-            const double wi = w[i];
-            q_lam += lamb[i] * (wi * wi);
-            q_ty += wi * qty[i];
-            q_ww += wi * wi;
-        }
+        double q[3];
+        chain_vector_part(lamb, qty, v, p1, inv_tau, sig, w, q);
+        const double q_lam = q[0], q_ty = q[1], q_ww = q[2];
         const double bstar = b + 0.5 * (q_lam - 2.0 * q_ty + dtd + q_ww / tausqd);
         if (bstar < 0.0) {
             sigsqd = NAN;                              // FR:1538-1539: no gamma draw in this branch
@@ -688,14 +766,9 @@ inline void chain_step(const double *__restrict__ lamb, const double *__restrict
 {
     const double inv_tau = 1.0 / st.tausqd;
     const double sig = std::sqrt(st.sigsqd);
-    draw_in_eigenbasis(lamb, qty, vec, p1, inv_tau, sig, w);
-    double q_lam = 0.0, q_ty = 0.0, q_ww = 0.0;
-    for (int i = 0; i < p1; ++i) {
-        const double wi = w[i];
-        q_lam += lamb[i] * (wi * wi);
-        q_ty += wi * qty[i];
-        q_ww += wi * wi;
-    }
+    double q[3];
+    chain_vector_part(lamb, qty, vec, p1, inv_tau, sig, w, q);
+    const double q_lam = q[0], q_ty = q[1], q_ww = q[2];
     const double bstar = b + 0.5 * (q_lam - 2.0 * q_ty + dtd + q_ww / st.tausqd);
     if (bstar < 0.0) {
         st.flagged = 1;                                // the tape holds a gamma the reference would not have drawn

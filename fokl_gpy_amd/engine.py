@@ -15,7 +15,9 @@ are sub-blocks of the sub-stage Gram held on the host; the BIC stil
 residual pass over the device columns, never from the cancellation-prone Gram identity.
 The *logical* candidate-term count (what the reference would have built) is tallied per call.
 """
+import collections
 import itertools
+import threading
 import math
 import os
 import time
@@ -112,6 +114,25 @@ def eigh_canonical(A):
 # device backend protocol
 # ---------------------------------------------------------------------------------------------------------
 
+# FOKL_POOL_TRACE=<file>: the driver's side of the noise thread's trace (csrc/fokl_hostpool.cpp), same monotonic clock;
+# tools/pool_trace.py lines the two up.  A diagnostic: nothing is recorded without the variable.
+_TRACE_PATH = os.environ.get('FOKL_POOL_TRACE')
+_trace_log = []
+
+
+def _mark(tag, info=''):
+    if _TRACE_PATH:
+        _trace_log.append((time.monotonic_ns(), tag, info))
+
+
+def _flush_marks():
+    if _TRACE_PATH and _trace_log:
+        with open(_TRACE_PATH, 'a') as f:
+            for t, tag, info in _trace_log:
+                f.write(f"driver {t} {tag} {info}\n")
+        del _trace_log[:]
+
+
 class HipBackend:
     """The shipped backend: a ``_capi.DeviceContext`` on one MI355X.  No CPU path exists in the product."""
 
@@ -136,6 +157,12 @@ class HipBackend:
 
     def gram(self, row_slots, col_slots, allreduce=False):
         return self.ctx.gram(row_slots, col_slots, 0, allreduce)
+
+    def gram_launch(self, row_slots, col_slots, allreduce=False):
+        return self.ctx.gram_launch(row_slots, col_slots, allreduce)
+
+    def gram_fetch(self, shape):
+        return self.ctx.gram_fetch(shape)
 
     def bic_resid(self, slots, betahat, allreduce=False):
         return self.ctx.bic_resid(slots, betahat, allreduce)
@@ -297,6 +324,32 @@ def _thread_plan():
     return max(1, chain), max(0, finish), max(1, spectral)       # the threaded search needs a chain and a spectral thread
 
 
+# Spare tape / draw buffers of the calling thread, by size class: they survive the fit that allocated them, so that the
+# next fit on this thread does not page-fault a few hundred MB in again (FOKL_HOST_POOL_MB caps what is kept, default
+# 2048; the count is per process and approximate when several threads fit at once -- it only bounds memory).
+class _SpareAccount:
+    doubles = 0
+    limit = int(float(os.environ.get('FOKL_HOST_POOL_MB', '2048')) * 131072)
+
+
+_SPARES = _SpareAccount()
+_SPARE_LISTS = threading.local()
+
+
+def _thread_spares():
+    spares = getattr(_SPARE_LISTS, 'by_class', None)
+    if spares is None:
+        spares = _SPARE_LISTS.by_class = {}
+    return spares
+
+
+def drop_spare_buffers():
+    """Give the calling thread's spare tape / draw buffers back to the allocator."""
+    spares = _thread_spares()
+    _SPARES.doubles = max(0, _SPARES.doubles - sum(raw.shape[0] for stack in spares.values() for raw in stack))
+    spares.clear()
+
+
 class HostPipeline:
     """
     The host threads of one fit (include/fokl_hip.h: fokl_pool_*), all native, none holding the GIL:
@@ -338,18 +391,24 @@ class HostPipeline:
         # or not the driver still cares about the result (a rejected candidate's tape is recorded all the same).
         self._live = []
         # Tapes and draws are a few MB per model evaluation; fresh allocations would be page-faulted in by the noise
-        # and chain threads (measured: a third of the tape time).  Buffers go round in 512 KB size classes instead.
-        self._spare = {}
+        # and chain threads (measured: a third of the tape time).  Buffers go round in 512 KB size classes instead, and
+        # stay with the thread from one fit to the next (_thread_spares).
+        self._spare = _thread_spares()
 
     CLASS_DOUBLES = 65536
 
     def _take(self, doubles):
         cls = -(-doubles // self.CLASS_DOUBLES)
         spare = self._spare.get(cls)
-        return spare.pop() if spare else np.empty(cls * self.CLASS_DOUBLES, dtype=np.float64)
+        if spare:
+            _SPARES.doubles -= cls * self.CLASS_DOUBLES
+            return spare.pop()
+        return np.empty(cls * self.CLASS_DOUBLES, dtype=np.float64)
 
     def give(self, raw):
-        self._spare.setdefault(raw.shape[0] // self.CLASS_DOUBLES, []).append(raw)
+        if _SPARES.doubles + raw.shape[0] <= _SPARES.limit:
+            _SPARES.doubles += raw.shape[0]
+            self._spare.setdefault(raw.shape[0] // self.CLASS_DOUBLES, []).append(raw)
 
     def _reap(self):
         live = []
@@ -374,7 +433,7 @@ class HostPipeline:
         tentative: recorded ahead of the decision that the evaluation happens -- the caller owes the job a
         ``resolve(True / False)`` (False rewinds the stream to where the tape began)."""
         raw = self._take(_capi.NoiseTape.doubles_needed(p1, self.draws))
-        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative)
+        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative, finish=True)
         # The tape's last reader is the chain job, which does not exist yet: until chain() or discard() the buffer is
         # only `held`, so that a _reap() between request and chain (the recorder may well be done by then) cannot hand
         # it out again -- chain() would then get the tape's own memory as its output buffer.
@@ -458,8 +517,8 @@ class HostPipeline:
                 job.resolve(False)
         for job in self._live:
             job.wait()
+        self._reap()                        # buffers of the jobs that have run now go back to the thread's spares
         self._live = []
-        self._spare = {}
         busy = self.pool.busy_seconds()
         self.pool.close()
         self._restore_affinity()
@@ -632,6 +691,10 @@ class ForwardSelection:
         mode = os.environ.get('FOKL_TENTATIVE_TAPES', '1')
         self.tentative_tapes = mode != '0'
         self._test_rewinds = mode == 'test'
+        # how many tapes may be on order ahead of the decisions that they are needed (_speculate, _drop_speculation)
+        self.speculation_max = max(1, min(16, int(os.environ.get('FOKL_SPECULATION', '12'))))
+        self._speculation = self.speculation_max
+        self._spec = collections.deque()    # (model size, tentative noise job): on order, in stream order, no verdict yet
         # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model;
         # 'gram' = residual moments from the sub-stage's Gram (no device work per candidate; agrees with
         # the device pass to < 1e-10 relative on the BIC); 'check' = device, recording the largest disagreement with
@@ -648,11 +711,12 @@ class ForwardSelection:
             self.lookahead = max(self.lookahead, 3 * comm.world)
         self.trace = []                     # one record per gibbs evaluation
         self._outcomes = []                 # pipelined evaluations whose draws sit in pooled buffers (see _retire)
+        self._retiring = []                 # ... and those of them nobody will look at any more
         self._ev_cache = {}                 # model (set of terms) -> its BIC, see _same_model_same_ev
         self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0, tapes_rewound=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
+                          bic_gram_max_rel=0.0, tapes_rewound=0, tapes_wasted=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
                           spectral_submitted=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
@@ -712,7 +776,7 @@ class ForwardSelection:
 
     def _set_active_terms(self, damtx):
         """Terms of the active columns of the sub-stage that begins (column 0 = intercept)."""
-        self._active_terms = [()] + [tuple(int(v) for v in row) for row in damtx]
+        self._active_terms = [()] + list(map(tuple, np.asarray(damtx, dtype=np.int64).tolist()))
         self._terms_arr = None
         if self._matrix_free and damtx.shape[0]:
             arr = np.ascontiguousarray(damtx, dtype=np.int32)
@@ -724,11 +788,65 @@ class ForwardSelection:
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
         return self.host.request(p1, astar, atau_star, tentative)
 
+    # Tapes on order.  A tape's content depends on nothing but the model size and the position of the stream, so the
+    # driver keeps the noise thread supplied with the sizes the search will PROBABLY ask for next -- several deep, across
+    # kill tests and sub-stage boundaries -- as tentative requests; the evaluation that really comes takes the oldest one
+    # if the size fits (commit) and otherwise sends them all back (the stream is rewound to where the oldest began).  The
+    # stream's consumption therefore is exactly the reference's whatever was guessed.
+    def _drop_speculation(self, keep=0):
+        """Send back the tapes on order beyond the first `keep`.  What a wrong guess costs is the recorder's time on
+        tapes it had begun: each of those takes two off the depth of the speculation (every tape that is used grows it
+        back by one); orders the recorder had not reached yet cost nothing."""
+        while len(self._spec) > keep:
+            _, job = self._spec.pop()                                 # youngest first
+            begun = job.result.progress[0] > 0
+            self.host.discard(job)
+            self.stats['tapes_rewound'] += 1
+            if begun:
+                self.stats['tapes_wasted'] += 1
+                self._speculation = max(1, self._speculation - 2)
+
+    def _tape_for(self, p1):
+        """The tape of the model evaluation that happens now (p1 columns)."""
+        if self._spec:
+            size, job = self._spec[0]
+            if size == p1:
+                self._spec.popleft()
+                job.resolve(True)
+                self._speculation = min(self.speculation_max, self._speculation + 1)
+                _mark('tape_committed', str(p1))
+                return job
+            self._drop_speculation()
+        _mark('tape_requested', str(p1))
+        return self._request_noise(p1)
+
+    def _speculate(self, sizes):
+        """sizes: the models the stream will probably serve next, in order (as far as the caller can see).  Orders that
+        agree with them stay, the others are sent back, missing ones are placed until self._speculation tapes are on
+        order."""
+        if not self.tentative_tapes or self.host is None:
+            return
+        sizes = list(sizes)
+        k = 0
+        while k < len(self._spec) and k < len(sizes) and self._spec[k][0] == sizes[k]:
+            k += 1
+        if k < len(self._spec):
+            self._drop_speculation(k)
+        for size in sizes[k:max(k, self._speculation)]:
+            if self._test_rewinds:                                    # tests: a recorded tape that is then discarded
+                bogus = self._request_noise(size + 1, tentative=True)
+                while bogus.result.progress[0] < self.draws:
+                    time.sleep(0)
+                self.host.discard(bogus)
+                self.stats['tapes_rewound'] += 1
+            self._spec.append((size, self._request_noise(size, tentative=True)))
+        _mark('speculating', ' '.join(str(size) for size, _ in self._spec))
+
     def _commit(self, pending, noise_job=None):
         """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
         spec, idx, _, dtd, _ = pending
         if noise_job is None:
-            noise_job = self._request_noise(idx.shape[0])
+            noise_job = self._tape_for(idx.shape[0])
         chain_job, w_raw = self.host.chain(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job)
         return noise_job, chain_job, w_raw
 
@@ -755,26 +873,32 @@ class ForwardSelection:
             self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
         return self._same_model_same_ev(idx, ev)
 
-    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None):
+    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None, then=()):
         """
         gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
         slots : device slot of each active column
         idx   : active-column indices of this candidate model (idx[0] == 0, the intercept)
         spectral_job : G2 of exactly this model submitted earlier (pipelined search), if any
         overlap : called once G2 is under way -- work for the driver thread in its shadow (pipelined search)
+        then  : sizes of the models that will probably be evaluated after this one (tapes ordered ahead, _speculate)
         """
         idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
         if self.host is not None:
             # not speculative: the tape is requested first, so that it is recorded while G2 runs
-            noise_job = self._request_noise(p1)
+            noise_job = self._tape_for(p1)
+            self._speculate(then)
             if spectral_job is None:
                 spectral_job = self.host.spectral(gram, idx)
+            _mark('eval_requested', str(p1))
             if overlap is not None:
                 overlap()
+                _mark('eval_overlap')
             pending = self._begin(gram, slots, idx, spectral_job)
+            _mark('eval_begun')
             jobs = self._commit(pending, noise_job)
             ev = self._score(pending)
+            _mark('eval_scored')
             self._record(p1, n_prev_cols, ev, kill)
             outcome = GibbsOutcome(self, pending[0], ev, idx, *jobs)
             outcome.siglik = self._last_siglik
@@ -810,11 +934,15 @@ class ForwardSelection:
 
     def _retire(self, *keep):
         """End of a sub-stage: the draws of every model evaluated so far except `keep` (the best model of the search and
-        the model the next sub-stage starts from) can no longer be looked at -- their buffers go back to the pool."""
-        for outcome in self._outcomes:
-            if not any(outcome is k for k in keep):
-                outcome.release()
+        the model the next sub-stage starts from) can no longer be looked at -- their buffers go back to the pool, a
+        little later (_release_retired): the noise thread is waiting for the coming sub-stage's orders right now."""
+        self._retiring += [o for o in self._outcomes if not any(o is k for k in keep)]
         self._outcomes = [k for k in keep if isinstance(k, GibbsOutcome)]
+
+    def _release_retired(self):
+        for outcome in self._retiring:
+            outcome.release()
+        self._retiring = []
 
     @staticmethod
     def _columns_without(count, removed):
@@ -830,22 +958,36 @@ class ForwardSelection:
         tape_s = self.draws * (40.0 + columns) * 1e-9
         return resid_s < 0.6 * tape_s
 
-    def _guess_first_tests(self, gram, full, n_new):
-        """G2 jobs for the first kill tests of the sub-stage model `full` (its last n_new columns are new), guessed from
-        the least-squares fit before the model's chain is there: the proposals will be ordered by |mean beta| ~
-        |betahat| and can pass FR:1670 only if std beta / |mean beta| ~ (siglik (XtX)^-1_jj)^1/2 / |betahat_j| exceeds
-        the smaller threshold.  Returns {trial set -> job}; a wrong guess costs a spectral thread a few milliseconds."""
-        A = gram.shape[0] - 1
+    def _likely_first_tests(self, spec, n_new, siglik=None):
+        """The kill tests a sub-stage will probably run, guessed from the least-squares fit of its model (spec: G2 of that
+        model, its last n_new columns are new) before the model's chain is there: the proposals will be ordered by
+        |mean beta| ~ |betahat| and can pass FR:1670 only if std beta / |mean beta| ~ (siglik (XtX)^-1_jj)^1/2 /
+        |betahat_j| exceeds the smaller threshold (siglik from the Gram: G2 brings the residual moments along).
+        Returns the active-column indices in testing order."""
+        A = spec.betahat.shape[0]
         new = np.arange(A - n_new, A)
-        guess_mean = np.abs(full.betahat[new])
-        guess_std = np.sqrt(max(full.siglik, 0.0) * np.sum(full.Qt[:, new] ** 2 / full.lamb[:, None], axis=0))
+        if siglik is None:
+            siglik = spec.moments[1] / self.n - (spec.moments[0] / self.n) ** 2
+        guess_mean = np.abs(spec.betahat[new])
+        guess_std = np.sqrt(max(siglik, 0.0) * np.sum(spec.Qt[:, new] ** 2 / spec.lamb[:, None], axis=0))
         floor = min(self.threshstda, self.threshstdb)
-        likely = [int(new[j]) for j in np.argsort(guess_mean) if guess_std[j] > floor * guess_mean[j]]
+        return [int(new[j]) for j in np.argsort(guess_mean) if guess_std[j] > floor * guess_mean[j]]
+
+    def _guess_first_tests(self, gram, spec, n_new, siglik=None, before_model=False):
+        """G2 jobs for the first kill tests of the sub-stage whose model's G2 is `spec` (_likely_first_tests), and the
+        tapes of all the likely ones (before_model: the model's own tape has not been taken yet and leads them).
+        Returns ({trial set -> job}, sizes of the likely tests); a wrong guess costs a spectral thread a few
+        milliseconds."""
+        A = gram.shape[0] - 1
+        likely = self._likely_first_tests(spec, n_new, siglik)
         jobs, cur = {}, frozenset()
         for c in likely[:1 + self.lookahead]:
             cur = cur | {c}
             jobs[cur] = self.host.spectral(gram, self._columns_without(A, cur))
-        return jobs
+        # and their tapes: test t of the sub-stage has A - 1 - t columns if the tests before it were accepted
+        sizes = [A - 1 - t for t in range(len(likely))]
+        self._speculate(([A] if before_model else []) + sizes)
+        return jobs, sizes
 
     def _intercept_scale(self, outcome, half0):
         """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
@@ -855,7 +997,7 @@ class ForwardSelection:
         return outcome.intercept_scale
 
     def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None,
-                              ahead=None, first_tape=None):
+                              ahead=None, vm_next=None, idle_work=None, peek=None):
         """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
 
         Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
@@ -863,7 +1005,12 @@ class ForwardSelection:
         the residual pass of the upcoming one is in flight while this thread waits for that chain.
         foresee(killed set) is told, towards the end of the loop, which columns the loop will probably have removed
         when it is done (the caller starts G2 of the next sub-stage's model with it).  `ahead` may bring G2 jobs the
-        caller has already submitted (trial set -> job).
+        caller has already submitted (trial set -> job).  vm_next: number of columns the coming sub-stage adds (None:
+        there is none) -- the tapes ordered ahead go on across the boundary with that sub-stage's model and first tests.
+        idle_work: called once, when the first test's tape and G2 are under way (or, without a test, at the end): work of
+        the driver that nothing in this loop waits for (the caller builds the coming sub-stage's columns with it).
+        peek(killed set): how many kill tests the coming sub-stage will probably run if this one ends with that kill set
+        (None: not known yet).
         """
         A = len(slots)
         vm = cand_col.shape[0]
@@ -879,13 +1026,6 @@ class ForwardSelection:
         evmin = best.ev
         ahead = {} if ahead is None else ahead                        # trial set -> spectral job submitted ahead
         last_accepted = True                                          # predictor: proposals go the way the last went
-        # The tape of the NEXT test, requested as soon as this one's BIC is known (its size needs the kill set) instead
-        # of after the chain that decides whether that test is run: the noise thread then goes from one tape to the
-        # next without a pause.  (proposal index, model size, job); rewound if the guess was wrong.
-        # first_tape: recorded straight after the sub-stage model's own tape, before the statistics that order the
-        # proposals exist -- every first test has A - 1 columns whichever proposal it removes, so the tape fits any of
-        # them (proposal index None); rewound if no proposal is tested at all
-        pending_tape = None if first_tape is None else (None, A - 1, first_tape)
         likely = lambda j: clause1[j] or mean_abs[j] < self.threshav * scale_guess
 
         def forecast(pos):
@@ -894,95 +1034,103 @@ class ForwardSelection:
             if foresee is not None and len(rest) <= self.foresight:
                 foresee(killed | {cols[j] for j in rest})
 
-        def drop_pending():
-            nonlocal pending_tape
-            if pending_tape is not None:
-                self.host.discard(pending_tape[2])
-                self.stats['tapes_rewound'] += 1
-                pending_tape = None
-
-        try:
-            forecast(0)
-            for pos, i in enumerate(proposal):
-                decided = clause1[i]
-                if not decided and best.intercept_scale is not None:      # second clause without waiting for a chain
-                    if not mean_abs[i] < self.threshav * best.intercept_scale:
-                        if pending_tape is not None and pending_tape[0] == i:
-                            drop_pending()
-                        continue
-                    decided = True
-                # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
-                cur = killed
-                upcoming = itertools.islice((j for j in proposal[pos + 1:] if likely(j)), self.lookahead)
-                for j in itertools.chain((i,), upcoming):
-                    key = cur | {cols[j]}
-                    if key not in ahead:
-                        ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
+        def order_tapes(pos):
+            # The tapes of what the stream serves next if the search goes on as predicted -- the likely tests from
+            # proposal[pos] on, each one column smaller than the one before while tests are being accepted, then the
+            # coming sub-stage's model and its first test -- ordered as soon as this test's BIC is known (the sizes need
+            # the kill set) instead of after the chains that decide whether those tests run: the noise thread goes from
+            # one tape to the next without a pause.
+            sizes, pred = [], set(killed)
+            for j in proposal[pos:]:
+                if len(sizes) >= self.speculation_max:
+                    break
+                if likely(j):
+                    sizes.append(A - len(pred) - 1)
                     if last_accepted:
-                        cur = key
-                trial = killed | {cols[i]}
-                idx = self._columns_without(A, trial)
-                early_tape = None
-                if decided and pending_tape is None:
-                    # the test runs for sure and its tape is not on its way yet (first test of a sub-stage, or after
-                    # a wrong guess): have it recorded while this thread waits for G2
-                    early_tape = self._request_noise(idx.shape[0])
-                pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=on_device)
-                if not decided:
-                    scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
-                    if not mean_abs[i] < self.threshav * scale_guess:
-                        if self._async_resid and pending[2] is not None:
-                            self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
-                        if pending_tape is not None and pending_tape[0] == i:
-                            drop_pending()
-                        continue
-                noise_job = early_tape
-                if pending_tape is not None:
-                    if pending_tape[0] in (i, None) and pending_tape[1] == idx.shape[0]:
-                        noise_job = pending_tape[2]
-                        noise_job.resolve(True)
-                        pending_tape = None
-                    else:
-                        drop_pending()                                    # recorded for a test that is not the next one
-                if pending[2] is None:
-                    # the BIC comes from the Gram and is known now, before anything is spent on the candidate's draws:
-                    # a rejected candidate only has to advance the random stream (its tape is recorded, never finished
-                    # nor chained -- nobody reads the draws of a model that loses, FR:1686-1690)
-                    ev = self._score(pending)
-                    if ev < evmin:
-                        jobs = self._commit(pending, noise_job)
-                    else:
-                        if noise_job is None:
-                            noise_job = self._request_noise(idx.shape[0])
-                        self.host.abandon(noise_job)
-                        self.stats['chains_skipped'] += 1
-                        jobs = None
-                else:
-                    jobs = self._commit(pending, noise_job)
-                    ev = self._score(pending)
-                self._record(idx.shape[0], n_prev, ev, True)
-                last_accepted = bool(ev < evmin)
+                        pred.add(cols[j])
+            else:
+                if vm_next is not None:
+                    # across the boundary: the coming model, its first test (every first test is one column smaller
+                    # whichever proposal it removes) -- or, if G2 of that model is there already, all the tests its
+                    # least-squares fit makes likely
+                    tests = peek(pred) if peek is not None else None
+                    if tests is None:
+                        tests = min(vm_next, 1)
+                    sizes += [A - len(pred) + vm_next - t for t in range(tests + 1)]
+            self._speculate(sizes)
+
+        forecast(0)
+        order_tapes(0)
+        for pos, i in enumerate(proposal):
+            decided = clause1[i]
+            _mark('test', f"{pos} decided={int(decided)} known={int(best.intercept_scale is not None)}")
+            if not decided and (best.intercept_scale is not None or not likely(i)):
+                # second clause without G2 of a model that will probably not be needed: from the known scale, or --
+                # the test looks unlikely -- after waiting for the chain of `best`
+                scale_guess = self._intercept_scale(best, half0)
+                if not mean_abs[i] < self.threshav * scale_guess:
+                    continue
+                decided = True
+            # G2 of the models on the predicted path, self.lookahead tests deep (a wrong guess costs latency only)
+            cur = killed
+            upcoming = itertools.islice((j for j in proposal[pos + 1:] if likely(j)), self.lookahead)
+            for j in itertools.chain((i,), upcoming):
+                key = cur | {cols[j]}
+                if key not in ahead:
+                    ahead[key] = self.host.spectral(gram, self._columns_without(A, key))
                 if last_accepted:
-                    killed, evmin = trial, ev
-                    best.release()                                        # the model it replaces: its draws are history
-                    best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
-                    self._outcomes.append(best)
-                elif jobs is not None:
-                    jobs[1].recycle.append(jobs[2])                       # nobody will read a rejected candidate's draws
-                forecast(pos + 1)
-                if self.tentative_tapes:
-                    nxt = next((j for j in proposal[pos + 1:] if likely(j)), None)
-                    if nxt is not None:
-                        p1_next = A - len(killed) - 1
-                        if self._test_rewinds:                            # tests: a recorded tape that is then discarded
-                            bogus = self._request_noise(p1_next + 1, tentative=True)
-                            while bogus.result.progress[0] < self.draws:
-                                time.sleep(0)
-                            self.host.discard(bogus)
-                            self.stats['tapes_rewound'] += 1
-                        pending_tape = (nxt, p1_next, self._request_noise(p1_next, tentative=True))
-        finally:
-            drop_pending()                                            # also on an exception: the noise thread must not wait
+                    cur = key
+            trial = killed | {cols[i]}
+            idx = self._columns_without(A, trial)
+            p1 = idx.shape[0]
+            # the test runs for sure: its tape is committed (or, not on order after a wrong guess, requested) now, so
+            # that the stream moves on while this thread waits for G2
+            noise_job = self._tape_for(p1) if decided else None
+            _mark('g2_submitted')
+            if idle_work is not None:
+                idle_work()
+                idle_work = None
+                _mark('idle_work')
+            pending = self._begin(gram, slots, idx, ahead.pop(trial), on_device=on_device)
+            _mark('begun')
+            if not decided:
+                scale_guess = self._intercept_scale(best, half0)      # waits for the chain of `best`
+                _mark('chain_of_best')
+                if not mean_abs[i] < self.threshav * scale_guess:
+                    if self._async_resid and pending[2] is not None:
+                        self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
+                    continue
+                noise_job = self._tape_for(p1)
+            if pending[2] is None:
+                # the BIC comes from the Gram and is known now, before anything is spent on the candidate's draws:
+                # a rejected candidate only has to advance the random stream (its tape is recorded, never finished
+                # nor chained -- nobody reads the draws of a model that loses, FR:1686-1690)
+                ev = self._score(pending)
+                if ev < evmin:
+                    jobs = self._commit(pending, noise_job)
+                else:
+                    self.host.abandon(noise_job)
+                    self.stats['chains_skipped'] += 1
+                    jobs = None
+            else:
+                jobs = self._commit(pending, noise_job)
+                ev = self._score(pending)
+            _mark('scored')
+            self._record(p1, n_prev, ev, True)
+            last_accepted = bool(ev < evmin)
+            if last_accepted:
+                killed, evmin = trial, ev
+                best.release()                                        # the model it replaces: its draws are history
+                best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                self._outcomes.append(best)
+            elif jobs is not None:
+                jobs[1].recycle.append(jobs[2])                       # nobody will read a rejected candidate's draws
+            forecast(pos + 1)
+            order_tapes(pos + 1)
+        order_tapes(len(proposal))                                    # the kill set is final
+        if idle_work is not None:
+            idle_work()
+            forecast(len(proposal))
         return sorted(killed), evmin, best
 
     # -- the search ---------------------------------------------------------------------------------------
@@ -1011,6 +1159,7 @@ class ForwardSelection:
                                   spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
                                   spectral_submitted=self.host.spectral_submitted)
                 self.host = None
+                _flush_marks()
 
     def _patterns(self):
         """(stage ind, indvec) of every sub-stage in the reference's order (FR:1602-1613, FR:1722-1747)."""
@@ -1034,8 +1183,18 @@ class ForwardSelection:
         slots = self.pool.take(vecs.shape[0])
         self.backend.build_terms(vecs.astype(np.int32), slots)
         self.stats['terms_physical'] += vecs.shape[0]
-        block = self.backend.gram(slots, active_slots + slots + [SLOT_Y], self.allreduce)
-        return dict(indvec=indvec, vecs=vecs, slots=slots, block=block, over=len(active_slots))
+        ahead = dict(indvec=indvec, vecs=vecs, slots=slots, over=len(active_slots))
+        if hasattr(self.backend, 'gram_launch'):
+            # the driver does not wait: the block is fetched when somebody looks at it (_ahead_block)
+            ahead['pending'] = self.backend.gram_launch(slots, active_slots + slots + [SLOT_Y], self.allreduce)
+        else:
+            ahead['block'] = self.backend.gram(slots, active_slots + slots + [SLOT_Y], self.allreduce)
+        return ahead
+
+    def _ahead_block(self, ahead):
+        if 'block' not in ahead:
+            ahead['block'] = self.backend.gram_fetch(ahead.pop('pending'))
+        return ahead['block']
 
     @staticmethod
     def _extend_gram(gram, keep, block, block_kept, over):
@@ -1093,7 +1252,8 @@ class ForwardSelection:
                     spectral_job, gram = hit
                     self.stats['forecasts_used'] += 1
                 else:
-                    gram = self._extend_gram(gram, keep, ahead['block'], keep, ahead['over'])
+                    gram = self._extend_gram(gram, keep, self._ahead_block(ahead), keep, ahead['over'])
+                self._ahead_block(ahead)                    # a launched block is always fetched
                 ahead, forecasts = None, {}
             else:
                 # K1 + K2: build the new columns once, extend the Gram
@@ -1103,28 +1263,39 @@ class ForwardSelection:
                 self.stats['terms_physical'] += vecs.shape[0]
                 block = self.backend.gram(new_slots, [SLOT_ONES] + model_slots + new_slots + [SLOT_Y], self.allreduce)
                 gram = self._extend_gram(gram, keep, block, list(range(n_prev)), n_prev)
+            _mark('substage', f"{ind} hit={int(spectral_job is not None)}")
             vm = vecs.shape[0]
             damtx = np.append(damtx, vecs, axis=0)
             dam = damtx.shape[0]
             self._set_active_terms(damtx)
             active_slots = [SLOT_ONES] + model_slots + new_slots
             A = len(active_slots)
+            pipelined = self.host is not None
+            # G2 of this model may be there already (started while the sub-stage before was being decided): the first
+            # kill tests are guessed from it -- their G2 jobs and tapes -- before anything else happens
+            early, then = None, [A - 1] if vm > 0 and A > 1 else []
+            if pipelined and self.lookahead > 0 and spectral_job is not None and getattr(
+                    spectral_job, 'done', lambda: False)():
+                early, then = self._guess_first_tests(gram, spectral_job.wait(), vm, before_model=True)
 
             def build_next(coming=pattern, active=active_slots):
                 nonlocal ahead
+                self._release_retired()
                 if look_ahead and coming is not None:
                     ahead = self._build_ahead(coming[1], active)
 
+            # the tape of the first kill test, whichever proposal that will be (every first test has A - 1 columns), is
+            # ordered together with the model's own (which may be on its way already, see _kill_tests_pipelined): the
+            # noise thread goes straight on instead of idling until the model's chain has finished and its statistics
+            # have ordered the proposals
             full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False, spectral_job=spectral_job,
-                                  overlap=build_next)
+                                  overlap=None if pipelined else build_next, then=then)
             best = full
             ev = full.ev
-            # the tape of the first kill test, whichever proposal that will be (see _kill_tests_pipelined): the noise
-            # thread goes straight on after the sub-stage model's tape instead of idling until that model's chain has
-            # finished and its statistics have ordered the proposals
-            first_tape = None
-            if self.host is not None and self.tentative_tapes and vm > 0 and A > 1:
-                first_tape = self._request_noise(A - 1, tentative=True)
+            _mark('full_evaluated', str(A))
+            vm_next = None
+            if pipelined and pattern is not None:
+                vm_next = distinct_arrangements(pattern[1]).shape[0]
 
             def foresee(pred_killed, gram=gram, active=active_slots, A=A):
                 # G2 of the coming sub-stage's model if the kill tests end as predicted (at most two guesses)
@@ -1133,18 +1304,33 @@ class ForwardSelection:
                 keep_pred = [c for c in range(A) if c not in pred_killed]
                 key = tuple(active[c] for c in keep_pred[1:])
                 if key not in forecasts:
-                    g = self._extend_gram(gram, keep_pred, ahead['block'], keep_pred, ahead['over'])
+                    g = self._extend_gram(gram, keep_pred, self._ahead_block(ahead), keep_pred, ahead['over'])
                     forecasts[key] = (self.host.spectral(g, np.arange(g.shape[0] - 1, dtype=np.int32)), g)
 
-            early = {}
-            if self.host is not None and self.lookahead > 0:
-                # guess the first tests now, while the chain of the sub-stage model is still running
-                early = self._guess_first_tests(gram, full, vm)
+            guesses = {}
+
+            def coming_tests(pred_killed, active=active_slots, A=A):
+                # kill tests the coming sub-stage will probably run if this one ends with that kill set -- known once
+                # G2 of its model (foresee) is there
+                key = tuple(active[c] for c in range(1, A) if c not in pred_killed)
+                if key not in guesses:
+                    hit = forecasts.get(key)
+                    if hit is None or not getattr(hit[0], 'done', lambda: False)():
+                        return None
+                    guesses[key] = len(self._likely_first_tests(hit[0].wait(), vm_next))
+                return guesses[key]
+
+            if early is None:
+                early = {}
+                if pipelined and self.lookahead > 0:
+                    # guess the first tests now, while the chain of the sub-stage model is still running
+                    early, _ = self._guess_first_tests(gram, full, vm, siglik=full.siglik)
 
             # statistics of the new terms (FR:1656-1664)
             tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
             mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
             rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
+            _mark('full_statistics')
             order = np.argsort(mean_abs)
             cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
             mean_abs, rel_std = mean_abs[order], rel_std[order]
@@ -1168,8 +1354,10 @@ class ForwardSelection:
                             best = res
             else:
                 killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
-                                                                 rel_std, best, half0, foresee, early, first_tape)
+                                                                 rel_std, best, half0, foresee, early, vm_next,
+                                                                 build_next, coming_tests)
             ev = evmin
+            _mark('tests_over', str(len(killed)))
 
             # commit the surviving columns (FR:1691-1695)
             keep = [c for c in range(A) if c not in set(killed)]
@@ -1200,7 +1388,10 @@ class ForwardSelection:
                 evs = np.append(evs, ev)
             self._retire(betas, best)
 
-        if ahead is not None:                      # the search stopped: the columns built ahead are not needed
+        if self.host is not None:                  # the search stopped: tapes on order for a sub-stage that does not come
+            self._drop_speculation()
+        if ahead is not None:                      # ... and the columns built ahead are not needed
+            self._ahead_block(ahead)
             self.pool.give(ahead['slots'])
 
         if self.gimmie:                            # FR:1751-1753

@@ -124,6 +124,15 @@ int fokl_build_terms_deriv(fokl_ctx *ctx, const int32_t *terms, int T, const int
  */
 int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc,
               double *out, int path, int allreduce);
+/*
+ * The same block in two halves (path 0): the launch returns at once and other work may be launched behind it on the
+ * context's stream (residual passes, basis builds); fokl_gram_fetch waits for the block only and copies its
+ * `count` = nr * nc doubles to `out`.  One block can be on its way at a time (a launch drops a block nobody fetched).  The shipped driver builds the coming
+ * sub-stage's Gram block this way while the kill tests of the current one go on (FR:1492-1494 for the next call of
+ * gibbs()).
+ */
+int fokl_gram_launch(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int allreduce);
+int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* K3: residual moments for the BIC.  Replaces siglik = var(y - X betahat), FR:1551 (and FR:1505).         */
@@ -302,25 +311,33 @@ int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads
 void fokl_pool_destroy(fokl_host_pool *pool);
 /*
  * fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0).
- * tentative != 0: the tape is recorded ahead of the decision that it is needed; the noise thread then holds the stream
- * until fokl_pool_resolve(job, commit) -- commit keeps the tape (identical to a plain submission at that point of the
- * stream), otherwise the stream is rewound to where the tape began and `progress` is set to -1.  Every tentative
- * job MUST be resolved, or the noise thread (and fokl_pool_destroy) waits for ever.
+ * tentative != 0: the tape is recorded ahead of the decision that it is needed, and fokl_pool_resolve(job, commit) is
+ * its verdict -- commit keeps the tape (identical to a plain submission at that point of the stream), otherwise the
+ * stream is rewound to where the tape began and `progress` is set to -1.  Tentative tapes may be NESTED: up to 16 can be
+ * on record without a verdict, the noise thread goes on recording behind them.  A commit of the oldest makes it final;
+ * an abort takes every younger tentative tape with it (the caller resolves those to "abort" as well: what they hold is
+ * no longer what the stream serves there); an abort of the youngest rewinds just that one.  A plain request waits until
+ * nothing tentative is left.  Every tentative job MUST be resolved, or the noise thread (and fokl_pool_destroy) waits
+ * for ever.
+ * block_done [ceil(draws / block)] (zero-initialised; may be NULL): with finish threads in the pool, the tape is
+ * completed IN PLACE (fokl_finish_tape_blocks) while it is recorded, whether or not a chain has been asked for yet;
+ * the job then counts as run only when those threads have left the tape too.
  */
 int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, double *normals,
                            double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau, int32_t *progress,
-                           int tentative, fokl_host_job **out);
+                           int tentative, int32_t *block_done, int block, fokl_host_job **out);
 int fokl_pool_resolve(fokl_host_job *job, int commit);
 /*
  * The draws of one candidate from its tape (whose noise job must have been submitted): with finish threads and
- * block_done [ceil(draws / block)] (zero-initialised) given, the tape is completed IN PLACE by the finish threads and
- * the recursion follows them; otherwise fokl_gibbs_chain_from_tape runs on a chain thread, following `progress`.
+ * block_done given, the recursion follows the finish threads' flags -- the tape is completed by them IN PLACE, started
+ * here unless the noise job was submitted with the same block_done (finishing_requested != 0); otherwise
+ * fokl_gibbs_chain_from_tape runs on a chain thread, following `progress`.
  */
 int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b, double btau,
                            double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
                            const double *pair_r2, const int32_t *lead, const double *gam_sig, const double *gam_tau,
-                           const int32_t *progress, int32_t *block_done, int block, double *w_out,
-                           int32_t *bstar_negative, fokl_host_job **out);
+                           const int32_t *progress, int32_t *block_done, int block, int finishing_requested,
+                           double *w_out, int32_t *bstar_negative, fokl_host_job **out);
 /*
  * G2 for the candidate model made of columns idx[0..p1) of `gram` (row-major, leading dimension ld, y in column
  * ycol): XtX = gram[idx][:, idx], Xty = gram[idx, ycol].  Outputs: lamb_out [p1] ascending eigenvalues,

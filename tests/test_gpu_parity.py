@@ -198,6 +198,24 @@ def test_k2_paths_agree_and_are_reproducible(device_ctx):
     assert np.max(np.abs(g1 - want) / scale) < 1e-13 and np.max(np.abs(g2 - want) / scale) < 1e-13
     assert np.array_equal(g2, device_ctx.gram(rs, cs, path=2))          # fixed-order reduction: bitwise repeatable
     assert np.array_equal(g1, device_ctx.gram(rs, cs, path=1))
+    # the launch / fetch pair returns the blocking call's block whatever is launched in between (other Gram blocks and
+    # residual passes use other result buffers); a launch drops a block that was never fetched
+    auto = device_ctx.gram(rs, cs)
+    small = device_ctx.gram(rs[:3], cs[:9])
+    device_ctx.gram_launch(rs[:5], cs[:7])
+    shape = device_ctx.gram_launch(rs, cs)
+    beta = rng.standard_normal(cs.shape[0] - 1)
+    moments = device_ctx.bic_resid(cs[:-1], beta)
+    device_ctx.bic_resid_launch(cs[:-1], beta)
+    assert np.array_equal(device_ctx.gram(rs[:3], cs[:9]), small)
+    assert np.array_equal(device_ctx.gram_fetch(shape), auto)
+    assert device_ctx.bic_resid_fetch() == moments
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.gram_fetch(shape)                                     # nothing on its way any more
+    device_ctx.gram_launch(rs[:2], cs[:4])
+    with pytest.raises(_capi.FoklNativeError):
+        device_ctx.gram_fetch((3, 4))                                    # not the block that was launched
+    np.testing.assert_allclose(device_ctx.gram_fetch((2, 4)), auto[:2, :4], rtol=1e-12, atol=1e-9)
 
 
 def test_k3_residual_moments(device_ctx):

@@ -533,6 +533,7 @@ def test_a_reap_between_tape_request_and_chain_cannot_recycle_the_tape(monkeypat
     monkeypatch.setenv('FOKL_PIN_L3', '0')
     np.random.seed(3)
     stream = _capi.LegacyStream()
+    engine.drop_spare_buffers()                            # spares stay with the thread from one fit to the next
     host = engine.HostPipeline(stream, 40)
     try:
         p1 = 5

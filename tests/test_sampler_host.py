@@ -1,4 +1,5 @@
 """Host half of the sampler (C++ in libfokl_hip.so): numpy-legacy random stream and the eigenbasis Gibbs chain."""
+import os
 import numpy as np
 import pytest
 
@@ -265,6 +266,61 @@ def test_pool_tentative_tape_commit_and_rewind():
         _capi._check(_capi.load().fokl_pool_resolve(None, 1))
 
 
+def test_pool_nested_tentative_tapes_settle_from_both_ends():
+    """Several tentative tapes may be on record without a verdict.  Whatever the order in which a caller that follows
+    the rules (an abort of one takes every younger one with it) hands in its verdicts, and however late, the kept tapes
+    are the tapes plain requests at those points of the stream record, and the stream ends where those leave it."""
+    import time
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        np.random.seed(int(rng.integers(0, 2 ** 32)))
+        s_pool, s_ref = _capi.LegacyStream(), _capi.LegacyStream()
+        pool = _capi.HostPool(s_pool, 1, 0, 0)
+        kept_specs, kept_jobs, everything = [], [], []
+        for burst in range(int(rng.integers(1, 4))):
+            depth = int(rng.integers(1, 7))
+            specs = [(int(rng.integers(1, 90)), 40, float(rng.choice([0.4, 2.5, 300.0])), float(rng.choice([0.7, 9.0])))
+                     for _ in range(depth)]
+            jobs = [pool.submit_noise(_capi.NoiseTape(p, d), a1, a2, tentative=True) for p, d, a1, a2 in specs]
+            everything += jobs
+            if rng.integers(0, 2):                                       # let the recorder run ahead of the verdicts
+                deadline = time.time() + 5.0
+                while jobs[-1].result.progress[0] < 40 and time.time() < deadline:
+                    time.sleep(0.0005)
+                assert jobs[-1].result.progress[0] == 40, "a nested tentative tape was not recorded ahead of its verdict"
+            cut = int(rng.integers(0, depth + 1))                        # tapes cut .. are aborted, the others kept
+            order = list(range(depth))
+            style = int(rng.integers(0, 3))
+            if style == 0:                                               # youngest first
+                order = order[::-1]
+            elif style == 1:                                             # aborts first, oldest aborted one leading
+                order = list(range(cut, depth)) + list(range(cut))
+            for k in order:
+                jobs[k].resolve(k < cut)
+            kept_specs += specs[:cut]
+            kept_jobs += jobs[:cut]
+            if rng.integers(0, 2):                                       # a plain request waits for all of that
+                spec = (int(rng.integers(1, 50)), 40, 5.5, 3.0)
+                job = pool.submit_noise(_capi.NoiseTape(spec[0], spec[1]), spec[2], spec[3])
+                kept_specs.append(spec)
+                kept_jobs.append(job)
+                everything.append(job)
+        for job in everything:
+            job.wait()
+        for (p, d, a1, a2), job in zip(kept_specs, kept_jobs):
+            want = _capi.noise_tape(p, d, a1, a2, s_ref)
+            got = job.result
+            assert got.progress[0] == d
+            assert np.array_equal(got.normals, want.normals) and np.array_equal(got.lead, want.lead)
+            assert np.array_equal(got.gam_sig, want.gam_sig) and np.array_equal(got.gam_tau, want.gam_tau)
+        for job in everything:
+            if not any(job is k for k in kept_jobs):
+                assert job.result.progress[0] == -1
+        pool.close()
+        assert np.array_equal(s_pool.key, s_ref.key) and s_pool.pos.value == s_ref.pos.value
+        assert s_pool.has_gauss.value == s_ref.has_gauss.value and s_pool.cache.value == s_ref.cache.value
+
+
 def test_pool_spectral_job_is_scipy_eigh_and_rejects_bad_indices():
     import scipy.linalg
     rng = np.random.default_rng(5)
@@ -358,3 +414,34 @@ def test_fast_finishing_log_is_within_an_ulp_and_leaves_the_stream_alone(monkeyp
     assert np.max(np.abs(out['exact'][1] - out['fast'][1])) < 1e-13 * np.max(np.abs(out['exact'][1]))
     sa, sb = out['exact'][2], out['fast'][2]
     assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+
+
+def test_chain_vector_statements_agree_bit_for_bit():
+    """The portable, AVX2 and AVX-512 statements of an iteration's vector half (w and the three quadratic forms in
+    eight fixed lanes) are the same IEEE operations per element: the draws must not depend on which one runs.  Each
+    runs in a process of its own (the choice is made once per process); sizes around the lane and register widths."""
+    import subprocess, sys, hashlib
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from fokl_gpy_amd import _capi\n"
+        "np.random.seed(11)\n"
+        "h = hashlib.sha256()\n"
+        "for p1 in (1, 3, 7, 8, 9, 15, 16, 17, 31, 64, 65, 100, 143):\n"
+        "    s = _capi.LegacyStream()\n"
+        "    tape = _capi.noise_tape(p1, 60, 4e3 + p1 / 2, 4 + p1 / 2, s)\n"
+        "    _capi.finish_tape_blocks(tape)\n"
+        "    lamb = np.sort(np.random.rand(p1) * 1e4 + 1.0)\n"
+        "    qty = np.random.randn(p1) * 50\n"
+        "    w, flag = _capi.gibbs_chain_from_finished_tape(lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9, tape)\n"
+        "    h.update(w.tobytes())\n"
+        "    w2 = _capi.gibbs_chain(lamb, qty, 4e3 + p1 / 2, 4 + p1 / 2, 900.0, 2.0, 5e5, 0.3, 0.9, 60, _capi.LegacyStream())\n"
+        "    h.update(w2.tobytes())\n"
+        "print(h.hexdigest())\n" % os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    digests = {}
+    for isa in ('base', 'avx2', 'avx512'):
+        env = dict(os.environ, FOKL_CHAIN_ISA=isa, FOKL_FINISH_LOG='exact')
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        digests[isa] = out.stdout.strip()
+    assert len(set(digests.values())) == 1, digests

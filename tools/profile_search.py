@@ -19,4 +19,4 @@ with warnings.catch_warnings():
 print('time', dt, model.fit_stats, 'final terms', model.mtx.shape, 'max order', model.mtx.max())
 print('cols per call: max', max(t['cols'] for t in model.fit_trace), 'mean', np.mean([t['cols'] for t in model.fit_trace]))
 print('evs', model.evs)
-pstats.Stats(pr).sort_stats('tottime').print_stats(16)
+pstats.Stats(pr).sort_stats('tottime').print_stats(40)
