@@ -329,13 +329,15 @@ def _scipy_dsyevr_address():
 
 class PoolJob:
     """A job on a HostPool.  Keeps the buffers the job reads / writes alive; ``wait()`` may be called repeatedly."""
-    __slots__ = ('_h', 'keep', 'result', 'recycle', 'held', 'unresolved')
+    __slots__ = ('_h', 'keep', 'result', 'recycle', 'held', 'unresolved', 'ignore_failure', 'co_reader')
 
     def __init__(self, handle, keep, result=None, tentative=False):
         self._h, self.keep, self.result = handle, keep, result
         self.recycle = None                 # raw buffers the owner of the pool may reuse once the job has run
         self.held = None                    # raw buffer a LATER job will still read: not reusable when this one is done
         self.unresolved = bool(tentative)   # a tentative noise job that has not been given its verdict yet
+        self.ignore_failure = False         # a chain started ahead of the decision that it is needed: its tape may go
+        self.co_reader = None               # noise job: such a chain, given up, that may still be reading the tape
 
     def done(self):
         """True once the job has run (its native record is then released, the buffers may go)."""
@@ -352,7 +354,9 @@ class PoolJob:
     def wait(self):
         if self._h is not None:
             h, self._h = self._h, None
-            _check(load().fokl_pool_wait(h))
+            rc = load().fokl_pool_wait(h)
+            if not self.ignore_failure:
+                _check(rc)
         return self.result
 
 

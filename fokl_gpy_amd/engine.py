@@ -312,7 +312,10 @@ def _thread_plan():
     # item (0.13 CPU-seconds per fit): three spectral threads as soon as five CPUs are there.
     exact_log = os.environ.get('FOKL_FINISH_LOG', 'fast') == 'exact'
     if budget >= 12:
-        plan = (2, 3 if exact_log else 1, 3)                # second chain thread: models of hundreds of columns (configs[3])
+        # second chain thread: models of hundreds of columns (configs[3]) and chains started ahead; fourth spectral
+        # thread (round 2, with the tapes recorded ahead of the driver G2 of the 100-column models -- 1 ms each, a test
+        # every 0.2 ms -- was what the driver waited for: 3 / 4 / 5 / 6 threads 89.6 / 85.0 / 85.4 / 86.1 ms per fit)
+        plan = (2, 3 if exact_log else 1, 4)
     elif budget >= 5:
         plan = (1, 2 if exact_log else 1, 3)
     elif budget >= 3:
@@ -415,12 +418,39 @@ class HostPipeline:
         for job in self._live:
             if job.done():
                 if job.recycle:
-                    for raw in job.recycle:
-                        self.give(raw)
+                    for entry in job.recycle:
+                        self._retire_buffer(entry)
                     job.recycle = job.keep = None
             else:
                 live.append(job)
         self._live = live
+
+    def _retire_buffer(self, entry):
+        """A buffer whose owner has run: back to the spares -- or, if a chain that was started ahead and then given up may
+        still be reading it (entry = (buffer, that chain's job)), on to that job."""
+        if isinstance(entry, tuple):
+            raw, reader = entry
+            if reader.done():
+                self.give(raw)
+            else:
+                reader.recycle.append(raw)
+        else:
+            self.give(entry)
+
+    def _hand_tape(self, noise_job, owner):
+        """The tape's buffer passes from being `held` to the job that is its last reader (the noise job itself when no
+        chain will read the tape)."""
+        raw, noise_job.held = noise_job.held, None
+        if raw is None:
+            return
+        reader = noise_job.co_reader
+        entry = raw if reader is None or reader is owner else (raw, reader)
+        if owner.recycle is None:
+            if owner._h is None:            # has run and was reaped already
+                self._retire_buffer(entry)
+                return
+            owner.recycle = []
+        owner.recycle.append(entry)
 
     def _track(self, job):
         if len(self._live) >= 24:
@@ -443,15 +473,13 @@ class HostPipeline:
     def abandon(self, noise_job):
         """A tape that is recorded (the stream must advance exactly as if the model had been sampled) but that no chain
         will read: its buffer goes back to the pool once the recorder is done with it."""
-        if noise_job.held is not None:
-            noise_job.recycle, noise_job.held = [noise_job.held], None
+        self._hand_tape(noise_job, noise_job)
 
     def discard(self, noise_job):
         """A tentative tape that will not be used: rewind the stream to where it began; its buffer goes back to the
         pool once the recorder has let go of it."""
         noise_job.resolve(False)
-        if noise_job.held is not None:
-            noise_job.recycle, noise_job.held = [noise_job.held], None
+        self._hand_tape(noise_job, noise_job)
 
     def spectral(self, gram, idx):
         """Queue G2 for the model made of columns idx of gram; may be called ahead of need (no random numbers).
@@ -507,8 +535,34 @@ class HostPipeline:
         tape = noise_job.result
         w_raw = self._take(tape.draws * tape.p1)
         job = self.pool.submit_chain(spec.lamb, spec.qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw)
-        job.recycle, noise_job.held = [noise_job.held], None       # the chain job is the last reader of the tape
+        job.recycle = []
+        self._hand_tape(noise_job, job)                             # the chain job is the last reader of the tape
         return self._track(job), w_raw
+
+    def chain_ahead(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job):
+        """chain() for a tape that is still on order (tentative, no verdict yet): the draws are under way when the
+        decision comes that this model is evaluated -- adopt() -- or thrown away -- disown().  The tape stays `held` by
+        its noise job until then."""
+        tape = noise_job.result
+        w_raw = self._take(tape.draws * tape.p1)
+        job = self.pool.submit_chain(spec.lamb, spec.qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw)
+        job.recycle = []
+        job.ignore_failure = True                                   # the tape may be sent back under it
+        return self._track(job), w_raw
+
+    def adopt(self, chain_job, noise_job):
+        """The chain started ahead is the model's chain: from now on a failure counts, and it is the tape's last reader."""
+        chain_job.ignore_failure = False
+        self._hand_tape(noise_job, chain_job)
+
+    def disown(self, chain_job, w_raw, noise_job):
+        """A chain started ahead that nobody will look at: its buffer goes back when it has run, and the tape it reads is
+        not reused before that."""
+        if chain_job.done():
+            self.give(w_raw)
+        else:
+            chain_job.recycle.append(w_raw)
+            noise_job.co_reader = chain_job
 
     def close(self):
         """Run everything still queued (every requested tape advances the stream, used or not), stop the threads."""
@@ -695,11 +749,14 @@ class ForwardSelection:
         self.speculation_max = max(1, min(16, int(os.environ.get('FOKL_SPECULATION', '12'))))
         self._speculation = self.speculation_max
         self._spec = collections.deque()    # (model size, tentative noise job): on order, in stream order, no verdict yet
-        # BIC of kill-test candidates (pipelined search): 'device' = the K3 residual pass, as for every sub-stage model;
-        # 'gram' = residual moments from the sub-stage's Gram (no device work per candidate; agrees with
-        # the device pass to < 1e-10 relative on the BIC); 'check' = device, recording the largest disagreement with
-        # 'gram' seen; 'auto' (default) = device while a K3 pass fits in the shadow of the candidate's noise tape --
-        # it then costs the search nothing -- and gram once it would not (N = 1e7: 0.37 -> 0.16 s per fit).
+        self._prechain = None               # (noise job, spec, chain job, buffer of w): chain started ahead (_chain_ahead)
+        # BIC of kill-test candidates (pipelined search): 'gram' (= 'auto', the default) = residual moments from the
+        # sub-stage's Gram, computed by the spectral thread along with G2 (no device work per candidate, no
+        # wait of the driver; agrees with the device pass to < 1e-10 relative on the BIC; candidates that (nearly)
+        # interpolate the data get the device pass after all, see _score); 'device' = the K3 residual pass, as for
+        # every sub-stage model; 'check' = device, recording the largest disagreement with 'gram' seen.  (Up to round 2
+        # 'auto' meant the device pass while it hid behind the candidate's noise tape: with tapes recorded ahead of the
+        # driver the pass is latency on the driver's path instead, 0.115 of 0.175 ms per test at 60 columns.)
         self.kill_bic = os.environ.get('FOKL_KILL_BIC', 'auto')
         if self.kill_bic not in ('auto', 'gram', 'device', 'check'):
             raise ValueError("FOKL_KILL_BIC must be auto, gram, device or check")
@@ -716,7 +773,7 @@ class ForwardSelection:
         self._active_terms = [()]           # term of every active column of the current sub-stage (() = intercept)
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
-                          bic_gram_max_rel=0.0, tapes_rewound=0, tapes_wasted=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
+                          bic_gram_max_rel=0.0, tapes_rewound=0, tapes_wasted=0, chains_ahead=0, chains_ahead_unused=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
                           spectral_submitted=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
@@ -799,6 +856,8 @@ class ForwardSelection:
         back by one); orders the recorder had not reached yet cost nothing."""
         while len(self._spec) > keep:
             _, job = self._spec.pop()                                 # youngest first
+            if self._prechain is not None and self._prechain[0] is job:
+                self._drop_prechain()
             begun = job.result.progress[0] > 0
             self.host.discard(job)
             self.stats['tapes_rewound'] += 1
@@ -842,11 +901,42 @@ class ForwardSelection:
             self._spec.append((size, self._request_noise(size, tentative=True)))
         _mark('speculating', ' '.join(str(size) for size, _ in self._spec))
 
+    def _chain_ahead(self, spectral_job, p1, dtd):
+        """Start the chain of the evaluation expected next -- G2 `spectral_job`, p1 columns -- if its G2 has run and its
+        tape is the oldest on order: by the time the driver gets there (it may have to wait for exactly these draws to
+        decide the test after: second clause of FR:1670) they are under way.  Costs a chain thread some work when the
+        guess is wrong; results are untouched (same tape, same arithmetic, whoever submits the job)."""
+        if not self._spec or self._spec[0][0] != p1 or not getattr(spectral_job, 'done', lambda: False)():
+            return
+        noise_job = self._spec[0][1]
+        spec = spectral_job.wait()
+        if self._prechain is not None:
+            if self._prechain[0] is noise_job and self._prechain[1] is spec:
+                return
+            self._drop_prechain()
+        chain_job, w_raw = self.host.chain_ahead(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job)
+        self._prechain = (noise_job, spec, chain_job, w_raw)
+        self.stats['chains_ahead'] += 1
+
+    def _drop_prechain(self):
+        if self._prechain is not None:
+            noise_job, _, chain_job, w_raw = self._prechain
+            self._prechain = None
+            self.host.disown(chain_job, w_raw, noise_job)
+            self.stats['chains_ahead_unused'] += 1
+
     def _commit(self, pending, noise_job=None):
         """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
         spec, idx, _, dtd, _ = pending
         if noise_job is None:
             noise_job = self._tape_for(idx.shape[0])
+        if self._prechain is not None:
+            if self._prechain[0] is noise_job and self._prechain[1] is spec:
+                _, _, chain_job, w_raw = self._prechain
+                self._prechain = None
+                self.host.adopt(chain_job, noise_job)
+                return noise_job, chain_job, w_raw
+            self._drop_prechain()
         chain_job, w_raw = self.host.chain(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job)
         return noise_job, chain_job, w_raw
 
@@ -948,16 +1038,6 @@ class ForwardSelection:
     def _columns_without(count, removed):
         return np.array([c for c in range(count) if c not in removed], dtype=np.int32)
 
-    def _resid_fits_in_shadow(self, columns):
-        """FOKL_KILL_BIC=auto: does a K3 pass over `columns` columns (about 5.5 TB/s) take clearly less time than
-        recording the noise tape of a model of that size (about 40 ns + 1 ns per column and Gibbs iteration)?"""
-        # rows per rank as every rank computes it alike (shards differ by one row when N % world != 0, and ranks that
-        # decide differently here would disagree on whether the next call is a collective)
-        world = max(1, round(self.n / max(self.n_local, 1)))
-        resid_s = 8.0 * -(-self.n // world) * (columns + 2) / 5.5e12 + 20e-6
-        tape_s = self.draws * (40.0 + columns) * 1e-9
-        return resid_s < 0.6 * tape_s
-
     def _likely_first_tests(self, spec, n_new, siglik=None):
         """The kill tests a sub-stage will probably run, guessed from the least-squares fit of its model (spec: G2 of that
         model, its last n_new columns are new) before the model's chain is there: the proposals will be ordered by
@@ -997,7 +1077,7 @@ class ForwardSelection:
         return outcome.intercept_scale
 
     def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None,
-                              ahead=None, vm_next=None, idle_work=None, peek=None):
+                              ahead=None, vm_next=None, idle_work=None, peek=None, chain_coming=None):
         """FR:1666-1690 with the host pipeline: same tests, same order, same random-stream consumption.
 
         Whether proposal i is tested may hinge on the chain of the model accepted so far (second clause of FR:1670);
@@ -1010,9 +1090,11 @@ class ForwardSelection:
         idle_work: called once, when the first test's tape and G2 are under way (or, without a test, at the end): work of
         the driver that nothing in this loop waits for (the caller builds the coming sub-stage's columns with it).
         peek(killed set): how many kill tests the coming sub-stage will probably run if this one ends with that kill set
-        (None: not known yet).
+        (None: not known yet).  chain_coming(killed set): start the chain of the coming sub-stage's model if this one ends
+        with that kill set and G2 of that model is there.
         """
         A = len(slots)
+        dtd = gram[A, A]
         vm = cand_col.shape[0]
         cols = [int(c) for c in cand_col]
         clause1 = [bool(rel_std[j] > self.threshstdb) for j in range(vm)]
@@ -1021,7 +1103,7 @@ class ForwardSelection:
         # Guess at "mean_abs < threshav * |mean intercept draw|" for proposals further down the list: the posterior mean
         # of the intercept is close to its least-squares value, and it barely moves from one accepted model to the next.
         scale_guess = abs(float(best.betahat[0]))
-        on_device = self.kill_bic in ('device', 'check') or (self.kill_bic == 'auto' and self._resid_fits_in_shadow(A))
+        on_device = self.kill_bic in ('device', 'check')
         killed = frozenset()
         evmin = best.ev
         ahead = {} if ahead is None else ahead                        # trial set -> spectral job submitted ahead
@@ -1058,6 +1140,14 @@ class ForwardSelection:
                         tests = min(vm_next, 1)
                     sizes += [A - len(pred) + vm_next - t for t in range(tests + 1)]
             self._speculate(sizes)
+            # ... and the chain of the very next evaluation, if its G2 is there
+            nxt = next((j for j in proposal[pos:] if likely(j)), None)
+            if nxt is not None:
+                job = ahead.get(killed | {cols[nxt]})
+                if job is not None:
+                    self._chain_ahead(job, A - len(killed) - 1, dtd)
+            elif chain_coming is not None and vm_next is not None:
+                chain_coming(killed)
 
         forecast(0)
         order_tapes(0)
@@ -1109,6 +1199,8 @@ class ForwardSelection:
                 if ev < evmin:
                     jobs = self._commit(pending, noise_job)
                 else:
+                    if self._prechain is not None and self._prechain[0] is noise_job:
+                        self._drop_prechain()
                     self.host.abandon(noise_job)
                     self.stats['chains_skipped'] += 1
                     jobs = None
@@ -1320,6 +1412,12 @@ class ForwardSelection:
                     guesses[key] = len(self._likely_first_tests(hit[0].wait(), vm_next))
                 return guesses[key]
 
+            def chain_coming(pred_killed, active=active_slots, A=A):
+                # the chain of the coming sub-stage's model, should this one end with that kill set
+                hit = forecasts.get(tuple(active[c] for c in range(1, A) if c not in pred_killed))
+                if hit is not None:
+                    self._chain_ahead(hit[0], A - len(pred_killed) + vm_next, hit[1][-1, -1])
+
             if early is None:
                 early = {}
                 if pipelined and self.lookahead > 0:
@@ -1355,7 +1453,7 @@ class ForwardSelection:
             else:
                 killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
                                                                  rel_std, best, half0, foresee, early, vm_next,
-                                                                 build_next, coming_tests)
+                                                                 build_next, coming_tests, chain_coming)
             ev = evmin
             _mark('tests_over', str(len(killed)))
 

@@ -413,12 +413,12 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     monkeypatch.delenv('FOKL_FINISH_THREADS', raising=False)
     monkeypatch.delenv('FOKL_SPECTRAL_THREADS', raising=False)
     monkeypatch.delenv('FOKL_FINISH_LOG', raising=False)
-    cases = ((16, (2, 1, 3)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 1, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
+    cases = ((16, (2, 1, 4)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 1, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
     for budget, plan in cases:
         monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
         assert engine._thread_plan() == plan
     monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')                  # libm's scalar log: finishing needs three threads
-    for budget, plan in ((16, (2, 3, 3)), (7.5, (1, 2, 3))):
+    for budget, plan in ((16, (2, 3, 4)), (7.5, (1, 2, 3))):
         monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
         assert engine._thread_plan() == plan
     monkeypatch.delenv('FOKL_FINISH_LOG')
@@ -429,15 +429,83 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     assert engine._cpu_budget() >= 1
 
 
-def test_kill_bic_auto_switches_with_the_size_of_the_residual_pass():
-    """FOKL_KILL_BIC=auto keeps the K3 pass for kill-test candidates while it is clearly shorter than recording the
-    candidate's noise tape, i.e. for the benchmark's N = 1e6 with 2000 iterations but not for N = 1e7."""
-    def search(n, iterations):
-        return engine.ForwardSelection(OracleBackend(), n, 8, 20, 4, 1.0, 4, 1.0, 3, iterations, iterations // 2,
-                                       False, False, 0.05, 0.5, 2, False, None)
-    assert search(1_000_000, 2000)._resid_fits_in_shadow(60)
-    assert not search(10_000_000, 2000)._resid_fits_in_shadow(60)
-    assert not search(1_000_000, 200)._resid_fits_in_shadow(60)
+def _search_with_pipeline(monkeypatch, draws=40):
+    monkeypatch.setenv('FOKL_PIN_L3', '0')
+    np.random.seed(21)
+    stream = _capi.LegacyStream()
+    fs = engine.ForwardSelection(OracleBackend(), 1000, 3, 5, 4, 1.0, 4, 1.0, 3, draws, draws // 2, False, False,
+                                 0.05, 0.5, 2, False, stream)
+    fs.host = engine.HostPipeline(stream, draws)
+    return fs, stream
+
+
+def test_tapes_on_order_are_used_when_the_sizes_fit_and_sent_back_when_not(monkeypatch):
+    """ForwardSelection._speculate / _tape_for: orders that agree with a newer prediction stay, the rest goes back
+    (youngest first), the evaluation that comes takes the oldest order if its size fits and otherwise rewinds them all;
+    whatever was guessed, the stream ends exactly where the tapes that were used leave it."""
+    fs, stream = _search_with_pipeline(monkeypatch)
+    ref = _capi.LegacyStream()
+    try:
+        astar = lambda p1: (fs.a + 1 + fs.n / 2 + p1 / 2, fs.atau + (p1 - 1) / 2)
+        fs._speculate([9, 8, 7, 6])
+        assert [size for size, _ in fs._spec] == [9, 8, 7, 6]
+        fs._speculate([9, 8, 5])                            # 7, 6 go back, 5 is placed
+        assert [size for size, _ in fs._spec] == [9, 8, 5] and fs.stats['tapes_rewound'] == 2
+        used = [fs._tape_for(9), fs._tape_for(8)]           # as predicted
+        assert [size for size, _ in fs._spec] == [5] and not any(job.unresolved for job in used)
+        used.append(fs._tape_for(4))                        # not as predicted: 5 goes back, 4 is a plain request
+        assert not fs._spec and fs.stats['tapes_rewound'] == 3
+        fs._speculate([4, 3])
+        fs._drop_speculation()
+        for job in used:
+            fs.host.abandon(job)
+        for p1, job in zip((9, 8, 4), used):
+            want = _capi.noise_tape(p1, 40, *astar(p1), ref)
+            _capi.finish_tape_blocks(want)                  # the pipeline's tapes are completed as they are recorded
+            job.wait()
+            assert np.array_equal(job.result.normals, want.normals) and np.array_equal(job.result.gam_tau, want.gam_tau)
+    finally:
+        fs.host.close()
+        stream.publish()
+    a, b = stream.as_numpy_state(), ref.as_numpy_state()
+    assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+def test_a_chain_started_ahead_is_adopted_or_given_up_without_losing_its_tape(monkeypatch):
+    """ForwardSelection._chain_ahead: the chain of the evaluation expected next runs on its tentative tape before the
+    driver gets there.  Adopted, it is the chain a plain commit would have submitted (same draws); given up -- also with
+    its tape sent back under it -- nothing fails, and every buffer comes back to the spares exactly once."""
+    fs, stream = _search_with_pipeline(monkeypatch)
+    engine.drop_spare_buffers()
+    try:
+        p1 = 6
+        gram = np.eye(p1 + 1) * 40.0 + 1.0
+        g2 = fs.host.spectral(gram, np.arange(p1))
+        other = fs.host.spectral(gram, np.arange(p1 - 1))
+        g2.wait(), other.wait()
+        dtd = gram[p1, p1]
+        fs._speculate([p1, p1, p1 - 1])
+        fs._chain_ahead(g2, p1, dtd)
+        assert fs._prechain is not None and fs.stats['chains_ahead'] == 1
+        fs._chain_ahead(g2, p1, dtd)                        # the same guess again: nothing new
+        assert fs.stats['chains_ahead'] == 1
+        pending = (g2.wait(), np.arange(p1, dtype=np.int32), None, dtd, None)
+        noise_job, chain_job, w_raw = fs._commit(pending)   # adopted
+        assert fs._prechain is None and fs.stats['chains_ahead_unused'] == 0 and not chain_job.ignore_failure
+        w, flag = chain_job.wait()
+        noise_job.wait()
+        fs._chain_ahead(g2, p1, dtd)                        # second tape of that size: started, then the guess changes
+        first_guess = fs._prechain
+        pending = (other.wait(), np.arange(p1 - 1, dtype=np.int32), None, dtd, None)
+        fs._tape_for(p1 - 1)                                # not what is on order: everything goes back, chain given up
+        assert fs._prechain is None and fs.stats['chains_ahead_unused'] == 1 and not fs._spec
+        first_guess[2].wait()                               # its tape was sent back under it: no exception
+        assert np.all(np.isfinite(w)) and flag[0] == 0
+    finally:
+        fs.host.close()
+        stream.publish()
+    spares = [raw for stack in engine._thread_spares().values() for raw in stack]
+    assert len({raw.__array_interface__['data'][0] for raw in spares}) == len(spares)        # no buffer came back twice
 
 
 def _rendezvous_worker(rank, queue):

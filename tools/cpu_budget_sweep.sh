@@ -5,7 +5,7 @@
 out=${1:-gpurun_out/r2_cpu_sweep.txt}
 : > $out
 for c in 2 3 4 6 8 16; do
-  FOKL_BENCH_PIN=0 taskset -c 0-$((c-1)) python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-microbench --no-parity > /tmp/sweep_$c.json 2>/dev/null
+  FOKL_BENCH_PIN=0 taskset -c 0-$((c-1)) python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-microbench --no-parity --no-throughput > /tmp/sweep_$c.json 2>/dev/null
   python - <<PY >> $out
 import json
 d=json.load(open('/tmp/sweep_$c.json')); h=d['host_main_thread_s_per_step']
