@@ -318,8 +318,10 @@ def _thread_plan():
         plan = (2, 3 if exact_log else 1, 4)
     elif budget >= 5:
         plan = (1, 2 if exact_log else 1, 3)
-    elif budget >= 3:
+    elif budget >= 4:
         plan = (1, 1, 2)
+    elif budget >= 3:
+        plan = (1, 0, 2)                                    # round 2: 154.9 ms per fit against 165.9 with a finishing thread
     else:
         plan = (1, 0, 1)
     names = ('FOKL_CHAIN_THREADS', 'FOKL_FINISH_THREADS', 'FOKL_SPECTRAL_THREADS')

@@ -413,7 +413,7 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     monkeypatch.delenv('FOKL_FINISH_THREADS', raising=False)
     monkeypatch.delenv('FOKL_SPECTRAL_THREADS', raising=False)
     monkeypatch.delenv('FOKL_FINISH_LOG', raising=False)
-    cases = ((16, (2, 1, 4)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 1, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
+    cases = ((16, (2, 1, 4)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 0, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
     for budget, plan in cases:
         monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
         assert engine._thread_plan() == plan
