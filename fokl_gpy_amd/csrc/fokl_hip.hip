@@ -764,6 +764,178 @@ static gram_mfma_fn jsplit_kernel(int ti, int tj)
     return gram_mfma_kernel<2, 3, false>;
 }
 
+// ---- tile-list Gram (gram_tiles_kernel): launch planning ---------------------------------------------------
+
+struct GramPlan {
+    int nci = 0, it = 0, jt = 0;       // internal columns; i-tiles (row side), j-tiles (all internal columns)
+    int nt = 1, ct = 1, ks = 1, rb_shift = 0, depth = 1;
+    std::vector<int32_t> icols;        // internal column -> slot: the row-side columns first
+    std::vector<int32_t> perm;         // caller's column j -> internal column
+    std::vector<GramGroup> groups;
+};
+
+static int env_int(const char *name, int fallback)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : fallback;
+}
+
+// Internal column order, tile groups and kernel parameters for an nr x nc block (see gram_tiles_kernel).  Pure host
+// arithmetic: fokl_gram_plan exposes it to the CPU tests, which replay the lists with numpy.
+static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, GramPlan &pl)
+{
+    pl.icols.assign(row_slots, row_slots + nr);
+    pl.perm.resize(nc);
+    {
+        std::map<int32_t, int> where;
+        for (int i = 0; i < nr; ++i) where.emplace(row_slots[i], i);            // first occurrence wins
+        for (int j = 0; j < nc; ++j) {
+            auto f = where.find(col_slots[j]);
+            if (f != where.end()) {
+                pl.perm[j] = f->second;
+            } else {
+                pl.perm[j] = (int)pl.icols.size();
+                where.emplace(col_slots[j], (int)pl.icols.size());
+                pl.icols.push_back(col_slots[j]);
+            }
+        }
+    }
+    pl.nci = (int)pl.icols.size();
+    pl.it = (nr + 15) / 16;
+    pl.jt = (pl.nci + 15) / 16;
+
+    struct Cut {
+        std::vector<std::pair<int, int>> tiles;
+        std::vector<int> staged;
+    };
+    std::vector<Cut> cuts;
+    const int max_tiles = 4 * GT_MAX_NT;
+    for (int b0 = 0; b0 < pl.it; b0 += 4) {
+        const int i_hi = std::min(pl.it, b0 + 4);
+        std::vector<std::pair<int, int>> seq;              // tiles on or above the diagonal, column of tiles by column
+        for (int jt = b0; jt < pl.jt; ++jt)
+            for (int it = b0; it < std::min(i_hi, jt + 1); ++it) seq.emplace_back(it, jt);
+        const int T = (int)seq.size();
+        for (int G = std::max(1, (T + max_tiles - 1) / max_tiles);; ++G) {
+            std::vector<Cut> trial;
+            bool fits = true;
+            int at = 0;
+            for (int gi = 0; gi < G && fits; ++gi) {
+                const int size = T / G + (gi < T % G ? 1 : 0);
+                Cut c;
+                c.tiles.assign(seq.begin() + at, seq.begin() + at + size);
+                at += size;
+                for (auto &t : c.tiles) {
+                    c.staged.push_back(t.first);
+                    c.staged.push_back(t.second);
+                }
+                std::sort(c.staged.begin(), c.staged.end());
+                c.staged.erase(std::unique(c.staged.begin(), c.staged.end()), c.staged.end());
+                fits = (int)c.staged.size() <= GT_MAX_CT && size <= max_tiles;
+                if (size > 0) trial.push_back(std::move(c));
+            }
+            if (fits) {
+                for (auto &c : trial) cuts.push_back(std::move(c));
+                break;
+            }
+        }
+    }
+
+    int most_tiles = 1, most_staged = 1;
+    for (auto &c : cuts) {
+        most_tiles = std::max(most_tiles, (int)c.tiles.size());
+        most_staged = std::max(most_staged, (int)c.staged.size());
+    }
+    pl.ks = most_tiles == 1 ? 4 : most_tiles == 2 ? 2 : 1;
+    const int teams = 4 / pl.ks;
+    pl.nt = (most_tiles + teams - 1) / teams;
+    pl.ct = most_staged;
+    // rows per chunk: as many sub-chunks of 32 rows as the 16 staging passes and FOKL_GRAM_RB allow
+    const int rb_cap = std::max(1, std::min(16, env_int("FOKL_GRAM_RB", 4)));
+    pl.rb_shift = 0;
+    while ((pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
+    pl.depth = pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 2))) : 1;
+
+    pl.groups.resize(cuts.size());
+    for (size_t gi = 0; gi < cuts.size(); ++gi) {
+        const Cut &c = cuts[gi];
+        GramGroup &g = pl.groups[gi];
+        std::memset(&g, 0, sizeof(g));
+        for (int p = 0; p < GT_MAX_CT; ++p) g.ct[p] = p < (int)c.staged.size() ? c.staged[p] : -1;
+        for (int w = 0; w < 4; ++w)
+            for (int k = 0; k < GT_MAX_NT; ++k) g.oi[w][k] = g.oj[w][k] = 0xFFFF;
+        for (int t = 0; t < (int)c.tiles.size(); ++t) {
+            const int team = t % teams, k = t / teams;
+            const int a = (int)(std::lower_bound(c.staged.begin(), c.staged.end(), c.tiles[t].first) - c.staged.begin());
+            const int b = (int)(std::lower_bound(c.staged.begin(), c.staged.end(), c.tiles[t].second) - c.staged.begin());
+            for (int w = team * pl.ks; w < (team + 1) * pl.ks; ++w) {
+                g.a[w][k] = (uint8_t)a;
+                g.b[w][k] = (uint8_t)b;
+                g.oi[w][k] = (uint16_t)c.tiles[t].first;
+                g.oj[w][k] = (uint16_t)c.tiles[t].second;
+            }
+        }
+    }
+}
+
+typedef void (*gram_tiles_fn)(double *const *, const int *, int, const GramGroup *, int, int, int64_t, double *, int,
+                              int, const double *);
+
+template <int NT>
+static gram_tiles_fn tiles_kernel_nt(int depth, int ks)
+{
+    if (NT == 1 && ks == 4) return depth == 2 ? gram_tiles_kernel<1, 2, 4> : gram_tiles_kernel<1, 1, 4>;
+    if (NT == 1 && ks == 2) return depth == 2 ? gram_tiles_kernel<1, 2, 2> : gram_tiles_kernel<1, 1, 2>;
+    if (NT <= 4 && depth == 2) return gram_tiles_kernel<(NT <= 4 ? NT : 1), 2, 1>;
+    return gram_tiles_kernel<NT, 1, 1>;
+}
+
+static gram_tiles_fn tiles_kernel(int nt, int depth, int ks)
+{
+    switch (nt) {
+        case 1: return tiles_kernel_nt<1>(depth, ks);
+        case 2: return tiles_kernel_nt<2>(depth, ks);
+        case 3: return tiles_kernel_nt<3>(depth, ks);
+        case 4: return tiles_kernel_nt<4>(depth, ks);
+        case 5: return tiles_kernel_nt<5>(depth, ks);
+        case 6: return tiles_kernel_nt<6>(depth, ks);
+        case 7: return tiles_kernel_nt<7>(depth, ks);
+        case 8: return tiles_kernel_nt<8>(depth, ks);
+        case 9: return tiles_kernel_nt<9>(depth, ks);
+        case 10: return tiles_kernel_nt<10>(depth, ks);
+        case 11: return tiles_kernel_nt<11>(depth, ks);
+        default: return tiles_kernel_nt<12>(depth, ks);
+    }
+}
+
+extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int32_t *info,
+                              int32_t *icols, int32_t *perm, int32_t *staged, int32_t *tiles, int cap_groups)
+{
+    if (!row_slots || !col_slots || !info || nr <= 0 || nc <= 0)
+        return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_plan: bad argument");
+    GramPlan pl;
+    plan_gram(row_slots, nr, col_slots, nc, pl);
+    const int32_t head[9] = {pl.nci, pl.it, pl.jt, (int32_t)pl.groups.size(), pl.nt, pl.ct, pl.rb_shift, pl.ks, pl.depth};
+    std::memcpy(info, head, sizeof(head));
+    if ((int)pl.groups.size() > cap_groups) return FOKL_OK;      // sizes only: call again with room for the lists
+    if (icols) std::memcpy(icols, pl.icols.data(), pl.icols.size() * sizeof(int32_t));
+    if (perm) std::memcpy(perm, pl.perm.data(), pl.perm.size() * sizeof(int32_t));
+    for (size_t gi = 0; gi < pl.groups.size(); ++gi) {
+        const GramGroup &g = pl.groups[gi];
+        if (staged) std::memcpy(staged + gi * GT_MAX_CT, g.ct, sizeof(g.ct));
+        if (tiles)
+            for (int w = 0; w < 4; ++w)
+                for (int k = 0; k < GT_MAX_NT; ++k) {
+                    int32_t *t = tiles + ((gi * 4 + w) * GT_MAX_NT + k) * 4;
+                    t[0] = g.a[w][k];
+                    t[1] = g.b[w][k];
+                    t[2] = g.oi[w][k] == 0xFFFF ? -1 : g.oi[w][k];
+                    t[3] = g.oj[w][k] == 0xFFFF ? -1 : g.oj[w][k];
+                }
+    }
+    return FOKL_OK;
+}
+
 // Everything of a Gram block up to the copy into pinned host memory, enqueued on the context's stream.  aside: the
 // result goes to the d_gout / h_gout pair (fokl_gram_launch) instead of d_out / h_out.
 static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int path,
@@ -771,84 +943,136 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
 {
     if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_gram: call fokl_upload first");
     if (nr <= 0 || nc <= 0) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: empty block");
-    if (path < 0 || path > 2) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: path must be 0, 1 or 2");
+    if (path < 0 || path > 3) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: path must be 0, 1, 2 or 3");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = check_slots(ctx, row_slots, nr, "fokl_gram");
     if (rc) return rc;
     rc = check_slots(ctx, col_slots, nc, "fokl_gram");
     if (rc) return rc;
 
-    const size_t arg_bytes = (size_t)(nr + nc) * sizeof(int);
-    rc = begin_args(ctx, arg_bytes);
-    if (rc) return rc;
-    int *h = reinterpret_cast<int *>(ctx->h_args);
-    std::memcpy(h, row_slots, (size_t)nr * sizeof(int));
-    std::memcpy(h + nr, col_slots, (size_t)nc * sizeof(int));
-    rc = push_args(ctx, arg_bytes);
-    if (rc) return rc;
-    const int *d_rows = reinterpret_cast<const int *>(ctx->d_args);
-    const int *d_cols = d_rows + nr;
-
     // path choice: the VALU kernel re-reads operands once per 4x4 register tile, fine while the block is small;
-    // the MFMA kernel reads every column of a panel once per row chunk.
-    const bool use_mfma = path == 2 || (path == 0 && (int64_t)nr * nc > 64);
+    // the MFMA kernels read every column of a group of tiles once per row chunk.
+    if (path == 0) path = (int64_t)nr * nc > 64 ? env_int("FOKL_GRAM_PATH", 2) : 1;
+    if (path < 1 || path > 3) path = 2;
     const int cus = cu_count(ctx);
-    int S, nr_pad, nc_pad;
-    dim3 grid;
-    gram_mfma_fn mfma_fn = nullptr;
-    if (use_mfma) {
-        int BI, BJ;
-        const int j_tiles = (nc + 15) / 16;
-        if (nr > 32) {                                   // i-split: wave w <-> i-tile w, panel of TJ j-tiles
-            const int panels = (j_tiles + 11) / 12;
-            const int tj = (j_tiles + panels - 1) / panels;
-            mfma_fn = isplit_kernel(tj);
-            BI = 64;
-            BJ = 16 * tj;
-        } else {                                         // j-split: every wave all i-tiles, j-tiles dealt over waves
-            const int ti = nr > 16 ? 2 : 1;
-            const int per_wave = (j_tiles + 3) / 4;
-            const int panels = (per_wave + 2) / 3;
-            const int tj = (per_wave + panels - 1) / panels;
-            mfma_fn = jsplit_kernel(ti, tj);
-            BI = 16 * ti;
-            BJ = 64 * tj;
-        }
-        const int gz = (nr + BI - 1) / BI, gy = (nc + BJ - 1) / BJ;
-        nr_pad = gz * BI;
-        nc_pad = gy * BJ;
-        const int64_t n_chunks = (ctx->n + GM_R - 1) / GM_R;
-        const int per_cu = blocks_per_cu(mfma_fn, GM_THREADS, 0);
-        const int target = std::max(1, (per_cu * cus) / (gz * gy));
-        S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
-        grid = dim3(S, gy, gz);
-    } else {
-        const int gz = (nr + GV_TI - 1) / GV_TI, gy = (nc + GV_TJ - 1) / GV_TJ;
-        nr_pad = gz * GV_TI;
-        nc_pad = gy * GV_TJ;
-        const int64_t n_row_blocks = (ctx->n + GV_THREADS * 2 - 1) / (GV_THREADS * 2);
-        const int target = std::max(1, (8 * cus) / (gz * gy));
-        S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, target));
-        grid = dim3(S, gy, gz);
-    }
-    rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
-    if (rc) return rc;
     rc = aside ? ensure_gout(ctx, (size_t)nr * nc) : ensure_out(ctx, (size_t)nr * nc);
     if (rc) return rc;
     double *d_dst = aside ? ctx->d_gout : ctx->d_out;
     double *h_dst = aside ? ctx->h_gout : ctx->h_out;
 
-    {
+    // algorithmic traffic: every distinct column read once (row-side columns usually reappear on the column side)
+    std::vector<int32_t> uniq(row_slots, row_slots + nr);
+    uniq.insert(uniq.end(), col_slots, col_slots + nc);
+    std::sort(uniq.begin(), uniq.end());
+    const double distinct = (double)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
+    const double bytes = 8.0 * (double)ctx->n * distinct;
+    const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
+    const int total = nr * nc;
+    const int epb = reduce_elements_per_block(total);
+
+    if (path == 2) {
+        // tile lists over the internal column order; tiles below the diagonal of the row-side x row-side part skipped
+        GramPlan pl;
+        plan_gram(row_slots, nr, col_slots, nc, pl);
+        const size_t ints = (size_t)pl.nci + (size_t)nc;
+        const size_t group_off = (ints * sizeof(int32_t) + 15) / 16 * 16;
+        const size_t arg_bytes = group_off + pl.groups.size() * sizeof(GramGroup);
+        rc = begin_args(ctx, arg_bytes);
+        if (rc) return rc;
+        std::memcpy(ctx->h_args, pl.icols.data(), (size_t)pl.nci * sizeof(int32_t));
+        std::memcpy(ctx->h_args + (size_t)pl.nci * sizeof(int32_t), pl.perm.data(), (size_t)nc * sizeof(int32_t));
+        std::memcpy(ctx->h_args + group_off, pl.groups.data(), pl.groups.size() * sizeof(GramGroup));
+        rc = push_args(ctx, arg_bytes);
+        if (rc) return rc;
+        const int *d_icols = reinterpret_cast<const int *>(ctx->d_args);
+        const int *d_perm = d_icols + pl.nci;
+        const GramGroup *d_groups = reinterpret_cast<const GramGroup *>(ctx->d_args + group_off);
+
+        gram_tiles_fn fn = tiles_kernel(pl.nt, pl.depth, pl.ks);
+        const int R = 32 << pl.rb_shift;
+        const size_t lds = (size_t)pl.ct * 16 * (R + 2) * sizeof(double);
+        static std::mutex attr_mutex;
+        static std::map<const void *, size_t> attr_set;            // kernels whose dynamic LDS limit was raised already
         {
-            // algorithmic traffic: every distinct column read once (row-side columns usually reappear on the column side)
-            std::vector<int32_t> uniq(row_slots, row_slots + nr);
-            uniq.insert(uniq.end(), col_slots, col_slots + nc);
-            std::sort(uniq.begin(), uniq.end());
-            const double distinct = (double)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
-            const double bytes = 8.0 * (double)ctx->n * distinct;
-            const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
+            std::lock_guard<std::mutex> lock(attr_mutex);
+            size_t &have = attr_set[reinterpret_cast<const void *>(fn)];
+            if (have < lds) {
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                have = 160 * 1024;
+            }
+        }
+        const int nr_pad = 16 * pl.it, nc_pad = 16 * pl.jt;
+        const int64_t n_chunks = (ctx->n + R - 1) / R;
+        const int per_cu = blocks_per_cu(fn, GT_THREADS, lds);
+        const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+        rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
+        if (rc) return rc;
+        {
             TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
-            if (use_mfma) {
+            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
+                               ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,
+                               nr_pad, nc_pad, ctx->d_zero);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(reduce_slabs_sym_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
+                           ctx->d_slab, S * pl.ks, nr, nc, nr_pad, nc_pad, epb, d_perm, d_dst);
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        const size_t arg_bytes = (size_t)(nr + nc) * sizeof(int);
+        rc = begin_args(ctx, arg_bytes);
+        if (rc) return rc;
+        int *h = reinterpret_cast<int *>(ctx->h_args);
+        std::memcpy(h, row_slots, (size_t)nr * sizeof(int));
+        std::memcpy(h + nr, col_slots, (size_t)nc * sizeof(int));
+        rc = push_args(ctx, arg_bytes);
+        if (rc) return rc;
+        const int *d_rows = reinterpret_cast<const int *>(ctx->d_args);
+        const int *d_cols = d_rows + nr;
+        int S, nr_pad, nc_pad;
+        dim3 grid;
+        gram_mfma_fn mfma_fn = nullptr;
+        if (path == 3) {                                     // rectangular panels, one i-tile or j-tile set per wavefront
+            int BI, BJ;
+            const int j_tiles = (nc + 15) / 16;
+            if (nr > 32) {                                   // i-split: wave w <-> i-tile w, panel of TJ j-tiles
+                const int panels = (j_tiles + 11) / 12;
+                const int tj = (j_tiles + panels - 1) / panels;
+                mfma_fn = isplit_kernel(tj);
+                BI = 64;
+                BJ = 16 * tj;
+            } else {                                         // j-split: every wave all i-tiles, j-tiles dealt over waves
+                const int ti = nr > 16 ? 2 : 1;
+                const int per_wave = (j_tiles + 3) / 4;
+                const int panels = (per_wave + 2) / 3;
+                const int tj = (per_wave + panels - 1) / panels;
+                mfma_fn = jsplit_kernel(ti, tj);
+                BI = 16 * ti;
+                BJ = 64 * tj;
+            }
+            const int gz = (nr + BI - 1) / BI, gy = (nc + BJ - 1) / BJ;
+            nr_pad = gz * BI;
+            nc_pad = gy * BJ;
+            const int64_t n_chunks = (ctx->n + GM_R - 1) / GM_R;
+            const int per_cu = blocks_per_cu(mfma_fn, GM_THREADS, 0);
+            const int target = std::max(1, (per_cu * cus) / (gz * gy));
+            S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+            grid = dim3(S, gy, gz);
+        } else {
+            const int gz = (nr + GV_TI - 1) / GV_TI, gy = (nc + GV_TJ - 1) / GV_TJ;
+            nr_pad = gz * GV_TI;
+            nc_pad = gy * GV_TJ;
+            const int64_t n_row_blocks = (ctx->n + GV_THREADS * 2 - 1) / (GV_THREADS * 2);
+            const int target = std::max(1, (8 * cus) / (gz * gy));
+            S = (int)std::max<int64_t>(1, std::min<int64_t>(n_row_blocks, target));
+            grid = dim3(S, gy, gz);
+        }
+        rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
+        if (rc) return rc;
+        {
+            TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
+            if (path == 3) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
                                    nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);
             } else {
@@ -857,8 +1081,6 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             }
         }
         HIP_TRY(ctx, hipGetLastError());
-        const int total = nr * nc;
-        const int epb = reduce_elements_per_block(total);
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
                            ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, d_dst);
         HIP_TRY(ctx, hipGetLastError());

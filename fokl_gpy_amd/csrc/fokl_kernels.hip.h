@@ -643,6 +643,233 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K2c: Gram block as lists of 16 x 16 MFMA tiles (round 2; the default MFMA path)
+// ---------------------------------------------------------------------------------------------------------
+//
+// The host (fokl_hip.hip: plan_gram) puts the columns of a launch in an INTERNAL order -- the row-side columns first,
+// then the column-side columns that are not among them -- so that the part of the block that is the Gram matrix of
+// the row-side columns with themselves is symmetric about the diagonal of the internal tile grid: tile (it, jt) with
+// jt < it is never computed, the reduction kernel reads its mirror image.  What is left is cut, band of four i-tiles
+// by band, into groups of tiles; a workgroup takes one group and one row split:
+//   * it stages, per chunk of R = 32 rb rows, the <= 16 column tiles (16 columns each) its tiles touch -- row-side
+//     and column-side tiles share that list, on the diagonal they are the same columns -- as [column][R + 2] in LDS
+//     (pitch R + 2: conflict-free 16-column x 4-row fragment reads for R a multiple of 32);
+//   * its tiles are dealt over the four wavefronts (NT per wavefront, each an (a, b) pair of staged column tiles; a
+//     list is padded with tiles whose result goes nowhere) -- balanced whatever the shape of the group, which the
+//     fixed i-tile-per-wave map of gram_mfma_kernel is not once the tiles below the diagonal are gone;
+//   * narrow blocks (one or two tiles in all) split the k-steps of a chunk over KS wavefronts per tile instead; the
+//     wavefronts of a team write their partial tiles to KS different slabs and the slab reduction adds them;
+//   * DEPTH = 2 keeps the loads of two chunks in flight (HBM-bound shapes: few tiles, little MFMA work to hide a
+//     chunk's latency behind).
+// Operand maps as for gram_mfma_kernel.
+
+constexpr int GT_THREADS = 256;
+constexpr int GT_MAX_NT = 12;          // tiles per wavefront
+constexpr int GT_MAX_CT = 16;          // staged column tiles per group
+constexpr int GT_MAX_PASS = 16;        // staging passes per chunk (ct * rb): one 16-byte load per thread and pass
+constexpr int GT_AHEAD = 3;            // fragment pairs read ahead of the MFMA that consumes them
+
+struct GramGroup {
+    int32_t ct[GT_MAX_CT];             // internal column tile staged at local index p (-1: none, reads as zeros)
+    uint16_t oi[4][GT_MAX_NT];         // output tile coordinates per wavefront and list position; 0xFFFF: padding tile
+    uint16_t oj[4][GT_MAX_NT];
+    uint8_t a[4][GT_MAX_NT];           // local indices of the tile's row-side and column-side column tiles
+    uint8_t b[4][GT_MAX_NT];
+};
+
+template <int NT, int DEPTH, int KS>
+__global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const *__restrict__ slot_ptr,
+                                                                const int *__restrict__ icols, int nci,
+                                                                const GramGroup *__restrict__ groups, int ct_count,
+                                                                int rb_shift, int64_t n, double *__restrict__ slab,
+                                                                int nr_pad, int nc_pad,
+                                                                const double *__restrict__ zero_col)
+{
+    static_assert(KS == 1 || NT == 1, "k-split teams hold one tile");
+    extern __shared__ __attribute__((aligned(16))) double gt_tile[];
+    const int rb = 1 << rb_shift, R = 32 << rb_shift, pitch = R + 2;
+    const int passes = ct_count << rb_shift;
+    const GramGroup &g = groups[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int phase = wave % KS;
+    const int spair = tid & 15, scol = tid >> 4;
+
+    // staging map: pass q = (column tile p = q >> rb_shift, sub-chunk s = q & (rb - 1)); thread t loads rows
+    // 32 s + 2 (t & 15) + {0, 1} of column 16 p + (t >> 4) of the group's list
+    const double *cb[GT_MAX_PASS];
+    uint32_t padding = 0;
+#pragma unroll
+    for (int q = 0; q < GT_MAX_PASS; ++q) {
+        cb[q] = zero_col;
+        if (q < passes) {
+            const int ct = g.ct[q >> rb_shift];
+            const int c = 16 * ct + scol;
+            if (ct >= 0 && c < nci) cb[q] = slot_ptr[icols[c]];
+            else padding |= 1u << q;
+        }
+    }
+
+    // fragment addresses: a per-lane part (row fm of a 16-column tile, k-step row fk) + a wave-uniform tile offset kept
+    // in scalar registers (twelve tiles' worth of per-lane offsets would cost the second wavefront per SIMD)
+    int aoff[NT], boff[NT];
+    const int fm = lane & 15, fk = lane >> 4;
+    const int frag = fm * pitch + fk;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        aoff[k] = __builtin_amdgcn_readfirstlane(16 * (int)g.a[wave][k] * pitch);
+        boff[k] = __builtin_amdgcn_readfirstlane(16 * (int)g.b[wave][k] * pitch);
+    }
+    d4 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int64_t n_chunks = (n + R - 1) / R;
+    const int64_t stride = gridDim.x;
+    d2 stage[DEPTH][GT_MAX_PASS];
+
+    auto issue = [&](d2(&st)[GT_MAX_PASS], int64_t chunk) {
+        const int64_t r0 = chunk * R + 2 * spair;
+#pragma unroll
+        for (int q = 0; q < GT_MAX_PASS; ++q)
+            if (q < passes) {
+                const int64_t r = r0 + 32 * (q & (rb - 1));
+                const int64_t rc = ((padding >> q) & 1u) || r >= n ? 0 : r;      // rows past the end are masked at commit
+                st[q] = load_d2(cb[q] + rc);
+            }
+    };
+    auto commit = [&](const d2(&st)[GT_MAX_PASS], int64_t chunk) {
+        const int64_t r0 = chunk * R + 2 * spair;
+#pragma unroll
+        for (int q = 0; q < GT_MAX_PASS; ++q)
+            if (q < passes) {
+                const int s = q & (rb - 1);
+                const int64_t r = r0 + 32 * s;
+                d2 v = st[q];
+                if (r >= n) v.x = 0.0;
+                if (r + 1 >= n) v.y = 0.0;
+                *reinterpret_cast<d2 *>(&gt_tile[(16 * (q >> rb_shift) + scol) * pitch + 32 * s + 2 * spair]) = v;
+            }
+    };
+    // The MFMA phase is written as an explicit pipeline over the (k-step, tile) sequence of a sub-chunk: the fragments of
+    // step t + GT_AHEAD are read before the MFMA of step t is issued, and the order is pinned -- left to itself the
+    // scheduler hoists all 2 NT fragment reads of a k-step (48 registers at NT = 12) and spills the accumulators.
+    auto multiply = [&]() {
+        for (int s = 0; s < rb; ++s) {
+            const double *lds = gt_tile + frag + 32 * s;
+            if (KS == 1) {
+                constexpr int STEPS = 8 * NT;
+                double af[GT_AHEAD], bf[GT_AHEAD];
+                // (the tile offsets pass through an empty asm so that the per-tile sums lane part + tile offset are formed
+                // where they are used, one add per read, instead of living in 2 NT registers across the loop)
+                auto fragment = [&](int scalar_off, int k0) {
+                    asm volatile("" : "+s"(scalar_off));
+                    return lds[scalar_off + k0];
+                };
+#pragma unroll
+                for (int t = 0; t < GT_AHEAD && t < STEPS; ++t) {
+                    af[t] = fragment(aoff[t % NT], 4 * (t / NT));
+                    bf[t] = fragment(boff[t % NT], 4 * (t / NT));
+                }
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t) {
+                    const double a = af[t % GT_AHEAD], b = bf[t % GT_AHEAD];
+                    const int u = t + GT_AHEAD;
+                    if (u < STEPS) {
+                        af[t % GT_AHEAD] = fragment(aoff[u % NT], 4 * (u / NT));
+                        bf[t % GT_AHEAD] = fragment(boff[u % NT], 4 * (u / NT));
+                    }
+                    acc[t % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t % NT], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8 / KS; ++u) {
+                    const int k0 = 4 * (u * KS + phase);
+                    const double a = lds[aoff[0] + k0];
+                    const double b = lds[boff[0] + k0];
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[0], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int64_t chunk = blockIdx.x;
+    if (chunk < n_chunks) issue(stage[0], chunk);
+    if (DEPTH == 2 && chunk + stride < n_chunks) issue(stage[DEPTH - 1], chunk + stride);
+    while (chunk < n_chunks) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (chunk < n_chunks) {                        // uniform over the workgroup
+                commit(stage[d], chunk);
+                __syncthreads();
+                const int64_t ahead = chunk + DEPTH * stride;
+                if (ahead < n_chunks) issue(stage[d], ahead);
+                multiply();
+                __syncthreads();
+                chunk += stride;
+            }
+        }
+    }
+
+    double *out = slab + ((size_t)blockIdx.x * KS + phase) * nr_pad * nc_pad;
+    asm volatile("" ::: "memory");                          // the output coordinates are fetched here, not before the loop
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int oi = g.oi[wave][k], oj = g.oj[wave][k];
+        if (oi != 0xFFFF) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) out[(size_t)(16 * oi + fk + 4 * v) * nc_pad + 16 * oj + fm] = acc[k][v];
+        }
+    }
+}
+
+// reduce_slabs_kernel for gram_tiles_kernel's slabs: element (i, j) of the caller's block sits at internal column
+// perm[j]; a position in a tile below the diagonal of the internal tile grid was not computed and is read from its
+// mirror image (both indices are then row-side columns).  Same fixed summation order.
+__global__ __launch_bounds__(RD_THREADS) void reduce_slabs_sym_kernel(const double *__restrict__ slab, int S, int nr,
+                                                                      int nc, int nr_pad, int nc_pad, int epb,
+                                                                      const int *__restrict__ perm,
+                                                                      double *__restrict__ out)
+{
+    __shared__ double part_sum[RD_THREADS];
+    const int parts = RD_THREADS / epb;
+    const int el = threadIdx.x % epb, part = threadIdx.x / epb;
+    const int e = blockIdx.x * epb + el;
+    const int total = nr * nc;
+    double acc = 0.0;
+    if (e < total) {
+        int i = e / nc, c = perm[e % nc];
+        if ((c >> 4) < (i >> 4)) {
+            const int t = i;
+            i = c;
+            c = t;
+        }
+        const size_t plane = (size_t)nr_pad * nc_pad;
+        const double *p = slab + (size_t)i * nc_pad + c;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int k = part;
+        for (; k + 3 * parts < S; k += 4 * parts) {
+            const double v0 = p[(size_t)k * plane], v1 = p[(size_t)(k + parts) * plane];
+            const double v2 = p[(size_t)(k + 2 * parts) * plane], v3 = p[(size_t)(k + 3 * parts) * plane];
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+        }
+        for (; k < S; k += parts) a0 += p[(size_t)k * plane];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    part_sum[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0 && e < total) {
+        double s = part_sum[el];
+        for (int q = 1; q < parts; ++q) s += part_sum[q * epb + el];
+        out[e] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K3: residual moments  r = y - sum_j beta_j X_j ;  partial (sum r, sum r^2) per workgroup
 // ---------------------------------------------------------------------------------------------------------
 

@@ -175,8 +175,18 @@ def test_k2_exact_on_integer_data(device_ctx, n):
         rs = (2 + rng.permutation(150)[:nr]).astype(np.int32)
         cs = (2 + rng.permutation(150)[:nc]).astype(np.int32)
         want = cols[:, rs - 2].T @ cols[:, cs - 2]
-        for path in (0, 1, 2):
+        for path in (0, 1, 2, 3):
             assert np.array_equal(device_ctx.gram(rs, cs, path=path), want), (nr, nc, path)
+        # the search's own pattern: the row-side columns reappear in the middle of the column list, so the tile-list
+        # kernel computes their square once (tiles on or above the diagonal) and mirrors the rest
+        if nc > nr:
+            rest = np.setdiff1d(np.arange(2, 152), rs)
+            cs2 = np.concatenate([[0], rest[:nc - nr - 2], rs, [1]])[:nc].astype(np.int32) if nc - nr >= 2 else \
+                np.concatenate([rs, rest[:nc - nr]]).astype(np.int32)
+            ref = np.concatenate([np.ones((n, 1)), device_ctx.read_slot(1)[:, None], cols], axis=1)
+            want2 = ref[:, rs].T @ ref[:, cs2]
+            for path in (2, 3):
+                assert np.array_equal(device_ctx.gram(rs, cs2, path=path), want2), (nr, nc, path, 'symmetric')
     g = device_ctx.gram([0, 1, 2], [0, 1, 2])
     y = device_ctx.read_slot(1)
     assert g[0, 0] == n and g[0, 1] == y.sum() and g[1, 1] == y @ y and g[0, 2] == cols[:, 0].sum()
