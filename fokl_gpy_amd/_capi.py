@@ -137,7 +137,7 @@ def device_count():
 def gram_plan(row_slots, col_slots):
     """fokl_gram_plan: the tile lists fokl_gram's MFMA path would use for this block (host arithmetic, no device).
     -> dict(nci, i_tiles, j_tiles, nt, ct, rows_per_chunk, ks, depth, icols, perm, staged [G, 16],
-            tiles [G, 4, 12, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
+            tiles [G, 4, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
     rs = np.ascontiguousarray(row_slots, dtype=np.int32)
     cs = np.ascontiguousarray(col_slots, dtype=np.int32)
     info = np.zeros(9, dtype=np.int32)
@@ -147,7 +147,7 @@ def gram_plan(row_slots, col_slots):
     icols = np.empty(int(info[0]), dtype=np.int32)
     perm = np.empty(cs.shape[0], dtype=np.int32)
     staged = np.empty((groups, 16), dtype=np.int32)
-    tiles = np.empty((groups, 4, 12, 4), dtype=np.int32)
+    tiles = np.empty((groups, 4, 10, 4), dtype=np.int32)
     _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], _ptr(info), _ptr(icols), _ptr(perm),
                               _ptr(staged), _ptr(tiles), groups))
     return dict(nci=int(info[0]), i_tiles=int(info[1]), j_tiles=int(info[2]), nt=int(info[4]), ct=int(info[5]),

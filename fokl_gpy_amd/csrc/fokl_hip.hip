@@ -851,10 +851,10 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
     pl.nt = (most_tiles + teams - 1) / teams;
     pl.ct = most_staged;
     // rows per chunk: as many sub-chunks of 32 rows as the 16 staging passes and FOKL_GRAM_RB allow
-    const int rb_cap = std::max(1, std::min(16, env_int("FOKL_GRAM_RB", 4)));
+    const int rb_cap = std::max(1, std::min(16, env_int("FOKL_GRAM_RB", 1)));
     pl.rb_shift = 0;
     while ((pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
-    pl.depth = pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 2))) : 1;
+    pl.depth = pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 1))) : 1;
 
     pl.groups.resize(cuts.size());
     for (size_t gi = 0; gi < cuts.size(); ++gi) {
@@ -879,32 +879,57 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
 }
 
 typedef void (*gram_tiles_fn)(double *const *, const int *, int, const GramGroup *, int, int, int64_t, double *, int,
-                              int, const double *);
+                              int, const double *, const double *);
 
-template <int NT>
-static gram_tiles_fn tiles_kernel_nt(int depth, int ks)
+// Lowest address among the slot chunks and the zero column, if every one of them lies within 2^32 units of 256 bytes
+// above it on that grid (gram_tiles_kernel keeps columns as 32-bit distances); nullptr otherwise.
+static const double *slot_grid_base(fokl_ctx *ctx)
 {
-    if (NT == 1 && ks == 4) return depth == 2 ? gram_tiles_kernel<1, 2, 4> : gram_tiles_kernel<1, 1, 4>;
-    if (NT == 1 && ks == 2) return depth == 2 ? gram_tiles_kernel<1, 2, 2> : gram_tiles_kernel<1, 1, 2>;
-    if (NT <= 4 && depth == 2) return gram_tiles_kernel<(NT <= 4 ? NT : 1), 2, 1>;
-    return gram_tiles_kernel<NT, 1, 1>;
+    uintptr_t lo = reinterpret_cast<uintptr_t>(ctx->d_zero), hi = lo;
+    for (double *c : ctx->chunks) {
+        lo = std::min(lo, reinterpret_cast<uintptr_t>(c));
+        hi = std::max(hi, reinterpret_cast<uintptr_t>(c));
+    }
+    if ((ctx->ld * sizeof(double)) % 256 != 0 || (reinterpret_cast<uintptr_t>(ctx->d_zero) - lo) % 256 != 0) return nullptr;
+    for (double *c : ctx->chunks)
+        if ((reinterpret_cast<uintptr_t>(c) - lo) % 256 != 0) return nullptr;
+    const uintptr_t span = hi - lo + (uintptr_t)fokl_ctx::CHUNK_SLOTS * ctx->ld * sizeof(double);
+    if ((span >> 8) >= (uintptr_t(1) << 32)) return nullptr;
+    return reinterpret_cast<const double *>(lo);
 }
 
-static gram_tiles_fn tiles_kernel(int nt, int depth, int ks)
+// Instantiations: NT = 1..4 (HBM-bound shapes) for P = 4, 8, 16 staging passes and one or two chunks in flight, the
+// k-split teams (NT = 1) likewise; NT = 5..10 (MFMA-bound) for P = 16, one chunk in flight.
+template <int NT, int P>
+static gram_tiles_fn tiles_kernel_np(int depth, int ks)
+{
+    if (NT == 1 && ks == 4) return depth == 2 ? gram_tiles_kernel<1, P, 2, 4> : gram_tiles_kernel<1, P, 1, 4>;
+    if (NT == 1 && ks == 2) return depth == 2 ? gram_tiles_kernel<1, P, 2, 2> : gram_tiles_kernel<1, P, 1, 2>;
+    if (depth == 2) return gram_tiles_kernel<NT, P, 2, 1>;
+    return gram_tiles_kernel<NT, P, 1, 1>;
+}
+
+template <int NT>
+static gram_tiles_fn tiles_kernel_n(int passes, int depth, int ks)
+{
+    if (passes <= 4) return tiles_kernel_np<NT, 4>(depth, ks);
+    if (passes <= 8) return tiles_kernel_np<NT, 8>(depth, ks);
+    return tiles_kernel_np<NT, 16>(depth, ks);
+}
+
+static gram_tiles_fn tiles_kernel(int nt, int passes, int depth, int ks)
 {
     switch (nt) {
-        case 1: return tiles_kernel_nt<1>(depth, ks);
-        case 2: return tiles_kernel_nt<2>(depth, ks);
-        case 3: return tiles_kernel_nt<3>(depth, ks);
-        case 4: return tiles_kernel_nt<4>(depth, ks);
-        case 5: return tiles_kernel_nt<5>(depth, ks);
-        case 6: return tiles_kernel_nt<6>(depth, ks);
-        case 7: return tiles_kernel_nt<7>(depth, ks);
-        case 8: return tiles_kernel_nt<8>(depth, ks);
-        case 9: return tiles_kernel_nt<9>(depth, ks);
-        case 10: return tiles_kernel_nt<10>(depth, ks);
-        case 11: return tiles_kernel_nt<11>(depth, ks);
-        default: return tiles_kernel_nt<12>(depth, ks);
+        case 1: return tiles_kernel_n<1>(passes, depth, ks);
+        case 2: return tiles_kernel_n<2>(passes, depth, ks);
+        case 3: return tiles_kernel_n<3>(passes, depth, ks);
+        case 4: return tiles_kernel_n<4>(passes, depth, ks);
+        case 5: return gram_tiles_kernel<5, 16, 1, 1>;
+        case 6: return gram_tiles_kernel<6, 16, 1, 1>;
+        case 7: return gram_tiles_kernel<7, 16, 1, 1>;
+        case 8: return gram_tiles_kernel<8, 16, 1, 1>;
+        case 9: return gram_tiles_kernel<9, 16, 1, 1>;
+        default: return gram_tiles_kernel<10, 16, 1, 1>;
     }
 }
 
@@ -954,6 +979,8 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
     // the MFMA kernels read every column of a group of tiles once per row chunk.
     if (path == 0) path = (int64_t)nr * nc > 64 ? env_int("FOKL_GRAM_PATH", 2) : 1;
     if (path < 1 || path > 3) path = 2;
+    const double *grid_base = path == 2 ? slot_grid_base(ctx) : nullptr;
+    if (path == 2 && !grid_base) path = 3;                   // slots off the 256-byte grid (never seen): panel kernel
     const int cus = cu_count(ctx);
     rc = aside ? ensure_gout(ctx, (size_t)nr * nc) : ensure_out(ctx, (size_t)nr * nc);
     if (rc) return rc;
@@ -988,7 +1015,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int *d_perm = d_icols + pl.nci;
         const GramGroup *d_groups = reinterpret_cast<const GramGroup *>(ctx->d_args + group_off);
 
-        gram_tiles_fn fn = tiles_kernel(pl.nt, pl.depth, pl.ks);
+        gram_tiles_fn fn = tiles_kernel(pl.nt, pl.ct << pl.rb_shift, pl.depth, pl.ks);
         const int R = 32 << pl.rb_shift;
         const size_t lds = (size_t)pl.ct * 16 * (R + 2) * sizeof(double);
         static std::mutex attr_mutex;
@@ -1013,7 +1040,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,
-                               nr_pad, nc_pad, ctx->d_zero);
+                               nr_pad, nc_pad, ctx->d_zero, grid_base);
         }
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(reduce_slabs_sym_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,

@@ -659,12 +659,15 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
 //     fixed i-tile-per-wave map of gram_mfma_kernel is not once the tiles below the diagonal are gone;
 //   * narrow blocks (one or two tiles in all) split the k-steps of a chunk over KS wavefronts per tile instead; the
 //     wavefronts of a team write their partial tiles to KS different slabs and the slab reduction adds them;
+//   * P = staging passes per chunk the kernel is compiled for (ct * rb <= P): narrow blocks take the small-P builds,
+//     whose few registers let eight workgroups share a CU -- that, not the depth of a chunk, is what keeps enough
+//     bytes in flight when a chunk has little MFMA work to hide its latency behind;
 //   * DEPTH = 2 keeps the loads of two chunks in flight (HBM-bound shapes: few tiles, little MFMA work to hide a
 //     chunk's latency behind).
 // Operand maps as for gram_mfma_kernel.
 
 constexpr int GT_THREADS = 256;
-constexpr int GT_MAX_NT = 12;          // tiles per wavefront
+constexpr int GT_MAX_NT = 10;          // tiles per wavefront (2 NT fragment addresses + 8 NT accumulator registers)
 constexpr int GT_MAX_CT = 16;          // staged column tiles per group
 constexpr int GT_MAX_PASS = 16;        // staging passes per chunk (ct * rb): one 16-byte load per thread and pass
 constexpr int GT_AHEAD = 3;            // fragment pairs read ahead of the MFMA that consumes them
@@ -677,13 +680,14 @@ struct GramGroup {
     uint8_t b[4][GT_MAX_NT];
 };
 
-template <int NT, int DEPTH, int KS>
+template <int NT, int P, int DEPTH, int KS>
 __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const *__restrict__ slot_ptr,
                                                                 const int *__restrict__ icols, int nci,
                                                                 const GramGroup *__restrict__ groups, int ct_count,
                                                                 int rb_shift, int64_t n, double *__restrict__ slab,
                                                                 int nr_pad, int nc_pad,
-                                                                const double *__restrict__ zero_col)
+                                                                const double *__restrict__ zero_col,
+                                                                const double *__restrict__ base)
 {
     static_assert(KS == 1 || NT == 1, "k-split teams hold one tile");
     extern __shared__ __attribute__((aligned(16))) double gt_tile[];
@@ -697,28 +701,34 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 
     // staging map: pass q = (column tile p = q >> rb_shift, sub-chunk s = q & (rb - 1)); thread t loads rows
     // 32 s + 2 (t & 15) + {0, 1} of column 16 p + (t >> 4) of the group's list
-    const double *cb[GT_MAX_PASS];
+    // (two rounds of independent loads -- slot numbers, then column pointers -- instead of a dependent pair per pass).
+    // A column is remembered as its distance from `base` in units of 256 bytes: one register per pass instead of two
+    // (the host checks that every slot and the zero column lie on that grid within 2^32 units above base).
+    uint32_t cb[P];
     uint32_t padding = 0;
+    int slot_of[P];
 #pragma unroll
-    for (int q = 0; q < GT_MAX_PASS; ++q) {
-        cb[q] = zero_col;
-        if (q < passes) {
-            const int ct = g.ct[q >> rb_shift];
-            const int c = 16 * ct + scol;
-            if (ct >= 0 && c < nci) cb[q] = slot_ptr[icols[c]];
-            else padding |= 1u << q;
-        }
+    for (int q = 0; q < P; ++q) {
+        const int ct = q < passes ? g.ct[q >> rb_shift] : -1;
+        const int c = 16 * ct + scol;
+        const bool real = ct >= 0 && c < nci;
+        slot_of[q] = icols[real ? c : 0];
+        if (!real) padding |= 1u << q;
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const double *ptr = slot_ptr[slot_of[q]];
+        cb[q] = (uint32_t)((((padding >> q) & 1u ? zero_col : ptr) - base) >> 5);
     }
 
-    // fragment addresses: a per-lane part (row fm of a 16-column tile, k-step row fk) + a wave-uniform tile offset kept
-    // in scalar registers (twelve tiles' worth of per-lane offsets would cost the second wavefront per SIMD)
+    // fragment addresses: lane part (column fm of a 16-column tile, row fk of a k-step) + the tile's offset
     int aoff[NT], boff[NT];
     const int fm = lane & 15, fk = lane >> 4;
     const int frag = fm * pitch + fk;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        aoff[k] = __builtin_amdgcn_readfirstlane(16 * (int)g.a[wave][k] * pitch);
-        boff[k] = __builtin_amdgcn_readfirstlane(16 * (int)g.b[wave][k] * pitch);
+        aoff[k] = frag + 16 * (int)g.a[wave][k] * pitch;
+        boff[k] = frag + 16 * (int)g.b[wave][k] * pitch;
     }
     d4 acc[NT];
 #pragma unroll
@@ -726,22 +736,24 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 
     const int64_t n_chunks = (n + R - 1) / R;
     const int64_t stride = gridDim.x;
-    d2 stage[DEPTH][GT_MAX_PASS];
+    d2 stage[DEPTH][P];
 
-    auto issue = [&](d2(&st)[GT_MAX_PASS], int64_t chunk) {
+    auto issue = [&](d2(&st)[P], int64_t chunk) {
         const int64_t r0 = chunk * R + 2 * spair;
 #pragma unroll
-        for (int q = 0; q < GT_MAX_PASS; ++q)
+        for (int q = 0; q < P; ++q)
             if (q < passes) {
                 const int64_t r = r0 + 32 * (q & (rb - 1));
                 const int64_t rc = ((padding >> q) & 1u) || r >= n ? 0 : r;      // rows past the end are masked at commit
-                st[q] = load_d2(cb[q] + rc);
+                uint32_t units = cb[q];
+                asm volatile("" : "+v"(units));            // keeps the 64-bit address from being formed once and kept
+                st[q] = load_d2(base + ((size_t)units << 5) + rc);
             }
     };
-    auto commit = [&](const d2(&st)[GT_MAX_PASS], int64_t chunk) {
+    auto commit = [&](const d2(&st)[P], int64_t chunk) {
         const int64_t r0 = chunk * R + 2 * spair;
 #pragma unroll
-        for (int q = 0; q < GT_MAX_PASS; ++q)
+        for (int q = 0; q < P; ++q)
             if (q < passes) {
                 const int s = q & (rb - 1);
                 const int64_t r = r0 + 32 * s;
@@ -751,21 +763,20 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
                 *reinterpret_cast<d2 *>(&gt_tile[(16 * (q >> rb_shift) + scol) * pitch + 32 * s + 2 * spair]) = v;
             }
     };
-    // The MFMA phase is written as an explicit pipeline over the (k-step, tile) sequence of a sub-chunk: the fragments of
-    // step t + GT_AHEAD are read before the MFMA of step t is issued, and the order is pinned -- left to itself the
-    // scheduler hoists all 2 NT fragment reads of a k-step (48 registers at NT = 12) and spills the accumulators.
+    // The MFMA phase is an explicit pipeline over the (k-step, tile) sequence of a sub-chunk: the fragments of step
+    // t + GT_AHEAD are read before the MFMA of step t is issued, and the order is pinned.  Measured on the 56 x 176
+    // block (N = 1e6): left to itself the scheduler either hoists all 2 NT fragment reads of a k-step and spills the
+    // accumulators, or (reads fenced) waits for every pair right before its MFMA, 562 us; pinned, with the tile
+    // offsets in scalar registers and one VALU add per read, 480 us; pinned with the 2 NT fragment addresses kept in
+    // vector registers -- this form -- 407 us (rectangular panels of gram_mfma_kernel: 434 us).  Reading further ahead
+    // (6, 10 pairs) changes nothing.
     auto multiply = [&]() {
         for (int s = 0; s < rb; ++s) {
-            const double *lds = gt_tile + frag + 32 * s;
+            const double *lds = gt_tile + 32 * s;
             if (KS == 1) {
                 constexpr int STEPS = 8 * NT;
                 double af[GT_AHEAD], bf[GT_AHEAD];
-                // (the tile offsets pass through an empty asm so that the per-tile sums lane part + tile offset are formed
-                // where they are used, one add per read, instead of living in 2 NT registers across the loop)
-                auto fragment = [&](int scalar_off, int k0) {
-                    asm volatile("" : "+s"(scalar_off));
-                    return lds[scalar_off + k0];
-                };
+                auto fragment = [&](int tile_off, int k0) { return lds[tile_off + k0]; };
 #pragma unroll
                 for (int t = 0; t < GT_AHEAD && t < STEPS; ++t) {
                     af[t] = fragment(aoff[t % NT], 4 * (t / NT));

@@ -165,7 +165,7 @@ def load_columns(ctx, cols):
         ctx.write_slot(2 + j, cols[:, j])
 
 
-@pytest.mark.parametrize('n', [1, 31, 32, 33, 1000, 4099])
+@pytest.mark.parametrize('n', [1, 31, 32, 33, 1000, 4099, 120001])     # the last: workgroups loop over several chunks
 def test_k2_exact_on_integer_data(device_ctx, n):
     rng = np.random.default_rng(n)
     upload(device_ctx, rng.random((n, 1)), rng.integers(-3, 4, n).astype(float), O.KERNEL_BERNOULLI)

@@ -16,7 +16,7 @@ def replay(cols, rs, cs):
     pl = _capi.gram_plan(rs, cs)
     ks, IT, JT, nci = pl['ks'], pl['i_tiles'], pl['j_tiles'], pl['nci']
     assert pl['rows_per_chunk'] in (32, 64, 128, 256, 512) and pl['ct'] * pl['rows_per_chunk'] // 32 <= 16
-    assert 1 <= pl['nt'] <= 12 and 1 <= pl['ct'] <= 16 and ks in (1, 2, 4) and (ks == 1 or pl['nt'] == 1)
+    assert 1 <= pl['nt'] <= 10 and 1 <= pl['ct'] <= 16 and ks in (1, 2, 4) and (ks == 1 or pl['nt'] == 1)
     assert np.array_equal(pl['icols'][:len(rs)], rs)
     X = np.zeros((n, 16 * JT))
     X[:, :nci] = cols[:, pl['icols']]
@@ -27,7 +27,7 @@ def replay(cols, rs, cs):
         st = pl['staged'][g]
         assert np.all(st[pl['ct']:] == -1)
         for w in range(4):
-            for k in range(12):
+            for k in range(10):
                 a, b, oi, oj = pl['tiles'][g, w, k]
                 if oi < 0:
                     assert 0 <= a < pl['ct'] and 0 <= b < pl['ct']        # padding tiles still read valid LDS
