@@ -358,6 +358,16 @@ def kernel_report(kern, n, m, cfg):
     return kernels, dominant, gpu_ms
 
 
+def bring_up_comm(ctx, rank, world, use_rccl, need_rccl):
+    """-> (comm, description): RCCL when it comes up on every rank, else (independent fits only) the TCP control plane."""
+    from fokl_gpy_amd import dist
+    if not use_rccl:
+        return dist.SingleComm(), 'single process'
+    if world == 1:                                            # FOKL_BENCH_FORCE_RCCL=1: RCCL in a world of one
+        return dist.RcclComm(ctx, rank, world), 'RCCL'
+    return dist.bring_up(ctx, rank, world, need_rccl, log=lambda msg: print(f"bench.py: {msg}", file=sys.stderr))
+
+
 def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done, gate=None):
     """One of the worker PROCESSES of `--config 4 --procs P`: its own device context(s), host threads and L3 domain; fits
     its share of the rank's datasets back to back.  (Threads of one process share the interpreter lock of the Python
@@ -442,7 +452,7 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
     use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
     backend = FoKLRoutines.device_backend(local)
     ctx = backend.ctx
-    comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
+    comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=False)
     comm.barrier()
     start.wait(timeout=1800)                                # every worker has prepared and warmed up: go
     t0 = time.perf_counter()
@@ -513,7 +523,7 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
                                                 f'processes per GPU',
                    'config_index': cfg, 'rows': rows, 'inputs': spec0['inputs'],
                    'parallelism': (f'independent fits x{world} GPUs, ' if world > 1 else 'single GPU, ') +
-                                  f'{procs} worker processes per GPU',
+                                  f'{procs} worker processes per GPU', 'collectives': comm_kind,
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
         'value_physical': tot_physical / t_max,
         'parity_checked': parity_checked,
@@ -641,7 +651,7 @@ def main():
     for _ in range(fits_per_step - 1):                        # one resident dataset (and stream) per fit of a step
         backends.append(engine.HipBackend(_capi.DeviceContext(local)))
     ctx = backends[0].ctx
-    comm = dist.RcclComm(ctx, rank, world) if use_rccl else dist.SingleComm()
+    comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=one_fit_for_all)
 
     units = [0] if one_fit_for_all else [rank * fits_per_step + i for i in range(fits_per_step)]
     fits = []                                                 # (model, backend, x, y, spec, n_local)
@@ -883,7 +893,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': spec0['label'] + (f', {fits_per_step} fits per rank and step, {concurrent} at a time' if cfg == 4 else
                                                  ', one full forward-selection fit per step'),
-                   'config_index': cfg, 'rows': n, 'inputs': m, 'parallelism': parallelism,
+                   'config_index': cfg, 'rows': n, 'inputs': m, 'parallelism': parallelism, 'collectives': comm_kind,
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
         'value_physical': tot_physical / t_max,
         'parity_checked': parity_checked,

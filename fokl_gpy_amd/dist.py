@@ -180,6 +180,163 @@ class RcclComm:
         flush_c_streams()
 
 
+class TcpComm:
+    """
+    Control-plane collectives of a launch over plain TCP sockets (rank 0 is the hub): barrier and all-gather of a few
+    doubles, nothing else.  The benchmark brings it up before RCCL so that (a) every rank learns whether RCCL came up
+    on ALL ranks before anybody calls an RCCL collective, and (b) a launch of independent fits -- which has no data-path
+    exchange at all -- can still be timed and reported if RCCL cannot initialise on the node.
+    """
+
+    def __init__(self, rank, world, tag='fokl_tcp', timeout_s=300.0):
+        import socket
+        import struct
+        import time
+        self.rank, self.world = int(rank), int(world)
+        self._struct, self._peers, self._hub = struct, [], None
+        if self.world == 1:
+            return
+        path = _rendezvous_path(tag)
+        host = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        deadline = time.monotonic() + timeout_s
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                try:
+                    srv.bind((host, 0))
+                except OSError:
+                    srv.bind(('0.0.0.0', 0))
+                srv.listen(self.world)
+                try:
+                    os.unlink(path)
+                except FileNotFoundError:
+                    pass
+                fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+                with os.fdopen(fd, 'w') as fh:
+                    fh.write(f'{srv.getsockname()[1]}\n')
+                peers = {}
+                while len(peers) < self.world - 1:
+                    srv.settimeout(max(0.1, deadline - time.monotonic()))
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError(f"rank 0: only {len(peers)} of {self.world - 1} ranks joined within "
+                                           f"{timeout_s:.0f} s")
+                    conn.settimeout(timeout_s)
+                    hello = self._recv(conn, 8)
+                    if hello[:4] == b'FTCP':
+                        peers[struct.unpack('<i', hello[4:])[0]] = conn
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    else:
+                        conn.close()
+                self._peers = [peers[r] for r in range(1, self.world)]
+            finally:
+                srv.close()
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            return
+        while True:
+            try:
+                st = os.stat(path)
+                if st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0:
+                    with open(path) as fh:
+                        port = int(fh.read().strip() or 0)
+                    conn = socket.create_connection((host, port), timeout=5.0)
+                    conn.settimeout(timeout_s)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(b'FTCP' + struct.pack('<i', self.rank))
+                    self._hub = conn
+                    return
+            except (FileNotFoundError, ValueError, ConnectionError, socket.timeout, OSError):
+                pass
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rank {self.rank}: rank 0 not reachable via {path} after {timeout_s:.0f} s")
+            time.sleep(0.02)
+
+    @staticmethod
+    def _recv(conn, count):
+        buf = b''
+        while len(buf) < count:
+            part = conn.recv(count - len(buf))
+            if not part:
+                raise ConnectionError("peer closed the control connection")
+            buf += part
+        return buf
+
+    def allgather(self, values):
+        v = np.asarray(values, dtype=np.float64).reshape(-1)
+        if self.world == 1:
+            return v[None, :].copy()
+        nbytes = v.shape[0] * 8
+        if self.rank == 0:
+            rows = [v] + [np.frombuffer(self._recv(c, nbytes), dtype=np.float64) for c in self._peers]
+            out = np.stack(rows, axis=0)
+            blob = out.tobytes()
+            for c in self._peers:
+                c.sendall(blob)
+            return out
+        self._hub.sendall(v.tobytes())
+        return np.frombuffer(self._recv(self._hub, nbytes * self.world), dtype=np.float64).reshape(self.world, -1).copy()
+
+    def allreduce_sum(self, values):
+        v = np.asarray(values, dtype=np.float64)
+        return self.allgather(v.reshape(-1)).sum(axis=0).reshape(v.shape)
+
+    def barrier(self):
+        self.allgather([0.0])
+
+    def close(self):
+        for c in self._peers + ([self._hub] if self._hub is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._hub = [], None
+
+
+def bring_up(ctx, rank, world, need_rccl, timeout_s=180.0, log=None):
+    """
+    Communicator for a benchmark / driver process of a `world`-rank launch.  The TCP control plane comes up first; RCCL
+    is then initialised on a helper thread with a deadline, and the ranks agree over TCP whether it came up everywhere.
+    -> (comm, description).  If it did not: a launch that needs RCCL on its data path (`need_rccl`: rows or candidates
+    sharded over ranks) raises on every rank; a launch of independent fits carries on over the control plane alone.
+    """
+    if world == 1:
+        return SingleComm(), 'single process'
+    import threading
+    tcp = TcpComm(rank, world)
+    box = {}
+
+    def attempt():
+        try:
+            box['comm'] = RcclComm(ctx, rank, world)
+        except BaseException as exc:                          # noqa: BLE001 -- reported to every rank below
+            box['error'] = f'{type(exc).__name__}: {exc}'
+
+    stdout_fd = os.dup(1)                                     # RcclComm parks fd 1 on stderr while librccl initialises
+    t = threading.Thread(target=attempt, name='fokl-rccl-init', daemon=True)
+    t.start()
+    t.join(timeout_s)
+    ok = 1.0 if 'comm' in box else 0.0
+    if t.is_alive():
+        box['error'] = f'RCCL initialisation did not return within {timeout_s:.0f} s'
+        os.dup2(stdout_fd, 1)                                 # the stuck thread will never restore it
+    os.close(stdout_fd)
+    everywhere = float(np.min(tcp.allgather([ok])[:, 0])) == 1.0
+    if everywhere:
+        tcp.close()
+        return box['comm'], 'RCCL'
+    why = box.get('error', 'RCCL failed on another rank')
+    if log is not None:
+        log(f"rank {rank}: RCCL not available ({why}); control-plane collectives over TCP")
+    if need_rccl:
+        tcp.close()
+        raise RuntimeError(f"this mode exchanges data through RCCL, which did not come up: {why}")
+    return tcp, f'TCP control plane only (RCCL did not come up: {why})'
+
+
 class GlooComm:
     """Same interface over an initialised ``torch.distributed`` process group (CPU tests)."""
 
