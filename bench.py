@@ -308,7 +308,10 @@ def kernel_report(kern, n, m, cfg):
                     frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None, launches=k['launches'], avg_ms=avg_ms,
                     total_ms=k['ms'])
 
-    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'), 'resid': roof('resid', 'hbm'),
+    # Gram launches are booked by the library under the roof that binds each of them (fokl_hip.h: FOKL_K_GRAM for
+    # 8 N distinct-columns / HBM peak > 2 N nr nc / fp64 peak, FOKL_K_GRAM_MFMA otherwise): two kernels for the roofline
+    kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'),
+               'gram_mfma': roof('gram_mfma', 'mfma'), 'resid': roof('resid', 'hbm'),
                'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
     mf = kernels['resid_matrix_free']
     if mf:
@@ -322,18 +325,22 @@ def kernel_report(kern, n, m, cfg):
         if k['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > k['bytes'] / (HBM_PEAK_GBS * 1e9):
             mf.update(bound='valu-fp64', achieved=tf, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                       frac=tf / FP64_MFMA_PEAK_TFLOPS, hbm_achieved_gbs=mf['achieved'], hbm_frac=mf['frac'])
-    if kernels['gram']:
-        # the Gram kernel crosses the ridge (HBM bound below ~40 columns, fp64-MFMA bound above): give both readings,
-        # `bound` = the roof that binds the launches of this run taken together ...
-        gm = roof('gram', 'mfma')
-        hb = kernels['gram']
-        if kern['gram']['flops'] / (FP64_MFMA_PEAK_TFLOPS * 1e12) > kern['gram']['bytes'] / (HBM_PEAK_GBS * 1e9):
-            kernels['gram'] = dict(gm, hbm_achieved_gbs=hb['achieved'], hbm_frac=hb['frac'],
-                                   algorithmic_bytes_per_launch=hb['algorithmic_bytes_per_launch'])
-        else:
-            kernels['gram'].update(mfma_achieved_tflops=gm['achieved'], mfma_frac=gm['frac'])
-        # ... and the launch-by-launch roofline: sum of max(bytes / HBM peak, flops / MFMA peak) over measured time
-        kernels['gram']['roofline_frac'] = kern['gram']['ideal_ms'] / kern['gram']['ms']
+    if kernels['gram_mfma']:
+        kernels['gram_mfma'].update(
+            algorithmic_flops_per_launch=kern['gram_mfma']['flops'] / kern['gram_mfma']['launches'],
+            algorithmic_bytes_per_launch=kern['gram_mfma']['bytes'] / kern['gram_mfma']['launches'])
+    both = [kern[name] for name in ('gram', 'gram_mfma') if kern[name]['launches']]
+    if both:
+        # all Gram launches of the run together, priced launch by launch: sum of max(bytes / HBM peak, flops / MFMA
+        # peak) over the measured time
+        ms = sum(k['ms'] for k in both)
+        gram_all = dict(launches=sum(k['launches'] for k in both), total_ms=ms,
+                        roofline_frac=sum(k['ideal_ms'] for k in both) / ms,
+                        hbm_achieved_gbs=sum(k['bytes'] for k in both) / (ms * 1e-3) / 1e9,
+                        mfma_achieved_tflops=sum(k['flops'] for k in both) / (ms * 1e-3) / 1e12)
+        for name in ('gram', 'gram_mfma'):
+            if kernels[name]:
+                kernels[name]['all_gram_launches'] = gram_all
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
     # rocprofv3 --pmc passes over this same command (profiles/pmc_r02.json, produced by tools/profile_r02.sh: separate
     # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
@@ -421,8 +428,8 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
             one_pass(acc)
         elapsed = time.perf_counter() - t0
     kern = {}
-    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID),
-                      ('resid_matrix_free', _capi.K_RESID_MF)):
+    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
+                      ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF)):
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
         for model, _ in fits:
             t = model._backend_override.ctx.timing_get(kid)
@@ -759,8 +766,8 @@ def main():
             backend.ctx.timing_enable(False)
 
     kern = {}
-    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('resid', _capi.K_RESID),
-                      ('resid_matrix_free', _capi.K_RESID_MF)):
+    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
+                      ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF)):
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
         for _, backend, *_ in fits:
             t = backend.ctx.timing_get(kid)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.so'))   # override: A/B builds
 
 UNIQUE_ID_BYTES = 128
-K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF = 0, 1, 2, 3, 4
+K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA = 0, 1, 2, 3, 4, 5
 RESID_TERMS_MAX_FACTORS = 48
 RESID_TERMS_MAX_ORDER = 8
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
@@ -635,6 +635,11 @@ class DeviceContext:
                                            ctypes.byref(nbytes), ctypes.byref(flops), ctypes.byref(ideal)))
         return dict(ms=ms.value, launches=launches.value, bytes=nbytes.value, flops=flops.value,
                     ideal_ms=ideal.value)
+
+    def timing_get_gram(self):
+        """All Gram launches: the HBM-bound ones (K_GRAM) and the fp64-MFMA-bound ones (K_GRAM_MFMA) together."""
+        a, b = self.timing_get(K_GRAM), self.timing_get(K_GRAM_MFMA)
+        return {key: a[key] + b[key] for key in a}
 
     # -- RCCL ------------------------------------------------------------------------------------------
     @staticmethod

@@ -994,6 +994,14 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
     const double distinct = (double)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
     const double bytes = 8.0 * (double)ctx->n * distinct;
     const double flops = 2.0 * (double)ctx->n * (double)nr * (double)nc;
+    // the launch is booked under the roof that binds it
+    const int gram_slot = flops / FOKL_PEAK_F64_FLOPS > bytes / FOKL_PEAK_HBM_BYTES_PER_S ? FOKL_K_GRAM_MFMA : FOKL_K_GRAM;
+    if (const char *trace = std::getenv("FOKL_GRAM_TRACE")) {   // profile runs: which class each launch was booked under
+        if (FILE *fh = std::fopen(trace, "a")) {
+            std::fprintf(fh, "%d %d %d %s\n", nr, nc, (int)distinct, gram_slot == FOKL_K_GRAM_MFMA ? "gram_mfma" : "gram");
+            std::fclose(fh);
+        }
+    }
     const int total = nr * nc;
     const int epb = reduce_elements_per_block(total);
 
@@ -1037,7 +1045,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
         if (rc) return rc;
         {
-            TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,
                                nr_pad, nc_pad, ctx->d_zero, grid_base);
@@ -1098,7 +1106,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
         if (rc) return rc;
         {
-            TimedRegion timed(ctx, FOKL_K_GRAM, bytes, flops);      // brackets the Gram kernel only
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             if (path == 3) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
                                    nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);

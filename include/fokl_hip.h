@@ -40,11 +40,13 @@ extern "C" {
 
 /* ids for fokl_timing_get() */
 #define FOKL_K_BASIS   0        /* K1 basis-build kernel                */
-#define FOKL_K_GRAM    1        /* K2 Gram kernels (+ slab reduction)   */
+#define FOKL_K_GRAM    1        /* K2 Gram kernels, HBM-bound launches  */
 #define FOKL_K_RESID   2        /* K3 residual / BIC kernel             */
 #define FOKL_K_PREDICT 3        /* evaluate(): X * beta^T + order stats */
 #define FOKL_K_RESID_MF 4       /* K3 without the stored columns (fokl_bic_resid_terms_launch) */
-#define FOKL_K_COUNT   5
+#define FOKL_K_GRAM_MFMA 5      /* K2 launches bound by the fp64 MFMA roof (2 N nr nc / peak flops > 8 N distinct columns /
+                                   peak bytes, i.e. nr nc / distinct > ~39); FOKL_K_GRAM then holds the HBM-bound ones */
+#define FOKL_K_COUNT   6
 
 typedef struct fokl_ctx fokl_ctx;
 

@@ -195,7 +195,7 @@ def main():
                 ctx.timing_reset()
                 for _ in range(5):
                     ctx.gram(slots, allc, path=path)
-                t = ctx.timing_get(_capi.K_GRAM)
+                t = ctx.timing_get_gram()
                 per = t['ms'] / t['launches']
                 print(f'   K2 path{path} {T}x{T + 2}: {per * 1e3:.1f} us, {t["bytes"] / t["launches"] / per / 1e6:.1f} GB/s, '
                       f'{t["flops"] / t["launches"] / per / 1e9:.2f} TFLOP/s', flush=True)

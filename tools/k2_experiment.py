@@ -38,7 +38,7 @@ for nr, nc in ((8, 10), (28, 38), (8, 40), (56, 58), (56, 80), (56, 98), (56, 11
         ctx.timing_reset()
         for _ in range(reps):
             ctx.gram(rs, cs, path=path)
-        t = ctx.timing_get(_capi.K_GRAM)
+        t = ctx.timing_get_gram()
         per = t['ms'] / t['launches']
         line += (f'  path {path}: {per * 1e3:7.1f} us {t["bytes"] / t["launches"] / per / 1e6:7.0f} GB/s '
                  f'{t["flops"] / t["launches"] / per / 1e9:6.2f} TF/s frac {t["ideal_ms"] / t["ms"]:.2f}'

@@ -22,8 +22,8 @@ def find(dirname, suffix):
 
 def short(name):
     name = name.replace('void ', '')
-    for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_mfma_kernel', 'gram_valu_kernel',
-                'resid_terms_lds_kernel', 'resid_terms_kernel', 'resid_kernel', 'reduce_slabs_kernel',
+    for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_tiles_kernel', 'gram_mfma_kernel', 'gram_valu_kernel',
+                'resid_terms_lds_kernel', 'resid_terms_kernel', 'resid_kernel', 'reduce_slabs_sym_kernel', 'reduce_slabs_kernel',
                 'transpose_inputs_kernel', 'predict_mfma_kernel', 'predict_kernel'):
         if key in name:
             tag = ''
@@ -79,7 +79,7 @@ def cmd_pmc(dirname, out, counters):
 
 def family(name):
     for key, fam in (('basis_build_reg_kernel', 'basis_build'), ('basis_build_kernel', 'basis_build'),
-                     ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
+                     ('gram_tiles_kernel', 'gram'), ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
                      ('resid_terms_lds_kernel', 'resid_matrix_free'), ('resid_terms_kernel', 'resid_matrix_free'),
                      ('resid_kernel', 'resid')):
         if key in name:
@@ -87,26 +87,44 @@ def family(name):
     return None
 
 
-def cmd_json(fetch_dir, write_dir, out, rows, inputs):
+def cmd_json(fetch_dir, write_dir, out, rows, inputs, fetch_trace=None, write_trace=None):
     """Per kernel family: average raw FETCH_SIZE / WRITE_SIZE (KiB per dispatch) -> HBM bytes per launch with the
-    gfx950 correction (FETCH_SIZE x 2 for wide coalesced streams), for bench.py's `roofline.traffic`."""
+    gfx950 correction (FETCH_SIZE x 2 for wide coalesced streams), for bench.py's `roofline.traffic`.
+    The Gram launches are split into the two classes the library books them under (FOKL_K_GRAM: HBM-bound, FOKL_K_GRAM_MFMA:
+    fp64-MFMA-bound) with the FOKL_GRAM_TRACE file of the same run: its i-th line belongs to the i-th Gram dispatch."""
     import json
     res = {}
-    for counter, dirname in (('FETCH_SIZE', fetch_dir), ('WRITE_SIZE', write_dir)):
-        agg = defaultdict(list)
+    for counter, dirname, trace in (('FETCH_SIZE', fetch_dir, fetch_trace), ('WRITE_SIZE', write_dir, write_trace)):
+        classes = None
+        if trace and os.path.exists(trace):
+            classes = [line.split()[3] for line in open(trace) if line.strip()]
+        rows_ = []
         for path in find(dirname, 'counter_collection.csv'):
             with open(path) as fh:
-                for r in csv.DictReader(fh):
-                    fam = family(r['Kernel_Name'])
-                    if fam and r['Counter_Name'] == counter:
-                        agg[fam].append(float(r['Counter_Value']))
+                rows_ += [r for r in csv.DictReader(fh) if r['Counter_Name'] == counter]
+        rows_.sort(key=lambda r: int(r['Dispatch_Id']))
+        agg = defaultdict(list)
+        seen_gram = 0
+        for r in rows_:
+            fam = family(r['Kernel_Name'])
+            if not fam:
+                continue
+            if fam == 'gram' and classes is not None:
+                if seen_gram >= len(classes):
+                    raise SystemExit(f'{trace}: fewer lines than Gram dispatches')
+                fam = classes[seen_gram]
+                seen_gram += 1
+            agg[fam].append(float(r['Counter_Value']))
+        if classes is not None and seen_gram != len(classes):
+            raise SystemExit(f'{trace}: {len(classes)} lines for {seen_gram} Gram dispatches')
         for fam, v in agg.items():
             res.setdefault(fam, {})[counter + '_KiB_avg'] = sum(v) / len(v)
             res[fam]['dispatches'] = len(v)
     for fam, d in res.items():
         d['hbm_bytes_per_launch'] = 1024.0 * (2.0 * d.get('FETCH_SIZE_KiB_avg', 0.0) + d.get('WRITE_SIZE_KiB_avg', 0.0))
     payload = dict(workload=dict(rows=int(rows), inputs=int(inputs)), correction='FETCH_SIZE x 2 (gfx950), WRITE_SIZE exact',
-                   command='rocprofv3 --pmc <COUNTER> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline',
+                   command='rocprofv3 --pmc <COUNTER> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 '
+                           '--no-cpu-baseline --no-microbench --no-throughput',
                    kernels=res)
     with open(out, 'w') as fh:
         json.dump(payload, fh, indent=1)
@@ -118,6 +136,6 @@ if __name__ == '__main__':
     if mode == 'stats':
         cmd_stats(sys.argv[2], sys.argv[3])
     elif mode == 'json':
-        cmd_json(*sys.argv[2:7])
+        cmd_json(*sys.argv[2:9])
     else:
         cmd_pmc(sys.argv[2], sys.argv[3], sys.argv[4:])
