@@ -769,7 +769,8 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
     // accumulators, or (reads fenced) waits for every pair right before its MFMA, 562 us; pinned, with the tile
     // offsets in scalar registers and one VALU add per read, 480 us; pinned with the 2 NT fragment addresses kept in
     // vector registers -- this form -- 407 us (rectangular panels of gram_mfma_kernel: 434 us).  Reading further ahead
-    // (6, 10 pairs) changes nothing.
+    // (6, 10 pairs) changes nothing, and neither does leaving out most of the row-side fragment reads (a timing
+    // experiment: lists whose tiles share their row-side tile would gain nothing): the fp64 MFMA pipe is what is left.
     auto multiply = [&]() {
         for (int s = 0; s < rb; ++s) {
             const double *lds = gt_tile + 32 * s;
