@@ -38,7 +38,7 @@ SIGNATURES = {
     'fokl_gram': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_gram_launch': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_gram_fetch': (c_int, [c_vp, c_vp, c_i64]),
-    'fokl_gram_plan': (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
+    'fokl_gram_plan': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
     'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_bic_resid_fetch': (c_int, [c_vp, c_vp, c_int]),
@@ -134,25 +134,27 @@ def device_count():
 # numpy legacy RNG state <-> the C sampler
 # ---------------------------------------------------------------------------------------------------------
 
-def gram_plan(row_slots, col_slots):
-    """fokl_gram_plan: the tile lists fokl_gram's MFMA path would use for this block (host arithmetic, no device).
-    -> dict(nci, i_tiles, j_tiles, nt, ct, rows_per_chunk, ks, depth, icols, perm, staged [G, 16],
-            tiles [G, 4, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
+def gram_plan(row_slots, col_slots, kind=0):
+    """fokl_gram_plan: the tile lists fokl_gram's MFMA path would use for this block (host arithmetic, no device);
+    kind 0 = gram_tiles_kernel (16x16x4 MFMA, 4 wavefronts), kind 1 = gram_tiles4_kernel (4x4x4 MFMA, 8 wavefronts).
+    -> dict(nci, i_tiles, j_tiles, nt, ct, rows_per_chunk, ks, depth, waves, icols, perm, staged [G, 16],
+            tiles [G, 8, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
     rs = np.ascontiguousarray(row_slots, dtype=np.int32)
     cs = np.ascontiguousarray(col_slots, dtype=np.int32)
-    info = np.zeros(9, dtype=np.int32)
+    info = np.zeros(10, dtype=np.int32)
     lib = load()
-    _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], _ptr(info), None, None, None, None, 0))
+    _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], int(kind), _ptr(info), None, None, None,
+                              None, 0))
     groups = int(info[3])
     icols = np.empty(int(info[0]), dtype=np.int32)
     perm = np.empty(cs.shape[0], dtype=np.int32)
     staged = np.empty((groups, 16), dtype=np.int32)
-    tiles = np.empty((groups, 4, 10, 4), dtype=np.int32)
-    _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], _ptr(info), _ptr(icols), _ptr(perm),
-                              _ptr(staged), _ptr(tiles), groups))
+    tiles = np.empty((groups, 8, 10, 4), dtype=np.int32)
+    _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], int(kind), _ptr(info), _ptr(icols),
+                              _ptr(perm), _ptr(staged), _ptr(tiles), groups))
     return dict(nci=int(info[0]), i_tiles=int(info[1]), j_tiles=int(info[2]), nt=int(info[4]), ct=int(info[5]),
-                rows_per_chunk=32 << int(info[6]), ks=int(info[7]), depth=int(info[8]), icols=icols, perm=perm,
-                staged=staged, tiles=tiles)
+                rows_per_chunk=32 << int(info[6]), ks=int(info[7]), depth=int(info[8]), waves=int(info[9]), icols=icols,
+                perm=perm, staged=staged, tiles=tiles)
 
 
 class LegacyStream:

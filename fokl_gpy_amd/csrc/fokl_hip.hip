@@ -769,6 +769,7 @@ static gram_mfma_fn jsplit_kernel(int ti, int tj)
 struct GramPlan {
     int nci = 0, it = 0, jt = 0;       // internal columns; i-tiles (row side), j-tiles (all internal columns)
     int nt = 1, ct = 1, ks = 1, rb_shift = 0, depth = 1;
+    int kind = 0, waves = 4;           // 0: gram_tiles_kernel (16x16x4 MFMA, 4 wavefronts), 1: gram_tiles4_kernel (4x4x4, 8)
     std::vector<int32_t> icols;        // internal column -> slot: the row-side columns first
     std::vector<int32_t> perm;         // caller's column j -> internal column
     std::vector<GramGroup> groups;
@@ -782,8 +783,11 @@ static int env_int(const char *name, int fallback)
 
 // Internal column order, tile groups and kernel parameters for an nr x nc block (see gram_tiles_kernel).  Pure host
 // arithmetic: fokl_gram_plan exposes it to the CPU tests, which replay the lists with numpy.
-static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, GramPlan &pl)
+static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, GramPlan &pl)
 {
+    pl.kind = kind;
+    pl.waves = kind == 1 ? 8 : 4;
+    const int nt_max = kind == 1 ? G4_MAX_NT : GT_MAX_NT, ct_max = kind == 1 ? G4_MAX_CT : GT_MAX_CT;
     pl.icols.assign(row_slots, row_slots + nr);
     pl.perm.resize(nc);
     {
@@ -809,7 +813,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
         std::vector<int> staged;
     };
     std::vector<Cut> cuts;
-    const int max_tiles = 4 * GT_MAX_NT;
+    const int max_tiles = pl.waves * nt_max;
     for (int b0 = 0; b0 < pl.it; b0 += 4) {
         const int i_hi = std::min(pl.it, b0 + 4);
         std::vector<std::pair<int, int>> seq;              // tiles on or above the diagonal, column of tiles by column
@@ -831,7 +835,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
                 }
                 std::sort(c.staged.begin(), c.staged.end());
                 c.staged.erase(std::unique(c.staged.begin(), c.staged.end()), c.staged.end());
-                fits = (int)c.staged.size() <= GT_MAX_CT && size <= max_tiles;
+                fits = (int)c.staged.size() <= ct_max && size <= max_tiles;
                 if (size > 0) trial.push_back(std::move(c));
             }
             if (fits) {
@@ -846,15 +850,15 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
         most_tiles = std::max(most_tiles, (int)c.tiles.size());
         most_staged = std::max(most_staged, (int)c.staged.size());
     }
-    pl.ks = most_tiles == 1 ? 4 : most_tiles == 2 ? 2 : 1;
-    const int teams = 4 / pl.ks;
+    pl.ks = kind == 1 ? 1 : most_tiles == 1 ? 4 : most_tiles == 2 ? 2 : 1;
+    const int teams = pl.waves / pl.ks;
     pl.nt = (most_tiles + teams - 1) / teams;
     pl.ct = most_staged;
     // rows per chunk: as many sub-chunks of 32 rows as the 16 staging passes and FOKL_GRAM_RB allow
     const int rb_cap = std::max(1, std::min(16, env_int("FOKL_GRAM_RB", 1)));
     pl.rb_shift = 0;
-    while ((pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
-    pl.depth = pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 1))) : 1;
+    while (kind == 0 && (pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
+    pl.depth = kind == 0 && pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 1))) : 1;
 
     pl.groups.resize(cuts.size());
     for (size_t gi = 0; gi < cuts.size(); ++gi) {
@@ -862,7 +866,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
         GramGroup &g = pl.groups[gi];
         std::memset(&g, 0, sizeof(g));
         for (int p = 0; p < GT_MAX_CT; ++p) g.ct[p] = p < (int)c.staged.size() ? c.staged[p] : -1;
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < GT_MAX_WAVES; ++w)
             for (int k = 0; k < GT_MAX_NT; ++k) g.oi[w][k] = g.oj[w][k] = 0xFFFF;
         for (int t = 0; t < (int)c.tiles.size(); ++t) {
             const int team = t % teams, k = t / teams;
@@ -933,14 +937,36 @@ static gram_tiles_fn tiles_kernel(int nt, int passes, int depth, int ks)
     }
 }
 
-extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int32_t *info,
+typedef void (*gram_tiles4_fn)(double *const *, const int *, int, const GramGroup *, int, int64_t, double *, int, int,
+                               const double *, const double *);
+
+template <int NT>
+static gram_tiles4_fn tiles4_kernel_n(int passes)
+{
+    if (passes <= 2) return gram_tiles4_kernel<NT, 2>;
+    if (passes <= 4) return gram_tiles4_kernel<NT, 4>;
+    return gram_tiles4_kernel<NT, 5>;
+}
+
+static gram_tiles4_fn tiles4_kernel(int nt, int passes)
+{
+    switch (nt) {
+        case 1: return tiles4_kernel_n<1>(passes);
+        case 2: return tiles4_kernel_n<2>(passes);
+        case 3: return tiles4_kernel_n<3>(passes);
+        default: return tiles4_kernel_n<4>(passes);
+    }
+}
+
+extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
                               int32_t *icols, int32_t *perm, int32_t *staged, int32_t *tiles, int cap_groups)
 {
-    if (!row_slots || !col_slots || !info || nr <= 0 || nc <= 0)
+    if (!row_slots || !col_slots || !info || nr <= 0 || nc <= 0 || kind < 0 || kind > 1)
         return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_plan: bad argument");
     GramPlan pl;
-    plan_gram(row_slots, nr, col_slots, nc, pl);
-    const int32_t head[9] = {pl.nci, pl.it, pl.jt, (int32_t)pl.groups.size(), pl.nt, pl.ct, pl.rb_shift, pl.ks, pl.depth};
+    plan_gram(row_slots, nr, col_slots, nc, kind, pl);
+    const int32_t head[10] = {pl.nci, pl.it, pl.jt, (int32_t)pl.groups.size(), pl.nt, pl.ct, pl.rb_shift, pl.ks, pl.depth,
+                              pl.waves};
     std::memcpy(info, head, sizeof(head));
     if ((int)pl.groups.size() > cap_groups) return FOKL_OK;      // sizes only: call again with room for the lists
     if (icols) std::memcpy(icols, pl.icols.data(), pl.icols.size() * sizeof(int32_t));
@@ -949,9 +975,9 @@ extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *c
         const GramGroup &g = pl.groups[gi];
         if (staged) std::memcpy(staged + gi * GT_MAX_CT, g.ct, sizeof(g.ct));
         if (tiles)
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < GT_MAX_WAVES; ++w)
                 for (int k = 0; k < GT_MAX_NT; ++k) {
-                    int32_t *t = tiles + ((gi * 4 + w) * GT_MAX_NT + k) * 4;
+                    int32_t *t = tiles + ((gi * GT_MAX_WAVES + w) * GT_MAX_NT + k) * 4;
                     t[0] = g.a[w][k];
                     t[1] = g.b[w][k];
                     t[2] = g.oi[w][k] == 0xFFFF ? -1 : g.oi[w][k];
@@ -1007,8 +1033,11 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
 
     if (path == 2) {
         // tile lists over the internal column order; tiles below the diagonal of the row-side x row-side part skipped
+        // launches the fp64 matrix pipe bounds go to the 4x4x4 form of the instruction (FOKL_GRAM_MFMA4: 0 never, 1 always)
+        const int want4 = env_int("FOKL_GRAM_MFMA4", -1);
+        const int kind = want4 >= 0 ? (want4 ? 1 : 0) : (gram_slot == FOKL_K_GRAM_MFMA ? 1 : 0);
         GramPlan pl;
-        plan_gram(row_slots, nr, col_slots, nc, pl);
+        plan_gram(row_slots, nr, col_slots, nc, kind, pl);
         const size_t ints = (size_t)pl.nci + (size_t)nc;
         const size_t group_off = (ints * sizeof(int32_t) + 15) / 16 * 16;
         const size_t arg_bytes = group_off + pl.groups.size() * sizeof(GramGroup);
@@ -1023,28 +1052,47 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int *d_perm = d_icols + pl.nci;
         const GramGroup *d_groups = reinterpret_cast<const GramGroup *>(ctx->d_args + group_off);
 
-        gram_tiles_fn fn = tiles_kernel(pl.nt, pl.ct << pl.rb_shift, pl.depth, pl.ks);
-        const int R = 32 << pl.rb_shift;
-        const size_t lds = (size_t)pl.ct * 16 * (R + 2) * sizeof(double);
         static std::mutex attr_mutex;
         static std::map<const void *, size_t> attr_set;            // kernels whose dynamic LDS limit was raised already
-        {
+        auto raise_lds_limit = [&](const void *fn, size_t lds) -> int {
             std::lock_guard<std::mutex> lock(attr_mutex);
-            size_t &have = attr_set[reinterpret_cast<const void *>(fn)];
+            size_t &have = attr_set[fn];
             if (have < lds) {
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 have = 160 * 1024;
             }
-        }
+            return FOKL_OK;
+        };
         const int nr_pad = 16 * pl.it, nc_pad = 16 * pl.jt;
-        const int64_t n_chunks = (ctx->n + R - 1) / R;
-        const int per_cu = blocks_per_cu(fn, GT_THREADS, lds);
-        const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
-        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
-        rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
-        if (rc) return rc;
-        {
+        int S;
+        if (kind == 1) {
+            const int passes = (pl.ct + 1) / 2;
+            gram_tiles4_fn fn = tiles4_kernel(pl.nt, passes);
+            const size_t lds = (size_t)passes * 32 * G4_PITCH * sizeof(double);
+            rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
+            if (rc) return rc;
+            const int64_t n_chunks = (ctx->n + 31) / 32;
+            const int per_cu = blocks_per_cu(fn, G4_THREADS, lds);
+            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+            rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
+            if (rc) return rc;
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
+            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4_THREADS), lds, ctx->stream,
+                               ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
+                               ctx->d_zero, grid_base);
+        } else {
+            gram_tiles_fn fn = tiles_kernel(pl.nt, pl.ct << pl.rb_shift, pl.depth, pl.ks);
+            const int R = 32 << pl.rb_shift;
+            const size_t lds = (size_t)pl.ct * 16 * (R + 2) * sizeof(double);
+            rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
+            if (rc) return rc;
+            const int64_t n_chunks = (ctx->n + R - 1) / R;
+            const int per_cu = blocks_per_cu(fn, GT_THREADS, lds);
+            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+            rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
+            if (rc) return rc;
             TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,

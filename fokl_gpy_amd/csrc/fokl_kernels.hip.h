@@ -672,12 +672,14 @@ constexpr int GT_MAX_CT = 16;          // staged column tiles per group
 constexpr int GT_MAX_PASS = 16;        // staging passes per chunk (ct * rb): one 16-byte load per thread and pass
 constexpr int GT_AHEAD = 3;            // fragment pairs read ahead of the MFMA that consumes them
 
+constexpr int GT_MAX_WAVES = 8;        // gram_tiles_kernel: 4 wavefronts per workgroup, gram_tiles4_kernel: 8
+
 struct GramGroup {
-    int32_t ct[GT_MAX_CT];             // internal column tile staged at local index p (-1: none, reads as zeros)
-    uint16_t oi[4][GT_MAX_NT];         // output tile coordinates per wavefront and list position; 0xFFFF: padding tile
-    uint16_t oj[4][GT_MAX_NT];
-    uint8_t a[4][GT_MAX_NT];           // local indices of the tile's row-side and column-side column tiles
-    uint8_t b[4][GT_MAX_NT];
+    int32_t ct[GT_MAX_CT];                     // internal column tile staged at local index p (-1: none, reads as zeros)
+    uint16_t oi[GT_MAX_WAVES][GT_MAX_NT];      // output tile coordinates per wavefront and list position; 0xFFFF: padding
+    uint16_t oj[GT_MAX_WAVES][GT_MAX_NT];
+    uint8_t a[GT_MAX_WAVES][GT_MAX_NT];        // local indices of the tile's row-side and column-side column tiles
+    uint8_t b[GT_MAX_WAVES][GT_MAX_NT];
 };
 
 template <int NT, int P, int DEPTH, int KS>
@@ -833,6 +835,168 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 #pragma unroll
             for (int v = 0; v < 4; ++v) out[(size_t)(16 * oi + fk + 4 * v) * nc_pad + 16 * oj + fm] = acc[k][v];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 -- for the launches the fp64 matrix pipe bounds
+// ---------------------------------------------------------------------------------------------------------
+//
+// Measured on this part (tools/mfma_f64_peak.hip, operands in registers, in-kernel clock 2.38 GHz throughout -- it is
+// not a power limit): v_mfma_f64_16x16x4_f64 issues once per ~105 cycles and SIMD, 47-49 TFLOP/s = 0.61 of the
+// 78.6 TFLOP/s the data sheet gives for fp64 matrix work; v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4
+// blocks, 512 flops) sustains 72-75 TFLOP/s.  Lane maps of the latter (tools/mfma_f64_4x4_map.hip, by experiment):
+// A[blk][i][k] sits in lane i + 4 blk + 16 k, B[blk][k][j] in lane j + 4 blk + 16 k, D[blk][i][j] in lane
+// j + 4 blk + 16 i.  Here block blk takes the rows blk + 4 k of a group of 16 rows, so one instruction multiplies
+// 4 row-side by 4 column-side columns over 16 rows; a 16 x 16 tile is 4 x 4 such instructions on 4 + 4 operand
+// fragments per group of 16 rows, its 16 accumulators hold four partial sums each (one per block) that are added
+// across lanes once, at the end.  The price is registers -- 32 per tile instead of 8 -- so a workgroup has 8 wavefronts
+// (two per SIMD) with at most 4 tiles each, and the LDS pitch is 32 + 8: lanes i + 4 blk + 16 k read element
+// (column i, row blk + 4 k), conflict-free in both halves of a ds_read_b64 when 2 * pitch = 16 (mod 64).
+// Same staging (one 16-byte load per thread and pass, 32 columns per pass), same group lists, same slab layout.
+
+constexpr int G4_THREADS = 512;
+constexpr int G4_MAX_NT = 4;
+constexpr int G4_MAX_CT = 10;
+constexpr int G4_PITCH = 40;
+
+template <int NT, int P>
+__global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *const *__restrict__ slot_ptr,
+                                                                    const int *__restrict__ icols, int nci,
+                                                                    const GramGroup *__restrict__ groups, int ct_count,
+                                                                    int64_t n, double *__restrict__ slab, int nr_pad,
+                                                                    int nc_pad, const double *__restrict__ zero_col,
+                                                                    const double *__restrict__ base)
+{
+    extern __shared__ __attribute__((aligned(16))) double g4_tile[];
+    constexpr int R = 32, pitch = G4_PITCH;
+    const GramGroup &g = groups[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int spair = tid & 15, scol = tid >> 4;               // pass p: column 32 p + scol of the group's list
+
+    uint32_t cb[P];
+    uint32_t padding = 0;
+    int slot_of[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int local = 2 * p + (scol >> 4);
+        const int ct = local < ct_count ? g.ct[local] : -1;
+        const int c = 16 * ct + (scol & 15);
+        const bool real = ct >= 0 && c < nci;
+        slot_of[p] = icols[real ? c : 0];
+        if (!real) padding |= 1u << p;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const double *ptr = slot_ptr[slot_of[p]];
+        cb[p] = (uint32_t)((((padding >> p) & 1u ? zero_col : ptr) - base) >> 5);
+    }
+
+    // operand fragment of lane i + 4 blk + 16 k: column i of a group of 4 columns, row blk + 4 k of a group of 16 rows
+    const int frag = (lane & 3) * pitch + ((lane >> 2) & 3) + 4 * (lane >> 4);
+    int aoff[NT], boff[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        aoff[k] = frag + 16 * (int)g.a[wave][k] * pitch;
+        boff[k] = frag + 16 * (int)g.b[wave][k] * pitch;
+    }
+    int real_tiles = 0;                                        // lists are packed: real tiles first, padding behind
+#pragma unroll
+    for (int k = 0; k < NT; ++k) real_tiles += g.oi[wave][k] != 0xFFFF ? 1 : 0;
+    real_tiles = __builtin_amdgcn_readfirstlane(real_tiles);
+    double acc[NT][4][4];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[k][ia][jb] = 0.0;
+
+    const int64_t n_chunks = (n + R - 1) / R;
+    const int64_t stride = gridDim.x;
+    d2 stage[P];
+
+    auto issue = [&](int64_t chunk) {
+        const int64_t r = chunk * R + 2 * spair;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (2 * p < ct_count) {
+                const int64_t rc = ((padding >> p) & 1u) || r >= n ? 0 : r;
+                uint32_t units = cb[p];
+                asm volatile("" : "+v"(units));
+                stage[p] = load_d2(base + ((size_t)units << 5) + rc);
+            }
+    };
+    auto commit = [&](int64_t chunk) {
+        const int64_t r = chunk * R + 2 * spair;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (2 * p < ct_count) {
+                d2 v = stage[p];
+                if (r >= n) v.x = 0.0;
+                if (r + 1 >= n) v.y = 0.0;
+                *reinterpret_cast<d2 *>(&g4_tile[(32 * p + scol) * pitch + 2 * spair]) = v;
+            }
+    };
+    // steps = (group of 16 rows, tile): the 4 + 4 fragments of the next step are read before the 16 MFMAs of this one
+    auto multiply = [&]() {
+        constexpr int STEPS = 2 * NT;
+        double af[2][4], bf[2][4];
+        auto fetch = [&](int s, int buf) {
+            const int k = s % NT, rows = 16 * (s / NT);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[buf][q] = g4_tile[aoff[k] + 4 * q * pitch + rows];
+                bf[buf][q] = g4_tile[boff[k] + 4 * q * pitch + rows];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + 1 < STEPS) fetch(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s % NT < real_tiles) {                         // wave-uniform: a padding tile costs its reads only
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb)
+                        acc[s % NT][ia][jb] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[s & 1][ia], bf[s & 1][jb],
+                                                                                acc[s % NT][ia][jb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int64_t chunk = blockIdx.x;
+    if (chunk < n_chunks) issue(chunk);
+    while (chunk < n_chunks) {
+        commit(chunk);
+        __syncthreads();
+        const int64_t next = chunk + stride;
+        if (next < n_chunks) issue(next);
+        multiply();
+        __syncthreads();
+        chunk = next;
+    }
+
+    // D[blk][i][j] of lane j + 4 blk + 16 i: add the four blocks (lanes that differ in bits 2, 3), lanes of block 0 write
+    double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
+    asm volatile("" ::: "memory");
+    const int dj = lane & 3, di = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int oi = g.oi[wave][k], oj = g.oj[wave][k];
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                double v = acc[k][ia][jb];
+                v += __shfl_xor(v, 4, WAVE);
+                v += __shfl_xor(v, 8, WAVE);
+                if (oi != 0xFFFF && (lane & 12) == 0)
+                    out[(size_t)(16 * oi + 4 * ia + di) * nc_pad + 16 * oj + 4 * jb + dj] = v;
+            }
     }
 }
 

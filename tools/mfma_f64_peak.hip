@@ -2,16 +2,21 @@
 // the ceiling the Gram kernel's MFMA-bound launches are to be read against.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_peak.hip -o mfma_f64_peak && ./mfma_f64_peak
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// stamps[2 b], stamps[2 b + 1] = shader-clock cycles and 100 MHz ticks workgroup b spent in its loop (diagnostic
+// build only: MI355X_MICROARCH.md, DVFS item 6 -- in-kernel clock = cycles / ticks x 100 MHz)
 template <int ACC>
-__global__ __launch_bounds__(256) void spin(double *out, int iters, double a0, double b0)
+__global__ __launch_bounds__(256) void spin(double *out, int iters, double a0, double b0, unsigned long long *stamps)
 {
     d4 acc[ACC];
 #pragma unroll
     for (int j = 0; j < ACC; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
     double a = a0 + threadIdx.x * 1e-9, b = b0 + threadIdx.x * 1e-9;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < ACC; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
@@ -19,7 +24,55 @@ __global__ __launch_bounds__(256) void spin(double *out, int iters, double a0, d
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < ACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;                 // (waits for the accumulators: the loop has drained)
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = c1 - c0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+// the other fp64 MFMA shape: four 4 x 4 x 4 blocks per instruction (512 flops, one accumulator register per lane)
+template <int ACC>
+__global__ __launch_bounds__(256) void spin_4x4(double *out, int iters, double a0, double b0)
+{
+    double acc[ACC];
+#pragma unroll
+    for (int j = 0; j < ACC; ++j) acc[j] = 0.0;
+    double a = a0 + threadIdx.x * 1e-9, b = b0 + threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < ACC; ++j) acc[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[j], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < ACC; ++j) s += acc[j];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int ACC>
+void run_4x4(int waves_per_simd)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int blocks = prop.multiProcessorCount * waves_per_simd;
+    double *out;
+    hipMalloc(&out, sizeof(double) * 256 * blocks);
+    const int iters = 40000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int warm = 0; warm < 10; ++warm) spin_4x4<ACC><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e0);
+    spin_4x4<ACC><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 2.0 * 4 * 4 * 4 * 4 * (double)ACC * iters * 4.0 * blocks;
+    printf("v_mfma_f64_4x4x4: %d wave(s) per SIMD, %d independent accumulators: %.1f TFLOP/s\n", waves_per_simd, ACC,
+           flops / ms / 1e9);
+    hipFree(out);
 }
 
 template <int ACC>
@@ -31,21 +84,34 @@ void run(int waves_per_simd)
     double *out;
     hipMalloc(&out, sizeof(double) * 256 * blocks);
     const int iters = 20000;
+    unsigned long long *stamps;
+    hipMalloc(&stamps, sizeof(unsigned long long) * 2 * blocks);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    spin<ACC><<<blocks, 256>>>(out, 100, 1.0, 2.0);
+    spin<ACC><<<blocks, 256>>>(out, 100, 1.0, 2.0, nullptr);
     hipDeviceSynchronize();
+    for (int warm = 0; warm < 40; ++warm) spin<ACC><<<blocks, 256>>>(out, iters, 1.0, 2.0, nullptr);   // ~ a second of load
     hipEventRecord(e0);
-    spin<ACC><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    spin<ACC><<<blocks, 256>>>(out, iters, 1.0, 2.0, stamps);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(2 * blocks);
+    hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
+    std::vector<double> ghz(blocks), cyc(blocks);
+    for (int b = 0; b < blocks; ++b) {
+        ghz[b] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;
+        cyc[b] = (double)h[2 * b] / ((double)ACC * iters * waves_per_simd);
+    }
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(cyc.begin(), cyc.end());
     const double flops = 2.0 * 16 * 16 * 4 * (double)ACC * iters * 4.0 * blocks;
-    printf("CUs %d, %d wave(s) per SIMD, %d independent accumulators: %.1f TFLOP/s  (%.1f cycles per MFMA at %d MHz)\n",
-           prop.multiProcessorCount, waves_per_simd, ACC, flops / ms / 1e9,
-           ms * 1e-3 * prop.clockRate * 1e3 / ((double)ACC * iters * waves_per_simd), prop.clockRate / 1000);
+    printf("CUs %d, %d wave(s) per SIMD, %d independent accumulators: %.1f TFLOP/s; in-kernel clock %.2f GHz (median over "
+           "workgroups), %.1f shader cycles per MFMA and SIMD while resident (median)\n",
+           prop.multiProcessorCount, waves_per_simd, ACC, flops / ms / 1e9, ghz[blocks / 2], cyc[blocks / 2]);
+    hipFree(stamps);
     hipFree(out);
 }
 
@@ -59,5 +125,9 @@ int main()
     run<8>(4);
     run<4>(8);
     run<2>(8);
+    run_4x4<8>(1);
+    run_4x4<16>(1);
+    run_4x4<16>(2);
+    run_4x4<8>(4);
     return 0;
 }
