@@ -136,9 +136,9 @@ def device_count():
 
 def gram_plan(row_slots, col_slots, kind=0):
     """fokl_gram_plan: the tile lists fokl_gram's MFMA path would use for this block (host arithmetic, no device);
-    kind 0 = gram_tiles_kernel (16x16x4 MFMA, 4 wavefronts), kind 1 = gram_tiles4_kernel (4x4x4 MFMA, 8 wavefronts).
+    kind 0 = gram_tiles_kernel (16x16x4 MFMA; the default), kind 1 = gram_tiles4s_kernel (4x4x4 MFMA; FOKL_GRAM_MFMA4=2).
     -> dict(nci, i_tiles, j_tiles, nt, ct, rows_per_chunk, ks, depth, waves, icols, perm, staged [G, 16],
-            tiles [G, 8, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
+            tiles [G, 4, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
     rs = np.ascontiguousarray(row_slots, dtype=np.int32)
     cs = np.ascontiguousarray(col_slots, dtype=np.int32)
     info = np.zeros(10, dtype=np.int32)
@@ -149,7 +149,7 @@ def gram_plan(row_slots, col_slots, kind=0):
     icols = np.empty(int(info[0]), dtype=np.int32)
     perm = np.empty(cs.shape[0], dtype=np.int32)
     staged = np.empty((groups, 16), dtype=np.int32)
-    tiles = np.empty((groups, 8, 10, 4), dtype=np.int32)
+    tiles = np.empty((groups, 4, 10, 4), dtype=np.int32)
     _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], int(kind), _ptr(info), _ptr(icols),
                               _ptr(perm), _ptr(staged), _ptr(tiles), groups))
     return dict(nci=int(info[0]), i_tiles=int(info[1]), j_tiles=int(info[2]), nt=int(info[4]), ct=int(info[5]),

@@ -769,7 +769,7 @@ static gram_mfma_fn jsplit_kernel(int ti, int tj)
 struct GramPlan {
     int nci = 0, it = 0, jt = 0;       // internal columns; i-tiles (row side), j-tiles (all internal columns)
     int nt = 1, ct = 1, ks = 1, rb_shift = 0, depth = 1;
-    int kind = 0, waves = 4;           // 0: gram_tiles_kernel (16x16x4 MFMA, 4 wavefronts), 1: gram_tiles4_kernel (4x4x4, 8)
+    int kind = 0, waves = 4;           // 0: gram_tiles_kernel (16x16x4 MFMA), 1: gram_tiles4s_kernel (4x4x4 MFMA)
     std::vector<int32_t> icols;        // internal column -> slot: the row-side columns first
     std::vector<int32_t> perm;         // caller's column j -> internal column
     std::vector<GramGroup> groups;
@@ -786,8 +786,9 @@ static int env_int(const char *name, int fallback)
 static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, GramPlan &pl)
 {
     pl.kind = kind;
-    pl.waves = kind == 1 ? 8 : 4;
-    const int nt_max = kind == 1 ? G4_MAX_NT : GT_MAX_NT, ct_max = kind == 1 ? G4_MAX_CT : GT_MAX_CT;
+    pl.waves = 4;
+    const int nt_max = kind == 1 ? G4S_MAX_NT : GT_MAX_NT;
+    const int ct_max = kind == 1 ? G4S_MAX_CT : GT_MAX_CT;
     pl.icols.assign(row_slots, row_slots + nr);
     pl.perm.resize(nc);
     {
@@ -850,7 +851,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
         most_tiles = std::max(most_tiles, (int)c.tiles.size());
         most_staged = std::max(most_staged, (int)c.staged.size());
     }
-    pl.ks = kind == 1 ? 1 : most_tiles == 1 ? 4 : most_tiles == 2 ? 2 : 1;
+    pl.ks = kind != 0 ? 1 : most_tiles == 1 ? 4 : most_tiles == 2 ? 2 : 1;
     const int teams = pl.waves / pl.ks;
     pl.nt = (most_tiles + teams - 1) / teams;
     pl.ct = most_staged;
@@ -940,24 +941,6 @@ static gram_tiles_fn tiles_kernel(int nt, int passes, int depth, int ks)
 typedef void (*gram_tiles4_fn)(double *const *, const int *, int, const GramGroup *, int, int64_t, double *, int, int,
                                const double *, const double *);
 
-template <int NT>
-static gram_tiles4_fn tiles4_kernel_n(int passes)
-{
-    if (passes <= 2) return gram_tiles4_kernel<NT, 2>;
-    if (passes <= 4) return gram_tiles4_kernel<NT, 4>;
-    return gram_tiles4_kernel<NT, 5>;
-}
-
-static gram_tiles4_fn tiles4_kernel(int nt, int passes)
-{
-    switch (nt) {
-        case 1: return tiles4_kernel_n<1>(passes);
-        case 2: return tiles4_kernel_n<2>(passes);
-        case 3: return tiles4_kernel_n<3>(passes);
-        default: return tiles4_kernel_n<4>(passes);
-    }
-}
-
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
                               int32_t *icols, int32_t *perm, int32_t *staged, int32_t *tiles, int cap_groups)
 {
@@ -1033,9 +1016,8 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
 
     if (path == 2) {
         // tile lists over the internal column order; tiles below the diagonal of the row-side x row-side part skipped
-        // launches the fp64 matrix pipe bounds go to the 4x4x4 form of the instruction (FOKL_GRAM_MFMA4: 0 never, 1 always)
-        const int want4 = env_int("FOKL_GRAM_MFMA4", -1);
-        const int kind = want4 >= 0 ? (want4 ? 1 : 0) : (gram_slot == FOKL_K_GRAM_MFMA ? 1 : 0);
+        // FOKL_GRAM_MFMA4=2: the 4x4x4 form of the fp64 MFMA instruction (A/B runs; slower beyond the smallest blocks)
+        const int kind = env_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
         GramPlan pl;
         plan_gram(row_slots, nr, col_slots, nc, kind, pl);
         const size_t ints = (size_t)pl.nci + (size_t)nc;
@@ -1066,19 +1048,19 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int nr_pad = 16 * pl.it, nc_pad = 16 * pl.jt;
         int S;
         if (kind == 1) {
-            const int passes = (pl.ct + 1) / 2;
-            gram_tiles4_fn fn = tiles4_kernel(pl.nt, passes);
-            const size_t lds = (size_t)passes * 32 * G4_PITCH * sizeof(double);
+            const int P = pl.ct <= 2 ? 2 : pl.ct <= 4 ? 4 : pl.ct <= 6 ? 6 : 8;
+            gram_tiles4_fn fn = tiles4s_kernel(pl.nt, pl.ct);
+            const size_t lds = (size_t)P * 16 * G4_PITCH * sizeof(double);
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
-            const int per_cu = blocks_per_cu(fn, G4_THREADS, lds);
+            const int per_cu = blocks_per_cu(fn, G4S_THREADS, lds);
             const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
             TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
-            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4_THREADS), lds, ctx->stream,
+            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
         } else {

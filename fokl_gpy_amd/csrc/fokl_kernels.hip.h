@@ -672,7 +672,7 @@ constexpr int GT_MAX_CT = 16;          // staged column tiles per group
 constexpr int GT_MAX_PASS = 16;        // staging passes per chunk (ct * rb): one 16-byte load per thread and pass
 constexpr int GT_AHEAD = 3;            // fragment pairs read ahead of the MFMA that consumes them
 
-constexpr int GT_MAX_WAVES = 8;        // gram_tiles_kernel: 4 wavefronts per workgroup, gram_tiles4_kernel: 8
+constexpr int GT_MAX_WAVES = 4;        // wavefronts per workgroup
 
 struct GramGroup {
     int32_t ct[GT_MAX_CT];                     // internal column tile staged at local index p (-1: none, reads as zeros)
@@ -839,50 +839,59 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 -- for the launches the fp64 matrix pipe bounds
+// K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 (opt-in: FOKL_GRAM_MFMA4=2)
 // ---------------------------------------------------------------------------------------------------------
 //
 // Measured on this part (tools/mfma_f64_peak.hip, operands in registers, in-kernel clock 2.38 GHz throughout -- it is
 // not a power limit): v_mfma_f64_16x16x4_f64 issues once per ~105 cycles and SIMD, 47-49 TFLOP/s = 0.61 of the
-// 78.6 TFLOP/s the data sheet gives for fp64 matrix work; v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4
-// blocks, 512 flops) sustains 72-75 TFLOP/s.  Lane maps of the latter (tools/mfma_f64_4x4_map.hip, by experiment):
-// A[blk][i][k] sits in lane i + 4 blk + 16 k, B[blk][k][j] in lane j + 4 blk + 16 k, D[blk][i][j] in lane
-// j + 4 blk + 16 i.  Here block blk takes the rows blk + 4 k of a group of 16 rows, so one instruction multiplies
-// 4 row-side by 4 column-side columns over 16 rows; a 16 x 16 tile is 4 x 4 such instructions on 4 + 4 operand
-// fragments per group of 16 rows, its 16 accumulators hold four partial sums each (one per block) that are added
-// across lanes once, at the end.  The price is registers -- 32 per tile instead of 8 -- so a workgroup has 8 wavefronts
-// (two per SIMD) with at most 4 tiles each, and the LDS pitch is 32 + 8: lanes i + 4 blk + 16 k read element
-// (column i, row blk + 4 k), conflict-free in both halves of a ds_read_b64 when 2 * pitch = 16 (mod 64).
-// Same staging (one 16-byte load per thread and pass, 32 columns per pass), same group lists, same slab layout.
-
-constexpr int G4_THREADS = 512;
-constexpr int G4_MAX_NT = 4;
-constexpr int G4_MAX_CT = 10;
+// 78.6 TFLOP/s the data sheet gives for fp64 matrix work (the busy counter books 64 cycles per instruction: the pipe
+// idles 40 % of the time between two of them); v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks, 512
+// flops) sustains 72-75 TFLOP/s, also with 4 + 4 different operand registers feeding 16 accumulators.  Lane maps of
+// the latter (tools/mfma_f64_4x4_map.hip, by experiment): A[blk][i][k] sits in lane i + 4 blk + 16 k, B[blk][k][j]
+// in lane j + 4 blk + 16 k, D[blk][i][j] in lane j + 4 blk + 16 i.  Here block blk takes the rows blk + 4 k of a
+// group of 16 rows, so one instruction multiplies 4 row-side by 4 column-side columns over 16 rows; a 16 x 16 tile
+// is 4 x 4 such instructions on 4 + 4 operand fragments per group of 16 rows, and its 16 accumulators hold four
+// partial sums each (one per block) that are added across lanes once, at the end.  The price is registers -- 32 per
+// tile instead of 8 -- so a wavefront has at most 4 tiles, a group 16 tiles on at most 8 staged column tiles (more
+// groups per launch, each re-staging the columns of its i-tiles), and the LDS pitch is 32 + 8: lanes
+// i + 4 blk + 16 k read element (column i, row blk + 4 k), conflict-free in both halves of a ds_read_b64 when
+// 2 * pitch = 16 (mod 64); the fragment reads are volatile LDS loads, because merged into ds_read2_b64 they run at
+// half the rate on 32 banks, where columns i and i + 2 of this pitch collide.
+// Result (N = 1e6, back to back, us; 16x16x4 lists / this kernel): 28 x 38: 92 / 77, 56 x 58: 132 / 127,
+// 56 x 80: 167 / 188, 56 x 128: 290 / 353, 56 x 176: 411 / 509, 28 x 120: 181 / 194 -- the faster instruction does
+// not pay beyond the smallest blocks.  A second form (8 wavefronts, 40 tiles per group, two LDS buffers and two or
+// three sets of staging registers with the loads and their s_waitcnt written by hand, the two wavefronts of a SIMD
+// committing at different steps) read 295 / 455 us on 56 x 128 / 56 x 176 whatever the depth of its pipeline, its
+// matrix pipe busy 55 % of the time (SQ_VALU_MFMA_BUSY_CYCLES) with the MFMAs alone worth 177 us and everything but
+// the MFMAs 185 us: the two do not overlap, for a reason the counters at hand did not name.  It was withdrawn; this
+// one stays for A/B runs.  The default is the 16x16x4 kernel for every launch.
 constexpr int G4_PITCH = 40;
+constexpr int G4S_THREADS = 256;
+constexpr int G4S_MAX_NT = 4;
+constexpr int G4S_MAX_CT = 8;
 
 template <int NT, int P>
-__global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *const *__restrict__ slot_ptr,
-                                                                    const int *__restrict__ icols, int nci,
-                                                                    const GramGroup *__restrict__ groups, int ct_count,
-                                                                    int64_t n, double *__restrict__ slab, int nr_pad,
-                                                                    int nc_pad, const double *__restrict__ zero_col,
-                                                                    const double *__restrict__ base)
+__global__ __launch_bounds__(G4S_THREADS, 2) void gram_tiles4s_kernel(double *const *__restrict__ slot_ptr,
+                                                                      const int *__restrict__ icols, int nci,
+                                                                      const GramGroup *__restrict__ groups, int ct_count,
+                                                                      int64_t n, double *__restrict__ slab, int nr_pad,
+                                                                      int nc_pad, const double *__restrict__ zero_col,
+                                                                      const double *__restrict__ base)
 {
-    extern __shared__ __attribute__((aligned(16))) double g4_tile[];
+    extern __shared__ __attribute__((aligned(16))) double g4s_tile[];
     constexpr int R = 32, pitch = G4_PITCH;
     const GramGroup &g = groups[blockIdx.y];
     const int tid = threadIdx.x, lane = tid % WAVE;
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-    const int spair = tid & 15, scol = tid >> 4;               // pass p: column 32 p + scol of the group's list
+    const int spair = tid & 15, scol = tid >> 4;               // pass p: column scol of the group's p-th column tile
 
     uint32_t cb[P];
     uint32_t padding = 0;
     int slot_of[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int local = 2 * p + (scol >> 4);
-        const int ct = local < ct_count ? g.ct[local] : -1;
-        const int c = 16 * ct + (scol & 15);
+        const int ct = p < ct_count ? g.ct[p] : -1;
+        const int c = 16 * ct + scol;
         const bool real = ct >= 0 && c < nci;
         slot_of[p] = icols[real ? c : 0];
         if (!real) padding |= 1u << p;
@@ -893,7 +902,6 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *cons
         cb[p] = (uint32_t)((((padding >> p) & 1u ? zero_col : ptr) - base) >> 5);
     }
 
-    // operand fragment of lane i + 4 blk + 16 k: column i of a group of 4 columns, row blk + 4 k of a group of 16 rows
     const int frag = (lane & 3) * pitch + ((lane >> 2) & 3) + 4 * (lane >> 4);
     int aoff[NT], boff[NT];
 #pragma unroll
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *cons
         aoff[k] = frag + 16 * (int)g.a[wave][k] * pitch;
         boff[k] = frag + 16 * (int)g.b[wave][k] * pitch;
     }
-    int real_tiles = 0;                                        // lists are packed: real tiles first, padding behind
+    int real_tiles = 0;
 #pragma unroll
     for (int k = 0; k < NT; ++k) real_tiles += g.oi[wave][k] != 0xFFFF ? 1 : 0;
     real_tiles = __builtin_amdgcn_readfirstlane(real_tiles);
@@ -920,35 +928,34 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *cons
     auto issue = [&](int64_t chunk) {
         const int64_t r = chunk * R + 2 * spair;
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            if (2 * p < ct_count) {
-                const int64_t rc = ((padding >> p) & 1u) || r >= n ? 0 : r;
-                uint32_t units = cb[p];
-                asm volatile("" : "+v"(units));
-                stage[p] = load_d2(base + ((size_t)units << 5) + rc);
-            }
+        for (int p = 0; p < P; ++p) {
+            const int64_t rc = ((padding >> p) & 1u) || r >= n ? 0 : r;
+            uint32_t units = cb[p];
+            asm volatile("" : "+v"(units));
+            stage[p] = load_d2(base + ((size_t)units << 5) + rc);
+        }
     };
     auto commit = [&](int64_t chunk) {
         const int64_t r = chunk * R + 2 * spair;
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            if (2 * p < ct_count) {
-                d2 v = stage[p];
-                if (r >= n) v.x = 0.0;
-                if (r + 1 >= n) v.y = 0.0;
-                *reinterpret_cast<d2 *>(&g4_tile[(32 * p + scol) * pitch + 2 * spair]) = v;
-            }
+        for (int p = 0; p < P; ++p) {
+            d2 v = stage[p];
+            if (r >= n) v.x = 0.0;
+            if (r + 1 >= n) v.y = 0.0;
+            *reinterpret_cast<d2 *>(&g4s_tile[(16 * p + scol) * pitch + 2 * spair]) = v;
+        }
     };
-    // steps = (group of 16 rows, tile): the 4 + 4 fragments of the next step are read before the 16 MFMAs of this one
     auto multiply = [&]() {
         constexpr int STEPS = 2 * NT;
         double af[2][4], bf[2][4];
+        typedef __attribute__((address_space(3))) const volatile double lds_cv_double;
+        lds_cv_double *lds_v = (lds_cv_double *)g4s_tile;
         auto fetch = [&](int s, int buf) {
             const int k = s % NT, rows = 16 * (s / NT);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                af[buf][q] = g4_tile[aoff[k] + 4 * q * pitch + rows];
-                bf[buf][q] = g4_tile[boff[k] + 4 * q * pitch + rows];
+                af[buf][q] = lds_v[aoff[k] + 4 * q * pitch + rows];      // (volatile: see above)
+                bf[buf][q] = lds_v[boff[k] + 4 * q * pitch + rows];
             }
         };
         fetch(0, 0);
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *cons
         for (int s = 0; s < STEPS; ++s) {
             if (s + 1 < STEPS) fetch(s + 1, (s + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (s % NT < real_tiles) {                         // wave-uniform: a padding tile costs its reads only
+            if (s % NT < real_tiles) {
 #pragma unroll
                 for (int ia = 0; ia < 4; ++ia)
 #pragma unroll
@@ -980,7 +987,6 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gram_tiles4_kernel(double *cons
         chunk = next;
     }
 
-    // D[blk][i][j] of lane j + 4 blk + 16 i: add the four blocks (lanes that differ in bits 2, 3), lanes of block 0 write
     double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
     asm volatile("" ::: "memory");
     const int dj = lane & 3, di = lane >> 4;

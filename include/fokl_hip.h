@@ -121,8 +121,7 @@ int fokl_build_terms_deriv(fokl_ctx *ctx, const int32_t *terms, int T, const int
  * Passing FOKL_SLOT_Y among the column slots yields X'y, FOKL_SLOT_ONES yields column sums.
  * `path`: 0 = choose automatically, 1 = force the wavefront-reduction (VALU) kernel, 2 = force the fp64
  * MFMA kernels (lists of 16 x 16 tiles; where row-side columns reappear on the column side only the tiles on or
- * above the diagonal are computed and the rest is mirrored; launches bound by the matrix pipe use the 4x4x4 form of
- * the fp64 MFMA instruction, which this part issues at 1.5 times the rate of the 16x16x4 form), 3 = the earlier MFMA kernel over rectangular panels
+ * above the diagonal are computed and the rest is mirrored), 3 = the earlier MFMA kernel over rectangular panels
  * (kept for A/B runs).  Partial sums are combined in a fixed order, so results are bitwise reproducible.
  * If a communicator is attached (fokl_comm_init) and `allreduce` != 0 the block is summed over ranks
  * (row-sharded data) before it is returned.  Blocking.
@@ -140,13 +139,13 @@ int fokl_gram_launch(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int3
 int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count);
 /*
  * The launch plan path 2 would use for such a block -- host arithmetic only, no device needed (the CPU tests replay it
- * with numpy).  kind 0: gram_tiles_kernel (v_mfma_f64_16x16x4, 4 wavefronts per workgroup; the HBM-bound launches),
- * kind 1: gram_tiles4_kernel (v_mfma_f64_4x4x4_4b, 8 wavefronts; the launches the fp64 matrix pipe bounds).
+ * with numpy).  kind 0: gram_tiles_kernel (v_mfma_f64_16x16x4; what fokl_gram runs), kind 1: gram_tiles4s_kernel (the
+ * 4x4x4 form of the instruction, at most 4 tiles per wavefront and 8 staged column tiles; FOKL_GRAM_MFMA4=2, A/B runs).
  * info[10] = {internal columns, i-tiles, j-tiles, groups, tiles per wavefront NT, staged column tiles CT,
  * log2(sub-chunks of 32 rows per chunk), wavefronts per tile KS, chunks in flight, wavefronts per workgroup}.  With
  * cap_groups >= groups also: icols[internal columns] (internal column -> slot: the row-side columns first), perm[nc]
  * (caller's column -> internal column), staged[groups][16] (column tile staged at each local index, -1 = none) and
- * tiles[groups][8 wavefronts][10][4] = {local row-side tile, local column-side tile, output i-tile, output j-tile}
+ * tiles[groups][4 wavefronts][10][4] = {local row-side tile, local column-side tile, output i-tile, output j-tile}
  * with -1, -1 for padding entries.  Any of the four may be NULL.
  */
 int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,

@@ -16,8 +16,8 @@ def replay(cols, rs, cs, kind=0):
     pl = _capi.gram_plan(rs, cs, kind)
     ks, IT, JT, nci = pl['ks'], pl['i_tiles'], pl['j_tiles'], pl['nci']
     assert pl['rows_per_chunk'] in (32, 64, 128, 256, 512) and pl['ct'] * pl['rows_per_chunk'] // 32 <= 16
-    assert 1 <= pl['nt'] <= (4 if kind else 10) and 1 <= pl['ct'] <= (10 if kind else 16)
-    assert ks in (1, 2, 4) and (ks == 1 or pl['nt'] == 1) and pl['waves'] == (8 if kind else 4) and (ks == 1 or not kind)
+    assert 1 <= pl['nt'] <= (4 if kind else 10) and 1 <= pl['ct'] <= (8 if kind else 16)
+    assert ks in (1, 2, 4) and (ks == 1 or pl['nt'] == 1) and pl['waves'] == 4 and (ks == 1 or not kind)
     assert np.array_equal(pl['icols'][:len(rs)], rs)
     X = np.zeros((n, 16 * JT))
     X[:, :nci] = cols[:, pl['icols']]
@@ -27,12 +27,9 @@ def replay(cols, rs, cs, kind=0):
     for g in range(pl['tiles'].shape[0]):
         st = pl['staged'][g]
         assert np.all(st[pl['ct']:] == -1)
-        for w in range(8):
+        for w in range(4):
             for k in range(10):
                 a, b, oi, oj = pl['tiles'][g, w, k]
-                if w >= pl['waves']:
-                    assert oi < 0
-                    continue
                 if oi < 0:
                     assert 0 <= a < pl['ct'] and 0 <= b < pl['ct']        # padding tiles still read valid LDS
                     continue
@@ -82,16 +79,15 @@ def test_symmetric_part_is_computed_once_and_work_is_balanced():
     rs = np.arange(100, 156, dtype=np.int32)
     cs = np.concatenate([[0], np.arange(200, 318), rs, [1]]).astype(np.int32)
     pl = _capi.gram_plan(rs, cs)
-    real = pl['tiles'][:, :4, :, 2] >= 0
+    real = pl['tiles'][..., 2] >= 0
     assert pl['i_tiles'] == 4 and pl['j_tiles'] == 11 and int(real.sum()) == 38 and pl['nt'] == 10
     per_wave = real.sum(axis=2)
     assert per_wave.max() - per_wave.min() <= 1
-    # the same block for the 4x4x4 kernel: two groups of 19 tiles over 8 wavefronts each, 3 at most per wavefront
+    # the same block for the 4x4x4 kernel: 16 tiles per group at most, lists packed (the kernel skips the MFMAs of
+    # padding entries by counting the real ones)
     p4 = _capi.gram_plan(rs, cs, kind=1)
     real4 = p4['tiles'][..., 2] >= 0
-    assert p4['tiles'].shape[0] == 2 and int(real4.sum()) == 38 and p4['nt'] == 3 and p4['ct'] <= 10
-    assert real4.sum(axis=2).max() - real4.sum(axis=2).min() <= 1
-    # lists are packed: the kernel skips the MFMAs of padding entries by counting the real ones
+    assert int(real4.sum()) == 38 and p4['nt'] <= 4 and p4['ct'] <= 8 and p4['tiles'].shape[0] >= 3
     assert np.all(np.diff(real4.astype(int), axis=2) <= 0)
     # a big block (configs[3]): every group within the kernel's limits, nearly half of the square part skipped
     rs = np.arange(1000, 1560, dtype=np.int32)
@@ -106,4 +102,4 @@ def test_symmetric_part_is_computed_once_and_work_is_balanced():
 def test_narrow_blocks_split_the_k_steps_over_wavefronts():
     pl = _capi.gram_plan(np.arange(2, 10, dtype=np.int32), np.concatenate([[0], np.arange(2, 10), [1]]).astype(np.int32))
     assert pl['i_tiles'] == 1 and pl['j_tiles'] == 1 and pl['ks'] == 4 and pl['nt'] == 1
-    assert np.all(pl['tiles'][0, :4, 0, 2:] == 0)              # all four wavefronts work on the one tile
+    assert np.all(pl['tiles'][0, :, 0, 2:] == 0)              # all four wavefronts work on the one tile

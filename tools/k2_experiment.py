@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from fokl_gpy_amd import _capi, getKernels, engine
 
 ctx = _capi.DeviceContext(0)
-n, m = 1_000_000, 8
+n, m = int(os.environ.get("K2_N", "1000000")), 8
 rng = np.random.default_rng(12)
 x = rng.random((n, m)); y = rng.standard_normal(n)
 packed, nb, width = getKernels.pack_phis(getKernels.bernoulli(), 1)

@@ -50,6 +50,58 @@ __global__ __launch_bounds__(256) void spin_4x4(double *out, int iters, double a
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the way a Gram tile uses it: 4 row-side x 4 column-side operand fragments, 16 accumulators
+__global__ __launch_bounds__(256) void spin_4x4_tile(double *out, int iters, double a0, double b0)
+{
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = a0 + threadIdx.x * 1e-9 + i;
+        b[i] = b0 + threadIdx.x * 1e-9 - i;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+void run_4x4_tile(int waves_per_simd)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int blocks = prop.multiProcessorCount * waves_per_simd;
+    double *out;
+    hipMalloc(&out, sizeof(double) * 256 * blocks);
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int warm = 0; warm < 10; ++warm) spin_4x4_tile<<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e0);
+    spin_4x4_tile<<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 2.0 * 4 * 4 * 4 * 4 * 16.0 * iters * 4.0 * blocks;
+    printf("v_mfma_f64_4x4x4, 4 x 4 operand fragments -> 16 accumulators: %d wave(s) per SIMD: %.1f TFLOP/s\n", waves_per_simd,
+           flops / ms / 1e9);
+    hipFree(out);
+}
+
 template <int ACC>
 void run_4x4(int waves_per_simd)
 {
@@ -129,5 +181,7 @@ int main()
     run_4x4<16>(1);
     run_4x4<16>(2);
     run_4x4<8>(4);
+    run_4x4_tile(1);
+    run_4x4_tile(2);
     return 0;
 }
