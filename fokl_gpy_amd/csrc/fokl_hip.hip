@@ -941,6 +941,25 @@ static gram_tiles_fn tiles_kernel(int nt, int passes, int depth, int ks)
 typedef void (*gram_tiles4_fn)(double *const *, const int *, int, const GramGroup *, int, int64_t, double *, int, int,
                                const double *, const double *);
 
+template <int NT>
+static gram_tiles4_fn tiles4s_kernel_n(int passes)
+{
+    if (passes <= 2) return gram_tiles4s_kernel<NT, 2>;
+    if (passes <= 4) return gram_tiles4s_kernel<NT, 4>;
+    if (passes <= 6) return gram_tiles4s_kernel<NT, 6>;
+    return gram_tiles4s_kernel<NT, 8>;
+}
+
+static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
+{
+    switch (nt) {
+        case 1: return tiles4s_kernel_n<1>(passes);
+        case 2: return tiles4s_kernel_n<2>(passes);
+        case 3: return tiles4s_kernel_n<3>(passes);
+        default: return tiles4s_kernel_n<4>(passes);
+    }
+}
+
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
                               int32_t *icols, int32_t *perm, int32_t *staged, int32_t *tiles, int cap_groups)
 {
