@@ -710,8 +710,11 @@ static int comm_allreduce_device(fokl_ctx *ctx, double *d_buf, size_t count);   
 // Output elements handled by one 256-thread block of the slab reduction: few elements -> many parts per element.
 static int reduce_elements_per_block(int total)
 {
+    // 16 elements (one 128-byte line per slab) x 16 parts while that keeps the grid below ~4096 blocks: many blocks with
+    // short per-thread chains; wider blocks only for very large outputs
     int epb = 1;
-    while (epb < 64 && epb * 64 < total) epb *= 2;     // keep >= 64 blocks in flight before widening
+    while (epb < 16 && epb * 64 < total) epb *= 2;
+    while (epb < 64 && (total + epb - 1) / epb > 4096) epb *= 2;
     return epb;
 }
 
@@ -1065,7 +1068,11 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             return FOKL_OK;
         };
         const int nr_pad = 16 * pl.it, nc_pad = 16 * pl.jt;
+        // workgroups per CU that share the rows of a group: more of them hide more latency but every one writes a
+        // partial block the reduction has to read back (FOKL_GRAM_WGS caps it)
+        const int wgs_cap = std::max(1, env_int("FOKL_GRAM_WGS", 3));
         int S;
+        TimedRegion timed(ctx, gram_slot, bytes, flops);          // brackets the Gram kernel and its slab reduction
         if (kind == 1) {
             const int P = pl.ct <= 2 ? 2 : pl.ct <= 4 ? 4 : pl.ct <= 6 ? 6 : 8;
             gram_tiles4_fn fn = tiles4s_kernel(pl.nt, pl.ct);
@@ -1073,12 +1080,11 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
-            const int per_cu = blocks_per_cu(fn, G4S_THREADS, lds);
+            const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, G4S_THREADS, lds));
             const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
-            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
@@ -1089,12 +1095,11 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + R - 1) / R;
-            const int per_cu = blocks_per_cu(fn, GT_THREADS, lds);
+            const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, GT_THREADS, lds));
             const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
             if (rc) return rc;
-            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,
                                nr_pad, nc_pad, ctx->d_zero, grid_base);
@@ -1155,7 +1160,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
         if (rc) return rc;
         {
-            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel and its slab reduction
             if (path == 3) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
                                    nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);
@@ -1163,10 +1168,9 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
                 hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
                                    nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
             }
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
+                               ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, d_dst);
         }
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
-                           ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, d_dst);
         HIP_TRY(ctx, hipGetLastError());
     }
     // row-sharded fit: the block is summed over the ranks where it lies -- RCCL on the device, stream-ordered behind

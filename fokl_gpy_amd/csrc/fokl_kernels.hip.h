@@ -479,18 +479,19 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_slabs_kernel(const double *
         const int i = e / nc, j = e % nc;
         const size_t plane = (size_t)nr_pad * nc_pad;
         const double *p = slab + (size_t)i * nc_pad + j;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        // eight independent running sums: eight loads in flight per thread (a thread's chain of dependent rounds, not
+        // bandwidth, is what a reduction over a few hundred slabs costs)
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int k = part;
-        for (; k + 3 * parts < S; k += 4 * parts) {
-            const double v0 = p[(size_t)k * plane], v1 = p[(size_t)(k + parts) * plane];
-            const double v2 = p[(size_t)(k + 2 * parts) * plane], v3 = p[(size_t)(k + 3 * parts) * plane];
-            a0 += v0;
-            a1 += v1;
-            a2 += v2;
-            a3 += v3;
+        for (; k + 7 * parts < S; k += 8 * parts) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u * parts) * plane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += v[u];
         }
-        for (; k < S; k += parts) a0 += p[(size_t)k * plane];
-        acc = (a0 + a1) + (a2 + a3);
+        for (int u = 0; k < S; k += parts, ++u) a[u & 7] += p[(size_t)k * plane];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     part_sum[threadIdx.x] = acc;
     __syncthreads();
@@ -1029,18 +1030,19 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_slabs_sym_kernel(const doub
         }
         const size_t plane = (size_t)nr_pad * nc_pad;
         const double *p = slab + (size_t)i * nc_pad + c;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        // eight independent running sums: eight loads in flight per thread (a thread's chain of dependent rounds, not
+        // bandwidth, is what a reduction over a few hundred slabs costs)
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int k = part;
-        for (; k + 3 * parts < S; k += 4 * parts) {
-            const double v0 = p[(size_t)k * plane], v1 = p[(size_t)(k + parts) * plane];
-            const double v2 = p[(size_t)(k + 2 * parts) * plane], v3 = p[(size_t)(k + 3 * parts) * plane];
-            a0 += v0;
-            a1 += v1;
-            a2 += v2;
-            a3 += v3;
+        for (; k + 7 * parts < S; k += 8 * parts) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u * parts) * plane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += v[u];
         }
-        for (; k < S; k += parts) a0 += p[(size_t)k * plane];
-        acc = (a0 + a1) + (a2 + a3);
+        for (int u = 0; k < S; k += parts, ++u) a[u & 7] += p[(size_t)k * plane];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     part_sum[threadIdx.x] = acc;
     __syncthreads();

@@ -102,6 +102,58 @@ void run_4x4_tile(int waves_per_simd)
     hipFree(out);
 }
 
+// both forms in one instruction stream: does the 4x4x4 form fit into the gaps the 16x16x4 form leaves?
+template <int SMALL>
+__global__ __launch_bounds__(256) void spin_mixed(double *out, int iters, double a0, double b0)
+{
+    d4 big[4];
+    double small[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) big[j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) small[j] = 0.0;
+    double a = a0 + threadIdx.x * 1e-9, b = b0 + threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            big[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, big[j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < SMALL; ++q)
+                small[(j * SMALL + q) % 8] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, small[(j * SMALL + q) % 8], 0, 0, 0);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += big[j][0] + big[j][1] + big[j][2] + big[j][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += small[j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int SMALL>
+void run_mixed(int waves_per_simd)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int blocks = prop.multiProcessorCount * waves_per_simd;
+    double *out;
+    hipMalloc(&out, sizeof(double) * 256 * blocks);
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int warm = 0; warm < 10; ++warm) spin_mixed<SMALL><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e0);
+    spin_mixed<SMALL><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (2048.0 + 512.0 * SMALL) * 4.0 * iters * 4.0 * blocks;
+    printf("one 16x16x4 + %d 4x4x4 alternating, %d wave(s) per SIMD: %.1f TFLOP/s in all\n", SMALL, waves_per_simd, flops / ms / 1e9);
+    hipFree(out);
+}
+
 template <int ACC>
 void run_4x4(int waves_per_simd)
 {
@@ -183,5 +235,9 @@ int main()
     run_4x4<8>(4);
     run_4x4_tile(1);
     run_4x4_tile(2);
+    run_mixed<1>(2);
+    run_mixed<2>(2);
+    run_mixed<3>(2);
+    run_mixed<4>(2);
     return 0;
 }
