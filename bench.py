@@ -290,6 +290,13 @@ def pin_to_l3_domain(local, ranks=1):
     return None
 
 
+def KERNEL_SLOTS():
+    """(name in the JSON line, timing slot of the library) of every kernel a fit launches."""
+    from fokl_gpy_amd import _capi
+    return (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
+            ('gram_reduce', _capi.K_GRAM_REDUCE), ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF))
+
+
 def kernel_report(kern, n, m, cfg):
     """Per-kernel roofline readings from the HIP-event totals `kern` (name -> ms, launches, bytes, flops, ideal_ms).
     -> (kernels, dominant kernel's `roofline` object, device milliseconds)"""
@@ -311,7 +318,8 @@ def kernel_report(kern, n, m, cfg):
     # Gram launches are booked by the library under the roof that binds each of them (fokl_hip.h: FOKL_K_GRAM for
     # 8 N distinct-columns / HBM peak > 2 N nr nc / fp64 peak, FOKL_K_GRAM_MFMA otherwise): two kernels for the roofline
     kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'),
-               'gram_mfma': roof('gram_mfma', 'mfma'), 'resid': roof('resid', 'hbm'),
+               'gram_mfma': roof('gram_mfma', 'mfma'), 'gram_reduce': roof('gram_reduce', 'hbm'),
+               'resid': roof('resid', 'hbm'),
                'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
     mf = kernels['resid_matrix_free']
     if mf:
@@ -428,8 +436,7 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
             one_pass(acc)
         elapsed = time.perf_counter() - t0
     kern = {}
-    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
-                      ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF)):
+    for name, kid in KERNEL_SLOTS():
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
         for model, _ in fits:
             t = model._backend_override.ctx.timing_get(kid)
@@ -470,7 +477,7 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         w.join(60)
 
     kern = {}
-    for name in ('basis_build', 'gram', 'resid', 'resid_matrix_free'):
+    for name, _ in KERNEL_SLOTS():
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
         for r in results:
             for key in tot:
@@ -766,8 +773,7 @@ def main():
             backend.ctx.timing_enable(False)
 
     kern = {}
-    for name, kid in (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
-                      ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF)):
+    for name, kid in KERNEL_SLOTS():
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
         for _, backend, *_ in fits:
             t = backend.ctx.timing_get(kid)

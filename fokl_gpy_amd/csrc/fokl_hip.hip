@@ -1072,7 +1072,6 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         // partial block the reduction has to read back (FOKL_GRAM_WGS caps it)
         const int wgs_cap = std::max(1, env_int("FOKL_GRAM_WGS", 3));
         int S;
-        TimedRegion timed(ctx, gram_slot, bytes, flops);          // brackets the Gram kernel and its slab reduction
         if (kind == 1) {
             const int P = pl.ct <= 2 ? 2 : pl.ct <= 4 ? 4 : pl.ct <= 6 ? 6 : 8;
             gram_tiles4_fn fn = tiles4s_kernel(pl.nt, pl.ct);
@@ -1085,6 +1084,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
@@ -1100,13 +1100,18 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
             if (rc) return rc;
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GT_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, pl.rb_shift, ctx->n, ctx->d_slab,
                                nr_pad, nc_pad, ctx->d_zero, grid_base);
         }
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(reduce_slabs_sym_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
-                           ctx->d_slab, S * pl.ks, nr, nc, nr_pad, nc_pad, epb, d_perm, d_dst);
+        {
+            // the reduction is a kernel of its own in the timing table (and in rocprofv3's): slabs read + block written
+            TimedRegion timed(ctx, FOKL_K_GRAM_REDUCE, 8.0 * ((double)S * pl.ks + 1.0) * total, 0.0);
+            hipLaunchKernelGGL(reduce_slabs_sym_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
+                               ctx->d_slab, S * pl.ks, nr, nc, nr_pad, nc_pad, epb, d_perm, d_dst);
+        }
         HIP_TRY(ctx, hipGetLastError());
     } else {
         const size_t arg_bytes = (size_t)(nr + nc) * sizeof(int);
@@ -1160,7 +1165,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
         if (rc) return rc;
         {
-            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel and its slab reduction
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
             if (path == 3) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
                                    nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);
@@ -1168,6 +1173,9 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
                 hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
                                    nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
             }
+        }
+        {
+            TimedRegion timed(ctx, FOKL_K_GRAM_REDUCE, 8.0 * ((double)S + 1.0) * total, 0.0);
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + epb - 1) / epb), dim3(RD_THREADS), 0, ctx->stream,
                                ctx->d_slab, S, nr, nc, nr_pad, nc_pad, epb, d_dst);
         }

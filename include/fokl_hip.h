@@ -46,7 +46,8 @@ extern "C" {
 #define FOKL_K_RESID_MF 4       /* K3 without the stored columns (fokl_bic_resid_terms_launch) */
 #define FOKL_K_GRAM_MFMA 5      /* K2 launches bound by the fp64 MFMA roof (2 N nr nc / peak flops > 8 N distinct columns /
                                    peak bytes, i.e. nr nc / distinct > ~39); FOKL_K_GRAM then holds the HBM-bound ones */
-#define FOKL_K_COUNT   6
+#define FOKL_K_GRAM_REDUCE 6    /* K2's second kernel: fixed-order sum of the per-workgroup partial blocks (bytes = slabs read) */
+#define FOKL_K_COUNT   7
 
 typedef struct fokl_ctx fokl_ctx;
 

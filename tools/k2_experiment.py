@@ -39,9 +39,10 @@ for nr, nc in ((8, 10), (28, 38), (8, 40), (56, 58), (56, 80), (56, 98), (56, 11
         for _ in range(reps):
             ctx.gram(rs, cs, path=path)
         t = ctx.timing_get_gram()
+        red = ctx.timing_get(_capi.K_GRAM_REDUCE)
         per = t['ms'] / t['launches']
         line += (f'  path {path}: {per * 1e3:7.1f} us {t["bytes"] / t["launches"] / per / 1e6:7.0f} GB/s '
-                 f'{t["flops"] / t["launches"] / per / 1e9:6.2f} TF/s frac {t["ideal_ms"] / t["ms"]:.2f}'
+                 f'{t["flops"] / t["launches"] / per / 1e9:6.2f} TF/s frac {t["ideal_ms"] / t["ms"]:.2f} (+ reduction {1e3 * red["ms"] / max(red["launches"], 1):5.1f} us)'
                  f'{"" if same else " DIFFERENT BITS"}')
     if 2 in paths:
         pl = _capi.gram_plan(rs, cs)
