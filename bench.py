@@ -373,6 +373,16 @@ def kernel_report(kern, n, m, cfg):
     return kernels, dominant, gpu_ms
 
 
+def device_of(local):
+    """HIP device of the rank with this LOCAL_RANK.  FOKL_BENCH_SHARE_GPU=1 (launcher rehearsals on a box with fewer GPUs
+    than ranks) wraps the ranks round the devices there are -- RCCL then refuses to initialise (two ranks on one device) and
+    independent fits carry on over the TCP control plane."""
+    if os.environ.get('FOKL_BENCH_SHARE_GPU', '0') == '1':
+        from fokl_gpy_amd import _capi
+        return local % max(1, _capi.device_count())
+    return local
+
+
 def bring_up_comm(ctx, rank, world, use_rccl, need_rccl):
     """-> (comm, description): RCCL when it comes up on every rank, else (independent fits only) the TCP control plane."""
     from fokl_gpy_amd import dist
@@ -398,7 +408,7 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
                       ('FOKL_SPECTRAL_THREADS', '2' if procs > 2 else '3')):
         os.environ.setdefault(name, val)
-    os.environ['FOKL_DEVICE'] = str(local)
+    os.environ['FOKL_DEVICE'] = str(device_of(local))
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     fits = []
     prep_s = 0.0
@@ -408,7 +418,7 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
             x, y, spec = config_workload(cfg, unit, rows)
             kernel, phis, _ = kernel_and_phis(spec)
             model = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **spec['fit'])
-            model._backend_override = engine.HipBackend(_capi.DeviceContext(local))
+            model._backend_override = engine.HipBackend(_capi.DeviceContext(device_of(local)))
             t0 = time.perf_counter()
             model._prepare_fit(x, y, dict(clean=True))
             prep_s += time.perf_counter() - t0
@@ -464,7 +474,7 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
 
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
-    backend = FoKLRoutines.device_backend(local)
+    backend = FoKLRoutines.device_backend(device_of(local))
     ctx = backend.ctx
     comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=False)
     comm.barrier()
@@ -603,7 +613,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
             sys.exit(2)
-    os.environ['FOKL_DEVICE'] = str(local)
+    os.environ['FOKL_DEVICE'] = str(device_of(local))
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     cfg = args.config
     # Secondary measurement of the default run (one GPU, configs[2]): how many candidate terms per second the same GPU
@@ -661,9 +671,9 @@ def main():
 
     # FOKL_BENCH_FORCE_RCCL=1 takes the RCCL bootstrap + collectives also in a world of one (launcher smoke test)
     use_rccl = world > 1 or os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') == '1'
-    backends = [FoKLRoutines.device_backend(local)]          # raises without libfokl_hip.so / a gfx950 device
+    backends = [FoKLRoutines.device_backend(device_of(local))]          # raises without libfokl_hip.so / a gfx950 device
     for _ in range(fits_per_step - 1):                        # one resident dataset (and stream) per fit of a step
-        backends.append(engine.HipBackend(_capi.DeviceContext(local)))
+        backends.append(engine.HipBackend(_capi.DeviceContext(device_of(local))))
     ctx = backends[0].ctx
     comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=one_fit_for_all)
 
@@ -808,7 +818,7 @@ def main():
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     side = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False)
-                    side._backend_override = engine.HipBackend(_capi.DeviceContext(local))
+                    side._backend_override = engine.HipBackend(_capi.DeviceContext(device_of(local)))
                     np.random.seed(sp['seed_fit'])
                     sb, sm, se = side.fit(xs, ys, clean=True, **sp['fit'], **over)
                 parity = compare_with_golden(name, side, sb, sm, se, np.random.get_state())
