@@ -23,8 +23,11 @@ ctx.timing_enable(True)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 paths = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [2, 3]
 # shapes of the benchmark fit's launches: nr new columns against [ones | model | new | y]
-for nr, nc in ((8, 10), (28, 38), (8, 40), (56, 58), (56, 80), (56, 98), (56, 112), (56, 128), (56, 142), (56, 176), (28, 120),
-               (8, 100), (8, 150)):
+SHAPES = ((8, 10), (28, 38), (8, 40), (56, 58), (56, 80), (56, 98), (56, 112), (56, 128), (56, 142), (56, 176), (28, 120),
+          (8, 100), (8, 150))
+if os.environ.get('K2_SHAPES'):                               # e.g. K2_SHAPES=56x128,8x150
+    SHAPES = tuple(tuple(int(v) for v in item.split('x')) for item in os.environ['K2_SHAPES'].split(','))
+for nr, nc in SHAPES:
     rs = slots[:nr]
     model = slots[nr:nr + nc - nr - 2]
     cs = np.concatenate([[0], model, rs, [1]]).astype(np.int32)
