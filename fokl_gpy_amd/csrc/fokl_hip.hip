@@ -1534,3 +1534,11 @@ extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, i
 #include "fokl_comm.inc"
 #include "fokl_predict.inc"
 #include "fokl_probe.inc"
+
+#ifdef FOKL_GT_STAMP
+// diagnostic build only (tools/k2_clock.sh): the clock stamps of the last gram_tiles_kernel launch
+extern "C" int fokl_debug_stamps_read(unsigned long long *out, int count)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fokl::fokl_debug_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#endif

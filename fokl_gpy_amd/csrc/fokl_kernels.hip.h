@@ -683,6 +683,10 @@ struct GramGroup {
     uint8_t b[GT_MAX_WAVES][GT_MAX_NT];
 };
 
+#ifdef FOKL_GT_STAMP
+__device__ unsigned long long fokl_debug_stamps[8192];
+#endif
+
 template <int NT, int P, int DEPTH, int KS>
 __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const *__restrict__ slot_ptr,
                                                                 const int *__restrict__ icols, int nci,
@@ -773,7 +777,8 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
     // offsets in scalar registers and one VALU add per read, 480 us; pinned with the 2 NT fragment addresses kept in
     // vector registers -- this form -- 407 us (rectangular panels of gram_mfma_kernel: 434 us).  Reading further ahead
     // (6, 10 pairs) changes nothing, and neither does leaving out most of the row-side fragment reads (a timing
-    // experiment: lists whose tiles share their row-side tile would gain nothing): the fp64 MFMA pipe is what is left.
+    // experiment: lists whose tiles share their row-side tile would gain nothing).  The matrix pipe is busy 63 % of this
+    // kernel (80 % with the staging compiled out) where an assembly loop fed from LDS holds it at 100 %: DESIGN.md section 3.
     auto multiply = [&]() {
         for (int s = 0; s < rb; ++s) {
             const double *lds = gt_tile + 32 * s;
@@ -810,6 +815,9 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
     };
 
     int64_t chunk = blockIdx.x;
+#ifdef FOKL_GT_STAMP
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (chunk < n_chunks) issue(stage[0], chunk);
     if (DEPTH == 2 && chunk + stride < n_chunks) issue(stage[DEPTH - 1], chunk + stride);
     while (chunk < n_chunks) {
@@ -827,6 +835,14 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
         }
     }
 
+#ifdef FOKL_GT_STAMP
+    // diagnostic build only (tools/k2_clock.sh; MI355X_MICROARCH.md, DVFS item 6): shader cycles and 100 MHz ticks this
+    // workgroup spent in its loop, to a buffer nothing else reads
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+        fokl_debug_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        fokl_debug_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
     double *out = slab + ((size_t)blockIdx.x * KS + phase) * nr_pad * nc_pad;
     asm volatile("" ::: "memory");                          // the output coordinates are fetched here, not before the loop
 #pragma unroll
@@ -843,11 +859,10 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 // K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 (opt-in: FOKL_GRAM_MFMA4=2)
 // ---------------------------------------------------------------------------------------------------------
 //
-// Measured on this part (tools/mfma_f64_peak.hip, operands in registers, in-kernel clock 2.38 GHz throughout -- it is
-// not a power limit): v_mfma_f64_16x16x4_f64 issues once per ~105 cycles and SIMD, 47-49 TFLOP/s = 0.61 of the
-// 78.6 TFLOP/s the data sheet gives for fp64 matrix work (the busy counter books 64 cycles per instruction: the pipe
-// idles 40 % of the time between two of them); v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks, 512
-// flops) sustains 72-75 TFLOP/s, also with 4 + 4 different operand registers feeding 16 accumulators.  Lane maps of
+// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 blocks, 512 flops; 71-75 TFLOP/s in a C++ loop on register
+// operands (tools/mfma_f64_peak.hip), where the same loop on the 16x16x4 form reads 47-49 -- an artefact of that loop, as
+// it turned out: written in assembly the 16x16x4 form issues every 64 cycles, 78 TFLOP/s (tools/mfma_f64_issue.hip), so
+// the premise of this kernel (a faster instruction) does not hold and neither did its result.  Lane maps of
 // the latter (tools/mfma_f64_4x4_map.hip, by experiment): A[blk][i][k] sits in lane i + 4 blk + 16 k, B[blk][k][j]
 // in lane j + 4 blk + 16 k, D[blk][i][j] in lane j + 4 blk + 16 i.  Here block blk takes the rows blk + 4 k of a
 // group of 16 rows, so one instruction multiplies 4 row-side by 4 column-side columns over 16 rows; a 16 x 16 tile

@@ -1,0 +1,28 @@
+"""Development aid: in-kernel clock of the Gram kernel (diagnostic build with -DFOKL_GT_STAMP, see tools/k2_clock.sh)."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, ROOT)
+from fokl_gpy_amd import _capi, getKernels, engine
+ctx = _capi.DeviceContext(0)
+n, m = 1_000_000, 8
+rng = np.random.default_rng(12)
+x = rng.random((n, m)); y = rng.standard_normal(n)
+packed, nb, width = getKernels.pack_phis(getKernels.bernoulli(), 1)
+ctx.upload(x, y, 1, packed, nb, width)
+ctx.reserve_slots(2 + 200)
+terms = np.vstack([engine.distinct_arrangements(p + [0] * 6) for p in ([2, 1], [1, 1], [3, 2], [4, 3])]).astype(np.int32)
+slots = np.arange(2, 2 + terms.shape[0], dtype=np.int32)
+ctx.build_terms(terms, slots); ctx.sync()
+lib = ctypes.CDLL(_capi.LIB_PATH)
+for nr, nc in ((56, 58), (56, 128), (56, 176), (8, 150)):
+    rs = slots[:nr]; cs = np.concatenate([[0], slots[nr:nc - 2], rs, [1]]).astype(np.int32)
+    for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 200):          # a second or so of back-to-back launches
+        ctx.gram(rs, cs, path=2)
+    st = np.zeros(1024, dtype=np.uint64)
+    assert lib.fokl_debug_stamps_read(st.ctypes.data_as(ctypes.c_void_p), 1024) == 0
+    cyc, ticks = st[0::2].astype(float), st[1::2].astype(float)
+    ok = ticks > 0
+    ghz = cyc[ok] / ticks[ok] * 0.1
+    print(f'gram {nr} x {nc}: in-kernel clock {np.median(ghz):.2f} GHz (median over {ok.sum()} workgroups; min {ghz.min():.2f}, max {ghz.max():.2f}), '
+          f'{np.median(ticks[ok]) / 100:.0f} us per workgroup', flush=True)

@@ -154,6 +154,63 @@ void run_mixed(int waves_per_simd)
     hipFree(out);
 }
 
+// does the 16x16x4 form issue faster when it does not accumulate in place?  MODE 0: D = A B + 0, summed by VALU adds;
+// MODE 1: D = A B + C with D and C different registers (ping-pong)
+template <int MODE>
+__global__ __launch_bounds__(256) void spin_noacc(double *out, int iters, double a0, double b0)
+{
+    d4 acc[8], other[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = other[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    double a = a0 + threadIdx.x * 1e-9, b = b0 + threadIdx.x * 1e-9;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 0) {
+                asm volatile("" : "+v"(a));                   // (not loop invariant)
+                const d4 t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, zero, 0, 0, 0);
+                acc[j] += t;
+            } else if (MODE == 1) {
+                other[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, other[j], 0, 0, 0);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3] + other[j][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run_noacc(int waves_per_simd)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int blocks = prop.multiProcessorCount * waves_per_simd;
+    double *out;
+    hipMalloc(&out, sizeof(double) * 256 * blocks);
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int warm = 0; warm < 10; ++warm) spin_noacc<MODE><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e0);
+    spin_noacc<MODE><<<blocks, 256>>>(out, iters, 1.0, 2.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 2048.0 * 8.0 * (MODE == 0 ? 1 : 2) * iters * 4.0 * blocks;
+    printf("16x16x4, %s, %d wave(s) per SIMD: %.1f TFLOP/s of MFMA work\n",
+           MODE == 0 ? "C = 0 and the sum kept by VALU adds" : "D and C in different registers", waves_per_simd, flops / ms / 1e9);
+    hipFree(out);
+}
+
 template <int ACC>
 void run_4x4(int waves_per_simd)
 {
@@ -235,6 +292,9 @@ int main()
     run_4x4<8>(4);
     run_4x4_tile(1);
     run_4x4_tile(2);
+    run_noacc<0>(2);
+    run_noacc<0>(4);
+    run_noacc<1>(2);
     run_mixed<1>(2);
     run_mixed<2>(2);
     run_mixed<3>(2);
