@@ -889,7 +889,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
 typedef void (*gram_tiles_fn)(double *const *, const int *, int, const GramGroup *, int, int, int64_t, double *, int,
                               int, const double *, const double *);
 
-// Lowest address among the slot chunks and the zero column, if every one of them lies within 2^32 units of 256 bytes
+// Lowest address among the slot chunks and the zero column, if every one of them lies within 2^31 units of 256 bytes
 // above it on that grid (gram_tiles_kernel keeps columns as 32-bit distances); nullptr otherwise.
 static const double *slot_grid_base(fokl_ctx *ctx)
 {
@@ -902,7 +902,7 @@ static const double *slot_grid_base(fokl_ctx *ctx)
     for (double *c : ctx->chunks)
         if ((reinterpret_cast<uintptr_t>(c) - lo) % 256 != 0) return nullptr;
     const uintptr_t span = hi - lo + (uintptr_t)fokl_ctx::CHUNK_SLOTS * ctx->ld * sizeof(double);
-    if ((span >> 8) >= (uintptr_t(1) << 32)) return nullptr;
+    if ((span >> 8) >= (uintptr_t(1) << 31)) return nullptr;          // bit 31 of a distance flags a padding column
     return reinterpret_cast<const double *>(lo);
 }
 
@@ -1042,6 +1042,19 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int kind = env_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
         GramPlan pl;
         plan_gram(row_slots, nr, col_slots, nc, kind, pl);
+        // column addresses for the groups' descriptors (distances on the 256-byte slot grid)
+        {
+            const uintptr_t lo = reinterpret_cast<uintptr_t>(grid_base);
+            const uint32_t zero_units = (uint32_t)((reinterpret_cast<uintptr_t>(ctx->d_zero) - lo) >> 8) | 0x80000000u;
+            for (GramGroup &g : pl.groups)
+                for (int p = 0; p < GT_MAX_CT; ++p)
+                    for (int c = 0; c < 16; ++c) {
+                        const int col = g.ct[p] >= 0 ? 16 * g.ct[p] + c : -1;
+                        g.col_units[p][c] = col >= 0 && col < pl.nci
+                                                ? (uint32_t)((reinterpret_cast<uintptr_t>(ctx->slot_ptr[pl.icols[col]]) - lo) >> 8)
+                                                : zero_units;
+                    }
+        }
         const size_t ints = (size_t)pl.nci + (size_t)nc;
         const size_t group_off = (ints * sizeof(int32_t) + 15) / 16 * 16;
         const size_t arg_bytes = group_off + pl.groups.size() * sizeof(GramGroup);

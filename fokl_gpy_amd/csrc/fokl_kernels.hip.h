@@ -681,6 +681,10 @@ struct GramGroup {
     uint16_t oj[GT_MAX_WAVES][GT_MAX_NT];
     uint8_t a[GT_MAX_WAVES][GT_MAX_NT];        // local indices of the tile's row-side and column-side column tiles
     uint8_t b[GT_MAX_WAVES][GT_MAX_NT];
+    // where every staged column lives, as its distance from the slot grid's base in units of 256 bytes (padding
+    // columns: the zero column, flagged in bit 31) -- filled in by the host, so that a workgroup's prologue is one round of loads instead
+    // of three dependent ones (descriptor -> slot number -> pointer)
+    uint32_t col_units[GT_MAX_CT][16];
 };
 
 #ifdef FOKL_GT_STAMP
@@ -708,24 +712,16 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 
     // staging map: pass q = (column tile p = q >> rb_shift, sub-chunk s = q & (rb - 1)); thread t loads rows
     // 32 s + 2 (t & 15) + {0, 1} of column 16 p + (t >> 4) of the group's list
-    // (two rounds of independent loads -- slot numbers, then column pointers -- instead of a dependent pair per pass).
     // A column is remembered as its distance from `base` in units of 256 bytes: one register per pass instead of two
-    // (the host checks that every slot and the zero column lie on that grid within 2^32 units above base).
+    // (the host checks that every slot and the zero column lie on that grid within 2^32 units above base, and writes the
+    // distances into the group's descriptor: padding columns point at the zero column).
     uint32_t cb[P];
-    uint32_t padding = 0;
-    int slot_of[P];
-#pragma unroll
+    uint32_t padding = 0;                                  // bit q: pass q stages a padding column, which re-reads the first
+#pragma unroll                                             // 16 bytes of the zero column (a cache hit) instead of streaming it
     for (int q = 0; q < P; ++q) {
-        const int ct = q < passes ? g.ct[q >> rb_shift] : -1;
-        const int c = 16 * ct + scol;
-        const bool real = ct >= 0 && c < nci;
-        slot_of[q] = icols[real ? c : 0];
-        if (!real) padding |= 1u << q;
-    }
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const double *ptr = slot_ptr[slot_of[q]];
-        cb[q] = (uint32_t)((((padding >> q) & 1u ? zero_col : ptr) - base) >> 5);
+        const uint32_t u = q < passes ? g.col_units[q >> rb_shift][scol] : 0x80000000u;
+        cb[q] = u & 0x7fffffffu;
+        padding |= (u >> 31) << q;
     }
 
     // fragment addresses: lane part (column fm of a 16-column tile, row fk of a k-step) + the tile's offset
@@ -903,19 +899,11 @@ __global__ __launch_bounds__(G4S_THREADS, 2) void gram_tiles4s_kernel(double *co
 
     uint32_t cb[P];
     uint32_t padding = 0;
-    int slot_of[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int ct = p < ct_count ? g.ct[p] : -1;
-        const int c = 16 * ct + scol;
-        const bool real = ct >= 0 && c < nci;
-        slot_of[p] = icols[real ? c : 0];
-        if (!real) padding |= 1u << p;
-    }
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const double *ptr = slot_ptr[slot_of[p]];
-        cb[p] = (uint32_t)((((padding >> p) & 1u ? zero_col : ptr) - base) >> 5);
+        const uint32_t u = p < ct_count ? g.col_units[p][scol] : 0x80000000u;
+        cb[p] = u & 0x7fffffffu;
+        padding |= (u >> 31) << p;
     }
 
     const int frag = (lane & 3) * pitch + ((lane >> 2) & 3) + 4 * (lane >> 4);

@@ -10,11 +10,14 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void spin(double *out, int iters)
 {
-    __shared__ double lds_buf[2048];
+    __shared__ double lds_buf[4096];
     lds_buf[threadIdx.x] = 1.0 + threadIdx.x;
     lds_buf[threadIdx.x + 256] = 2.0;
     __syncthreads();
-    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds_buf + 8 * (threadIdx.x & 63);
+    // MODE 5: lane-contiguous reads; MODE 6: the Gram kernel's fragment pattern (column lane & 15 of a [column][34] tile, row lane >> 4)
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds_buf +
+                              (MODE == 6 ? 8 * ((lane & 15) * 34 + (lane >> 4)) : 8 * lane);
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0)
             asm volatile(M("v[8:15]", "v[8:15]") M("v[16:23]", "v[16:23]") M("v[24:31]", "v[24:31]") M("v[32:39]", "v[32:39]")
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void spin(double *out, int iters)
                          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
                          "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
                          "v68", "v69", "v70", "v71");
-        if (MODE == 5)          // operands refreshed from LDS before every MFMA, the way the Gram kernel does it
+        if (MODE == 5 || MODE == 6)   // operands refreshed from LDS before every MFMA, the way the Gram kernel does it
             asm volatile("ds_read_b64 v[0:1], %0\n ds_read_b64 v[2:3], %0 offset:512\n s_waitcnt lgkmcnt(2)\n v_mfma_f64_16x16x4_f64 v[8:15], v[72:73], v[74:75], v[8:15]\n"
                          "ds_read_b64 v[72:73], %0 offset:1024\n ds_read_b64 v[74:75], %0 offset:1536\n s_waitcnt lgkmcnt(2)\n v_mfma_f64_16x16x4_f64 v[16:23], v[0:1], v[2:3], v[16:23]\n"
                          "ds_read_b64 v[0:1], %0 offset:2048\n ds_read_b64 v[2:3], %0 offset:2560\n s_waitcnt lgkmcnt(2)\n v_mfma_f64_16x16x4_f64 v[24:31], v[72:73], v[74:75], v[24:31]\n"
@@ -106,6 +109,7 @@ int main()
         run<3>("D != C, accumulation registers:", w);
         run<4>("A, B in the same banks, D = C:", w);
         run<5>("operands from LDS every time:", w);
+        run<6>("... in the Gram fragment pattern:", w);
     }
     return 0;
 }
