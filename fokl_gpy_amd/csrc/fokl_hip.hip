@@ -963,6 +963,19 @@ static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
     }
 }
 
+typedef void (*gram_dma_fn)(const GramGroup *, int, int, int64_t, double *, int, int, const double *, uint32_t);
+
+static gram_dma_fn tiles_dma_kernel(int nt8)
+{
+    switch (nt8) {
+        case 1: return gram_tiles_dma_kernel<1>;
+        case 2: return gram_tiles_dma_kernel<2>;
+        case 3: return gram_tiles_dma_kernel<3>;
+        case 4: return gram_tiles_dma_kernel<4>;
+        default: return gram_tiles_dma_kernel<5>;
+    }
+}
+
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
                               int32_t *icols, int32_t *perm, int32_t *staged, int32_t *tiles, int cap_groups)
 {
@@ -1101,6 +1114,24 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
+        } else if (env_int("FOKL_GRAM_DMA", 1) == 1 && pl.ks == 1 && gram_slot == FOKL_K_GRAM_MFMA) {
+            // the launches the matrix pipe bounds: LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers
+            // (FOKL_GRAM_DMA=0: gram_tiles_kernel for these too)
+            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2);
+            const int pieces = (pl.ct * 16 * 34 * 8 + 1023) / 1024;
+            const size_t lds = 2 * (size_t)pieces * 1024;
+            rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
+            if (rc) return rc;
+            const int64_t n_chunks = (ctx->n + 31) / 32;
+            const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, GD_THREADS, lds));
+            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
+            rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
+            if (rc) return rc;
+            const uint32_t zero_units = (uint32_t)((reinterpret_cast<uintptr_t>(ctx->d_zero) - reinterpret_cast<uintptr_t>(grid_base)) >> 8);
+            TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
+            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GD_THREADS), lds, ctx->stream, d_groups,
+                               pl.ct, pieces, ctx->n, ctx->d_slab, nr_pad, nc_pad, grid_base, zero_units);
         } else {
             gram_tiles_fn fn = tiles_kernel(pl.nt, pl.ct << pl.rb_shift, pl.depth, pl.ks);
             const int R = 32 << pl.rb_shift;

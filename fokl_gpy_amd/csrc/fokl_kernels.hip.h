@@ -852,6 +852,160 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K2c': the tile lists with LDS-DMA staging (global_load_lds_dwordx4) -- for the launches the matrix pipe bounds
+// ---------------------------------------------------------------------------------------------------------
+//
+// gram_tiles_kernel keeps the fp64 matrix pipe busy 63 % of the time: its staging costs every thread some twenty
+// VALU / LDS / VMEM instructions per pass, which share the SIMD's issue slots with the MFMA stream, and two barriers
+// per 32-row chunk.  Here the staging is one instruction per KiB: a wavefront's global_load_lds_dwordx4 moves 64 x 16
+// bytes from 64 per-lane SOURCE addresses to 1 KiB of consecutive LDS -- no staging registers, no ds_write, no row
+// masks.  The LDS image keeps gram_tiles_kernel's layout ([column][34 doubles]: conflict-free fragment reads); as a
+// byte stream it is 256 bytes of column 0, 16 of pad, 256 of column 1, ...: lane L of piece k lands on byte
+// 1024 k + 16 L, so it loads rows 2 j, 2 j + 1 of the column that byte belongs to (pad bytes and padding columns: the
+// first 16 bytes of the zero column).  One workgroup of 8 wavefronts per CU, two LDS buffers, one barrier per chunk:
+// every wavefront issues its share of the next chunk's pieces (one in eight), multiplies the current chunk, waits
+// for its pieces, barrier.  The last chunk of the rows arrives like the others (a column's allocation covers the
+// chunk) and has its rows past the end zeroed in LDS before it is used.  Tile lists as for gram_tiles_kernel, the
+// four lists of a group dealt over eight wavefronts (wavefront w takes every other entry of list w & 3).
+
+constexpr int GD_THREADS = 512;
+constexpr int GD_MAX_PIECES = 9;       // per wavefront: 16 column tiles x 16 columns x 272 bytes / 1 KiB / 8 wavefronts
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef __attribute__((address_space(1))) const void *global_cvoid_ptr;
+
+template <int NT>
+__global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count,
+                                                                       int pieces, int64_t n, double *__restrict__ slab,
+                                                                       int nr_pad, int nc_pad,
+                                                                       const double *__restrict__ base, uint32_t zero_units)
+{
+    extern __shared__ __attribute__((aligned(1024))) double gd_tile[];
+    constexpr int R = 32, pitch = R + 2;
+    const GramGroup &g = groups[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int buf_doubles = pieces * 128;                       // whole KiB pieces per buffer
+    const int64_t n_chunks = (n + R - 1) / R;
+    const int64_t stride = gridDim.x;
+
+    // this lane's part in the pieces its wavefront issues (piece wave, wave + 8, ...): source column and row pair
+    uint32_t units[GD_MAX_PIECES];
+    int rowoff[GD_MAX_PIECES];                                  // first of its two rows within a chunk; -1: no row advance
+#pragma unroll
+    for (int i = 0; i < GD_MAX_PIECES; ++i) {
+        const int piece = wave + 8 * i;
+        const int byte = 1024 * piece + 16 * lane;
+        const int col = byte / (8 * pitch), within = byte % (8 * pitch);
+        uint32_t u = 0x80000000u;                              // (flag: padding, the zero column)
+        if (piece < pieces && col < 16 * ct_count) u = g.col_units[col >> 4][col & 15];
+        const bool pad = (u >> 31) || within >= 8 * R;
+        units[i] = pad ? zero_units : u;
+        rowoff[i] = pad ? -1 : within / 8;
+    }
+    auto issue = [&](int64_t chunk, int buf) {
+        const int64_t row0 = chunk * R;
+#pragma unroll
+        for (int i = 0; i < GD_MAX_PIECES; ++i)
+            if (wave + 8 * i < pieces) {                       // wave-uniform
+                uint32_t u = units[i];
+                asm volatile("" : "+v"(u));
+                const double *src = base + ((size_t)u << 5) + (rowoff[i] < 0 ? 0 : row0 + rowoff[i]);
+                __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src,
+                                                 (lds_void_ptr)(gd_tile + buf * buf_doubles + 128 * (wave + 8 * i)), 16, 0, 0);
+            }
+    };
+
+    // tiles: list w & 3 of the group, every other entry
+    const int fm = lane & 15, fk = lane >> 4;
+    const int frag = fm * pitch + fk;
+    const int row = wave & 3, first = wave >> 2;
+    int aoff[2][NT], boff[2][NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int j = 2 * k + first;
+        const bool have = j < GT_MAX_NT;
+        aoff[0][k] = frag + 16 * (have ? (int)g.a[row][j] : 0) * pitch;
+        boff[0][k] = frag + 16 * (have ? (int)g.b[row][j] : 0) * pitch;
+        aoff[1][k] = aoff[0][k] + buf_doubles;
+        boff[1][k] = boff[0][k] + buf_doubles;
+    }
+    d4 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+    int real_tiles = 0;                                        // lists are packed: real tiles first, padding behind
+#pragma unroll
+    for (int k = 0; k < NT; ++k) real_tiles += (2 * k + first < GT_MAX_NT && g.oi[row][2 * k + first] != 0xFFFF) ? 1 : 0;
+    real_tiles = __builtin_amdgcn_readfirstlane(real_tiles);
+
+    auto multiply = [&](const int (&ao)[NT], const int (&bo)[NT]) {
+        constexpr int STEPS = 8 * NT;
+#ifndef FOKL_GD_AHEAD
+#define FOKL_GD_AHEAD 3
+#endif
+        constexpr int AHEAD = FOKL_GD_AHEAD;
+        double af[AHEAD], bf[AHEAD];
+#pragma unroll
+        for (int t = 0; t < AHEAD && t < STEPS; ++t) {
+            af[t] = gd_tile[ao[t % NT] + 4 * (t / NT)];
+            bf[t] = gd_tile[bo[t % NT] + 4 * (t / NT)];
+        }
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+            const double a = af[t % AHEAD], b = bf[t % AHEAD];
+            const int u = t + AHEAD;
+            if (u < STEPS) {
+                af[t % AHEAD] = gd_tile[ao[u % NT] + 4 * (u / NT)];
+                bf[t % AHEAD] = gd_tile[bo[u % NT] + 4 * (u / NT)];
+            }
+            if (t % NT < real_tiles)                           // wave-uniform: a padding entry costs its reads only (the two
+                acc[t % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t % NT], 0, 0, 0);   // wavefronts of a SIMD share a list)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // rows past the end of the data, in the last chunk: zero them where they landed
+    auto trim = [&](int64_t chunk, int buf) {
+        if (chunk != n_chunks - 1 || n % R == 0) return;
+        const int keep = (int)(n - chunk * R);
+        for (int c = tid; c < 16 * ct_count; c += GD_THREADS)
+            for (int r = keep; r < R; ++r) gd_tile[buf * buf_doubles + c * pitch + r] = 0.0;
+        __syncthreads();
+    };
+    auto one_chunk = [&](int64_t chunk, int buf) {
+        if (chunk + stride < n_chunks) issue(chunk + stride, buf ^ 1);
+        trim(chunk, buf);
+        if (buf == 0) multiply(aoff[0], boff[0]);
+        else multiply(aoff[1], boff[1]);
+        __syncthreads();                                       // (waits for this wavefront's pieces: vmcnt(0), then the barrier)
+    };
+
+    int64_t chunk = blockIdx.x;
+    if (chunk < n_chunks) issue(chunk, 0);
+    __syncthreads();
+    while (chunk < n_chunks) {
+        one_chunk(chunk, 0);
+        chunk += stride;
+        if (chunk >= n_chunks) break;
+        one_chunk(chunk, 1);
+        chunk += stride;
+    }
+
+    double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int j = 2 * k + first;
+        if (j < GT_MAX_NT) {
+            const int oi = g.oi[row][j], oj = g.oj[row][j];
+            if (oi != 0xFFFF) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) out[(size_t)(16 * oi + fk + 4 * v) * nc_pad + 16 * oj + fm] = acc[k][v];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 (opt-in: FOKL_GRAM_MFMA4=2)
 // ---------------------------------------------------------------------------------------------------------
 //

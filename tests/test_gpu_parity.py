@@ -165,10 +165,12 @@ def load_columns(ctx, cols):
         ctx.write_slot(2 + j, cols[:, j])
 
 
-@pytest.mark.parametrize('mfma4', ['default', '2'])                   # 16x16x4 tile lists / the 4x4x4 form (opt-in)
+@pytest.mark.parametrize('mfma4', ['default', '2', 'nodma'])          # default / the 4x4x4 form (opt-in) / no LDS-DMA kernel
 @pytest.mark.parametrize('n', [1, 31, 32, 33, 1000, 4099, 120001])     # the last: workgroups loop over several chunks
 def test_k2_exact_on_integer_data(device_ctx, n, mfma4, monkeypatch):
-    if mfma4 != 'default':
+    if mfma4 == 'nodma':
+        monkeypatch.setenv('FOKL_GRAM_DMA', '0')
+    elif mfma4 != 'default':
         monkeypatch.setenv('FOKL_GRAM_MFMA4', mfma4)
     rng = np.random.default_rng(n)
     upload(device_ctx, rng.random((n, 1)), rng.integers(-3, 4, n).astype(float), O.KERNEL_BERNOULLI)
