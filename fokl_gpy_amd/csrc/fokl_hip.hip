@@ -1114,9 +1114,10 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
-        } else if (env_int("FOKL_GRAM_DMA", 1) == 1 && pl.ks == 1 && gram_slot == FOKL_K_GRAM_MFMA) {
-            // the launches the matrix pipe bounds: LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers
-            // (FOKL_GRAM_DMA=0: gram_tiles_kernel for these too)
+        } else if (pl.ks == 1 && (env_int("FOKL_GRAM_DMA", 2) == 2 ||
+                                  (env_int("FOKL_GRAM_DMA", 2) == 1 && gram_slot == FOKL_K_GRAM_MFMA))) {
+            // LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers: every block of three tiles or more
+            // (FOKL_GRAM_DMA=1: only the launches the matrix pipe bounds, 0: gram_tiles_kernel for everything)
             gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2);
             const int pieces = (pl.ct * 16 * 34 * 8 + 1023) / 1024;
             const size_t lds = 2 * (size_t)pieces * 1024;
