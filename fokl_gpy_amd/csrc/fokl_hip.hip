@@ -965,15 +965,21 @@ static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
 
 typedef void (*gram_dma_fn)(const GramGroup *, int, int, int64_t, double *, int, int, const double *, uint32_t);
 
-static gram_dma_fn tiles_dma_kernel(int nt8)
+template <int NBUF>
+static gram_dma_fn tiles_dma_kernel_b(int nt8)
 {
     switch (nt8) {
-        case 1: return gram_tiles_dma_kernel<1>;
-        case 2: return gram_tiles_dma_kernel<2>;
-        case 3: return gram_tiles_dma_kernel<3>;
-        case 4: return gram_tiles_dma_kernel<4>;
-        default: return gram_tiles_dma_kernel<5>;
+        case 1: return gram_tiles_dma_kernel<1, NBUF>;
+        case 2: return gram_tiles_dma_kernel<2, NBUF>;
+        case 3: return gram_tiles_dma_kernel<3, NBUF>;
+        case 4: return gram_tiles_dma_kernel<4, NBUF>;
+        default: return gram_tiles_dma_kernel<5, NBUF>;
     }
+}
+
+static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf)
+{
+    return nbuf == 3 ? tiles_dma_kernel_b<3>(nt8) : tiles_dma_kernel_b<2>(nt8);
 }
 
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
@@ -1118,9 +1124,12 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
                                   (env_int("FOKL_GRAM_DMA", 2) == 1 && gram_slot == FOKL_K_GRAM_MFMA))) {
             // LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers: every block of three tiles or more
             // (FOKL_GRAM_DMA=1: only the launches the matrix pipe bounds, 0: gram_tiles_kernel for everything)
-            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2);
             const int pieces = (pl.ct * 16 * 34 * 8 + 1023) / 1024;
-            const size_t lds = 2 * (size_t)pieces * 1024;
+            // three LDS buffers (a chunk's pieces in flight across the barrier) where they fit, FOKL_GRAM_BUFS to force
+            int nbuf = env_int("FOKL_GRAM_BUFS", 2);
+            if (nbuf == 3 && 3 * (size_t)pieces * 1024 > 160 * 1024) nbuf = 2;
+            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf);
+            const size_t lds = (size_t)nbuf * pieces * 1024;
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;

@@ -874,7 +874,7 @@ constexpr int GD_MAX_PIECES = 9;       // per wavefront: 16 column tiles x 16 co
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 typedef __attribute__((address_space(1))) const void *global_cvoid_ptr;
 
-template <int NT>
+template <int NT, int NBUF>
 __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count,
                                                                        int pieces, int64_t n, double *__restrict__ slab,
                                                                        int nr_pad, int nc_pad,
@@ -920,15 +920,16 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int fm = lane & 15, fk = lane >> 4;
     const int frag = fm * pitch + fk;
     const int row = wave & 3, first = wave >> 2;
-    int aoff[2][NT], boff[2][NT];
+    int aoff[NBUF][NT], boff[NBUF][NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
         const int j = 2 * k + first;
         const bool have = j < GT_MAX_NT;
-        aoff[0][k] = frag + 16 * (have ? (int)g.a[row][j] : 0) * pitch;
-        boff[0][k] = frag + 16 * (have ? (int)g.b[row][j] : 0) * pitch;
-        aoff[1][k] = aoff[0][k] + buf_doubles;
-        boff[1][k] = boff[0][k] + buf_doubles;
+#pragma unroll
+        for (int bf_ = 0; bf_ < NBUF; ++bf_) {
+            aoff[bf_][k] = frag + 16 * (have ? (int)g.a[row][j] : 0) * pitch + bf_ * buf_doubles;
+            boff[bf_][k] = frag + 16 * (have ? (int)g.b[row][j] : 0) * pitch + bf_ * buf_doubles;
+        }
     }
     d4 acc[NT];
 #pragma unroll
@@ -971,23 +972,77 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
             for (int r = keep; r < R; ++r) gd_tile[buf * buf_doubles + c * pitch + r] = 0.0;
         __syncthreads();
     };
-    auto one_chunk = [&](int64_t chunk, int buf) {
-        if (chunk + stride < n_chunks) issue(chunk + stride, buf ^ 1);
-        trim(chunk, buf);
-        if (buf == 0) multiply(aoff[0], boff[0]);
-        else multiply(aoff[1], boff[1]);
-        __syncthreads();                                       // (waits for this wavefront's pieces: vmcnt(0), then the barrier)
+    // NBUF = 2: the next chunk's pieces are issued, this chunk multiplied, then all pieces waited for and a barrier.
+    // NBUF = 3: the pieces of the chunk after next are issued instead and stay in flight across the barrier -- a counted
+    // s_waitcnt vmcnt(this wavefront's pieces per chunk) retires the older chunk only, and the barrier is a raw s_barrier
+    // (__syncthreads() would drain every LDS-DMA write first).
+    int my_pieces = 0;
+#pragma unroll
+    for (int i = 0; i < GD_MAX_PIECES; ++i) my_pieces += wave + 8 * i < pieces ? 1 : 0;
+    my_pieces = __builtin_amdgcn_readfirstlane(my_pieces);
+    auto wait_all_but_newest = [&](bool newest_in_flight) {
+        if (!newest_in_flight) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        switch (my_pieces) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        }
     };
-
+    auto raw_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     int64_t chunk = blockIdx.x;
-    if (chunk < n_chunks) issue(chunk, 0);
-    __syncthreads();
-    while (chunk < n_chunks) {
-        one_chunk(chunk, 0);
-        chunk += stride;
-        if (chunk >= n_chunks) break;
-        one_chunk(chunk, 1);
-        chunk += stride;
+    if (NBUF == 2) {
+        auto one_chunk = [&](int64_t c, int buf) {
+            if (c + stride < n_chunks) issue(c + stride, buf ^ 1);
+            trim(c, buf);
+            multiply(aoff[buf], boff[buf]);
+            __syncthreads();                                   // (waits for this wavefront's pieces: vmcnt(0), then the barrier)
+        };
+        if (chunk < n_chunks) issue(chunk, 0);
+        __syncthreads();
+        while (chunk < n_chunks) {
+            one_chunk(chunk, 0);
+            chunk += stride;
+            if (chunk >= n_chunks) break;
+            one_chunk(chunk, 1);
+            chunk += stride;
+        }
+    } else {
+        auto one_chunk = [&](int64_t c, int buf) {
+            const bool ahead = c + 2 * stride < n_chunks;
+            if (ahead) issue(c + 2 * stride, (buf + 2) % 3);
+            trim(c, buf);
+            multiply(aoff[buf % NBUF], boff[buf % NBUF]);
+            wait_all_but_newest(ahead);
+            raw_barrier();
+        };
+        if (chunk < n_chunks) issue(chunk, 0);
+        const bool second = chunk + stride < n_chunks;
+        if (second) issue(chunk + stride, 1);
+        wait_all_but_newest(second);
+        raw_barrier();
+        while (chunk < n_chunks) {
+            one_chunk(chunk, 0);
+            chunk += stride;
+            if (chunk >= n_chunks) break;
+            one_chunk(chunk, 1);
+            chunk += stride;
+            if (chunk >= n_chunks) break;
+            one_chunk(chunk, 2);
+            chunk += stride;
+        }
     }
 
     double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
