@@ -2,8 +2,11 @@
 //
 //   K1  basis_build_reg_kernel  fused _inputs_to_phind + evaluate_basis + term products (HBM write bound);
 //       basis_build_kernel      the same with the factor table in LDS (terms with more than 16 factors)
-//   K2a gram_valu_kernel     Gram block with per-thread register tiles + wavefront reductions
-//   K2b gram_mfma_kernel     Gram block on v_mfma_f64_16x16x4_f64 tiles staged through LDS
+//   K2a gram_valu_kernel     Gram block with per-thread register tiles + wavefront reductions (tiny blocks)
+//   K2b gram_mfma_kernel     Gram block on v_mfma_f64_16x16x4_f64 tiles, rectangular panels (round 1; path 3)
+//   K2c gram_tiles_kernel    ... as lists of 16 x 16 tiles, symmetric half skipped, register staging (1-2 tile blocks)
+//       gram_tiles_dma_kernel  the same lists staged by LDS-DMA: what every larger block runs
+//   K2d gram_tiles4s_kernel  the lists on v_mfma_f64_4x4x4 (opt-in, A/B)
 //   K3  resid_kernel         residual moments for the BIC
 //       reduce_slabs_kernel  fixed-order combination of per-workgroup partial sums
 //
