@@ -58,12 +58,41 @@ def analyse(path, which=-1, show=12):
                 print(f"      {(t - a) / 1e3:8.1f} us  {tag} {info}")
 
 
+def cost(path, which=-1, draws=2000):
+    """ns per Gibbs iteration of the recorder by model size, from the tapes that ran to the end (to set beside
+    tools/tape_smt_bench.cpp's stand-alone figures)."""
+    fits, last = [], 'driver'
+    for line in open(path):
+        f = line.split()
+        if f[0] == 'noise' and last == 'driver':
+            fits.append([])
+        last = f[0]
+        if f[0] == 'noise':
+            fits[-1].append(tuple(int(v) for v in f[1:8]))
+    by_p = {}
+    for r in fits[which]:
+        if r[1] > 0 and not (r[5] and r[6] < 0):
+            by_p.setdefault(r[4], []).append((r[2] - r[1]) / draws)
+    print("p1: tapes, ns per iteration (min / median / mean)")
+    tot = cnt = 0
+    for p1 in sorted(by_p):
+        v = sorted(by_p[p1])
+        tot += sum(v)
+        cnt += len(v)
+        print(f"  {p1:4d}: {len(v):3d}  {v[0]:7.1f} {v[len(v) // 2]:7.1f} {sum(v) / len(v):7.1f}")
+    print(f"all: {cnt} tapes, mean {tot / max(cnt, 1):.1f} ns per iteration")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--cost', action='store_true', help='ns per iteration by model size instead of the gap report')
     ap.add_argument('trace')
     ap.add_argument('--fit', type=int, default=-1)
     ap.add_argument('--show', type=int, default=12)
     args = ap.parse_args()
+    if args.cost:
+        cost(args.trace, args.fit)
+        return
     analyse(args.trace, args.fit, args.show)
 
 

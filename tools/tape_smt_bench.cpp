@@ -15,6 +15,36 @@ typedef int (*tape_fn)(int, int, double, double, uint32_t *, int32_t *, int32_t 
                        double *, double *, int32_t *);
 static tape_fn f;
 
+// The same with a fresh set of buffers per tape out of `sets` (sets * ~(12 p + 24) * 2000 bytes: beyond the caches when
+// large, as in a fit, where 379 tapes of a few hundred KB each are written per 84 ms).
+static double run_cold(int cpu, int p, int reps, int sets)
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(cpu, &set);
+    sched_setaffinity(0, sizeof(set), &set);
+    const int D = 2000;
+    std::vector<uint32_t> key(624);
+    for (int i = 0; i < 624; i++) key[i] = i * 2654435761u + 1 + cpu;
+    int32_t pos = 624, hg = 0;
+    double c = 0;
+    struct Bufs { std::vector<double> nm, r2, g1, g2; std::vector<int32_t> lead; };
+    std::vector<Bufs> b(sets);
+    for (auto &x : b) {
+        x.nm.assign((size_t)D * p + 16, 0.0);
+        x.r2.assign((size_t)D * (p / 2 + 1) + 8, 0.0);
+        x.g1.assign(D, 0.0);
+        x.g2.assign(D, 0.0);
+        x.lead.assign(D, 0);
+    }
+    auto t = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; i++) {
+        Bufs &x = b[i % sets];
+        f(p, D, 5e5, 4.0 + (p - 1) / 2.0, key.data(), &pos, &hg, &c, x.nm.data(), x.r2.data(), x.lead.data(), x.g1.data(), x.g2.data(), nullptr);
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count() / reps / D * 1e9;
+}
+
 static double run(int cpu, int p, int reps)
 {
     cpu_set_t set;
@@ -56,6 +86,13 @@ int main(int argc, char **argv)
     int other = -1;
     for (int c = a + 1; c < CPU_SETSIZE && other < 0; ++c) if (CPU_ISSET(c, &mine) && c != s) other = c;
     printf("cpu %d, its sibling %d (siblings list '%s'), another core %d\n", a, s, line.c_str(), other);
+    if (argc > 2 && std::string(argv[2]) == "cold") {
+        for (int p : {2, 10, 19, 28, 38, 47, 60}) {
+            const double warm = run_cold(a, p, 400, 1), cold = run_cold(a, p, 400, 200);
+            printf("p = %3d (tau shape as in a fit): one buffer set %.1f ns per iteration; 200 sets in rotation %.1f\n", p, warm, cold);
+        }
+        return 0;
+    }
     for (int p : {2, 60, 120}) {
         const double alone = run(a, p, 100);
         double r1 = 0, r2v = 0, r3 = 0, r4 = 0;
