@@ -39,6 +39,11 @@ extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 // where only the tape recorder is exported (fokl_record_tape_wide) and chosen at run time -- measured on Zen 5:
 // 151 -> 120 ns per Gibbs iteration at 60 columns.  Same IEEE operations per element either way: identical numbers.
 #define FOKL_INTERNAL extern "C" __attribute__((visibility("hidden")))
+#ifndef FOKL_NO_FORCE_INLINE
+#define FOKL_HOT inline __attribute__((always_inline))
+#else
+#define FOKL_HOT inline
+#endif
 #ifdef FOKL_SAMPLER_WIDE
 #define FOKL_CLONES
 #else
@@ -167,7 +172,7 @@ struct LegacyRng {
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
 
-    inline double next_double()
+    FOKL_HOT double next_double()
     {
         for (;;) {
             if (dbase >= 0) {
@@ -297,7 +302,7 @@ struct LegacyRng {
         }
     }
 
-    inline double gauss_draw()
+    FOKL_HOT double gauss_draw()
     {
         if (has_gauss) {
             const double t = gauss;
@@ -350,7 +355,7 @@ struct LegacyRng {
 
     // numpy's shape > 1 branch with its two constants b = shape - 1/3, c = 1 / sqrt(9 b) computed by the caller
     // (once per tape instead of once per draw: the sqrt and the divide sat on the recorder's serial path)
-    double marsaglia_tsang(const double b, const double c)
+    FOKL_HOT double marsaglia_tsang(const double b, const double c)
     {
         for (;;) {
             double X, V;
@@ -538,22 +543,27 @@ inline void chain_vector_part(const double *lamb, const double *qty, const doubl
 }
 #endif
 
-// fokl_noise_tape's loop (see there).
-void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star, double *normals_out,
-                 double *pair_r2_out, int32_t *lead_out, double *gam_sig_out, double *gam_tau_out, int32_t *progress)
+// fokl_noise_tape's loop (see there).  Kept a function of its own with the two gamma draws inlined into the loop
+// (FOKL_HOT): with marsaglia_tsang called out of line the generator's position and block pointers went through memory
+// on every draw -- 42 + 0.93 p1 ns per iteration against 31 + 0.93 p1 this way (Zen 5, profiles/tape_cost_r02.txt).
+__attribute__((noinline)) void record_tape(LegacyRng &r, int p1, int draws, double astar, double atau_star,
+                                           double *normals_out, double *pair_r2_out, int32_t *lead_out,
+                                           double *gam_sig_out, double *gam_tau_out, int32_t *progress)
 {
     const size_t half = (size_t)p1 / 2 + 1;
     const bool fast_sig = astar > 1.0, fast_tau = atau_star > 1.0;     // always, for the hyper-parameters in use
     const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
     const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
-    for (int k = 0; k < draws; ++k) {
-        fill_normals_raw(r, p1, normals_out + (size_t)k * p1, pair_r2_out + (size_t)k * half, lead_out + k);
-        gam_sig_out[k] = fast_sig ? r.marsaglia_tsang(b_sig, c_sig) : r.std_gamma(astar);
-        gam_tau_out[k] = fast_tau ? r.marsaglia_tsang(b_tau, c_tau) : r.std_gamma(atau_star);
-        // iterations up to k are complete and visible.  Published per block, not per iteration: every store to a
+    for (int k0 = 0; k0 < draws; k0 += FOKL_TAPE_BLOCK) {
+        const int k1 = std::min(draws, k0 + FOKL_TAPE_BLOCK);
+        for (int k = k0; k < k1; ++k) {
+            fill_normals_raw(r, p1, normals_out + (size_t)k * p1, pair_r2_out + (size_t)k * half, lead_out + k);
+            gam_sig_out[k] = fast_sig ? r.marsaglia_tsang(b_sig, c_sig) : r.std_gamma(astar);
+            gam_tau_out[k] = fast_tau ? r.marsaglia_tsang(b_tau, c_tau) : r.std_gamma(atau_star);
+        }
+        // iterations up to k1 are complete and visible.  Published per block, not per iteration: every store to a
         // line that other cores are polling costs this thread a coherence round trip.
-        if (progress && ((k + 1) % FOKL_TAPE_BLOCK == 0 || k + 1 == draws))
-            __atomic_store_n(progress, k + 1, __ATOMIC_RELEASE);
+        if (progress) __atomic_store_n(progress, k1, __ATOMIC_RELEASE);
     }
 }
 
@@ -612,6 +622,7 @@ FOKL_INTERNAL void fokl_record_tape_wide(int p1, int draws, double astar, double
 }
 
 #else
+
 
 FOKL_INTERNAL void fokl_record_tape_wide(int p1, int draws, double astar, double atau_star, uint32_t *mt_key,
                                          int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
