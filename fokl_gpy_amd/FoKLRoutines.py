@@ -17,6 +17,7 @@ unknown keywords must keep raising ``ValueError`` exactly like the reference (FR
 import copy
 import os
 import pickle
+import sys
 import threading
 import time
 import warnings
@@ -126,6 +127,21 @@ _BLAS_LIMIT_USERS = 0
 _BLAS_LIMIT_CTX = None
 
 
+_BLAS_CONTROLLER = (None, None)
+
+
+def _blas_controller():
+    """threadpoolctl looks through every loaded shared library each time a limit is taken (1-2 ms per fit, measured
+    with FOKL_POOL_TRACE); the libraries do not change between fits, so the controller is kept -- and made again when
+    scipy's BLAS has been loaded since."""
+    global _BLAS_CONTROLLER
+    key = ('scipy.linalg' in sys.modules, 'scipy.linalg.cython_lapack' in sys.modules)
+    if _BLAS_CONTROLLER[0] != key:
+        from threadpoolctl import ThreadpoolController
+        _BLAS_CONTROLLER = (key, ThreadpoolController())
+    return _BLAS_CONTROLLER[1]
+
+
 class _host_blas_threads:
     """The per-candidate host algebra is tiny ((P+1)^2 eigenproblems, draws x (P+1) products): a BLAS pool sized for
     a 256-thread host spends more time waking threads than computing, and its spinning workers compete with the
@@ -139,9 +155,8 @@ class _host_blas_threads:
             _BLAS_LIMIT_USERS += 1
             if _BLAS_LIMIT_USERS == 1:
                 try:
-                    from threadpoolctl import threadpool_limits
-                    _BLAS_LIMIT_CTX = threadpool_limits(limits=int(os.environ.get('FOKL_HOST_THREADS', '1')),
-                                                        user_api='blas')
+                    _BLAS_LIMIT_CTX = _blas_controller().limit(limits=int(os.environ.get('FOKL_HOST_THREADS', '1')),
+                                                               user_api='blas')
                 except Exception:
                     _BLAS_LIMIT_CTX = None
         return self
@@ -580,6 +595,7 @@ class FoKL:
         ``rng_state``: a numpy legacy state (``np.random.RandomState(seed).get_state()``) to run the chain from instead
         of numpy's global generator -- fits running side by side on threads cannot share the global one; the state
         after the fit is left in ``self._rng_state_after`` and the global generator is not touched."""
+        _engine._mark('search_begin')
         stream = _capi.LegacyStream(rng_state)
         search = _engine.ForwardSelection(
             backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
@@ -597,6 +613,8 @@ class FoKL:
             self._rng_state_after = stream.as_numpy_state()
         self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0)
         self.fit_trace = search.trace
+        _engine._mark('search_end')
+        _engine._flush_marks()
 
         self.betas = betas
         self.avg_betas = np.mean(self.betas, axis=0)

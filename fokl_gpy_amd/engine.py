@@ -573,6 +573,7 @@ class HostPipeline:
                 job.resolve(False)
         for job in self._live:
             job.wait()
+        _mark('jobs_drained')
         self._reap()                        # buffers of the jobs that have run now go back to the thread's spares
         self._live = []
         busy = self.pool.busy_seconds()
@@ -1241,9 +1242,11 @@ class ForwardSelection:
                 import warnings
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
+        _mark('pool_up')
         try:
             return self._run()
         finally:
+            _mark('run_end')
             if self.host is not None:
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
@@ -1253,6 +1256,7 @@ class ForwardSelection:
                                   spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
                                   spectral_submitted=self.host.spectral_submitted)
                 self.host = None
+                _mark('pool_down')
                 _flush_marks()
 
     def _patterns(self):

@@ -32,6 +32,12 @@ def analyse(path, which=-1, show=12):
     rewound = sum(1 for r in noise if r[5] and r[6] < 0)
     print(f"{len(noise)} tapes recorded ({rewound} of them rewound) over {(t_end - t_begin) / 1e6:.1f} ms; "
           f"recording {sum(r[2] - r[1] for r in noise) / 1e6:.1f} ms")
+    edges = {tag: t for t, tag, _ in driver if tag in ('search_begin', 'run_end', 'search_end')}
+    if 'search_begin' in edges and 'search_end' in edges:
+        print(f"search {(edges['search_end'] - edges['search_begin']) / 1e6:.1f} ms: first recording starts "
+              f"{(t_begin - edges['search_begin']) / 1e6:.2f} ms in, last one ends "
+              f"{(edges['search_end'] - t_end) / 1e6:.2f} ms before the end"
+              + (f" (the search loop itself {(edges['run_end'] - t_end) / 1e6:.2f} ms of them)" if 'run_end' in edges else ''))
     # the recorder is idle between the end of one recording and the start of the next
     gaps = []
     for k in range(1, len(noise)):
