@@ -138,7 +138,8 @@ def gram_plan(row_slots, col_slots, kind=0):
     """fokl_gram_plan: the tile lists fokl_gram's MFMA path would use for this block (host arithmetic, no device);
     kind 0 = gram_tiles_kernel (16x16x4 MFMA; the default), kind 1 = gram_tiles4s_kernel (4x4x4 MFMA; FOKL_GRAM_MFMA4=2).
     -> dict(nci, i_tiles, j_tiles, nt, ct, rows_per_chunk, ks, depth, waves, icols, perm, staged [G, 16],
-            tiles [G, 4, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding))"""
+            tiles [G, 4, 10, 4] = (local row-side tile, local column-side tile, out i-tile, out j-tile; -1: padding),
+            half [G, 4, 10] = entries of a ragged last row tile that gram_tiles_dma_kernel forms with 4x4x4 MFMAs)"""
     rs = np.ascontiguousarray(row_slots, dtype=np.int32)
     cs = np.ascontiguousarray(col_slots, dtype=np.int32)
     info = np.zeros(10, dtype=np.int32)
@@ -152,9 +153,11 @@ def gram_plan(row_slots, col_slots, kind=0):
     tiles = np.empty((groups, 4, 10, 4), dtype=np.int32)
     _check(lib.fokl_gram_plan(_ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0], int(kind), _ptr(info), _ptr(icols),
                               _ptr(perm), _ptr(staged), _ptr(tiles), groups))
+    half = (tiles[..., 0] >= 256) & (tiles[..., 2] >= 0)       # entries the LDS-DMA kernel computes as half tiles
+    tiles[..., 0] &= 255
     return dict(nci=int(info[0]), i_tiles=int(info[1]), j_tiles=int(info[2]), nt=int(info[4]), ct=int(info[5]),
                 rows_per_chunk=32 << int(info[6]), ks=int(info[7]), depth=int(info[8]), waves=int(info[9]), icols=icols,
-                perm=perm, staged=staged, tiles=tiles)
+                perm=perm, staged=staged, tiles=tiles, half=half)
 
 
 class LegacyStream:

@@ -773,6 +773,7 @@ struct GramPlan {
     int nci = 0, it = 0, jt = 0;       // internal columns; i-tiles (row side), j-tiles (all internal columns)
     int nt = 1, ct = 1, ks = 1, rb_shift = 0, depth = 1;
     int kind = 0, waves = 4;           // 0: gram_tiles_kernel (16x16x4 MFMA), 1: gram_tiles4s_kernel (4x4x4 MFMA)
+    bool half = false;                 // entries 0 and 1 of every list are half-tile slots (gram_tiles_dma_kernel<.., true>)
     std::vector<int32_t> icols;        // internal column -> slot: the row-side columns first
     std::vector<int32_t> perm;         // caller's column j -> internal column
     std::vector<GramGroup> groups;
@@ -786,7 +787,8 @@ static int env_int(const char *name, int fallback)
 
 // Internal column order, tile groups and kernel parameters for an nr x nc block (see gram_tiles_kernel).  Pure host
 // arithmetic: fokl_gram_plan exposes it to the CPU tests, which replay the lists with numpy.
-static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, GramPlan &pl)
+static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, GramPlan &pl,
+                      bool allow_half = false)
 {
     pl.kind = kind;
     pl.waves = 4;
@@ -864,7 +866,23 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
     while (kind == 0 && (pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
     pl.depth = kind == 0 && pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 1))) : 1;
 
+    // Half-tile slots (gram_tiles_dma_kernel<NT, NBUF, true>): when 1 .. 8 of the 16 columns of the last row tile are
+    // row-side columns, a tile of that row tile costs the matrix pipe half a tile if it is formed as 8 x 16.  Entries 0
+    // and 1 of every list then are half-tile slots (one per wavefront; empty where there is nothing for them), the
+    // ordinary tiles follow from entry 2 and go to the list with the least work so far (ordinary tile = 2, half = 1).
+    // Only if every group keeps within 8 ordinary entries per list; the caller says whether the kernel is the one to run.
+    // (not for a single row tile: such blocks are HBM-bound and only pay for the extra slot: 8 x 40 measured 57 -> 65 us)
+    const int ragged = allow_half && kind == 0 && pl.ks == 1 && pl.it >= 2 && nr % 16 >= 1 && nr % 16 <= 8 ? pl.it - 1 : -1;
+    const int normal_cap = GT_MAX_NT - 2;
+    pl.half = ragged >= 0;
+    for (const Cut &c : cuts) {
+        int rag = 0;
+        for (auto &t : c.tiles) rag += t.first == ragged ? 1 : 0;
+        const int full = (int)c.tiles.size() - std::min(rag, 2 * teams);
+        if (full > teams * normal_cap) pl.half = false;
+    }
     pl.groups.resize(cuts.size());
+    int most_normal = 1;
     for (size_t gi = 0; gi < cuts.size(); ++gi) {
         const Cut &c = cuts[gi];
         GramGroup &g = pl.groups[gi];
@@ -872,8 +890,32 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
         for (int p = 0; p < GT_MAX_CT; ++p) g.ct[p] = p < (int)c.staged.size() ? c.staged[p] : -1;
         for (int w = 0; w < GT_MAX_WAVES; ++w)
             for (int k = 0; k < GT_MAX_NT; ++k) g.oi[w][k] = g.oj[w][k] = 0xFFFF;
-        for (int t = 0; t < (int)c.tiles.size(); ++t) {
-            const int team = t % teams, k = t / teams;
+        const int T = (int)c.tiles.size();
+        std::vector<std::pair<int, int>> place(T);               // tile -> (team, entry)
+        if (pl.half) {
+            int len[GT_MAX_WAVES] = {0, 0, 0, 0}, load[GT_MAX_WAVES] = {0, 0, 0, 0}, halves = 0;
+            std::vector<char> done(T, 0);
+            for (int t = 0; t < T && halves < 2 * teams; ++t)
+                if (c.tiles[t].first == ragged) {
+                    place[t] = {halves % teams, halves / teams};
+                    load[halves % teams] += 1;
+                    done[t] = 1;
+                    ++halves;
+                }
+            for (int t = 0; t < T; ++t) {
+                if (done[t]) continue;
+                int team = -1;
+                for (int w = 0; w < teams; ++w)
+                    if (len[w] < normal_cap && (team < 0 || load[w] < load[team])) team = w;
+                place[t] = {team, 2 + len[team]++};
+                load[team] += 2;
+            }
+            for (int w = 0; w < teams; ++w) most_normal = std::max(most_normal, len[w]);
+        } else {
+            for (int t = 0; t < T; ++t) place[t] = {t % teams, t / teams};
+        }
+        for (int t = 0; t < T; ++t) {
+            const int team = place[t].first, k = place[t].second;
             const int a = (int)(std::lower_bound(c.staged.begin(), c.staged.end(), c.tiles[t].first) - c.staged.begin());
             const int b = (int)(std::lower_bound(c.staged.begin(), c.staged.end(), c.tiles[t].second) - c.staged.begin());
             for (int w = team * pl.ks; w < (team + 1) * pl.ks; ++w) {
@@ -884,6 +926,7 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
             }
         }
     }
+    if (pl.half) pl.nt = most_normal;                            // ordinary entries per list (the kernel adds the slots)
 }
 
 typedef void (*gram_tiles_fn)(double *const *, const int *, int, const GramGroup *, int, int, int64_t, double *, int,
@@ -965,21 +1008,36 @@ static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
 
 typedef void (*gram_dma_fn)(const GramGroup *, int, int, int64_t, double *, int, int, const double *, uint32_t);
 
+// nt8: ordinary tiles per wavefront (1 .. 5; with half-tile slots 1 .. 4 + the slot)
 template <int NBUF>
-static gram_dma_fn tiles_dma_kernel_b(int nt8)
+static gram_dma_fn tiles_dma_kernel_b(int nt8, bool half)
 {
+    if (half) {
+        switch (nt8) {
+            case 1: return gram_tiles_dma_kernel<1, NBUF, true>;
+            case 2: return gram_tiles_dma_kernel<2, NBUF, true>;
+            case 3: return gram_tiles_dma_kernel<3, NBUF, true>;
+            default: return gram_tiles_dma_kernel<4, NBUF, true>;
+        }
+    }
     switch (nt8) {
-        case 1: return gram_tiles_dma_kernel<1, NBUF>;
-        case 2: return gram_tiles_dma_kernel<2, NBUF>;
-        case 3: return gram_tiles_dma_kernel<3, NBUF>;
-        case 4: return gram_tiles_dma_kernel<4, NBUF>;
-        default: return gram_tiles_dma_kernel<5, NBUF>;
+        case 1: return gram_tiles_dma_kernel<1, NBUF, false>;
+        case 2: return gram_tiles_dma_kernel<2, NBUF, false>;
+        case 3: return gram_tiles_dma_kernel<3, NBUF, false>;
+        case 4: return gram_tiles_dma_kernel<4, NBUF, false>;
+        default: return gram_tiles_dma_kernel<5, NBUF, false>;
     }
 }
 
-static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf)
+static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf, bool half)
 {
-    return nbuf == 3 ? tiles_dma_kernel_b<3>(nt8) : tiles_dma_kernel_b<2>(nt8);
+    return nbuf == 3 ? tiles_dma_kernel_b<3>(nt8, half) : tiles_dma_kernel_b<2>(nt8, half);
+}
+
+// Half-tile slots need the LDS-DMA kernel: asked for only where it runs every block (the default), FOKL_GRAM_HALF=0 for A/B
+static bool half_slots_wanted()
+{
+    return env_int("FOKL_GRAM_DMA", 2) == 2 && env_int("FOKL_GRAM_MFMA4", 0) != 2 && env_int("FOKL_GRAM_HALF", 1) != 0;
 }
 
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
@@ -988,7 +1046,7 @@ extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *c
     if (!row_slots || !col_slots || !info || nr <= 0 || nc <= 0 || kind < 0 || kind > 1)
         return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_plan: bad argument");
     GramPlan pl;
-    plan_gram(row_slots, nr, col_slots, nc, kind, pl);
+    plan_gram(row_slots, nr, col_slots, nc, kind, pl, half_slots_wanted());
     const int32_t head[10] = {pl.nci, pl.it, pl.jt, (int32_t)pl.groups.size(), pl.nt, pl.ct, pl.rb_shift, pl.ks, pl.depth,
                               pl.waves};
     std::memcpy(info, head, sizeof(head));
@@ -1002,7 +1060,7 @@ extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *c
             for (int w = 0; w < GT_MAX_WAVES; ++w)
                 for (int k = 0; k < GT_MAX_NT; ++k) {
                     int32_t *t = tiles + ((gi * GT_MAX_WAVES + w) * GT_MAX_NT + k) * 4;
-                    t[0] = g.a[w][k];
+                    t[0] = g.a[w][k] | (pl.half && k < 2 && g.oi[w][k] != 0xFFFF ? 256 : 0);   // + 256: in a half-tile slot
                     t[1] = g.b[w][k];
                     t[2] = g.oi[w][k] == 0xFFFF ? -1 : g.oi[w][k];
                     t[3] = g.oj[w][k] == 0xFFFF ? -1 : g.oj[w][k];
@@ -1060,7 +1118,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         // FOKL_GRAM_MFMA4=2: the 4x4x4 form of the fp64 MFMA instruction (A/B runs; slower beyond the smallest blocks)
         const int kind = env_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
         GramPlan pl;
-        plan_gram(row_slots, nr, col_slots, nc, kind, pl);
+        plan_gram(row_slots, nr, col_slots, nc, kind, pl, half_slots_wanted());
         // column addresses for the groups' descriptors (distances on the 256-byte slot grid)
         {
             const uintptr_t lo = reinterpret_cast<uintptr_t>(grid_base);
@@ -1128,7 +1186,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             // three LDS buffers (a chunk's pieces in flight across the barrier) where they fit, FOKL_GRAM_BUFS to force
             int nbuf = env_int("FOKL_GRAM_BUFS", 2);
             if (nbuf == 3 && 3 * (size_t)pieces * 1024 > 160 * 1024) nbuf = 2;
-            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf);
+            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half);
             const size_t lds = (size_t)nbuf * pieces * 1024;
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;

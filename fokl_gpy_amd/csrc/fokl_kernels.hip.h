@@ -5,7 +5,8 @@
 //   K2a gram_valu_kernel     Gram block with per-thread register tiles + wavefront reductions (tiny blocks)
 //   K2b gram_mfma_kernel     Gram block on v_mfma_f64_16x16x4_f64 tiles, rectangular panels (round 1; path 3)
 //   K2c gram_tiles_kernel    ... as lists of 16 x 16 tiles, symmetric half skipped, register staging (1-2 tile blocks)
-//       gram_tiles_dma_kernel  the same lists staged by LDS-DMA: what every larger block runs
+//       gram_tiles_dma_kernel  the same lists staged by LDS-DMA: what every larger block runs (HALF: + one 8 x 16
+//                              half tile per wavefront on v_mfma_f64_4x4x4_4b_f64, for a ragged last row tile)
 //   K2d gram_tiles4s_kernel  the lists on v_mfma_f64_4x4x4 (opt-in, A/B)
 //   K3  resid_kernel         residual moments for the BIC
 //       reduce_slabs_kernel  fixed-order combination of per-workgroup partial sums
@@ -869,7 +870,8 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
 // every wavefront issues its share of the next chunk's pieces (one in eight), multiplies the current chunk, waits
 // for its pieces, barrier.  The last chunk of the rows arrives like the others (a column's allocation covers the
 // chunk) and has its rows past the end zeroed in LDS before it is used.  Tile lists as for gram_tiles_kernel, the
-// four lists of a group dealt over eight wavefronts (wavefront w takes every other entry of list w & 3).
+// four lists of a group dealt over eight wavefronts (wavefront w takes every other entry of list w & 3).  HALF: entries 0
+// and 1 of every list are half-tile slots (see below), the ordinary entries start at 2.
 
 constexpr int GD_THREADS = 512;
 constexpr int GD_MAX_PIECES = 9;       // per wavefront: 16 column tiles x 16 columns x 272 bytes / 1 KiB / 8 wavefronts
@@ -877,7 +879,7 @@ constexpr int GD_MAX_PIECES = 9;       // per wavefront: 16 column tiles x 16 co
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 typedef __attribute__((address_space(1))) const void *global_cvoid_ptr;
 
-template <int NT, int NBUF>
+template <int NT, int NBUF, bool HALF>
 __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count,
                                                                        int pieces, int64_t n, double *__restrict__ slab,
                                                                        int nr_pad, int nc_pad,
@@ -923,10 +925,11 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int fm = lane & 15, fk = lane >> 4;
     const int frag = fm * pitch + fk;
     const int row = wave & 3, first = wave >> 2;
+    constexpr int E0 = HALF ? 2 : 0;                           // first ordinary entry of a list
     int aoff[NBUF][NT], boff[NBUF][NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        const int j = 2 * k + first;
+        const int j = E0 + 2 * k + first;
         const bool have = j < GT_MAX_NT;
 #pragma unroll
         for (int bf_ = 0; bf_ < NBUF; ++bf_) {
@@ -939,33 +942,64 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     for (int k = 0; k < NT; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
     int real_tiles = 0;                                        // lists are packed: real tiles first, padding behind
 #pragma unroll
-    for (int k = 0; k < NT; ++k) real_tiles += (2 * k + first < GT_MAX_NT && g.oi[row][2 * k + first] != 0xFFFF) ? 1 : 0;
+    for (int k = 0; k < NT; ++k)
+        real_tiles += (E0 + 2 * k + first < GT_MAX_NT && g.oi[row][E0 + 2 * k + first] != 0xFFFF) ? 1 : 0;
     real_tiles = __builtin_amdgcn_readfirstlane(real_tiles);
+    // HALF: entry `first` of the list is this wavefront's half tile -- a tile of the ragged last row tile, of which only
+    // rows 0 .. 7 are asked for.  Per k-step two v_mfma_f64_4x4x4_4b_f64 (16 cycles each, where the 16x16x4 form takes
+    // 64): D_blk[i][j] += sum_k A[4 q + i][k] B[k][4 blk + j] for q = 0, 1 -- the four blocks share the row-side operand
+    // (lane i + 4 blk + 16 k reads column 4 q + i, row k of the staged tile), the ordinary column-side fragment is their
+    // four operands side by side, and lane j + 4 blk + 16 i ends up with row 4 q + i, column 4 blk + j of the tile.
+    int hoff[NBUF][2] = {}, hboff[NBUF] = {};
+    double hacc[2] = {0.0, 0.0};
+    const bool half_real = HALF && __builtin_amdgcn_readfirstlane((int)g.oi[row][first]) != 0xFFFF;
+    if (HALF) {
+#pragma unroll
+        for (int bf_ = 0; bf_ < NBUF; ++bf_) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                hoff[bf_][q] = (16 * (half_real ? (int)g.a[row][first] : 0) + 4 * q + (lane & 3)) * pitch + fk + bf_ * buf_doubles;
+            hboff[bf_] = frag + 16 * (half_real ? (int)g.b[row][first] : 0) * pitch + bf_ * buf_doubles;
+        }
+    }
 
-    auto multiply = [&](const int (&ao)[NT], const int (&bo)[NT]) {
-        constexpr int STEPS = 8 * NT;
+    auto multiply = [&](const int (&ao)[NT], const int (&bo)[NT], const int (&ho)[2], const int hb) {
+        constexpr int W = NT + (HALF ? 1 : 0);                 // MFMA steps per k-step: the half tile first
+        constexpr int STEPS = 8 * W;
 #ifndef FOKL_GD_AHEAD
 #define FOKL_GD_AHEAD 3
 #endif
         constexpr int AHEAD = FOKL_GD_AHEAD;
-        double af[AHEAD], bf[AHEAD];
+        double af[AHEAD], bf[AHEAD], cf[HALF ? AHEAD : 1];
+#define FOKL_GD_FETCH(u)                                                                                   \
+    do {                                                                                                   \
+        if (HALF && (u) % W == 0) {                                                                        \
+            af[(u) % AHEAD] = gd_tile[ho[0] + 4 * ((u) / W)];                                              \
+            cf[HALF ? (u) % AHEAD : 0] = gd_tile[ho[1] + 4 * ((u) / W)];                                   \
+            bf[(u) % AHEAD] = gd_tile[hb + 4 * ((u) / W)];                                                 \
+        } else {                                                                                           \
+            af[(u) % AHEAD] = gd_tile[ao[(u) % W - (HALF ? 1 : 0)] + 4 * ((u) / W)];                       \
+            bf[(u) % AHEAD] = gd_tile[bo[(u) % W - (HALF ? 1 : 0)] + 4 * ((u) / W)];                       \
+        }                                                                                                  \
+    } while (0)
 #pragma unroll
-        for (int t = 0; t < AHEAD && t < STEPS; ++t) {
-            af[t] = gd_tile[ao[t % NT] + 4 * (t / NT)];
-            bf[t] = gd_tile[bo[t % NT] + 4 * (t / NT)];
-        }
+        for (int t = 0; t < AHEAD && t < STEPS; ++t) FOKL_GD_FETCH(t);
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
-            const double a = af[t % AHEAD], b = bf[t % AHEAD];
-            const int u = t + AHEAD;
-            if (u < STEPS) {
-                af[t % AHEAD] = gd_tile[ao[u % NT] + 4 * (u / NT)];
-                bf[t % AHEAD] = gd_tile[bo[u % NT] + 4 * (u / NT)];
+            const double a = af[t % AHEAD], b = bf[t % AHEAD], c = cf[HALF ? t % AHEAD : 0];
+            if (t + AHEAD < STEPS) FOKL_GD_FETCH(t + AHEAD);
+            if (HALF && t % W == 0) {
+                if (half_real) {                               // wave-uniform
+                    hacc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, hacc[0], 0, 0, 0);
+                    hacc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(c, b, hacc[1], 0, 0, 0);
+                }
+            } else if (t % W - (HALF ? 1 : 0) < real_tiles) {  // wave-uniform: a padding entry costs its reads only (the two
+                acc[t % W - (HALF ? 1 : 0)] =                  // wavefronts of a SIMD share a list)
+                    __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t % W - (HALF ? 1 : 0)], 0, 0, 0);
             }
-            if (t % NT < real_tiles)                           // wave-uniform: a padding entry costs its reads only (the two
-                acc[t % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t % NT], 0, 0, 0);   // wavefronts of a SIMD share a list)
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef FOKL_GD_FETCH
     };
     // rows past the end of the data, in the last chunk: zero them where they landed
     auto trim = [&](int64_t chunk, int buf) {
@@ -1010,7 +1044,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         auto one_chunk = [&](int64_t c, int buf) {
             if (c + stride < n_chunks) issue(c + stride, buf ^ 1);
             trim(c, buf);
-            multiply(aoff[buf], boff[buf]);
+            multiply(aoff[buf], boff[buf], hoff[buf], hboff[buf]);
             __syncthreads();                                   // (waits for this wavefront's pieces: vmcnt(0), then the barrier)
         };
         if (chunk < n_chunks) issue(chunk, 0);
@@ -1027,7 +1061,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
             const bool ahead = c + 2 * stride < n_chunks;
             if (ahead) issue(c + 2 * stride, (buf + 2) % 3);
             trim(c, buf);
-            multiply(aoff[buf % NBUF], boff[buf % NBUF]);
+            multiply(aoff[buf % NBUF], boff[buf % NBUF], hoff[buf % NBUF], hboff[buf % NBUF]);
             wait_all_but_newest(ahead);
             raw_barrier();
         };
@@ -1050,9 +1084,14 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
 
     double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
     asm volatile("" ::: "memory");
+    if (half_real) {                                           // rows 4 q + fk of the tile; its rows 8 .. 15 are nobody's
+        const int oi = g.oi[row][first], oj = g.oj[row][first];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) out[(size_t)(16 * oi + 4 * q + fk) * nc_pad + 16 * oj + fm] = hacc[q];
+    }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        const int j = 2 * k + first;
+        const int j = E0 + 2 * k + first;
         if (j < GT_MAX_NT) {
             const int oi = g.oi[row][j], oj = g.oj[row][j];
             if (oi != 0xFFFF) {

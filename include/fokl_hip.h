@@ -146,7 +146,8 @@ int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count);
  * log2(sub-chunks of 32 rows per chunk), wavefronts per tile KS, chunks in flight, wavefronts per workgroup}.  With
  * cap_groups >= groups also: icols[internal columns] (internal column -> slot: the row-side columns first), perm[nc]
  * (caller's column -> internal column), staged[groups][16] (column tile staged at each local index, -1 = none) and
- * tiles[groups][4 wavefronts][10][4] = {local row-side tile, local column-side tile, output i-tile, output j-tile}
+ * tiles[groups][4 wavefronts][10][4] = {local row-side tile (+ 256: a tile of a ragged last row tile that the LDS-DMA
+ * kernel forms as an 8 x 16 half tile; only entries 0 and 1 of a list), local column-side tile, output i-tile, output j-tile}
  * with -1, -1 for padding entries.  Any of the four may be NULL.
  */
 int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,

@@ -16,7 +16,7 @@ def replay(cols, rs, cs, kind=0):
     pl = _capi.gram_plan(rs, cs, kind)
     ks, IT, JT, nci = pl['ks'], pl['i_tiles'], pl['j_tiles'], pl['nci']
     assert pl['rows_per_chunk'] in (32, 64, 128, 256, 512) and pl['ct'] * pl['rows_per_chunk'] // 32 <= 16
-    assert 1 <= pl['nt'] <= (4 if kind else 10) and 1 <= pl['ct'] <= (8 if kind else 16)
+    assert 1 <= pl['nt'] <= (4 if kind else 8 if pl['half'].any() else 10) and 1 <= pl['ct'] <= (8 if kind else 16)
     assert ks in (1, 2, 4) and (ks == 1 or pl['nt'] == 1) and pl['waves'] == 4 and (ks == 1 or not kind)
     assert np.array_equal(pl['icols'][:len(rs)], rs)
     X = np.zeros((n, 16 * JT))
@@ -33,11 +33,19 @@ def replay(cols, rs, cs, kind=0):
                 if oi < 0:
                     assert 0 <= a < pl['ct'] and 0 <= b < pl['ct']        # padding tiles still read valid LDS
                     continue
-                assert k < pl['nt'] and st[a] == oi and st[b] == oj and oj >= oi
+                half_slots = bool(pl['half'].any())                       # entries 0, 1 of every list: half-tile slots
+                assert st[a] == oi and st[b] == oj and oj >= oi and (k - 2 if half_slots else k) < pl['nt']
                 phase = w % ks
                 assert (oi, oj, phase) not in written
                 written.add((oi, oj, phase))
                 sel = ((rows % 32) // 4) % ks == phase                    # the k-steps this wavefront multiplies
+                if pl['half'][g, w, k]:
+                    # formed as an 8 x 16 half tile: only where rows 8 .. 15 of the tile are nobody's (they stay NaN here)
+                    assert k < 2 and oi == IT - 1 and 1 <= len(rs) % 16 <= 8 and ks == 1 and not kind
+                    slab[phase, 16 * oi:16 * oi + 8, 16 * oj:16 * oj + 16] = \
+                        X[sel][:, 16 * oi:16 * oi + 8].T @ X[sel][:, 16 * oj:16 * oj + 16]
+                    continue
+                assert not (half_slots and k < 2)
                 slab[phase, 16 * oi:16 * oi + 16, 16 * oj:16 * oj + 16] = \
                     X[sel][:, 16 * oi:16 * oi + 16].T @ X[sel][:, 16 * oj:16 * oj + 16]
     total = slab.sum(axis=0)
@@ -80,9 +88,16 @@ def test_symmetric_part_is_computed_once_and_work_is_balanced():
     cs = np.concatenate([[0], np.arange(200, 318), rs, [1]]).astype(np.int32)
     pl = _capi.gram_plan(rs, cs)
     real = pl['tiles'][..., 2] >= 0
-    assert pl['i_tiles'] == 4 and pl['j_tiles'] == 11 and int(real.sum()) == 38 and pl['nt'] == 10
+    assert pl['i_tiles'] == 4 and pl['j_tiles'] == 11 and int(real.sum()) == 38
     per_wave = real.sum(axis=2)
     assert per_wave.max() - per_wave.min() <= 1
+    # its last row tile holds 8 of the 56 columns: the 8 tiles of that row sit in the half-tile slots (entries 0 and 1 of
+    # the four lists; half the matrix-pipe time each in gram_tiles_dma_kernel), the 30 others follow from entry 2 -- 8 of
+    # them per list at most -- and the lists carry 9, 9, 8, 8 tiles' worth of work where plain dealing gives 10, 10, 9, 9
+    assert int(pl['half'].sum()) == 8 and np.all(pl['half'][0, :, :2]) and np.all(pl['tiles'][0, :, :2, 2] == 3)
+    assert pl['nt'] == 8 and not pl['half'][0, :, 2:].any()
+    work = 2 * real.sum(axis=2) - pl['half'].sum(axis=2)
+    assert sorted(work[0].tolist()) == [16, 16, 18, 18]
     # the same block for the 4x4x4 kernel: 16 tiles per group at most, lists packed (the kernel skips the MFMAs of
     # padding entries by counting the real ones)
     p4 = _capi.gram_plan(rs, cs, kind=1)
