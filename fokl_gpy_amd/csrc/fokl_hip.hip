@@ -1647,8 +1647,8 @@ extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, i
 #include "fokl_predict.inc"
 #include "fokl_probe.inc"
 
-#ifdef FOKL_GT_STAMP
-// diagnostic build only (tools/k2_clock.sh): the clock stamps of the last gram_tiles_kernel launch
+#if defined(FOKL_GT_STAMP) || defined(FOKL_GD_STAMP)
+// diagnostic builds only (tools/k2_clock.sh, tools/k2_phases.sh): the clock stamps of the last Gram launch
 extern "C" int fokl_debug_stamps_read(unsigned long long *out, int count)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fokl::fokl_debug_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;

@@ -691,7 +691,7 @@ struct GramGroup {
     uint32_t col_units[GT_MAX_CT][16];
 };
 
-#ifdef FOKL_GT_STAMP
+#if defined(FOKL_GT_STAMP) || defined(FOKL_GD_STAMP)
 __device__ unsigned long long fokl_debug_stamps[8192];
 #endif
 
@@ -879,6 +879,15 @@ constexpr int GD_MAX_PIECES = 9;       // per wavefront: 16 column tiles x 16 co
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 typedef __attribute__((address_space(1))) const void *global_cvoid_ptr;
 
+#ifndef FOKL_GD_SPREAD
+#define FOKL_GD_SPREAD 1               // 0: the pieces of the next chunk in one burst at the head of a chunk (A/B builds)
+#endif
+#ifndef FOKL_GD_SPREAD_EVERY
+#define FOKL_GD_SPREAD_FIRST 1         // piece i goes out after MFMA step FIRST + EVERY * i of the chunk
+#define FOKL_GD_SPREAD_EVERY 1
+#endif
+
+
 template <int NT, int NBUF, bool HALF>
 __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count,
                                                                        int pieces, int64_t n, double *__restrict__ slab,
@@ -908,17 +917,20 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         units[i] = pad ? zero_units : u;
         rowoff[i] = pad ? -1 : within / 8;
     }
+#define FOKL_GD_ISSUE_PIECE(i, row0, buf)                                                                   \
+    do {                                                                                                   \
+        if (wave + 8 * (i) < pieces) {                         /* wave-uniform */                          \
+            uint32_t u_ = units[i];                                                                        \
+            asm volatile("" : "+v"(u_));                                                                   \
+            const double *src_ = base + ((size_t)u_ << 5) + (rowoff[i] < 0 ? 0 : (row0) + rowoff[i]);      \
+            __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src_,                                       \
+                                             (lds_void_ptr)(gd_tile + (buf) * buf_doubles + 128 * (wave + 8 * (i))), 16, 0, 0); \
+        }                                                                                                  \
+    } while (0)
     auto issue = [&](int64_t chunk, int buf) {
         const int64_t row0 = chunk * R;
 #pragma unroll
-        for (int i = 0; i < GD_MAX_PIECES; ++i)
-            if (wave + 8 * i < pieces) {                       // wave-uniform
-                uint32_t u = units[i];
-                asm volatile("" : "+v"(u));
-                const double *src = base + ((size_t)u << 5) + (rowoff[i] < 0 ? 0 : row0 + rowoff[i]);
-                __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src,
-                                                 (lds_void_ptr)(gd_tile + buf * buf_doubles + 128 * (wave + 8 * i)), 16, 0, 0);
-            }
+        for (int i = 0; i < GD_MAX_PIECES; ++i) FOKL_GD_ISSUE_PIECE(i, row0, buf);
     };
 
     // tiles: list w & 3 of the group, every other entry
@@ -926,6 +938,9 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int frag = fm * pitch + fk;
     const int row = wave & 3, first = wave >> 2;
     constexpr int E0 = HALF ? 2 : 0;                           // first ordinary entry of a list
+    // the next chunk's pieces issued among the MFMA steps (below) where a chunk has 24 steps or more; shorter loops leave
+    // the pieces too little time to land (8 x 40: 56 -> 65 us with the spread issue, 56 x 176: 338 -> 325 us)
+    constexpr bool SPREAD = FOKL_GD_SPREAD != 0 && 8 * (NT + (HALF ? 1 : 0)) >= 24;
     int aoff[NBUF][NT], boff[NBUF][NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
@@ -963,7 +978,13 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         }
     }
 
-    auto multiply = [&](const int (&ao)[NT], const int (&bo)[NT], const int (&ho)[2], const int hb) {
+    // The pieces of a later chunk are issued from INSIDE the loop, one per MFMA step from step 1 on: issued in a burst at
+    // the head of the chunk they cost every wavefront ~ 200 cycles apiece -- a fifth to a quarter of the chunk, the DMA
+    // itself never being waited for (tools/k2_phases.sh) -- among MFMAs a little of that overlaps: 2-4 % on the 56-row
+    // blocks.  (Not kept: only the second wavefront of every SIMD issuing, so that the first never stalls: 10-25 % slower.)
+    // next_buf < 0: nothing to issue.
+    auto multiply = [&](const int (&ao)[NT], const int (&bo)[NT], const int (&ho)[2], const int hb, const int64_t next_row0,
+                        const int next_buf) {
         constexpr int W = NT + (HALF ? 1 : 0);                 // MFMA steps per k-step: the half tile first
         constexpr int STEPS = 8 * W;
 #ifndef FOKL_GD_AHEAD
@@ -996,6 +1017,12 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
             } else if (t % W - (HALF ? 1 : 0) < real_tiles) {  // wave-uniform: a padding entry costs its reads only (the two
                 acc[t % W - (HALF ? 1 : 0)] =                  // wavefronts of a SIMD share a list)
                     __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t % W - (HALF ? 1 : 0)], 0, 0, 0);
+            }
+            if (SPREAD && next_buf >= 0) {                     // wave-uniform
+#pragma unroll
+                for (int i = 0; i < GD_MAX_PIECES; ++i)
+                    if (t == (FOKL_GD_SPREAD_FIRST + FOKL_GD_SPREAD_EVERY * i < STEPS ? FOKL_GD_SPREAD_FIRST + FOKL_GD_SPREAD_EVERY * i : STEPS - 1))
+                        FOKL_GD_ISSUE_PIECE(i, next_row0, next_buf);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1040,12 +1067,36 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         __builtin_amdgcn_s_barrier();
     };
     int64_t chunk = blockIdx.x;
+#ifdef FOKL_GD_STAMP
+    // diagnostic build only (tools/k2_phases.sh): shader cycles of wavefronts 0 and 7 in the four phases of a chunk
+    unsigned long long ph_issue = 0, ph_mult = 0, ph_wait = 0, ph_bar = 0;
+#define FOKL_GD_NOW() __builtin_amdgcn_s_memtime()
+#endif
     if (NBUF == 2) {
         auto one_chunk = [&](int64_t c, int buf) {
-            if (c + stride < n_chunks) issue(c + stride, buf ^ 1);
+#ifdef FOKL_GD_STAMP
+            const unsigned long long t0 = FOKL_GD_NOW();
+#endif
+            const bool more = c + stride < n_chunks;
+            if (!SPREAD && more) issue(c + stride, buf ^ 1);
+#ifdef FOKL_GD_STAMP
+            const unsigned long long t1 = FOKL_GD_NOW();
+#endif
             trim(c, buf);
-            multiply(aoff[buf], boff[buf], hoff[buf], hboff[buf]);
+            multiply(aoff[buf], boff[buf], hoff[buf], hboff[buf], (c + stride) * R, more ? buf ^ 1 : -1);
+#ifdef FOKL_GD_STAMP
+            const unsigned long long t2 = FOKL_GD_NOW();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t3 = FOKL_GD_NOW();
+#endif
             __syncthreads();                                   // (waits for this wavefront's pieces: vmcnt(0), then the barrier)
+#ifdef FOKL_GD_STAMP
+            const unsigned long long t4 = FOKL_GD_NOW();
+            ph_issue += t1 - t0;
+            ph_mult += t2 - t1;
+            ph_wait += t3 - t2;
+            ph_bar += t4 - t3;
+#endif
         };
         if (chunk < n_chunks) issue(chunk, 0);
         __syncthreads();
@@ -1059,9 +1110,10 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     } else {
         auto one_chunk = [&](int64_t c, int buf) {
             const bool ahead = c + 2 * stride < n_chunks;
-            if (ahead) issue(c + 2 * stride, (buf + 2) % 3);
+            if (!SPREAD && ahead) issue(c + 2 * stride, (buf + 2) % 3);
             trim(c, buf);
-            multiply(aoff[buf % NBUF], boff[buf % NBUF], hoff[buf % NBUF], hboff[buf % NBUF]);
+            multiply(aoff[buf % NBUF], boff[buf % NBUF], hoff[buf % NBUF], hboff[buf % NBUF], (c + 2 * stride) * R,
+                     ahead ? (buf + 2) % 3 : -1);
             wait_all_but_newest(ahead);
             raw_barrier();
         };
@@ -1082,6 +1134,15 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         }
     }
 
+#ifdef FOKL_GD_STAMP
+    if (lane == 0 && (wave == 0 || wave == 7) && blockIdx.y == 0 && blockIdx.x < 512) {
+        unsigned long long *st = fokl_debug_stamps + 8 * blockIdx.x + (wave == 7 ? 4 : 0);
+        st[0] = ph_issue;
+        st[1] = ph_mult;
+        st[2] = ph_wait;
+        st[3] = ph_bar;
+    }
+#endif
     double *out = slab + (size_t)blockIdx.x * nr_pad * nc_pad;
     asm volatile("" ::: "memory");
     if (half_real) {                                           // rows 4 q + fk of the tile; its rows 8 .. 15 are nobody's
