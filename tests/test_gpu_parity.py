@@ -197,7 +197,7 @@ def test_k2_exact_on_integer_data(device_ctx, n, mfma4, monkeypatch):
     assert g[0, 0] == n and g[0, 1] == y.sum() and g[1, 1] == y @ y and g[0, 2] == cols[:, 0].sum()
 
 
-def test_k2_paths_agree_and_are_reproducible(device_ctx):
+def test_k2_paths_agree_and_are_reproducible(device_ctx, monkeypatch):
     rng = np.random.default_rng(9)
     n = 50000
     upload(device_ctx, rng.random((n, 1)), rng.standard_normal(n), O.KERNEL_BERNOULLI)
@@ -213,6 +213,13 @@ def test_k2_paths_agree_and_are_reproducible(device_ctx):
     assert np.max(np.abs(g1 - want) / scale) < 1e-13 and np.max(np.abs(g2 - want) / scale) < 1e-13
     assert np.array_equal(g2, device_ctx.gram(rs, cs, path=2))          # fixed-order reduction: bitwise repeatable
     assert np.array_equal(g1, device_ctx.gram(rs, cs, path=1))
+    # the 56 row-side columns leave a ragged last row tile: its tiles are formed as 8 x 16 half tiles on the 4x4x4 MFMA
+    # (half-tile slots) -- same products, same order of summation per element, the same bits as whole tiles
+    assert _capi.gram_plan(rs, cs)['half'].sum() > 0
+    monkeypatch.setenv('FOKL_GRAM_HALF', '0')
+    assert _capi.gram_plan(rs, cs)['half'].sum() == 0
+    assert np.array_equal(g2, device_ctx.gram(rs, cs, path=2))
+    monkeypatch.delenv('FOKL_GRAM_HALF')
     # the launch / fetch pair returns the blocking call's block whatever is launched in between (other Gram blocks and
     # residual passes use other result buffers); a launch drops a block that was never fetched
     auto = device_ctx.gram(rs, cs)
