@@ -21,6 +21,45 @@ FIT_CASES = ['bern_m1', 'bern_m3', 'bern_m3_gimmie_tol1', 'bern_m4_way3', 'bern_
              'testdata10_default', 'testdata10_changed', 'splines_m4', 'sigmoid_splines']
 
 
+def host_fingerprint():
+    """Behavioural fingerprint of the numerical stack underneath the reference: BLAS ``dot``, LAPACK ``eigh`` (values AND
+    eigenvector signs), libm ``pow`` / ``log`` -- the third-party arithmetic of SURVEY 8(c).  Fixtures made by importing
+    the reference store the fingerprint of the host that made them (``host_fingerprint`` in the .npz,
+    tests/golden/make_golden.py); a test may ask for the reference's numbers bit for bit only where the two agree --
+    the reference's own tests are same-host regressions too (/root/reference/test/test_FoKL.py:42-56).  Sizes cover the
+    fixtures' (N up to 2 000 rows, up to 75 columns) so that a BLAS whose blocking depends on its thread count shows up."""
+    import hashlib
+    import scipy.linalg
+    h = hashlib.sha256()
+    rng = np.random.default_rng(20240229)
+    for n, p in ((10, 6), (300, 24), (441, 50), (1500, 45), (2000, 75)):
+        A = rng.random((n, p))
+        A[:, 0] = 1.0
+        y = rng.random((n, 1))
+        G = np.dot(A.T, A)
+        lam, Q = scipy.linalg.eigh(G)
+        for part in (G, np.dot(A.T, y), lam, Q, np.dot(A, Q[:, -1])):
+            h.update(np.ascontiguousarray(part).tobytes())
+    x = rng.random(4096)
+    for k in (2, 3, 7, 20):
+        h.update((x ** k).tobytes())
+        h.update(np.array([float(v) ** k for v in x[:256]]).tobytes())
+    h.update(np.log(x).tobytes())
+    return h.hexdigest()[:16]
+
+
+_FINGERPRINT = []
+
+
+def same_host_as(fixture):
+    """True when this host reproduces the numerical stack of the host that generated ``fixture`` (an open .npz)."""
+    if 'host_fingerprint' not in getattr(fixture, 'files', ()):
+        return False
+    if not _FINGERPRINT:
+        _FINGERPRINT.append(host_fingerprint())
+    return str(fixture['host_fingerprint']) == _FINGERPRINT[0]
+
+
 def load_case(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     hy = dict(zip([str(k) for k in g['hyper_keys']], [float(v) for v in g['hyper_vals']]))

@@ -1,16 +1,18 @@
 """Pins the oracle (oracle/fokl_oracle.py + oracle_c.c) to the REAL reference through the committed fixtures.
 
 The fixtures under tests/golden/ were produced by importing /root/reference/src in the build container
-(tests/golden/make_golden.py).  The oracle restates the reference operation for operation, so on the same
-numpy / scipy / glibc it must reproduce the fixtures exactly (differences of a few ulp are tolerated only
-for outputs that pass through BLAS, whose blocking may depend on the host).
+(tests/golden/make_golden.py).  The oracle restates the reference operation for operation: on the host
+that made a fixture (same BLAS / LAPACK / libm behaviour, ``helpers.host_fingerprint``, stored in the .npz) it must
+return the reference's numbers to the last bits, for the untouched reference and for the sign-canonical one; on any
+other host the sign-canonical fixtures hold to SURVEY 8(c)'s tolerances and the untouched ones as far as no decision
+depended on an eigenvector sign.  Every case runs by default (about a minute).
 """
 import os
 
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, load_case
+from helpers import GOLDEN, load_case, same_host_as
 from oracle import fokl_oracle as O
 from fokl_gpy_amd import getKernels
 
@@ -100,30 +102,86 @@ def test_indvec_progression():
 # full fits: oracle == reference (both the untouched reference and the sign-canonical variant)
 # ---------------------------------------------------------------------------------------------------------
 
-FAST = ['bern_m1', 'bern_m3_gimmie_tol1', 'bern_m3', 'bern_m4_way3']
-SLOW = ['bern_m8_capped', 'bern_m6', 'testdata10_default', 'testdata10_changed', 'splines_m4', 'sigmoid_splines']
-CASES = FAST + (SLOW if os.environ.get('FOKL_SLOW_TESTS') else [])
+CASES = ['bern_m1', 'bern_m3_gimmie_tol1', 'bern_m3', 'bern_m4_way3', 'bern_m8_capped', 'bern_m6', 'testdata10_default',
+         'testdata10_changed', 'splines_m4', 'sigmoid_splines']
+# The reference's 10-row dataset saturates (columns >= rows) after 7 sub-stages: beyond that its numbers are the
+# rounding noise of its BLAS; parity is asserted up to that point on any other host.
+SATURATES_AFTER = {'testdata10_default': 7, 'testdata10_changed': 7}
 
 
-@pytest.mark.parametrize('variant', ['canon', 'ref'])
+def scaled_gram_error(got, want):
+    """Largest element difference of two Gram matrices in units of sqrt(diag_i * diag_j): an element that is small by
+    cancellation carries the rounding of its summands, which is what a different BLAS blocking changes."""
+    d = np.sqrt(np.abs(np.diag(want)))
+    return np.max(np.abs(got - want) / np.outer(d, d))
+
+
+def first_parting(g):
+    """Index of the first sub-stage where the fixture's untouched and sign-canonical reference runs part ways (a kill
+    test decided differently because an eigenvector came out with the other sign); len(evs) if they never do."""
+    r, c = g['ref_evs'], g['canon_evs']
+    k = min(len(r), len(c))
+    apart = np.nonzero(np.abs(r[:k] - c[:k]) > 1e-9 * np.abs(c[:k]))[0]
+    return int(apart[0]) if len(apart) else k
+
+
 @pytest.mark.parametrize('name', CASES)
-def test_oracle_fit_reproduces_reference(name, variant):
-    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
-        pytest.skip('fixture not generated')
+def test_oracle_fit_reproduces_the_sign_canonical_reference(name):
+    """SURVEY 8(c)'s tolerances, valid on any host: model and call sequence exact, BIC 1e-9 relative, draws 1e-9 of the
+    column scale (1e-6 on the sigmoid grid, whose design has a degenerate spectrum), numpy's stream exact, Gram matrices
+    1e-13 of sqrt(diag x diag).  On the host that made the fixture (same BLAS / LAPACK / libm behaviour,
+    helpers.host_fingerprint) the oracle must ALSO return the reference's numbers to the last bits."""
     g, hy, kname, kid, phis = load_case(name)
-    eig = O.eigh_canonical if variant == 'canon' else O.eigh_reference
     trace = []
     np.random.seed(int(g['seed']))
-    betas, mtx, evs = O.fit(g[variant + '_norm_inputs'], g[variant + '_norm_data'], phis, kid, eigh=eig, trace=trace,
+    betas, mtx, evs = O.fit(g['canon_norm_inputs'], g['canon_norm_data'], phis, kid, eigh=O.eigh_canonical, trace=trace,
                             **hy)
-    assert mtx.shape == g[variant + '_mtx'].shape and np.array_equal(mtx, g[variant + '_mtx'])
-    assert np.allclose(evs, g[variant + '_evs'], rtol=1e-12, atol=0)
-    gb = g[variant + '_betas']
-    assert np.max(np.abs(betas - gb)) <= 1e-10 * np.max(np.abs(gb))
-    assert [t['cols'] for t in trace] == g[variant + '_gibbs_sizes'].tolist()
-    for i in range(int(g[variant + '_n_xtx'])):
-        ref_xtx = g[f'{variant}_xtx_{i}']
-        assert np.allclose(trace[i]['xtx'], ref_xtx, rtol=1e-13, atol=0)
+    st = np.random.get_state()
+    strict = same_host_as(g)
+    upto = len(g['canon_evs']) if strict else SATURATES_AFTER.get(name, len(g['canon_evs']))
+    assert np.max(np.abs(evs[:upto] - g['canon_evs'][:upto]) / np.abs(g['canon_evs'][:upto])) <= 1e-9
+    if upto < len(g['canon_evs']):
+        return                                            # saturated design: nothing beyond this point is defined
+    assert mtx.shape == g['canon_mtx'].shape and np.array_equal(mtx, g['canon_mtx'])
+    assert len(evs) == len(g['canon_evs'])
+    assert [t['cols'] for t in trace] == g['canon_gibbs_sizes'].tolist()
+    gb = g['canon_betas']
+    err = np.max(np.abs(betas - gb) / np.max(np.abs(gb), axis=0))
+    assert err <= (1e-6 if name == 'sigmoid_splines' else 1e-9)
+    assert st[2] == int(g['canon_rng_after_fit'][1]) and st[3] == int(g['canon_rng_after_fit'][2])
+    for i in range(int(g['canon_n_xtx'])):
+        assert scaled_gram_error(trace[i]['xtx'], g[f'canon_xtx_{i}']) <= 1e-13
+    if strict:
+        assert np.allclose(evs, g['canon_evs'], rtol=1e-13, atol=0)
+        assert np.max(np.abs(betas - gb)) <= 1e-12 * np.max(np.abs(gb))
+        for i in range(int(g['canon_n_xtx'])):
+            assert np.array_equal(trace[i]['xtx'], g[f'canon_xtx_{i}'])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_oracle_fit_reproduces_the_untouched_reference(name):
+    """The untouched reference's kill tests hinge on LAPACK's eigenvector signs, i.e. on the host's library build: its
+    numbers are reproducible on the host that made the fixture and nowhere else (the real reference, re-run elsewhere,
+    leaves its own fixture at the same sub-stage the oracle does).  Same host: everything, to the last bits.  Another
+    host: the BIC trace up to the first sub-stage where the fixture's untouched and sign-canonical runs part -- up to
+    there no decision depended on a sign -- then a skip that says so."""
+    g, hy, kname, kid, phis = load_case(name)
+    trace = []
+    np.random.seed(int(g['seed']))
+    betas, mtx, evs = O.fit(g['ref_norm_inputs'], g['ref_norm_data'], phis, kid, eigh=O.eigh_reference, trace=trace, **hy)
+    if same_host_as(g):
+        assert mtx.shape == g['ref_mtx'].shape and np.array_equal(mtx, g['ref_mtx'])
+        assert np.allclose(evs, g['ref_evs'], rtol=1e-13, atol=0)
+        assert np.max(np.abs(betas - g['ref_betas'])) <= 1e-12 * np.max(np.abs(g['ref_betas']))
+        assert [t['cols'] for t in trace] == g['ref_gibbs_sizes'].tolist()
+        for i in range(int(g['ref_n_xtx'])):
+            assert np.array_equal(trace[i]['xtx'], g[f'ref_xtx_{i}'])
+        return
+    k = min(first_parting(g), SATURATES_AFTER.get(name, 1 << 30), len(evs))
+    assert k >= 1 and np.max(np.abs(evs[:k] - g['ref_evs'][:k]) / np.abs(g['ref_evs'][:k])) <= 1e-9
+    made_on = str(g['host_fingerprint']) if 'host_fingerprint' in g.files else 'unrecorded'
+    pytest.skip(f"fixture made on a host with another BLAS / LAPACK build ({made_on}): BIC trace equal "
+                f"over the {k} sign-independent sub-stages, the rest of the untouched reference is host-specific")
 
 
 def test_reference_itself_depends_on_eigenvector_signs():
