@@ -1501,6 +1501,13 @@ class ForwardSelection:
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx
         out_betas = betas.betas[-self.draws_keep::, :]
+        lamb = np.sort(np.asarray(getattr(betas, 'lamb', ()), dtype=np.float64))
+        if lamb.shape[0] > 1:
+            # conditioning of the returned model's eigenproblem: betas = w Q', and an eigenvector moves by about
+            # eps ||XtX|| / gap under a rounding-level change of XtX -- what the draws' distance to another
+            # implementation's is made of (tools/draw_margin.py)
+            self.stats.update(final_cond=float(lamb[-1] / lamb[0]),
+                              final_eps_norm_over_gap=float(2.220446049250313e-16 * lamb[-1] / np.min(np.diff(lamb))))
         return out_betas, np.array(mtx, dtype=np.float64), evs
 
 

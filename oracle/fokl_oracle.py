@@ -261,12 +261,16 @@ class GibbsResult:
 
 
 def gibbs(inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, draws, phind, xsm, sigsqd, tausqd, dtd,
-          eigh=eigh_reference, build=build_columns_c):
+          eigh=eigh_reference, build=build_columns_c, timing=None):
     """
     One model evaluation (FR:1396-1558): build the missing columns of X (F3), XtX / Xty (G1, FR:1492-1494),
     spectral least squares (G2, FR:1499-1505), ``draws`` Gibbs iterations (G3, FR:1519-1548) and the
     BIC (G4, FR:1551-1554).  Consumes numpy's global legacy RNG exactly like the reference.
+    ``timing`` (optional dict, bench.py's CPU baseline): seconds spent in the parts whose cost grows with the number
+    of rows (``rows_s``: X-build, XtX / Xty, residual pass) and in the parts that do not (``chain_s``: eigh + sampler).
     """
+    import time as _time
+    _t0 = _time.perf_counter()
     n_obs = inputs.shape[0]
     discmtx = np.atleast_2d(discmtx)
     mmtx = discmtx.shape[0]
@@ -282,6 +286,7 @@ def gibbs(inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, draws, phi
     XtX = np.transpose(X).dot(X)
     Xty = np.transpose(X).dot(data)
 
+    _t1 = _time.perf_counter()
     lamb, Q = eigh(XtX)
     betahat = Q.dot(np.diag(1 / lamb)).dot(np.transpose(Q)).dot(Xty)
 
@@ -312,9 +317,13 @@ def gibbs(inputs, data, phis, kernel, Xin, discmtx, a, b, atau, btau, draws, phi
         tausqd = 1 / np.random.gamma(atau_star, 1 / btau_star)
         taus[k] = tausqd
 
+    _t2 = _time.perf_counter()
     siglik = np.var(data - np.matmul(X, betahat))
     lik = -(n / 2) * np.log(siglik) - (n - 1) / 2
     ev = (mmtx + 1) * np.log(n) - 2 * np.max(lik)
+    if timing is not None:
+        timing['rows_s'] = timing.get('rows_s', 0.0) + (_t1 - _t0) + (_time.perf_counter() - _t2)
+        timing['chain_s'] = timing.get('chain_s', 0.0) + (_t2 - _t1)
 
     res = GibbsResult()
     res.betas, res.sigs, res.taus, res.betahat = betas, sigs, taus, betahat
