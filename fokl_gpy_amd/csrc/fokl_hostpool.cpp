@@ -13,6 +13,7 @@
 //            so the driver may submit them speculatively for models it might evaluate next.
 //
 // Buffers named in a job belong to the caller and must stay alive until fokl_pool_wait returned for that job.
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <chrono>
@@ -109,6 +110,9 @@ struct fokl_host_pool {
     // tentative; verdict), appended when the pool is destroyed -- tools/pool_trace.py lines it up with the driver's log
     std::string trace_path;
     std::vector<std::array<int64_t, 7>> trace;
+    // FOKL_POOL_TEST_DELAY_US (tests only): the noise thread sleeps this long between looking at the verdicts of its open
+    // tapes and taking the next request -- the window in which a driver can send tapes back and queue a new one
+    int test_delay_us = 0;
 };
 
 namespace {
@@ -362,34 +366,35 @@ void noise_worker(fokl_host_pool *pool)
         trace_noise(pool, job, now_ns());
         settle(job);
     };
-    for (;;) {
-        // verdicts that can be acted on
-        while (!open.empty()) {
-            const int oldest = open.front().job->verdict.load(std::memory_order_acquire);
-            if (oldest > 0) {
-                fokl_host_job *job = open.front().job;
-                open.pop_front();
-                trace_noise(pool, job, now_ns());
-                settle(job);
-                continue;
-            }
-            if (oldest < 0) {
-                restore_stream(pool, open.front().at_start);
-                for (auto &sp : open) aborted(sp.job);
-                open.clear();
-                break;
-            }
-            if (open.back().job->verdict.load(std::memory_order_acquire) < 0) {
-                restore_stream(pool, open.back().at_start);
-                aborted(open.back().job);
-                open.pop_back();
-                continue;
-            }
-            break;
+    auto first_aborted = [&]() -> size_t {
+        size_t i = 0;
+        while (i < open.size() && open[i].job->verdict.load(std::memory_order_acquire) >= 0) ++i;
+        return i;
+    };
+    auto settle_verdicts = [&] {
+        while (!open.empty() && open.front().job->verdict.load(std::memory_order_acquire) > 0) {
+            fokl_host_job *job = open.front().job;
+            open.pop_front();
+            trace_noise(pool, job, now_ns());
+            settle(job);
         }
+        const size_t cut = first_aborted();
+        if (cut < open.size()) {
+            restore_stream(pool, open[cut].at_start);
+            for (size_t k = cut; k < open.size(); ++k) aborted(open[k].job);
+            open.erase(open.begin() + (std::ptrdiff_t)cut, open.end());
+        }
+    };
+    for (;;) {
+        // verdicts that can be acted on: commits from the old end; an abort ANYWHERE takes that tape and every younger
+        // one with it (the caller resolves those to "abort" as well -- it sends its orders back youngest first) and puts
+        // the stream back where the oldest aborted tape began
+        settle_verdicts();
+        if (pool->test_delay_us > 0)                        // tests: widen the window between the verdicts and the queue
+            std::this_thread::sleep_for(std::chrono::microseconds(pool->test_delay_us));
         // the next request, if it can be served now
         fokl_host_job *job = nullptr;
-        bool stopping = false;
+        bool stopping = false, must_settle = false;
         {
             std::unique_lock<std::mutex> lock(queue->m);
             if (open.empty()) {
@@ -403,19 +408,25 @@ void noise_worker(fokl_host_pool *pool)
             stopping = queue->stop;
             if (!queue->q.empty()) {
                 fokl_host_job *next = queue->q.front();
-                if (open.empty() || (next->tentative && open.size() < kMaxSpeculation)) {
+                // A request that was queued AFTER the driver sent tapes back must not be recorded behind those tapes
+                // (its content would be what the stream serves after them, not after the rewind).  Taking the queue's
+                // mutex makes the verdicts stored before that submit visible here: look again before recording
+                // anything behind what is open, and let the verdict step rewind first.
+                if (!open.empty() && first_aborted() < open.size())
+                    must_settle = true;
+                else if (open.empty() || (next->tentative && open.size() < kMaxSpeculation)) {
                     job = next;
                     queue->q.pop_front();
                 }
             }
         }
+        if (must_settle) continue;
         if (!job) {
             // something speculative is open and nothing can be recorded behind it: its verdict is what comes next
             (void)stopping;
             const auto w0 = std::chrono::steady_clock::now();
             auto settled = [&] {
-                return open.front().job->verdict.load(std::memory_order_acquire) != 0 ||
-                       open.back().job->verdict.load(std::memory_order_acquire) < 0;
+                return open.front().job->verdict.load(std::memory_order_acquire) > 0 || first_aborted() < open.size();
             };
             auto more = [&] {
                 if (open.size() >= kMaxSpeculation) return false;
@@ -493,6 +504,7 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
     pool->has_gauss = has_gauss;
     pool->gauss_cache = gauss_cache;
     if (const char *path = std::getenv("FOKL_POOL_TRACE")) pool->trace_path = path;
+    if (const char *us = std::getenv("FOKL_POOL_TEST_DELAY_US")) pool->test_delay_us = std::max(0, std::atoi(us));
     try {
         pool->threads.emplace_back(noise_worker, pool);
         if (noise_cpu >= 0 && noise_cpu < CPU_SETSIZE) {

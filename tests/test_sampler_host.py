@@ -321,6 +321,43 @@ def test_pool_nested_tentative_tapes_settle_from_both_ends():
         assert s_pool.has_gauss.value == s_ref.has_gauss.value and s_pool.cache.value == s_ref.cache.value
 
 
+def test_pool_request_queued_after_sending_tapes_back_starts_at_the_rewound_stream(monkeypatch):
+    """The driver sends the youngest tapes on order back (C, then B) and at once orders another one (D), while the noise
+    thread sits between its look at the verdicts and its look at the queue (FOKL_POOL_TEST_DELAY_US holds it there):
+    D must be recorded where the stream stands after the rewind -- behind A -- not behind the tapes that are aborted but
+    not rewound yet.  (Round-2 review: the thread recorded D behind C, restored the stream later and reported D as
+    aborted: 'tape producer failed' on a tape the driver held as valid.)"""
+    import time
+    monkeypatch.setenv('FOKL_POOL_TEST_DELAY_US', '30000')
+    for trial in range(3):
+        np.random.seed(100 + trial)
+        s_pool, s_ref = _capi.LegacyStream(), _capi.LegacyStream()
+        pool = _capi.HostPool(s_pool, 1, 0, 0)
+        a, b, c = (pool.submit_noise(_capi.NoiseTape(p, 60), 40.0 + p, 6.0, tentative=True) for p in (7, 11, 12))
+        deadline = time.time() + 10.0
+        while c.result.progress[0] < 60 and time.time() < deadline:      # all three recorded, no verdict yet
+            time.sleep(0.0002)
+        assert c.result.progress[0] == 60
+        time.sleep(0.005)                                                # the thread has looked at the verdicts: inside its delay
+        c.resolve(False)
+        b.resolve(False)
+        d = pool.submit_noise(_capi.NoiseTape(9, 60), 44.0, 5.0, tentative=True)
+        time.sleep(0.08)                                                 # ... and picks D up with B and C still open
+        a.resolve(True)
+        d.resolve(True)
+        for job in (a, b, c, d):
+            job.wait()
+        assert b.result.progress[0] == -1 and c.result.progress[0] == -1
+        assert a.result.progress[0] == 60 and d.result.progress[0] == 60, "the tape ordered after the rewind was lost"
+        for job, (p, a1, a2) in ((a, (7, 47.0, 6.0)), (d, (9, 44.0, 5.0))):
+            want = _capi.noise_tape(p, 60, a1, a2, s_ref)
+            assert np.array_equal(job.result.normals, want.normals) and np.array_equal(job.result.lead, want.lead)
+            assert np.array_equal(job.result.gam_sig, want.gam_sig) and np.array_equal(job.result.gam_tau, want.gam_tau)
+        pool.close()
+        assert np.array_equal(s_pool.key, s_ref.key) and s_pool.pos.value == s_ref.pos.value
+        assert s_pool.has_gauss.value == s_ref.has_gauss.value and s_pool.cache.value == s_ref.cache.value
+
+
 def test_pool_spectral_job_is_scipy_eigh_and_rejects_bad_indices():
     import scipy.linalg
     rng = np.random.default_rng(5)
