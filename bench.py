@@ -396,9 +396,23 @@ def device_of(local):
     than ranks) wraps the ranks round the devices there are -- RCCL then refuses to initialise (two ranks on one device) and
     independent fits carry on over the TCP control plane."""
     if os.environ.get('FOKL_BENCH_SHARE_GPU', '0') == '1':
-        from fokl_gpy_amd import _capi
-        return local % max(1, _capi.device_count())
+        return local % max(1, visible_device_count())
     return local
+
+
+def visible_device_count():
+    """Number of GPUs of this box WITHOUT initialising the HIP runtime in this process (worker processes are started
+    before the parent touches the GPU): FOKL_BENCH_DEVICES if set, the visible-devices lists, else the render nodes the
+    amdgpu driver exposes."""
+    if os.environ.get('FOKL_BENCH_DEVICES'):
+        return int(os.environ['FOKL_BENCH_DEVICES'])
+    for name in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'):
+        if os.environ.get(name):
+            return len([v for v in os.environ[name].split(',') if v.strip()])
+    try:
+        return len([d for d in os.listdir('/dev/dri') if d.startswith('renderD')]) or 1
+    except OSError:
+        return 1
 
 
 def bring_up_comm(ctx, rank, world, use_rccl, need_rccl):

@@ -79,6 +79,9 @@ SIGNATURES = {
     'fokl_comm_unique_id': (c_int, [c_vp]),
     'fokl_comm_init': (c_int, [c_vp, c_vp, c_int, c_int]),
     'fokl_comm_destroy': (c_int, [c_vp]),
+    'fokl_comm_init_detached': (c_int, [c_int, c_vp, c_int, c_int, ctypes.POINTER(c_vp)]),
+    'fokl_comm_adopt': (c_int, [c_vp, c_vp, c_int, c_int]),
+    'fokl_comm_release_detached': (c_int, [c_vp]),
     'fokl_comm_allgather_f64': (c_int, [c_vp, c_vp, c_int, c_vp]),
     'fokl_comm_allreduce_sum_f64': (c_int, [c_vp, c_vp, c_int]),
 }
@@ -659,6 +662,21 @@ class DeviceContext:
 
     def comm_destroy(self):
         self._ck(self._lib.fokl_comm_destroy(self._h))
+
+    @staticmethod
+    def comm_init_detached(device, unique_id, rank, world):
+        """ncclCommInitRank without a context (fokl_comm_init_detached) -> opaque communicator for comm_adopt."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        comm = c_vp(0)
+        _check(load().fokl_comm_init_detached(int(device), buf, int(rank), int(world), ctypes.byref(comm)))
+        return comm
+
+    def comm_adopt(self, comm, rank, world):
+        self._ck(self._lib.fokl_comm_adopt(self._h, comm, int(rank), int(world)))
+
+    @staticmethod
+    def comm_release_detached(comm):
+        load().fokl_comm_release_detached(comm)
 
     def allgather(self, values, world):
         v = np.ascontiguousarray(values, dtype=np.float64)

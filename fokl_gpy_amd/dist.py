@@ -87,7 +87,7 @@ def _exchange_unique_id(rank, world, make_id, tag='fokl', timeout_s=300.0):
             try:
                 srv.bind((host, 0))
             except OSError:
-                srv.bind(('0.0.0.0', 0))
+                srv.bind(('127.0.0.1', 0))                   # a name that does not resolve: loop-back, never 0.0.0.0
             srv.listen(world)
             try:
                 os.unlink(path)
@@ -108,9 +108,10 @@ def _exchange_unique_id(rank, world, make_id, tag='fokl', timeout_s=300.0):
                     conn.settimeout(10.0)
                     try:
                         hello = conn.recv(8, socket.MSG_WAITALL)
-                        if len(hello) == 8 and hello[:4] == b'FOKL':
+                        peer = struct.unpack('<i', hello[4:])[0] if len(hello) == 8 and hello[:4] == b'FOKL' else 0
+                        if 1 <= peer < world:                 # strays, retries with another number: not counted
                             conn.sendall(uid)
-                            served.add(struct.unpack('<i', hello[4:])[0])
+                            served.add(peer)                  # only once the id has gone out
                     except OSError:
                         pass
         finally:
@@ -144,26 +145,57 @@ def _exchange_unique_id(rank, world, make_id, tag='fokl', timeout_s=300.0):
 
 
 class RcclComm:
-    """RCCL communicator attached to a ``_capi.DeviceContext`` (backend "nccl" == RCCL on ROCm)."""
+    """RCCL communicator attached to a ``_capi.DeviceContext`` (backend "nccl" == RCCL on ROCm).
 
-    def __init__(self, ctx, rank, world, unique_id=None):
-        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
-        self._id_file = None
+    ``RcclComm(ctx, rank, world)`` initialises and attaches in one go.  ``RcclComm.initialise(...)`` only runs the
+    (collective, possibly never-returning) ncclCommInitRank and touches no context: it is what a helper thread with a
+    deadline calls; ``attach(ctx)`` on the main thread then hands the communicator to the context, ``drop()`` releases
+    one that will not be used (bring_up)."""
+
+    def __init__(self, ctx, rank, world, unique_id=None, _pending=None):
+        self.rank, self.world = int(rank), int(world)
+        self.ctx, self._id_file = None, None
+        self._pending = _pending
+        if _pending is None:
+            pending = RcclComm.initialise(ctx.device, rank, world, ctx.comm_unique_id, unique_id)
+            self._pending, self._id_file = pending._pending, pending._id_file
+            self.attach(ctx)
+
+    @classmethod
+    def initialise(cls, device, rank, world, make_id, unique_id=None):
+        """-> an RcclComm that owns a communicator but no context yet."""
+        id_file = None
         if unique_id is None:
-            unique_id, self._id_file = _exchange_unique_id(self.rank, self.world, ctx.comm_unique_id)
+            unique_id, id_file = _exchange_unique_id(int(rank), int(world), make_id)
         # librccl prints a version banner on C stdout during init; benchmark drivers parse stdout, so route file
         # descriptor 1 to stderr for the duration of the call
         import sys
+        from . import _capi
         sys.stdout.flush()
         flush_c_streams()
         saved = os.dup(1)
         try:
             os.dup2(2, 1)
-            ctx.comm_init(unique_id, self.rank, self.world)  # collective: returns once every rank has joined
+            comm = _capi.DeviceContext.comm_init_detached(device, unique_id, rank, world)   # collective
             flush_c_streams()
         finally:
             os.dup2(saved, 1)
             os.close(saved)
+        self = cls(None, rank, world, _pending=comm)
+        self._id_file = id_file
+        return self
+
+    def attach(self, ctx):
+        ctx.comm_adopt(self._pending, self.rank, self.world)
+        self.ctx, self._pending = ctx, None
+        return self
+
+    def drop(self):
+        """Release a communicator that was never attached."""
+        if self._pending is not None:
+            from . import _capi
+            _capi.DeviceContext.comm_release_detached(self._pending)
+            self._pending = None
 
     def allgather(self, values):
         return self.ctx.allgather(np.asarray(values, dtype=np.float64).reshape(-1), self.world)
@@ -176,7 +208,10 @@ class RcclComm:
         self.ctx.sync()
 
     def close(self):
-        self.ctx.comm_destroy()
+        if self.ctx is not None:
+            self.ctx.comm_destroy()
+            self.ctx = None
+        self.drop()
         flush_c_streams()
 
 
@@ -205,7 +240,7 @@ class TcpComm:
                 try:
                     srv.bind((host, 0))
                 except OSError:
-                    srv.bind(('0.0.0.0', 0))
+                    srv.bind(('127.0.0.1', 0))
                 srv.listen(self.world)
                 try:
                     os.unlink(path)
@@ -222,11 +257,17 @@ class TcpComm:
                     except socket.timeout:
                         raise TimeoutError(f"rank 0: only {len(peers)} of {self.world - 1} ranks joined within "
                                            f"{timeout_s:.0f} s")
-                    conn.settimeout(timeout_s)
-                    hello = self._recv(conn, 8)
-                    if hello[:4] == b'FTCP':
-                        peers[struct.unpack('<i', hello[4:])[0]] = conn
+                    conn.settimeout(10.0)
+                    try:
+                        hello = self._recv(conn, 8)
+                    except (ConnectionError, OSError):        # a client that connects and goes away is not a rank
+                        conn.close()
+                        continue
+                    peer = struct.unpack('<i', hello[4:])[0] if hello[:4] == b'FTCP' else 0
+                    if 1 <= peer < self.world and peer not in peers:
+                        conn.settimeout(timeout_s)
                         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        peers[peer] = conn
                     else:
                         conn.close()
                 self._peers = [peers[r] for r in range(1, self.world)]
@@ -308,26 +349,37 @@ def bring_up(ctx, rank, world, need_rccl, timeout_s=180.0, log=None):
     import threading
     tcp = TcpComm(rank, world)
     box = {}
+    device = getattr(ctx, 'device', 0)
+    initialise = getattr(ctx, 'rccl_initialise', None)        # tests: a stand-in context brings its own (test_dist_tcp)
+    if initialise is None:
+        initialise = lambda: RcclComm.initialise(device, rank, world, ctx.comm_unique_id)   # noqa: E731
 
     def attempt():
+        # touches nothing but `box`: if the deadline passes this thread is left behind for good, and whatever it does
+        # when ncclCommInitRank finally returns (peers exiting, say) must not reach a context the main thread is using
         try:
-            box['comm'] = RcclComm(ctx, rank, world)
+            box['pending'] = initialise()
         except BaseException as exc:                          # noqa: BLE001 -- reported to every rank below
             box['error'] = f'{type(exc).__name__}: {exc}'
 
-    stdout_fd = os.dup(1)                                     # RcclComm parks fd 1 on stderr while librccl initialises
+    stdout_fd = os.dup(1)                                     # initialise() parks fd 1 on stderr while librccl starts
     t = threading.Thread(target=attempt, name='fokl-rccl-init', daemon=True)
     t.start()
     t.join(timeout_s)
-    ok = 1.0 if 'comm' in box else 0.0
-    if t.is_alive():
-        box['error'] = f'RCCL initialisation did not return within {timeout_s:.0f} s'
+    timed_out = t.is_alive()                                  # decided first: a thread that finishes after this line
+    pending = None if timed_out else box.get('pending')       # is treated as timed out, its communicator never adopted
+    if timed_out:
+        box.setdefault('error', f'RCCL initialisation did not return within {timeout_s:.0f} s')
         os.dup2(stdout_fd, 1)                                 # the stuck thread will never restore it
     os.close(stdout_fd)
+    ok = 1.0 if pending is not None else 0.0
     everywhere = float(np.min(tcp.allgather([ok])[:, 0])) == 1.0
     if everywhere:
+        comm = pending.attach(ctx)
         tcp.close()
-        return box['comm'], 'RCCL'
+        return comm, 'RCCL'
+    if pending is not None:
+        pending.drop()                                        # came up here but not everywhere: nothing stays attached
     why = box.get('error', 'RCCL failed on another rank')
     if log is not None:
         log(f"rank {rank}: RCCL not available ({why}); control-plane collectives over TCP")

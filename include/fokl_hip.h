@@ -407,6 +407,13 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
 int fokl_comm_unique_id(char id[FOKL_UNIQUE_ID_BYTES]);
 int fokl_comm_init(fokl_ctx *ctx, const char id[FOKL_UNIQUE_ID_BYTES], int rank, int world);
 int fokl_comm_destroy(fokl_ctx *ctx);
+/* fokl_comm_init in two steps, for launchers that put a deadline on the (collective) initialisation: the first runs
+ * ncclCommInitRank on `device` and touches no context -- it may sit on a helper thread that is abandoned when the
+ * deadline passes; the second attaches the communicator to the context once every rank has reported success;
+ * fokl_comm_release_detached drops one that will not be used. */
+int fokl_comm_init_detached(int device, const char id[FOKL_UNIQUE_ID_BYTES], int rank, int world, void **comm_out);
+int fokl_comm_adopt(fokl_ctx *ctx, void *comm, int rank, int world);
+int fokl_comm_release_detached(void *comm);
 /* recv[r*count .. (r+1)*count) = send of rank r: the per-candidate BIC gather of the kill-test shard. */
 int fokl_comm_allgather_f64(fokl_ctx *ctx, const double *send, int count, double *recv);
 /* In-place sum over ranks (row-sharded Gram blocks / residual moments). */

@@ -14,22 +14,46 @@ import numpy as np
 from fokl_gpy_amd import dist
 
 
+class FakePending:
+    """What dist.bring_up touches of an RcclComm that has initialised but is not attached to a context yet."""
+
+    def __init__(self, ctx, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+
+    def attach(self, ctx):
+        assert ctx is self.ctx
+        ctx.state.append('attached')
+        return FakeRccl(ctx)
+
+    def drop(self):
+        self.ctx.state.append('dropped')
+
+
+class FakeRccl(dist.RcclComm):
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def close(self):
+        self.ctx.state.append('closed')
+
+
 class FakeContext:
-    """What dist.RcclComm touches of a _capi.DeviceContext."""
+    """Stand-in for a _capi.DeviceContext whose RCCL initialisation succeeds, fails, hangs or comes back late."""
+    device = 0
 
-    def __init__(self, behaviour):
-        self.behaviour = behaviour
+    def __init__(self, behaviour, rank, world):
+        self.behaviour, self.rank, self.world = behaviour, rank, world
+        self.state = []                         # what was done to the context, in order
 
-    @staticmethod
-    def comm_unique_id():
-        return bytes(range(128))
-
-    def comm_init(self, unique_id, rank, world):
-        assert bytes(unique_id) == bytes(range(128))
+    def rccl_initialise(self):
+        # runs on bring_up's helper thread: must not touch the context (self.state) -- only attach / drop may
         if self.behaviour == 'fail':
             raise RuntimeError('ncclCommInitRank: unhandled error (stand-in)')
         if self.behaviour == 'hang':
             time.sleep(3600)
+        if self.behaviour == 'late':
+            time.sleep(5.0)                     # beyond the deadline of 3 s: comes back when nobody wants it any more
+        return FakePending(self, self.rank, self.world)
 
     def allgather(self, values, world):
         raise AssertionError("no RCCL collective may run unless RCCL came up on every rank")
@@ -38,9 +62,6 @@ class FakeContext:
         raise AssertionError("no RCCL collective may run unless RCCL came up on every rank")
 
     def sync(self):
-        pass
-
-    def comm_destroy(self):
         pass
 
 
@@ -53,8 +74,9 @@ def _worker(rank, world, port, behaviours, need_rccl, out):
         tcp.barrier()
         tcp.close()
         res = dict(gather=g.tolist(), reduce=s.tolist())
+        fake = FakeContext(behaviours[rank], rank, world)
         try:
-            comm, kind = dist.bring_up(FakeContext(behaviours[rank]), rank, world, need_rccl, timeout_s=3.0)
+            comm, kind = dist.bring_up(fake, rank, world, need_rccl, timeout_s=3.0)
             res['kind'] = kind
             if not isinstance(comm, dist.RcclComm):
                 res['after'] = comm.allgather([rank + 0.5]).tolist()
@@ -62,6 +84,9 @@ def _worker(rank, world, port, behaviours, need_rccl, out):
             comm.close()
         except RuntimeError as exc:
             res['raised'] = str(exc)
+        if behaviours[rank] == 'late':
+            time.sleep(4.0)                     # the abandoned helper thread has returned by now
+        res['context'] = list(fake.state)
         out.put((rank, res))
     except BaseException as exc:                                  # noqa: BLE001
         out.put((rank, dict(crash=f'{type(exc).__name__}: {exc}')))
@@ -115,3 +140,21 @@ def test_modes_that_need_rccl_fail_everywhere_instead_of_hanging():
 def test_rccl_is_used_when_it_comes_up_everywhere():
     res = _launch(['ok', 'ok'], need_rccl=True)
     assert all(one.get('kind') == 'RCCL' for one in res), res
+
+
+def test_a_communicator_that_is_not_used_everywhere_is_dropped_and_a_late_one_never_reaches_the_context():
+    """Rank 0 initialises in time, rank 1 only after the deadline: nobody may keep a communicator attached (rank 0 drops
+    its own), and what rank 1's abandoned helper thread returns later is never attached to the context the main thread
+    has gone on to use (round-2 review: the late thread wrote ctx->comm under the running fit)."""
+    res = _launch(['ok', 'late'], need_rccl=False)
+    assert all('crash' not in one and one['kind'].startswith('TCP control plane only') for one in res), res
+    assert res[0]['context'] == ['dropped'], res[0]
+    assert res[1]['context'] == [], res[1]
+    assert 'did not return' in res[1]['kind']
+
+
+def test_attach_happens_only_when_every_rank_is_up():
+    res = _launch(['ok', 'ok', 'ok'], need_rccl=True)
+    assert all(one.get('kind') == 'RCCL' and one['context'] == ['attached', 'closed'] for one in res), res
+    res = _launch(['ok', 'fail', 'ok'], need_rccl=False)
+    assert [one['context'] for one in res] == [['dropped'], [], ['dropped']], res
