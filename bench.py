@@ -591,6 +591,8 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
         'host_prepare_s': sum(r['prep_s'] for r in results),
         'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
+        'cpu_seconds_per_step': cpu_s / max(args.steps, 1),   # process CPU time (every thread) over the timed region
+        'chain_mode': os.environ.get('FOKL_CHAIN', 'auto'),
         'worker_seconds': sorted(r['elapsed'] for r in results),
         'roofline': dominant,
         'kernels': kernels,
@@ -796,12 +798,14 @@ def main():
             backend.ctx.timing_reset()
         comm.barrier()
         ctx.sync()
+        cpu0 = time.process_time()                            # all threads of this process (pool, dispatcher, driver)
         t0 = time.perf_counter()
         logical = physical = calls = 0
         host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
                     pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0, spectral_remote=0,
                     exchanges=0, chains_skipped=0, spectral_submitted=0, resid_matrix_free=0, bic_from_gram=0,
-                    noise_queue_wait_s=0.0, noise_verdict_wait_s=0.0)
+                    noise_queue_wait_s=0.0, noise_verdict_wait_s=0.0, device_chains=0, chains_fetched=0, guessed=0,
+                    guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']
@@ -812,6 +816,7 @@ def main():
         ctx.sync()
         comm.barrier()
         elapsed = time.perf_counter() - t0
+        cpu_s = time.process_time() - cpu0
         end_state = np.random.get_state()
         for _, backend, *_ in fits:
             backend.ctx.timing_enable(False)

@@ -634,21 +634,38 @@ class FoKL:
         after the fit is left in ``self._rng_state_after`` and the global generator is not touched."""
         _engine._mark('search_begin')
         stream = _capi.LegacyStream(rng_state)
-        search = _engine.ForwardSelection(
-            backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
-            self.burnin + self.draws, self.draws, self.gimmie, self.way3, self.threshav, self.threshstda,
-            self.threshstdb, self.aic, stream, console=self.ConsoleOutput,
-            comm=comm if comm is not None else getattr(self, '_comm', None),
-            row_sharded=row_sharded, n_global=n_global, candidate_sharded=candidate_sharded)
+        state_at_start = stream.as_numpy_state()
+
+        def new_search(stream, device_chains=True):
+            search = _engine.ForwardSelection(
+                backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
+                self.burnin + self.draws, self.draws, self.gimmie, self.way3, self.threshav, self.threshstda,
+                self.threshstdb, self.aic, stream, console=self.ConsoleOutput,
+                comm=comm if comm is not None else getattr(self, '_comm', None),
+                row_sharded=row_sharded, n_global=n_global, candidate_sharded=candidate_sharded)
+            search.allow_device_chains = device_chains
+            return search
+
+        search = new_search(stream)
         t0 = time.perf_counter()
+        repeated = 0
         try:
             with _host_blas_threads():
-                betas, mtx, evs = search.run()
+                try:
+                    betas, mtx, evs = search.run()
+                except _engine.Misprediction:
+                    # a kill test decided from a guess that its (device) chain did not confirm: nothing of that search
+                    # is kept -- the stream goes back to where the fit began and the search runs again on host chains,
+                    # where no decision is taken before its chain has run
+                    repeated = 1
+                    stream = _capi.LegacyStream(state_at_start)
+                    search = new_search(stream, device_chains=False)
+                    betas, mtx, evs = search.run()
         finally:
             if rng_state is None:
                 stream.publish()       # numpy's global stream ends where the reference's would
             self._rng_state_after = stream.as_numpy_state()
-        self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0)
+        self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0, searches_repeated=repeated)
         self.fit_trace = search.trace
         _engine._mark('search_end')
         _engine._flush_marks()

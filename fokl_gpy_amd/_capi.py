@@ -76,6 +76,17 @@ SIGNATURES = {
     'fokl_rng_gammas': (c_int, [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_i64, c_vp]),
     'fokl_gp_integrate': (c_int, [c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                   c_dbl, c_vp, c_vp]),
+    'fokl_dchain_create': (c_int, [c_int, c_int, c_vp]),
+    'fokl_dchain_destroy': (None, [c_vp]),
+    'fokl_dchain_submit': (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'fokl_dchain_poll': (c_int, [c_vp, c_i64]),
+    'fokl_dchain_wait': (c_int, [c_vp, c_i64, c_vp]),
+    'fokl_dchain_fetch_w': (c_int, [c_vp, c_i64, c_vp]),
+    'fokl_dchain_release': (c_int, [c_vp, c_i64]),
+    'fokl_dchain_stats': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'fokl_host_alloc': (c_int, [ctypes.c_size_t, c_vp]),
+    'fokl_host_free': (c_int, [c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
     'fokl_comm_init': (c_int, [c_vp, c_vp, c_int, c_int]),
     'fokl_comm_destroy': (c_int, [c_vp]),
@@ -486,6 +497,136 @@ class HostPool:
         _check(self._lib.fokl_pool_noise_waits(self._h, ctypes.byref(w[0]), ctypes.byref(w[1])))
         return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value,
                     noise_queue_wait=w[0].value, noise_verdict_wait=w[1].value)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# G3 on the device
+# ---------------------------------------------------------------------------------------------------------
+
+class _PinnedBlock:
+    """Owner of one fokl_host_alloc allocation; freed when the last array view of it goes."""
+    __slots__ = ('ptr', 'nbytes')
+
+    def __init__(self, nbytes):
+        ptr = c_vp(0)
+        _check(load().fokl_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
+        self.ptr, self.nbytes = ptr.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().fokl_host_free(c_vp(self.ptr))
+        except Exception:                                          # interpreter shutdown: the driver reclaims it anyway
+            pass
+        self.ptr = None
+
+
+def pinned_empty(doubles):
+    """A float64 array of ``doubles`` elements in page-locked host memory (tapes that the device chains copy from)."""
+    block = _PinnedBlock(int(doubles) * 8)
+    raw = (ctypes.c_double * int(doubles)).from_address(block.ptr)
+    raw._fokl_owner = block                                       # the ctypes array is the ndarray's base: keeps the block
+    return np.ctypeslib.as_array(raw)
+
+
+class DeviceChainJob:
+    """One chain on a DeviceChainEngine (include/fokl_hip.h: fokl_dchain_*).  ``wait()`` -> (mean of w over the rows
+    from ``stat_first`` on, bstar-negative flag); ``fetch_w()`` -> the draws in the eigenbasis [draws, p1];
+    ``release()`` frees the device slot (idempotent).  Keeps the host buffers the job reads alive."""
+    __slots__ = ('_engine', '_ticket', 'p1', 'draws', 'keep', 'recycle', '_stats', 'ignore_failure')
+    unresolved = False                  # PoolJob's interface: only tentative noise jobs wait for a verdict
+
+    def __init__(self, engine, ticket, p1, draws, keep):
+        self._engine, self._ticket, self.p1, self.draws, self.keep = engine, ticket, p1, draws, keep
+        self.recycle = None
+        self._stats = None
+        self.ignore_failure = False
+
+    def resolve(self, commit):
+        pass
+
+    def done(self):
+        """True once the device is through with the job's host buffers (the chain has run, or the job has failed)."""
+        if self._ticket is None or self._stats is not None:
+            return True
+        return bool(self._engine._lib.fokl_dchain_poll(self._engine._h, self._ticket))
+
+    def wait(self):
+        if self._stats is None:
+            if self._ticket is None:
+                raise RuntimeError("device chain: released before anybody read its statistics")
+            buf = np.empty(4 + self.p1, dtype=np.float64)
+            _check(self._engine._lib.fokl_dchain_wait(self._engine._h, self._ticket, _ptr(buf)))
+            self._stats = buf
+        return self._stats[4:], np.array([int(self._stats[0])], dtype=np.int32)
+
+    @property
+    def last_state(self):
+        """(sigma^2, tau^2) after the last iteration."""
+        self.wait()
+        return float(self._stats[1]), float(self._stats[2])
+
+    def fetch_w(self, out=None):
+        w = np.empty((self.draws, self.p1), dtype=np.float64) if out is None else out
+        _check(self._engine._lib.fokl_dchain_fetch_w(self._engine._h, self._ticket, _ptr(w)))
+        return w
+
+    def release(self):
+        if self._ticket is not None and self._engine._h:
+            self._engine._lib.fokl_dchain_release(self._engine._h, self._ticket)
+        self._ticket = None
+        self.keep = None
+
+
+class DeviceChainEngine:
+    """include/fokl_hip.h: fokl_dchain_* -- finishing of the polar normals and the Gibbs recursion on the GPU."""
+
+    def __init__(self, device=0, slots=96):
+        self._lib = load()
+        self._h = None
+        h = c_vp(0)
+        _check(self._lib.fokl_dchain_create(int(device), int(slots), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.fokl_dchain_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def submit(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first=0, follow=True):
+        """Queue the chain of ``tape`` (a NoiseTape, possibly still on record: ``follow``) for the model (lamb, qty)."""
+        lamb = np.ascontiguousarray(lamb, dtype=np.float64)
+        qty = np.ascontiguousarray(qty, dtype=np.float64)
+        p1 = lamb.shape[0]
+        if p1 != tape.p1:
+            raise ValueError("tape was recorded for a different model size")
+        ptr = tape.pointers()
+        finished = bool(tape.finishing_requested)
+        ticket = c_i64(0)
+        _check(self._lib.fokl_dchain_submit(self._h, p1, tape.draws, _ptr(lamb), _ptr(qty), float(b), float(btau),
+                                            float(dtd), float(sigsqd0), float(tausqd0), ptr[0], ptr[2], ptr[3], ptr[4],
+                                            tape.progress_pointer() if follow else None,
+                                            tape.block_done_pointer() if finished else None, tape.BLOCK, int(finished),
+                                            int(stat_first), ctypes.byref(ticket)))
+        return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape,))
+
+    def stats(self):
+        busy, issued, launches = c_dbl(0), c_i64(0), c_i64(0)
+        _check(self._lib.fokl_dchain_stats(self._h, ctypes.byref(busy), ctypes.byref(issued), ctypes.byref(launches)))
+        return dict(dispatch_s=busy.value, issued=issued.value, launches=launches.value)
+
+
+def gibbs_chain_device(engine, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first=0):
+    """One chain on the device, start to finish: -> (w [draws, p1], mean of w from row stat_first, bstar-negative)."""
+    job = engine.submit(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first, follow=False)
+    try:
+        mean_w, flag = job.wait()
+        return job.fetch_w(), np.array(mean_w), bool(flag[0])
+    finally:
+        job.release()
 
 
 # ---------------------------------------------------------------------------------------------------------

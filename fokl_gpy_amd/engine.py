@@ -329,6 +329,55 @@ def _thread_plan():
     return max(1, chain), max(0, finish), max(1, spectral)       # the threaded search needs a chain and a spectral thread
 
 
+class Misprediction(RuntimeError):
+    """A kill-test decision that was taken from a guess (the intercept's posterior mean ~ its least-squares value) before
+    the chain that decides it had run turned out wrong when the chain arrived.  Every guess is verified; the caller
+    (FoKL._search) restores the random stream and repeats the search without guessing."""
+
+
+class ModelSize(int):
+    """Size of a tape on order that is meant for a sub-stage's MODEL (finished and chained on host threads: its
+    statistics order the kill tests, latency matters) as opposed to a kill-test candidate (device chain)."""
+    __slots__ = ()
+
+
+# G3 on the device (csrc/fokl_chain_device.inc): one engine per process and device, kept from fit to fit (its slots'
+# device buffers are allocated once).  FOKL_CHAIN = device | host | auto (default: device where an engine can be made).
+_CHAIN_ENGINES = {}
+_chain_engine_factory = None            # tests: a stand-in with the interface of _capi.DeviceChainEngine
+
+
+def chain_engine_for(device):
+    """The device-chain engine of HIP device `device`, or None (FOKL_CHAIN=host, no device, engine creation failed)."""
+    mode = os.environ.get('FOKL_CHAIN', 'auto')
+    if mode not in ('auto', 'device', 'host'):
+        raise ValueError("FOKL_CHAIN must be auto, device or host")
+    if mode == 'host':
+        return None
+    if _chain_engine_factory is not None:
+        return _chain_engine_factory()
+    if device is None:
+        if mode == 'device':
+            raise RuntimeError("FOKL_CHAIN=device: the backend has no HIP device")
+        return None
+    engine = _CHAIN_ENGINES.get(device)
+    if engine is None:
+        try:
+            engine = _capi.DeviceChainEngine(device, int(os.environ.get('FOKL_DCHAIN_SLOTS', '128')))
+        except _capi.FoklNativeError:
+            if mode == 'device':
+                raise
+            return None
+        _CHAIN_ENGINES[device] = engine
+    return engine
+
+
+def close_chain_engines():
+    for engine in _CHAIN_ENGINES.values():
+        engine.close()
+    _CHAIN_ENGINES.clear()
+
+
 # Spare tape / draw buffers of the calling thread, by size class: they survive the fit that allocated them, so that the
 # next fit on this thread does not page-fault a few hundred MB in again (FOKL_HOST_POOL_MB caps what is kept, default
 # 2048; the count is per process and approximate when several threads fit at once -- it only bounds memory).
@@ -370,8 +419,10 @@ class HostPipeline:
     The driver thread keeps what needs Python or the device: the sequential decisions, the K1 / K2 / K3 launches.
     """
 
-    def __init__(self, stream, draws, comm=None):
+    def __init__(self, stream, draws, comm=None, chain_engine=None):
         self.stream, self.draws = stream, int(draws)
+        self.dchain = chain_engine          # G3 of kill-test candidates on the device (None: host chain threads)
+        self._pinned = chain_engine is not None and getattr(chain_engine, 'wants_pinned_tapes', True)
         # candidate sharding (see ShardedSpectralJob): G2 jobs are dealt over the ranks of `comm` in submission order
         # (FOKL_CANDIDATE_SHARD_FORCE=1: also in a world of one, so that a 1-GPU box takes the exchange path)
         forced = os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1'
@@ -408,6 +459,12 @@ class HostPipeline:
         if spare:
             _SPARES.doubles -= cls * self.CLASS_DOUBLES
             return spare.pop()
+        if self._pinned:
+            # page-locked: the device chains' H2D copies of a tape are then DMA transfers, not staged copies
+            try:
+                return _capi.pinned_empty(cls * self.CLASS_DOUBLES)
+            except _capi.FoklNativeError:
+                self._pinned = False
         return np.empty(cls * self.CLASS_DOUBLES, dtype=np.float64)
 
     def give(self, raw):
@@ -460,12 +517,15 @@ class HostPipeline:
         self._live.append(job)
         return job
 
-    def request(self, p1, astar, atau_star, tentative=False):
+    def request(self, p1, astar, atau_star, tentative=False, finish=True):
         """Queue the tape of one model evaluation; the buffers exist at once and fill up in the background.
         tentative: recorded ahead of the decision that the evaluation happens -- the caller owes the job a
-        ``resolve(True / False)`` (False rewinds the stream to where the tape began)."""
+        ``resolve(True / False)`` (False rewinds the stream to where the tape began).
+        finish: host threads complete the normals while the tape is recorded (tapes whose chain runs on the host); a
+        tape meant for a device chain stays raw -- the device finishes it.  Either kind of chain takes either kind of
+        tape, so a tape ordered for one role may serve the other."""
         raw = self._take(_capi.NoiseTape.doubles_needed(p1, self.draws))
-        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative, finish=True)
+        job = self.pool.submit_noise(_capi.NoiseTape(p1, self.draws, raw), astar, atau_star, tentative, finish=finish)
         # The tape's last reader is the chain job, which does not exist yet: until chain() or discard() the buffer is
         # only `held`, so that a _reap() between request and chain (the recorder may well be done by then) cannot hand
         # it out again -- chain() would then get the tape's own memory as its output buffer.
@@ -541,6 +601,20 @@ class HostPipeline:
         self._hand_tape(noise_job, job)                             # the chain job is the last reader of the tape
         return self._track(job), w_raw
 
+    def chain_device(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job, stat_first):
+        """chain() on the device engine: -> the job (its draws stay in device memory until fetched), or None when the
+        engine has no free slot (the caller then takes the host chain).  The mean of w over the rows from stat_first
+        on comes back with the job -- what the kill tests look at."""
+        try:
+            job = self.dchain.submit(spec.lamb, spec.qty, b, btau, dtd, sigsqd0, tausqd0, noise_job.result, stat_first)
+        except _capi.FoklNativeError as exc:
+            if exc.code == -3:                                          # FOKL_ERR_STATE: every slot is alive
+                return None
+            raise
+        job.recycle = []
+        self._hand_tape(noise_job, job)                                 # the device job is the last reader of the tape
+        return self._track(job)
+
     def chain_ahead(self, spec, b, btau, dtd, sigsqd0, tausqd0, noise_job):
         """chain() for a tape that is still on order (tentative, no verdict yet): the draws are under way when the
         decision comes that this model is evaluated -- adopt() -- or thrown away -- disown().  The tape stays `held` by
@@ -572,7 +646,8 @@ class HostPipeline:
             if job.unresolved:              # only after an exception in the driver: never leave the noise thread waiting
                 job.resolve(False)
         for job in self._live:
-            job.wait()
+            if not (isinstance(job, _capi.DeviceChainJob) and job.done()):
+                job.wait()
         _mark('jobs_drained')
         self._reap()                        # buffers of the jobs that have run now go back to the thread's spares
         self._live = []
@@ -608,7 +683,7 @@ class GibbsOutcome:
     """One model evaluation.  The BIC is known at once; the draws arrive from a chain thread (chain arithmetic in the
     eigenbasis), betas = w Q' (FR:1528) is formed only for the columns somebody looks at."""
     __slots__ = ('lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'intercept_scale', 'siglik', '_jobs', '_owner', '_w',
-                 '_betas', '_w_raw', '_chain_job')
+                 '_betas', '_w_raw', '_chain_job', 'on_device', 'checks', '_release_wanted')
 
     def __init__(self, owner, spec, ev, idx, noise_job, chain_job, w_raw):
         self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
@@ -617,10 +692,22 @@ class GibbsOutcome:
         self._w = self._betas = self.intercept_scale = None
         self.siglik = 0.0
         self._w_raw, self._chain_job = w_raw, chain_job
+        self.on_device = isinstance(chain_job, _capi.DeviceChainJob)   # the draws live in device memory (dchain slot)
+        self.checks = []                    # (|mean beta| of a proposal, decision taken from the guessed intercept scale)
+        self._release_wanted = False
 
     def release(self):
         """Hand the buffer of w back to the pipeline's pool (directly, or through the chain job that is still writing
-        it).  Called by the search when no decision can look at this model's draws any more; idempotent."""
+        it) -- or the device slot to the chain engine.  Called by the search when no decision can look at this model's
+        draws any more; idempotent.  A device chain whose statistics still have to confirm guessed decisions keeps its
+        slot until they have (ForwardSelection._verify)."""
+        if self.on_device:
+            if self.checks:
+                self._release_wanted = True
+                return
+            self._w = self._jobs = None
+            self._owner._release_device_job(self._chain_job)
+            return
         raw, self._w_raw = self._w_raw, None
         host = self._owner.host
         if raw is None or host is None:
@@ -630,6 +717,24 @@ class GibbsOutcome:
             host.give(raw)
         else:
             self._chain_job.recycle.append(raw)
+
+    def chain_ready(self):
+        """The chain has run: looking at its results costs no wait."""
+        return self._w is not None or self.intercept_scale is not None or self._chain_job.done()
+
+    def mean_intercept_draw(self, first_row):
+        """np.mean(betas[first_row:, 0]) -- from the mean of w the device chain brings along (mean w . Q[0, :]), or from
+        the draws of a host chain."""
+        if self.on_device:
+            o = self._owner
+            t0 = time.perf_counter()
+            mean_w, negative = self._chain_job.wait()
+            o.stats['t_chain'] += time.perf_counter() - t0
+            if negative[0]:
+                raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
+                                   "cannot reproduce the reference's skipped draw (FR:1538-1539)")
+            return float(mean_w @ self.Qt[:, 0])
+        return float(np.mean(self.beta_columns(np.array([0]), first_row)[:, 0]))
 
     @property
     def Q(self):
@@ -641,7 +746,12 @@ class GibbsOutcome:
             o = self._owner
             noise_job, chain_job = self._jobs
             t0 = time.perf_counter()
-            self._w, negative = chain_job.wait()
+            if self.on_device:
+                _, negative = chain_job.wait()
+                self._w = chain_job.fetch_w()           # D2H of the draws: only models that are returned get here
+                o.stats['chains_fetched'] += 1
+            else:
+                self._w, negative = chain_job.wait()
             noise_job.wait()
             o.stats['t_chain'] += time.perf_counter() - t0
             o.stats['chains_materialised'] += 1
@@ -769,6 +879,20 @@ class ForwardSelection:
             # tests to keep the spectral threads of all ranks busy
             self.kill_bic = 'gram'
             self.lookahead = max(self.lookahead, 3 * comm.world)
+        # G3 of kill-test candidates on the device (chain_engine_for; decided in run()).  A device chain answers a
+        # millisecond or two after its tape, so nothing in the search waits for one: the only thing the tests want from
+        # the chain of the model accepted so far is the scale of its intercept draws (second clause of FR:1670), and that
+        # is its least-squares intercept to a fraction of a per cent.  A decision is taken from that guess when the
+        # proposal's |mean beta| is further than `guess_margin` (relative) from the threshold, noted with the model, and
+        # CONFIRMED against the chain's own statistics when they arrive (_verify); a decision that does not hold raises
+        # Misprediction and the search is repeated without guessing -- results never depend on a guess.
+        self.allow_device_chains = True
+        self.chain_engine = None
+        self.guess_margin = float(os.environ.get('FOKL_GUESS_MARGIN', '0.02'))
+        self._flip_guess = int(os.environ.get('FOKL_GUESS_TEST_FLIP', '0'))   # tests: the n-th guess is taken wrong
+        self._unverified = collections.deque()   # (device-chained outcome, half0) whose checks are open, oldest first
+        self._zombies = collections.deque()      # device jobs nobody will look at, released once they have run
+        self._device_jobs = []                   # every device chain of this search (all released when it ends)
         self.trace = []                     # one record per gibbs evaluation
         self._outcomes = []                 # pipelined evaluations whose draws sit in pooled buffers (see _retire)
         self._retiring = []                 # ... and those of them nobody will look at any more
@@ -777,7 +901,8 @@ class ForwardSelection:
         self.stats = dict(gibbs_calls=0, kill_tests=0, terms_logical=0, terms_physical=0, substages=0,
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
                           bic_gram_max_rel=0.0, tapes_rewound=0, tapes_wasted=0, chains_ahead=0, chains_ahead_unused=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
-                          spectral_submitted=0)
+                          spectral_submitted=0, device_chains=0, chains_fetched=0, guessed=0, guess_waits=0,
+                          guesses_verified=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _same_model_same_ev(self, idx, ev):
@@ -843,10 +968,12 @@ class ForwardSelection:
             if self.backend.resid_terms_supported(arr):
                 self._terms_arr = np.vstack([np.zeros((1, arr.shape[1]), dtype=np.int32), arr])
 
-    def _request_noise(self, p1, tentative=False):
+    def _request_noise(self, p1, tentative=False, model=True):
+        """model: the tape is meant for a sub-stage's model (host chain: finished by host threads while it is recorded);
+        False: for a kill-test candidate, whose chain runs on the device when there is an engine (the tape stays raw)."""
         astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        return self.host.request(p1, astar, atau_star, tentative)
+        return self.host.request(p1, astar, atau_star, tentative, finish=model or self.chain_engine is None)
 
     # Tapes on order.  A tape's content depends on nothing but the model size and the position of the stream, so the
     # driver keeps the noise thread supplied with the sizes the search will PROBABLY ask for next -- several deep, across
@@ -868,8 +995,9 @@ class ForwardSelection:
                 self.stats['tapes_wasted'] += 1
                 self._speculation = max(1, self._speculation - 2)
 
-    def _tape_for(self, p1):
-        """The tape of the model evaluation that happens now (p1 columns)."""
+    def _tape_for(self, p1, model=True):
+        """The tape of the model evaluation that happens now (p1 columns; model: see _request_noise -- a tape on order
+        is taken whatever role it was ordered for)."""
         if self._spec:
             size, job = self._spec[0]
             if size == p1:
@@ -880,7 +1008,7 @@ class ForwardSelection:
                 return job
             self._drop_speculation()
         _mark('tape_requested', str(p1))
-        return self._request_noise(p1)
+        return self._request_noise(p1, model=model)
 
     def _speculate(self, sizes):
         """sizes: the models the stream will probably serve next, in order (as far as the caller can see).  Orders that
@@ -901,7 +1029,7 @@ class ForwardSelection:
                     time.sleep(0)
                 self.host.discard(bogus)
                 self.stats['tapes_rewound'] += 1
-            self._spec.append((size, self._request_noise(size, tentative=True)))
+            self._spec.append((size, self._request_noise(size, tentative=True, model=isinstance(size, ModelSize))))
         _mark('speculating', ' '.join(str(size) for size, _ in self._spec))
 
     def _chain_ahead(self, spectral_job, p1, dtd):
@@ -911,6 +1039,8 @@ class ForwardSelection:
         guess is wrong; results are untouched (same tape, same arithmetic, whoever submits the job)."""
         if not self._spec or self._spec[0][0] != p1 or not getattr(spectral_job, 'done', lambda: False)():
             return
+        if self.chain_engine is not None and not isinstance(self._spec[0][0], ModelSize):
+            return                                                    # a kill test's chain: submitted to the device at commit
         noise_job = self._spec[0][1]
         spec = spectral_job.wait()
         if self._prechain is not None:
@@ -928,11 +1058,19 @@ class ForwardSelection:
             self.host.disown(chain_job, w_raw, noise_job)
             self.stats['chains_ahead_unused'] += 1
 
-    def _commit(self, pending, noise_job=None):
-        """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome."""
+    def _commit(self, pending, noise_job=None, test=False, stat_first=0):
+        """-> (noise job, chain job, raw buffer of w): the trailing arguments of GibbsOutcome.
+        test: a kill-test candidate -- its chain goes to the device engine if there is one (the mean of w over the rows
+        from stat_first on comes back with it); sub-stage models keep the host chain that follows the recorder."""
         spec, idx, _, dtd, _ = pending
         if noise_job is None:
-            noise_job = self._tape_for(idx.shape[0])
+            noise_job = self._tape_for(idx.shape[0], model=not test)
+        if test and self.chain_engine is not None and not (self._prechain is not None and self._prechain[0] is noise_job):
+            job = self.host.chain_device(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job, stat_first)
+            if job is not None:
+                self.stats['device_chains'] += 1
+                self._device_jobs.append(job)
+                return noise_job, job, None
         if self._prechain is not None:
             if self._prechain[0] is noise_job and self._prechain[1] is spec:
                 _, _, chain_job, w_raw = self._prechain
@@ -1069,15 +1207,64 @@ class ForwardSelection:
             jobs[cur] = self.host.spectral(gram, self._columns_without(A, cur))
         # and their tapes: test t of the sub-stage has A - 1 - t columns if the tests before it were accepted
         sizes = [A - 1 - t for t in range(len(likely))]
-        self._speculate(([A] if before_model else []) + sizes)
+        self._speculate(([ModelSize(A)] if before_model else []) + sizes)
         return jobs, sizes
 
     def _intercept_scale(self, outcome, half0):
         """np.mean(np.abs(np.mean(betas[half0:draws, 0]))) of FR:1671 for the model accepted so far (needs its chain)."""
         if outcome.intercept_scale is None:
-            outcome.intercept_scale = np.mean(np.abs(np.mean(
-                outcome.beta_columns(np.array([0]), half0)[:, 0])))
+            if getattr(outcome, 'on_device', False):
+                outcome.intercept_scale = abs(outcome.mean_intercept_draw(half0))
+            else:
+                outcome.intercept_scale = np.mean(np.abs(np.mean(
+                    outcome.beta_columns(np.array([0]), half0)[:, 0])))
         return outcome.intercept_scale
+
+    def _second_clause_now(self, outcome, value, half0):
+        """`value < threshav * |mean intercept draw of outcome|` (second clause of FR:1670) if it can be had without
+        waiting for a chain: from the chain's statistics if they are there, else -- device chains only -- from the
+        least-squares intercept when `value` is not within guess_margin of the threshold; the guess is noted with the
+        outcome and confirmed by _verify.  None: the caller has to wait for the chain."""
+        if outcome.intercept_scale is not None or (getattr(outcome, 'chain_ready', None) and outcome.chain_ready()):
+            return bool(value < self.threshav * self._intercept_scale(outcome, half0))
+        if not getattr(outcome, 'on_device', False):
+            return None
+        threshold = self.threshav * abs(float(outcome.betahat[0]))
+        if threshold <= 0.0 or not math.isfinite(threshold) or abs(value - threshold) <= self.guess_margin * threshold:
+            return None
+        decision = bool(value < threshold)
+        self.stats['guessed'] += 1
+        if self._flip_guess and self.stats['guessed'] == self._flip_guess:
+            decision = not decision                                   # tests: a guess that verification must catch
+        if not outcome.checks:
+            self._unverified.append((outcome, half0))
+        outcome.checks.append((float(value), decision))
+        return decision
+
+    def _release_device_job(self, job):
+        """A device chain nobody will look at again: its slot goes back once it has run (never a wait here)."""
+        if job.done():
+            job.release()
+        else:
+            self._zombies.append(job)
+
+    def _verify(self, block=False):
+        """Confirm the decisions that were taken from guessed intercept scales against the chains' own statistics --
+        those that have arrived, or (block) all of them.  Raises Misprediction if one does not hold."""
+        # chains complete in the order they were submitted, near enough: only the oldest is polled (one call per turn)
+        while self._zombies and (block or self._zombies[0].done()):
+            self._zombies.popleft().release()
+        while self._unverified and (block or self._unverified[0][0].chain_ready()):
+            outcome, half0 = self._unverified.popleft()
+            scale = self._intercept_scale(outcome, half0)
+            for value, decision in outcome.checks:
+                if bool(value < self.threshav * scale) != decision:
+                    raise Misprediction(f"kill test decided from a guessed intercept scale "
+                                        f"({abs(float(outcome.betahat[0]))!r}) that its chain does not confirm ({scale!r})")
+                self.stats['guesses_verified'] += 1
+            outcome.checks = []
+            if outcome._release_wanted:
+                outcome.release()
 
     def _kill_tests_pipelined(self, gram, slots, n_prev, cand_col, mean_abs, rel_std, best, half0, foresee=None,
                               ahead=None, vm_next=None, idle_work=None, peek=None, chain_coming=None):
@@ -1141,7 +1328,8 @@ class ForwardSelection:
                     tests = peek(pred) if peek is not None else None
                     if tests is None:
                         tests = min(vm_next, 1)
-                    sizes += [A - len(pred) + vm_next - t for t in range(tests + 1)]
+                    coming = A - len(pred) + vm_next
+                    sizes += [ModelSize(coming)] + [coming - t for t in range(1, tests + 1)]
             self._speculate(sizes)
             # ... and the chain of the very next evaluation, if its G2 is there
             nxt = next((j for j in proposal[pos:] if likely(j)), None)
@@ -1157,6 +1345,19 @@ class ForwardSelection:
         for pos, i in enumerate(proposal):
             decided = clause1[i]
             _mark('test', f"{pos} decided={int(decided)} known={int(best.intercept_scale is not None)}")
+            self._verify()
+            if not decided:
+                # the second clause without a wait: from the chain of `best` if it has run, from its least-squares
+                # intercept (confirmed later) if that is a device chain and the proposal is not a borderline case
+                quick = self._second_clause_now(best, mean_abs[i], half0)
+                if quick is False:
+                    continue
+                if quick:
+                    decided = True
+                    if best.intercept_scale is not None:
+                        scale_guess = best.intercept_scale
+                elif getattr(best, 'on_device', False):
+                    self.stats['guess_waits'] += 1
             if not decided and (best.intercept_scale is not None or not likely(i)):
                 # second clause without G2 of a model that will probably not be needed: from the known scale, or --
                 # the test looks unlikely -- after waiting for the chain of `best`
@@ -1178,7 +1379,7 @@ class ForwardSelection:
             p1 = idx.shape[0]
             # the test runs for sure: its tape is committed (or, not on order after a wrong guess, requested) now, so
             # that the stream moves on while this thread waits for G2
-            noise_job = self._tape_for(p1) if decided else None
+            noise_job = self._tape_for(p1, model=False) if decided else None
             _mark('g2_submitted')
             if idle_work is not None:
                 idle_work()
@@ -1193,14 +1394,14 @@ class ForwardSelection:
                     if self._async_resid and pending[2] is not None:
                         self.backend.bic_resid_fetch(self.allreduce)  # drains the speculative residual pass
                     continue
-                noise_job = self._tape_for(p1)
+                noise_job = self._tape_for(p1, model=False)
             if pending[2] is None:
                 # the BIC comes from the Gram and is known now, before anything is spent on the candidate's draws:
                 # a rejected candidate only has to advance the random stream (its tape is recorded, never finished
                 # nor chained -- nobody reads the draws of a model that loses, FR:1686-1690)
                 ev = self._score(pending)
                 if ev < evmin:
-                    jobs = self._commit(pending, noise_job)
+                    jobs = self._commit(pending, noise_job, test=True, stat_first=half0)
                 else:
                     if self._prechain is not None and self._prechain[0] is noise_job:
                         self._drop_prechain()
@@ -1208,7 +1409,7 @@ class ForwardSelection:
                     self.stats['chains_skipped'] += 1
                     jobs = None
             else:
-                jobs = self._commit(pending, noise_job)
+                jobs = self._commit(pending, noise_job, test=True, stat_first=half0)
                 ev = self._score(pending)
             _mark('scored')
             self._record(p1, n_prev, ev, True)
@@ -1219,7 +1420,10 @@ class ForwardSelection:
                 best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
                 self._outcomes.append(best)
             elif jobs is not None:
-                jobs[1].recycle.append(jobs[2])                       # nobody will read a rejected candidate's draws
+                if jobs[2] is None:
+                    self._release_device_job(jobs[1])                 # nobody will read a rejected candidate's draws
+                else:
+                    jobs[1].recycle.append(jobs[2])
             forecast(pos + 1)
             order_tapes(pos + 1)
         order_tapes(len(proposal))                                    # the kill set is final
@@ -1235,7 +1439,14 @@ class ForwardSelection:
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
         if pipelined:
             try:
-                self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None)
+                # device chains: one search per process at a time drives an engine's guesses; replicated searches (rows
+                # or candidates sharded over ranks) keep the host chains -- a rank whose chain had arrived decides from
+                # it, one that guesses would stop on a misprediction alone and leave the others in a collective
+                if self.allow_device_chains and not self.allreduce and not self.candidate_sharded:
+                    self.chain_engine = chain_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
+                    self._dchain_stats0 = self.chain_engine.stats() if self.chain_engine is not None else {}
+                self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None,
+                                         chain_engine=self.chain_engine)
             except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
                 # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
                 # line, only slower
@@ -1248,6 +1459,16 @@ class ForwardSelection:
         finally:
             _mark('run_end')
             if self.host is not None:
+                # every device chain of this search gives its slot back (the engine outlives the fit); idempotent, and
+                # a chain that has not run yet is waited for -- its tape is committed, so it will
+                for job in self._device_jobs:
+                    job.release()
+                self._device_jobs = []
+                self._zombies.clear()
+                self._unverified.clear()
+                if self.chain_engine is not None:
+                    now = self.chain_engine.stats()               # the engine outlives the fit: this fit's share
+                    self.stats.update({'dchain_' + k: v - self._dchain_stats0.get(k, 0) for k, v in now.items()})
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
                                   pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'],
@@ -1498,9 +1719,13 @@ class ForwardSelection:
             self._ahead_block(ahead)
             self.pool.give(ahead['slots'])
 
+        self._verify(block=True)                   # every decision taken from a guess is confirmed before anything returns
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx
         out_betas = betas.betas[-self.draws_keep::, :]
+        for keep_alive in (betas, last):           # the returned draws are on the host now: the device slots go back
+            if getattr(keep_alive, 'on_device', False):
+                keep_alive.release()
         lamb = np.sort(np.asarray(getattr(betas, 'lamb', ()), dtype=np.float64))
         if lamb.shape[0] > 1:
             # conditioning of the returned model's eigenproblem: betas = w Q', and an eigenvector moves by about

@@ -399,6 +399,46 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
                       double *trajectory);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* G3 on the device: finishing of the polar normals + the D-iteration recursion (FoKLRoutines.py:1519-1548)  */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* A device-chain engine on HIP device `device`: a dispatcher thread, a few streams, `slots` chains that may be
+ * alive (in flight, or finished with their draws still in device memory) at a time.  The random stream stays on
+ * the host (fokl_noise_tape / the pool's noise thread); what is submitted here is the arithmetic on a tape:
+ * the sqrt(-2 log r2 / r2) half of the polar method and the recursion in the eigenbasis that fokl_gibbs_chain
+ * runs on the host -- same operations in the same order, so the draws differ only through log() (1e-16).
+ *
+ * fokl_dchain_submit queues a chain and returns at once.  The tape may still be on record: `progress` (may be
+ * NULL: the tape is complete) is polled by the dispatcher until it reaches `draws`; a negative value fails the
+ * job.  `finished` != 0: the normals are final already (host finish threads; `block_done` / `block` as for
+ * fokl_gibbs_chain_from_finished_tape, polled the same way), else they are raw pairs + `lead` as fokl_noise_tape
+ * leaves them.  lamb / qty are copied at submit; the tape's arrays must stay valid until fokl_dchain_poll
+ * reports 1 or fokl_dchain_wait / fokl_dchain_release has returned.
+ * fokl_dchain_wait sleeps until the chain has run and returns stats_out[4 + p1] = {bstar < 0 seen, last sigma^2,
+ * last tau^2, rows averaged, mean over rows stat_first .. draws - 1 of w} -- what the kill tests look at
+ * (FR:1671: mean intercept draw = mean w . Q[0, :]).  fokl_dchain_fetch_w copies the draws in the eigenbasis
+ * w [draws, p1] (betas = w Q') to the host; fokl_dchain_release frees the slot (idempotent).
+ * Errors: FOKL_ERR_STATE when every slot is taken (the caller runs that chain on the host). */
+typedef struct fokl_dchain fokl_dchain;
+int fokl_dchain_create(int device, int slots, fokl_dchain **out);
+void fokl_dchain_destroy(fokl_dchain *engine);
+int fokl_dchain_submit(fokl_dchain *engine, int p1, int draws, const double *lamb, const double *qty, double b,
+                       double btau, double dtd, double sigsqd0, double tausqd0, const double *normals,
+                       const int32_t *lead, const double *gam_sig, const double *gam_tau, const int32_t *progress,
+                       const int32_t *block_done, int block, int finished, int stat_first, int64_t *ticket);
+int fokl_dchain_poll(fokl_dchain *engine, int64_t ticket);
+int fokl_dchain_wait(fokl_dchain *engine, int64_t ticket, double *stats_out);
+int fokl_dchain_fetch_w(fokl_dchain *engine, int64_t ticket, double *w_out);
+int fokl_dchain_release(fokl_dchain *engine, int64_t ticket);
+/* seconds the dispatcher spent issuing work, number of chains issued, number of recursion launches (chains whose
+ * tapes are ready together go out as one launch: FOKL_DCHAIN_BATCH chains or FOKL_DCHAIN_DELAY_US after the oldest was
+ * queued, at once when somebody waits for a result) */
+int fokl_dchain_stats(fokl_dchain *engine, double *busy_seconds, int64_t *issued, int64_t *launches);
+/* Page-locked host memory for tapes (the dispatcher's H2D copies are then DMA transfers instead of staged copies). */
+int fokl_host_alloc(size_t bytes, void **out);
+int fokl_host_free(void *ptr);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* multi-GPU: one process per GPU, RCCL over xGMI                                                          */
 /* ------------------------------------------------------------------------------------------------------ */
 

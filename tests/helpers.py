@@ -15,7 +15,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 from oracle import fokl_oracle as O  # noqa: E402
-from fokl_gpy_amd import getKernels  # noqa: E402
+from fokl_gpy_amd import getKernels, _capi  # noqa: E402
 
 FIT_CASES = ['bern_m1', 'bern_m3', 'bern_m3_gimmie_tol1', 'bern_m4_way3', 'bern_m6', 'bern_m8_capped',
              'testdata10_default', 'testdata10_changed', 'splines_m4', 'sigmoid_splines']
@@ -175,3 +175,72 @@ class OracleBackend:
         return mean, np.stack([srt[:, cut], srt[:, draws - cut]], axis=1)
 
 UNITS_PATH = os.path.join(GOLDEN, 'units.npz')
+
+
+class StandInChainJob(_capi.DeviceChainJob):
+    """DeviceChainJob whose chain runs on a host thread (tests of the search's device-chain logic without a GPU)."""
+    __slots__ = ('_future', '_released', '_engine_ref')
+
+    def __init__(self, engine, future, p1, draws, tape):
+        super().__init__(None, -1, p1, draws, (tape,))
+        self._future, self._released, self._engine_ref = future, False, engine
+
+    def done(self):
+        return self._released or self._future.done()
+
+    def _result(self):
+        if self._released:
+            raise RuntimeError("device chain: released before anybody read its statistics")
+        return self._future.result()
+
+    def wait(self):
+        w, flag, first = self._result()
+        return w[first:].mean(axis=0) if w.shape[0] > first else np.zeros(w.shape[1]), np.array([int(flag)], dtype=np.int32)
+
+    def fetch_w(self, out=None):
+        return np.array(self._result()[0])
+
+    def release(self):
+        if not self._released:
+            self._future.result()                              # the real engine waits until the tape has been read
+            self._released = True
+            self._engine_ref.alive -= 1
+            self._future = None
+            self.keep = None
+
+
+class StandInChainEngine:
+    """CPU stand-in for _capi.DeviceChainEngine (tests only; installed through engine._chain_engine_factory): the same
+    interface, the chain computed by the host sampler on a worker thread after `delay` seconds -- late enough for the
+    search to take its kill-test decisions from guesses, as it does with a real device."""
+    wants_pinned_tapes = False
+
+    def __init__(self, slots=64, delay=0.004):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(2)
+        self.slots, self.delay, self.alive, self.issued, self.refused = slots, delay, 0, 0, 0
+
+    def submit(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first=0, follow=True):
+        if self.alive >= self.slots:
+            self.refused += 1
+            raise _capi.FoklNativeError(-3, 'stand-in engine: every slot holds a chain that was not released')
+        lamb, qty = np.array(lamb, dtype=np.float64), np.array(qty, dtype=np.float64)
+
+        def work():
+            import time
+            time.sleep(self.delay)
+            if tape.finishing_requested:
+                w, flag = _capi.gibbs_chain_from_finished_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, follow=True)
+            else:
+                w, flag = _capi.gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, follow=True)
+            return w, flag, int(stat_first)
+
+        self.alive += 1
+        self.issued += 1
+        return StandInChainJob(self, self._pool.submit(work), lamb.shape[0], tape.draws, tape)
+
+    def stats(self):
+        return dict(dispatch_s=0.0, issued=self.issued, launches=self.issued)
+
+    def close(self):
+        self._pool.shutdown(wait=True)

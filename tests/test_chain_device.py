@@ -1,0 +1,135 @@
+"""
+G3 on the device (include/fokl_hip.h: fokl_dchain_*): the finishing of the polar normals and the Gibbs recursion of
+FR:1519-1548 on the GPU against the host chain (fokl_gibbs_chain_from_tape, itself pinned bit for bit to the
+reference's loop and numpy's stream in tests/test_sampler_host.py) on the same noise tapes.
+
+Tolerances: a tape whose normals were finished on the host goes through the device recursion BIT FOR BIT (same IEEE
+operations in the same order, the quadratic forms summed in the host's order); with the finishing on the device the
+normals differ from libm's in the last bit of log(), which reaches the draws at the 1e-16 level: bounded here by 1e-13
+of the column scale.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from fokl_gpy_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    eng = _capi.DeviceChainEngine(int(os.environ.get('FOKL_DEVICE', '0')), slots=8)
+    yield eng
+    eng.close()
+
+
+def model(p1, rng):
+    lamb = np.sort(rng.random(p1) * 1e5 + 1e-2)
+    lamb[0] = 3e-3
+    qty = rng.standard_normal(p1) * np.sqrt(lamb) * 3
+    return lamb, qty
+
+
+def host_tape(p1, draws, seed, exact=True):
+    np.random.seed(seed)
+    stream = _capi.LegacyStream()
+    return _capi.noise_tape(p1, draws, 500.0 + p1 / 2, 4 + (p1 - 1) / 2, stream)
+
+
+@pytest.mark.parametrize('p1', [1, 2, 7, 17, 60, 64, 65, 129, 200, 586])
+def test_device_chain_equals_the_host_chain_on_the_same_tape(engine, p1, monkeypatch):
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(p1)
+    draws = 300 if p1 > 200 else 700
+    lamb, qty = model(p1, rng)
+    tape = host_tape(p1, draws, 10 + p1)
+    args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
+    want, flag = _capi.gibbs_chain_from_tape(*args, tape)
+    half0 = draws // 2
+    w, mean_w, negative = _capi.gibbs_chain_device(engine, *args, tape, stat_first=half0)
+    assert not negative and not flag
+    scale = np.max(np.abs(want), axis=0)
+    assert np.max(np.abs(w - want) / scale) < 1e-13
+    assert np.max(np.abs(mean_w - want[half0:].mean(axis=0)) / scale) < 1e-13
+
+
+@pytest.mark.parametrize('p1', [3, 60, 150])
+def test_device_recursion_is_bitwise_the_host_recursion_on_finished_normals(engine, p1, monkeypatch):
+    """Finishing done by the host (exact log): what is left for the device is the recursion -- division, square root,
+    products and the three sums in the host's order -- and the draws come out bit for bit."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(100 + p1)
+    draws = 500
+    lamb, qty = model(p1, rng)
+    tape = host_tape(p1, draws, 77 + p1)
+    args = (lamb, qty, 40.0, 1.5, 2e4, 0.2, 1.1)
+    _capi.finish_tape_blocks(tape)
+    want, _ = _capi.gibbs_chain_from_finished_tape(*args, tape)
+    tape.finishing_requested = True
+    job = engine.submit(*args, tape, stat_first=0, follow=False)
+    try:
+        job.wait()
+        w = job.fetch_w()
+        sig, tau = job.last_state
+    finally:
+        job.release()
+    assert np.array_equal(w, want)
+    assert np.isfinite(sig) and np.isfinite(tau)
+
+
+def test_negative_bstar_is_flagged_and_goes_nan_like_the_host(engine, monkeypatch):
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(5)
+    lamb, qty = model(6, rng)
+    tape = host_tape(6, 50, 3)
+    args = (lamb, qty, -1e9, 2.0, 10.0, 0.3, 0.9)                     # b far below zero: bstar < 0 at once
+    want, flag = _capi.gibbs_chain_from_tape(*args, tape)
+    w, mean_w, negative = _capi.gibbs_chain_device(engine, *args, tape)
+    assert flag and negative
+    assert np.array_equal(np.isnan(w), np.isnan(want)) and np.isnan(w[1:]).all()
+    assert np.array_equal(w[0], want[0])
+
+
+def test_chains_follow_tapes_that_are_still_on_record_and_slots_are_recycled(engine):
+    """Jobs are submitted while the pool's noise thread is still recording the tapes (the dispatcher waits for each
+    tape's progress flag); more jobs than slots go through as slots are released; a full engine says so."""
+    rng = np.random.default_rng(9)
+    np.random.seed(4)
+    s_pool, s_ref = _capi.LegacyStream(), _capi.LegacyStream()
+    pool = _capi.HostPool(s_pool, chain_threads=1, finish_threads=0, spectral_threads=0)
+    draws, jobs = 400, []
+    sizes = [40, 61, 8, 130, 60, 60, 59, 58, 57, 12, 300, 5]
+    try:
+        for p in sizes:
+            lamb, qty = model(p, rng)
+            tape = _capi.NoiseTape(p, draws)
+            noise = pool.submit_noise(tape, 500.0 + p / 2, 4 + (p - 1) / 2)
+            args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
+            while True:
+                try:
+                    job = engine.submit(*args, tape, stat_first=draws // 2)
+                    break
+                except _capi.FoklNativeError as exc:                    # all 8 slots alive: release the oldest
+                    assert exc.code == -3
+                    old = jobs.pop(0)
+                    check(old, draws, s_ref)
+            jobs.append((job, noise, args, p))
+        while jobs:
+            check(jobs.pop(0), draws, s_ref)
+    finally:
+        pool.close()
+    assert engine.stats()['issued'] >= len(sizes)
+
+
+def check(entry, draws, s_ref):
+    job, noise, args, p = entry
+    mean_w, flag = job.wait()
+    noise.wait()
+    w = job.fetch_w()
+    job.release()
+    want = _capi.gibbs_chain(args[0], args[1], 500.0 + p / 2, 4 + (p - 1) / 2, *args[2:], draws, s_ref)
+    scale = np.max(np.abs(want), axis=0)
+    assert flag[0] == 0 and np.max(np.abs(w - want) / scale) < 1e-13
+    assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13

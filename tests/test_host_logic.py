@@ -593,6 +593,67 @@ def test_pipelined_search_equals_the_inline_search(monkeypatch, seed):
         np.testing.assert_allclose(got[0], ref[0], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize('seed', [3, 10, 29, 41, 53, 70, 91])
+def test_search_with_device_chains_equals_the_inline_search(monkeypatch, seed):
+    """G3 of the kill-test candidates on a (stand-in) device engine whose chains answer milliseconds late: the search
+    takes its second-clause decisions from the guessed intercept scale, confirms every one of them when the chains
+    arrive, and must select the same model, score the same BIC trace, return the same draws and leave numpy's stream
+    where the in-line search leaves it.  Also: a forced wrong guess is caught by the verification and the search is
+    repeated on host chains; an engine without free slots hands the chains back to the host threads."""
+    from helpers import StandInChainEngine
+    x, y, kw = _random_problem(seed)
+    made = []
+
+    def factory(**opts):
+        def make():
+            made.append(StandInChainEngine(**opts))
+            return made[-1]
+        return make
+
+    def run(factory_=None, **env):
+        for key in ('FOKL_NOISE_PIPELINE', 'FOKL_GUESS_TEST_FLIP', 'FOKL_GUESS_MARGIN', 'FOKL_KILL_BIC'):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        monkeypatch.setattr(engine, '_chain_engine_factory', factory_)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = FoKLRoutines.FoKL(**kw)
+            model._backend_override = OracleBackend()
+            np.random.seed(seed + 7)
+            betas, mtx, evs = model.fit(x, y, clean=True)
+        return betas, mtx, evs, rng_fingerprint(), model.fit_stats, [t['cols'] for t in model.fit_trace]
+
+    def same(got, ref):
+        assert np.array_equal(got[1], ref[1]) and got[3] == ref[3] and got[2].shape == ref[2].shape and got[5] == ref[5]
+        np.testing.assert_allclose(got[2], ref[2], rtol=1e-10)
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-7, atol=1e-9)
+
+    ref = run(FOKL_NOISE_PIPELINE='0')
+    got = run(factory(), FOKL_NOISE_PIPELINE='1')
+    same(got, ref)
+    st = got[4]
+    assert st['searches_repeated'] == 0 and st['guesses_verified'] == st['guessed']
+    assert st['device_chains'] == made[-1].issued and made[-1].alive == 0       # every slot went back
+    kills_accepted = st['device_chains']
+    if st['guessed']:
+        # the same search with one guess taken wrong on purpose: caught, repeated without guessing, same answer
+        flipped = run(factory(), FOKL_NOISE_PIPELINE='1', FOKL_GUESS_TEST_FLIP='1')
+        same(flipped, ref)
+        assert flipped[4]['searches_repeated'] == 1 and flipped[4]['device_chains'] == 0 and made[-1].alive == 0
+    # K3 per candidate: rejected candidates have device chains too (released without anybody reading them)
+    same(run(factory(), FOKL_NOISE_PIPELINE='1', FOKL_KILL_BIC='device'), ref)
+    assert made[-1].alive == 0
+    # an engine with a single slot: most chains fall back to the host threads, results unchanged
+    starved = run(factory(slots=1), FOKL_NOISE_PIPELINE='1')
+    same(starved, ref)
+    assert made[-1].alive == 0 and (kills_accepted < 2 or made[-1].refused > 0)
+    # borderline proposals wait for the chain instead of guessing: a margin nothing can clear
+    waited = run(factory(), FOKL_NOISE_PIPELINE='1', FOKL_GUESS_MARGIN='1e9')
+    same(waited, ref)
+    assert waited[4]['guessed'] == 0
+
+
 def test_a_reap_between_tape_request_and_chain_cannot_recycle_the_tape(monkeypatch):
     """the recorder may be done with a tape before the chain that reads it is submitted; a _reap() in
     between (HostPipeline.spectral -> _track does one whenever 24 jobs are live) must not hand the tape's buffer
