@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+SIDE_FITS = 4                  # fits per process in the throughput side measurement
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
 
@@ -437,8 +438,11 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
             os.sched_setaffinity(0, dom)
     except OSError:
         pass
+    # host chains: the chain + finishing threads follow the recorder (a core's worth each), two spectral threads fit next
+    # to them; device chains: those threads idle, the eigen-decompositions are what the driver waits for -- three
+    device_chains = os.environ.get('FOKL_CHAIN', 'auto') != 'host'
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
-                      ('FOKL_SPECTRAL_THREADS', '2' if procs > 2 else '3')):
+                      ('FOKL_SPECTRAL_THREADS', '3' if device_chains or procs <= 2 else '2')):
         os.environ.setdefault(name, val)
     os.environ['FOKL_DEVICE'] = str(device_of(local))
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
@@ -471,7 +475,8 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
             model._backend_override.ctx.timing_enable(True)
             model._backend_override.ctx.timing_reset()
         acc = dict(terms_logical=0, terms_physical=0, gibbs_calls=0, pool_noise_s=0.0, pool_chain_s=0.0,
-                   pool_finish_s=0.0, pool_spectral_s=0.0, t_eigh=0.0, t_resid=0.0, t_chain=0.0)
+                   pool_finish_s=0.0, pool_spectral_s=0.0, t_eigh=0.0, t_resid=0.0, t_chain=0.0, noise_verdict_wait_s=0.0,
+                   noise_queue_wait_s=0.0, seconds=0.0)
         start.wait()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -591,8 +596,6 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         'gpu_kernel_ms_per_step': gpu_ms / max(args.steps, 1),
         'host_prepare_s': sum(r['prep_s'] for r in results),
         'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
-        'cpu_seconds_per_step': cpu_s / max(args.steps, 1),   # process CPU time (every thread) over the timed region
-        'chain_mode': os.environ.get('FOKL_CHAIN', 'auto'),
         'worker_seconds': sorted(r['elapsed'] for r in results),
         'roofline': dominant,
         'kernels': kernels,
@@ -657,15 +660,20 @@ def main():
     side_job = None
     if (cfg == 2 and world == 1 and rank == 0 and not args.procs and not args.no_throughput and not args.mode
             and os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') != '1'):
-        side_procs = max(1, min(4, int(engine._cpu_budget() // 4)))
-        if side_procs > 1:
+        # worker processes next to this one, which fits along as one more (six processes on the GPU at most, this one
+        # included): one fitting process per ~2.6 CPUs with the chains of the kill tests on the device (a fit then costs
+        # ~0.27 CPU-seconds per ~0.1 s), one per 4 CPUs with host chains (0.4 CPU-seconds)
+        per_proc = 4.0 if os.environ.get('FOKL_CHAIN', 'auto') == 'host' else 2.6
+        side_procs = int(os.environ.get('FOKL_BENCH_SIDE_PROCS', max(1, min(6, int(engine._cpu_budget() / per_proc))) - 1))
+        if side_procs >= 1:
             try:
                 import multiprocessing as mp
                 ctx_mp = mp.get_context('spawn')
                 gate, start_b, done_q = ctx_mp.Event(), ctx_mp.Barrier(side_procs + 1), ctx_mp.Queue()
                 side_workers = [ctx_mp.Process(target=fits_worker, daemon=True,
-                                               args=(cfg, k, side_procs, local, [k], args.rows or CONFIGS[cfg]['rows'], 2, 1,
-                                                     start_b, done_q, gate)) for k in range(side_procs)]
+                                               args=(cfg, k + 1, side_procs + 1, local, [k + 1],
+                                                     args.rows or CONFIGS[cfg]['rows'], SIDE_FITS, 1, start_b, done_q, gate))
+                                for k in range(side_procs)]
                 for w in side_workers:
                     w.start()
                 side_job = (side_procs, gate, start_b, done_q, side_workers)
@@ -805,7 +813,8 @@ def main():
                     pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0, spectral_remote=0,
                     exchanges=0, chains_skipped=0, spectral_submitted=0, resid_matrix_free=0, bic_from_gram=0,
                     noise_queue_wait_s=0.0, noise_verdict_wait_s=0.0, device_chains=0, chains_fetched=0, guessed=0,
-                    guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0)
+                    guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0, t_final_verify=0.0,
+                    t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']
@@ -925,15 +934,25 @@ def main():
             gate.set()
             start_b.wait(timeout=300)                       # all of them have uploaded and warmed up
             t_side = time.perf_counter()
+            own_terms = 0
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for _ in range(SIDE_FITS):                  # this process fits along: one more fitting process on the GPU
+                    own_terms += sum(st['terms_logical'] for st in one_step())
             side_res = [done_q.get(timeout=300) for _ in side_workers]
             t_side = time.perf_counter() - t_side
-            side_terms = sum(r['stats']['terms_logical'] for r in side_res)
-            side_fits = side_procs * 2
+            side_terms = own_terms + sum(r['stats']['terms_logical'] for r in side_res)
+            side_fits = (side_procs + 1) * SIDE_FITS
             throughput_mode = dict(
-                workload=f'{side_procs} worker processes, each fitting its own configs[2] dataset (dataset seeds 12 .. '
-                         f'{11 + side_procs}) twice, back to back, on this one GPU',
-                procs=side_procs, value=side_terms / t_side, unit='candidate-terms/s', fits_per_s=side_fits / t_side,
-                seconds=t_side, ms_per_fit_per_worker=1e3 * t_side / 2)
+                workload=f'{side_procs + 1} processes (this one and {side_procs} workers), each fitting its own configs[2] '
+                         f'dataset (dataset seeds 12 .. {12 + side_procs}) {SIDE_FITS} times, back to back, on this one GPU',
+                procs=side_procs + 1, value=side_terms / t_side, unit='candidate-terms/s', fits_per_s=side_fits / t_side,
+                seconds=t_side, ms_per_fit_per_process=1e3 * t_side / SIDE_FITS,
+                chain_mode=os.environ.get('FOKL_CHAIN', 'auto'),
+                worker_s_per_fit={key: sum(r['stats'].get(key, 0.0) for r in side_res) / max(1, side_procs * SIDE_FITS)
+                                  for key in ('t_eigh', 't_chain', 'pool_noise_s', 'pool_spectral_s', 'noise_verdict_wait_s',
+                                              'noise_queue_wait_s', 'seconds')},
+                worker_elapsed_s=[r['elapsed'] for r in side_res])
         except Exception as exc:
             print(f"bench.py: throughput side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
         finally:
@@ -992,6 +1011,8 @@ def main():
         'fit_call': fit_call,
         'fit_call_ms': fit_call['fit_call_ms'] if fit_call else None,
         'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
+        'cpu_seconds_per_step': cpu_s / max(args.steps, 1),   # process CPU time (every thread) over the timed region
+        'chain_mode': os.environ.get('FOKL_CHAIN', 'auto'),
         'cpu_pinning': pinned,
         'roofline': dominant,
         'kernels': kernels,

@@ -79,12 +79,13 @@ SIGNATURES = {
     'fokl_dchain_create': (c_int, [c_int, c_int, c_vp]),
     'fokl_dchain_destroy': (None, [c_vp]),
     'fokl_dchain_submit': (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp,
-                                   c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+                                   c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    'fokl_dchain_try_release': (c_int, [c_vp, c_i64]),
     'fokl_dchain_poll': (c_int, [c_vp, c_i64]),
     'fokl_dchain_wait': (c_int, [c_vp, c_i64, c_vp]),
     'fokl_dchain_fetch_w': (c_int, [c_vp, c_i64, c_vp]),
     'fokl_dchain_release': (c_int, [c_vp, c_i64]),
-    'fokl_dchain_stats': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'fokl_dchain_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_host_alloc': (c_int, [ctypes.c_size_t, c_vp]),
     'fokl_host_free': (c_int, [c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
@@ -504,25 +505,39 @@ class HostPool:
 # ---------------------------------------------------------------------------------------------------------
 
 class _PinnedBlock:
-    """Owner of one fokl_host_alloc allocation; freed when the last array view of it goes."""
+    """Owner of one fokl_host_alloc allocation.  When the last array view of it goes the block returns to a free list
+    of its size (page-locking and unlocking cost milliseconds; tapes come and go by the hundred per fit)."""
     __slots__ = ('ptr', 'nbytes')
+    FREE = {}                                                     # nbytes -> [addresses]
+    KEEP_BYTES = int(float(os.environ.get('FOKL_PINNED_POOL_MB', '1024')) * (1 << 20))
+    kept = 0
 
     def __init__(self, nbytes):
-        ptr = c_vp(0)
-        _check(load().fokl_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
-        self.ptr, self.nbytes = ptr.value, nbytes
+        spare = _PinnedBlock.FREE.get(nbytes)
+        if spare:
+            self.ptr = spare.pop()
+            _PinnedBlock.kept -= nbytes
+        else:
+            ptr = c_vp(0)
+            _check(load().fokl_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
+            self.ptr = ptr.value
+        self.nbytes = nbytes
 
     def __del__(self):
         try:
             if self.ptr:
-                load().fokl_host_free(c_vp(self.ptr))
+                if _PinnedBlock.kept + self.nbytes <= _PinnedBlock.KEEP_BYTES:
+                    _PinnedBlock.FREE.setdefault(self.nbytes, []).append(self.ptr)
+                    _PinnedBlock.kept += self.nbytes
+                else:
+                    load().fokl_host_free(c_vp(self.ptr))
         except Exception:                                          # interpreter shutdown: the driver reclaims it anyway
             pass
         self.ptr = None
 
 
 def pinned_empty(doubles):
-    """A float64 array of ``doubles`` elements in page-locked host memory (tapes that the device chains copy from)."""
+    """A float64 array of ``doubles`` elements in page-locked host memory (tapes that the device chains read in place)."""
     block = _PinnedBlock(int(doubles) * 8)
     raw = (ctypes.c_double * int(doubles)).from_address(block.ptr)
     raw._fokl_owner = block                                       # the ctypes array is the ndarray's base: keeps the block
@@ -532,32 +547,48 @@ def pinned_empty(doubles):
 class DeviceChainJob:
     """One chain on a DeviceChainEngine (include/fokl_hip.h: fokl_dchain_*).  ``wait()`` -> (mean of w over the rows
     from ``stat_first`` on, bstar-negative flag); ``fetch_w()`` -> the draws in the eigenbasis [draws, p1];
-    ``release()`` frees the device slot (idempotent).  Keeps the host buffers the job reads alive."""
-    __slots__ = ('_engine', '_ticket', 'p1', 'draws', 'keep', 'recycle', '_stats', 'ignore_failure')
+    ``release()`` frees the device slot (idempotent).  Keeps the host buffers the job reads alive.
+    Completion is read from the job's statistics area in page-locked host memory (the kernel stores the ticket there
+    last): ``done()`` is a memory load, not a call into the runtime."""
+    __slots__ = ('_engine', '_ticket', 'p1', 'draws', 'keep', 'recycle', '_stats', 'ignore_failure', '_area', '_flag',
+                 '_mark')
     unresolved = False                  # PoolJob's interface: only tentative noise jobs wait for a verdict
 
-    def __init__(self, engine, ticket, p1, draws, keep):
+    def __init__(self, engine, ticket, p1, draws, keep, stats_address=None):
         self._engine, self._ticket, self.p1, self.draws, self.keep = engine, ticket, p1, draws, keep
         self.recycle = None
         self._stats = None
         self.ignore_failure = False
+        self._area = self._flag = None
+        self._mark = float(ticket) if ticket is not None else 0.0
+        if stats_address:
+            self._area = np.ctypeslib.as_array((ctypes.c_double * (5 + p1)).from_address(stats_address))
+            self._flag = ctypes.c_double.from_address(stats_address + 8 * (4 + p1))
 
     def resolve(self, commit):
         pass
 
+    def _ran(self):
+        return self._flag is not None and self._flag.value == self._mark
+
     def done(self):
         """True once the device is through with the job's host buffers (the chain has run, or the job has failed)."""
-        if self._ticket is None or self._stats is not None:
+        if self._ticket is None or self._stats is not None or self._ran():
             return True
+        if self._flag is not None:
+            return False                # a failed job never sets the flag: wait() / release() report it
         return bool(self._engine._lib.fokl_dchain_poll(self._engine._h, self._ticket))
 
     def wait(self):
         if self._stats is None:
             if self._ticket is None:
                 raise RuntimeError("device chain: released before anybody read its statistics")
-            buf = np.empty(4 + self.p1, dtype=np.float64)
-            _check(self._engine._lib.fokl_dchain_wait(self._engine._h, self._ticket, _ptr(buf)))
-            self._stats = buf
+            if self._ran():
+                self._stats = np.array(self._area[:4 + self.p1])
+            else:
+                buf = np.empty(4 + self.p1, dtype=np.float64)
+                _check(self._engine._lib.fokl_dchain_wait(self._engine._h, self._ticket, _ptr(buf)))
+                self._stats = buf
         return self._stats[4:], np.array([int(self._stats[0])], dtype=np.int32)
 
     @property
@@ -571,11 +602,22 @@ class DeviceChainJob:
         _check(self._engine._lib.fokl_dchain_fetch_w(self._engine._h, self._ticket, _ptr(w)))
         return w
 
+    def try_release(self):
+        """release() if that takes no waiting.  -> True when the slot is free."""
+        if self._ticket is None or not self._engine._h:
+            return True
+        if self._flag is not None and not self._ran() and self._stats is None:
+            return False
+        if self._engine._lib.fokl_dchain_try_release(self._engine._h, self._ticket):
+            self._ticket, self.keep, self._area, self._flag = None, None, None, None
+            return True
+        return False
+
     def release(self):
         if self._ticket is not None and self._engine._h:
             self._engine._lib.fokl_dchain_release(self._engine._h, self._ticket)
         self._ticket = None
-        self.keep = None
+        self.keep = self._area = self._flag = None
 
 
 class DeviceChainEngine:
@@ -605,18 +647,19 @@ class DeviceChainEngine:
             raise ValueError("tape was recorded for a different model size")
         ptr = tape.pointers()
         finished = bool(tape.finishing_requested)
-        ticket = c_i64(0)
+        ticket, area = c_i64(0), c_vp(0)
         _check(self._lib.fokl_dchain_submit(self._h, p1, tape.draws, _ptr(lamb), _ptr(qty), float(b), float(btau),
                                             float(dtd), float(sigsqd0), float(tausqd0), ptr[0], ptr[2], ptr[3], ptr[4],
                                             tape.progress_pointer() if follow else None,
                                             tape.block_done_pointer() if finished else None, tape.BLOCK, int(finished),
-                                            int(stat_first), ctypes.byref(ticket)))
-        return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape,))
+                                            int(stat_first), ctypes.byref(ticket), ctypes.byref(area)))
+        return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape,), area.value)
 
     def stats(self):
-        busy, issued, launches = c_dbl(0), c_i64(0), c_i64(0)
-        _check(self._lib.fokl_dchain_stats(self._h, ctypes.byref(busy), ctypes.byref(issued), ctypes.byref(launches)))
-        return dict(dispatch_s=busy.value, issued=issued.value, launches=launches.value)
+        busy, issued, launches, staged = c_dbl(0), c_i64(0), c_i64(0), c_i64(0)
+        _check(self._lib.fokl_dchain_stats(self._h, ctypes.byref(busy), ctypes.byref(issued), ctypes.byref(launches),
+                                           ctypes.byref(staged)))
+        return dict(dispatch_s=busy.value, issued=issued.value, launches=launches.value, staged=staged.value)
 
 
 def gibbs_chain_device(engine, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first=0):

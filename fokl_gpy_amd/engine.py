@@ -446,6 +446,7 @@ class HostPipeline:
         # Every job names buffers the native threads read and write: they are kept here until the job has run, whether
         # or not the driver still cares about the result (a rejected candidate's tape is recorded all the same).
         self._live = []
+        self._reap_at = 24
         # Tapes and draws are a few MB per model evaluation; fresh allocations would be page-faulted in by the noise
         # and chain threads (measured: a third of the tape time).  Buffers go round in 512 KB size classes instead, and
         # stay with the thread from one fit to the next (_thread_spares).
@@ -474,7 +475,13 @@ class HostPipeline:
 
     def _reap(self):
         live = []
+        device_busy = False                 # device chains complete in submission order: one poll finds the frontier
         for job in self._live:
+            if isinstance(job, _capi.DeviceChainJob):
+                if device_busy:
+                    live.append(job)
+                    continue
+                device_busy = not job.done()
             if job.done():
                 if job.recycle:
                     for entry in job.recycle:
@@ -512,8 +519,11 @@ class HostPipeline:
         owner.recycle.append(entry)
 
     def _track(self, job):
-        if len(self._live) >= 24:
+        if len(self._live) >= self._reap_at:
             self._reap()
+            # with chains in flight on the device (a millisecond or two each) the list does not empty: look again only
+            # after another dozen jobs, not on every submission
+            self._reap_at = max(24, len(self._live) + 12)
         self._live.append(job)
         return job
 
@@ -683,7 +693,7 @@ class GibbsOutcome:
     """One model evaluation.  The BIC is known at once; the draws arrive from a chain thread (chain arithmetic in the
     eigenbasis), betas = w Q' (FR:1528) is formed only for the columns somebody looks at."""
     __slots__ = ('lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'intercept_scale', 'siglik', '_jobs', '_owner', '_w',
-                 '_betas', '_w_raw', '_chain_job', 'on_device', 'checks', '_release_wanted')
+                 '_betas', '_w_raw', '_chain_job', 'on_device', 'checks', '_release_wanted', '_dtd')
 
     def __init__(self, owner, spec, ev, idx, noise_job, chain_job, w_raw):
         self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
@@ -695,6 +705,7 @@ class GibbsOutcome:
         self.on_device = isinstance(chain_job, _capi.DeviceChainJob)   # the draws live in device memory (dchain slot)
         self.checks = []                    # (|mean beta| of a proposal, decision taken from the guessed intercept scale)
         self._release_wanted = False
+        self._dtd = None                    # y'y of the fit (device-chained outcomes: intercept_scale_on_host)
 
     def release(self):
         """Hand the buffer of w back to the pipeline's pool (directly, or through the chain job that is still writing
@@ -717,6 +728,22 @@ class GibbsOutcome:
             host.give(raw)
         else:
             self._chain_job.recycle.append(raw)
+
+    def intercept_scale_on_host(self, first_row):
+        """|mean intercept draw| of a device-chained model NOW, from a chain run in line on the calling thread (a quarter
+        of a millisecond; the device's answer is a few milliseconds away).  For the rare proposal that sits too close
+        to the threshold to be decided from the least-squares guess.  The tape is still there: its buffer belongs to
+        the device job until that has run."""
+        o = self._owner
+        noise_job, chain_job = self._jobs
+        noise_job.wait()
+        tape = noise_job.result
+        chain = _capi.gibbs_chain_from_finished_tape if tape.finishing_requested else _capi.gibbs_chain_from_tape
+        w, negative = chain(self.lamb, self.qty, o.b, o.btau, self._dtd, o.sigsqd0, o.tausqd0, tape, follow=True)
+        if negative:
+            raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
+                               "cannot reproduce the reference's skipped draw (FR:1538-1539)")
+        return abs(float(np.mean(w[first_row:] @ self.Qt[:, 0])))
 
     def chain_ready(self):
         """The chain has run: looking at its results costs no wait."""
@@ -1231,7 +1258,15 @@ class ForwardSelection:
             return None
         threshold = self.threshav * abs(float(outcome.betahat[0]))
         if threshold <= 0.0 or not math.isfinite(threshold) or abs(value - threshold) <= self.guess_margin * threshold:
-            return None
+            # too close to call from the guess, and the device's answer is milliseconds away: the chain once more, in
+            # line on this thread (same tape, same arithmetic up to the last bit of log())
+            if outcome._dtd is None:
+                return None
+            self.stats['guess_waits'] += 1
+            t0 = time.perf_counter()
+            outcome.intercept_scale = outcome.intercept_scale_on_host(half0)
+            self.stats['t_chain'] += time.perf_counter() - t0
+            return bool(value < self.threshav * outcome.intercept_scale)
         decision = bool(value < threshold)
         self.stats['guessed'] += 1
         if self._flip_guess and self.stats['guessed'] == self._flip_guess:
@@ -1243,16 +1278,14 @@ class ForwardSelection:
 
     def _release_device_job(self, job):
         """A device chain nobody will look at again: its slot goes back once it has run (never a wait here)."""
-        if job.done():
-            job.release()
-        else:
+        if not job.try_release():
             self._zombies.append(job)
 
     def _verify(self, block=False):
         """Confirm the decisions that were taken from guessed intercept scales against the chains' own statistics --
         those that have arrived, or (block) all of them.  Raises Misprediction if one does not hold."""
         # chains complete in the order they were submitted, near enough: only the oldest is polled (one call per turn)
-        while self._zombies and (block or self._zombies[0].done()):
+        while self._zombies and (self._zombies[0].try_release() or block):
             self._zombies.popleft().release()
         while self._unverified and (block or self._unverified[0][0].chain_ready()):
             outcome, half0 = self._unverified.popleft()
@@ -1356,8 +1389,6 @@ class ForwardSelection:
                     decided = True
                     if best.intercept_scale is not None:
                         scale_guess = best.intercept_scale
-                elif getattr(best, 'on_device', False):
-                    self.stats['guess_waits'] += 1
             if not decided and (best.intercept_scale is not None or not likely(i)):
                 # second clause without G2 of a model that will probably not be needed: from the known scale, or --
                 # the test looks unlikely -- after waiting for the chain of `best`
@@ -1418,6 +1449,7 @@ class ForwardSelection:
                 killed, evmin = trial, ev
                 best.release()                                        # the model it replaces: its draws are history
                 best = GibbsOutcome(self, pending[0], ev, idx, *jobs)
+                best._dtd = dtd
                 self._outcomes.append(best)
             elif jobs is not None:
                 if jobs[2] is None:
@@ -1454,10 +1486,13 @@ class ForwardSelection:
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
         _mark('pool_up')
+        t_up = time.perf_counter()
         try:
             return self._run()
         finally:
             _mark('run_end')
+            t_down = time.perf_counter()
+            self.stats['t_search_body'] = t_down - t_up
             if self.host is not None:
                 # every device chain of this search gives its slot back (the engine outlives the fit); idempotent, and
                 # a chain that has not run yet is waited for -- its tape is committed, so it will
@@ -1477,6 +1512,7 @@ class ForwardSelection:
                                   spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
                                   spectral_submitted=self.host.spectral_submitted)
                 self.host = None
+                self.stats['t_teardown'] = time.perf_counter() - t_down
                 _mark('pool_down')
                 _flush_marks()
 
@@ -1719,10 +1755,14 @@ class ForwardSelection:
             self._ahead_block(ahead)
             self.pool.give(ahead['slots'])
 
+        t0 = time.perf_counter()
         self._verify(block=True)                   # every decision taken from a guess is confirmed before anything returns
+        self.stats['t_final_verify'] = time.perf_counter() - t0
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx
+        t0 = time.perf_counter()
         out_betas = betas.betas[-self.draws_keep::, :]
+        self.stats['t_final_draws'] = time.perf_counter() - t0
         for keep_alive in (betas, last):           # the returned draws are on the host now: the device slots go back
             if getattr(keep_alive, 'on_device', False):
                 keep_alive.release()

@@ -418,6 +418,10 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
  * last tau^2, rows averaged, mean over rows stat_first .. draws - 1 of w} -- what the kill tests look at
  * (FR:1671: mean intercept draw = mean w . Q[0, :]).  fokl_dchain_fetch_w copies the draws in the eigenbasis
  * w [draws, p1] (betas = w Q') to the host; fokl_dchain_release frees the slot (idempotent).
+ * `stats_area` (may be NULL) receives the address of the job's statistics in page-locked host memory: the five + p1
+ * doubles the recursion kernel writes -- the four + p1 of fokl_dchain_wait, then the job's ticket (as a double),
+ * stored last with system-wide release semantics: a caller may poll that word instead of calling fokl_dchain_poll.
+ * The area belongs to the job's slot: valid until the job is released.
  * Errors: FOKL_ERR_STATE when every slot is taken (the caller runs that chain on the host). */
 typedef struct fokl_dchain fokl_dchain;
 int fokl_dchain_create(int device, int slots, fokl_dchain **out);
@@ -425,16 +429,20 @@ void fokl_dchain_destroy(fokl_dchain *engine);
 int fokl_dchain_submit(fokl_dchain *engine, int p1, int draws, const double *lamb, const double *qty, double b,
                        double btau, double dtd, double sigsqd0, double tausqd0, const double *normals,
                        const int32_t *lead, const double *gam_sig, const double *gam_tau, const int32_t *progress,
-                       const int32_t *block_done, int block, int finished, int stat_first, int64_t *ticket);
+                       const int32_t *block_done, int block, int finished, int stat_first, int64_t *ticket,
+                       const double **stats_area);
 int fokl_dchain_poll(fokl_dchain *engine, int64_t ticket);
 int fokl_dchain_wait(fokl_dchain *engine, int64_t ticket, double *stats_out);
 int fokl_dchain_fetch_w(fokl_dchain *engine, int64_t ticket, double *w_out);
 int fokl_dchain_release(fokl_dchain *engine, int64_t ticket);
+/* The same without waiting: 1 = the slot is free (now or before), 0 = the chain has not run yet. */
+int fokl_dchain_try_release(fokl_dchain *engine, int64_t ticket);
 /* seconds the dispatcher spent issuing work, number of chains issued, number of recursion launches (chains whose
  * tapes are ready together go out as one launch: FOKL_DCHAIN_BATCH chains or FOKL_DCHAIN_DELAY_US after the oldest was
- * queued, at once when somebody waits for a result) */
-int fokl_dchain_stats(fokl_dchain *engine, double *busy_seconds, int64_t *issued, int64_t *launches);
-/* Page-locked host memory for tapes (the dispatcher's H2D copies are then DMA transfers instead of staged copies). */
+ * queued, at once when somebody waits for a result); `staged` = chains whose tape was not in page-locked memory and
+ * went through copy calls + a device staging buffer instead of being read in place */
+int fokl_dchain_stats(fokl_dchain *engine, double *busy_seconds, int64_t *issued, int64_t *launches, int64_t *staged);
+/* Page-locked host memory for tapes: the device reads such a tape in place (no copy calls on the dispatcher). */
 int fokl_host_alloc(size_t bytes, void **out);
 int fokl_host_free(void *ptr);
 

@@ -200,6 +200,14 @@ class StandInChainJob(_capi.DeviceChainJob):
     def fetch_w(self, out=None):
         return np.array(self._result()[0])
 
+    def try_release(self):
+        if self._released:
+            return True
+        if not self._future.done():
+            return False
+        self.release()
+        return True
+
     def release(self):
         if not self._released:
             self._future.result()                              # the real engine waits until the tape has been read
