@@ -266,6 +266,7 @@ def quietest_l3_domain(local, ranks, sample_s=0.25):
         return out
     try:
         allowed = set(os.sched_getaffinity(0))
+        near = gpu_numa_cpus(local)
         a = snap()
         time.sleep(sample_s)
         b = snap()
@@ -277,6 +278,8 @@ def quietest_l3_domain(local, ranks, sample_s=0.25):
             if not dom:
                 continue
             seen.update(dom)
+            if near is not None and not set(dom) <= near:
+                continue                                    # the other socket: far from the GPU's page-locked memory
             busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
             domains.append((sum(busy) / max(1, len(busy)), dom))
         mine = [d for i, d in enumerate(domains) if i % max(1, ranks) == local % max(1, ranks)]
@@ -285,6 +288,72 @@ def quietest_l3_domain(local, ranks, sample_s=0.25):
         return min(mine, key=lambda d: d[0])[1]
     except (OSError, ValueError, KeyError, IndexError):
         return None
+
+
+def gpu_numa_cpus(local=0):
+    """Logical CPUs of the NUMA node the rank's GPU hangs off (sysfs: the AMD render nodes this process can read, in
+    order), or None.  Tapes live in page-locked memory next to the GPU: a recorder on the other socket writes them
+    three times slower (measured: 0.23 instead of 0.08 s per fit), so threads are only ever pinned inside this set."""
+    try:
+        nodes = []
+        for name in sorted(os.listdir('/sys/class/drm'), key=lambda n: (len(n), n)):
+            if not name.startswith('renderD'):
+                continue
+            base = f'/sys/class/drm/{name}/device'
+            try:
+                with open(base + '/vendor') as fh:
+                    if fh.read().strip() != '0x1002':
+                        continue
+                with open(base + '/numa_node') as fh:
+                    nodes.append(int(fh.read().strip()))
+            except (OSError, ValueError):
+                continue
+        if not nodes:
+            return None
+        node = nodes[local % len(nodes)]
+        if node < 0:
+            return None
+        with open(f'/sys/devices/system/node/node{node}/cpulist') as fh:
+            cpus = set()
+            for part in fh.read().strip().split(','):
+                lo, _, hi = part.partition('-')
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+    except OSError:
+        return None
+
+
+def quiet_l3_domains(count, avoid=(), sample_s=0.25, near=None):
+    """The `count` least busy L3 domains that share no CPU with `avoid` (worker processes of the throughput modes: one
+    domain each, none on the domain this process has pinned itself to).  Fewer if the box has fewer."""
+    def snap():
+        out = {}
+        with open('/proc/stat') as fh:
+            for line in fh:
+                if line.startswith('cpu') and line[3].isdigit():
+                    p = line.split()
+                    out[int(p[0][3:])] = (sum(map(int, p[1:9])), int(p[4]) + int(p[5]))
+        return out
+    try:
+        avoid = set(avoid or ())
+        a = snap()
+        time.sleep(sample_s)
+        b = snap()
+        domains, seen = [], set()
+        for cpu in range(os.cpu_count() or 1):
+            if cpu in seen:
+                continue
+            dom = l3_domain_of(cpu)
+            if not dom:
+                continue
+            seen.update(dom)
+            if avoid & set(dom) or (near is not None and not set(dom) <= near):
+                continue
+            busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
+            domains.append((sum(busy) / max(1, len(busy)), dom))
+        return [dom for _, dom in sorted(domains, key=lambda d: d[0])[:count]]
+    except (OSError, ValueError, KeyError, IndexError):
+        return []
 
 
 def pin_to_l3_domain(local, ranks=1):
@@ -426,14 +495,14 @@ def bring_up_comm(ctx, rank, world, use_rccl, need_rccl):
     return dist.bring_up(ctx, rank, world, need_rccl, log=lambda msg: print(f"bench.py: {msg}", file=sys.stderr))
 
 
-def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done, gate=None):
+def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done, gate=None, domain=None):
     """One of the worker PROCESSES of `--config 4 --procs P`: its own device context(s), host threads and L3 domain; fits
     its share of the rank's datasets back to back.  (Threads of one process share the interpreter lock of the Python
     drivers; processes do not: 13.7 / 21.9 / 32.8 / 40.6 fits/s with 1 / 2 / 3 / 4 of them on one MI355X.)"""
     if gate is not None and not gate.wait(timeout=900):     # started early, used late (or never: then just leave)
         return
     try:
-        dom = l3_domain_of(8 * (local * procs + k))
+        dom = domain or l3_domain_of(8 * (local * procs + k))
         if dom:
             os.sched_setaffinity(0, dom)
     except OSError:
@@ -441,6 +510,9 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
     # host chains: the chain + finishing threads follow the recorder (a core's worth each), two spectral threads fit next
     # to them; device chains: those threads idle, the eigen-decompositions are what the driver waits for -- three
     device_chains = os.environ.get('FOKL_CHAIN', 'auto') != 'host'
+    # host threads that wait for the GPU sleep instead of spinning: with several processes on one GPU a wait is long, and
+    # what it burns is CPU of the shared quota (measured: 0.37 -> 0.31 CPU-seconds per fit with six processes)
+    os.environ.setdefault('FOKL_SYNC', 'blocking')
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
                       ('FOKL_SPECTRAL_THREADS', '3' if device_chains or procs <= 2 else '2')):
         os.environ.setdefault(name, val)
@@ -478,10 +550,12 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
                    pool_finish_s=0.0, pool_spectral_s=0.0, t_eigh=0.0, t_resid=0.0, t_chain=0.0, noise_verdict_wait_s=0.0,
                    noise_queue_wait_s=0.0, seconds=0.0)
         start.wait()
+        cpu0 = time.process_time()
         t0 = time.perf_counter()
         for _ in range(steps):
             one_pass(acc)
         elapsed = time.perf_counter() - t0
+        acc['cpu_s'] = time.process_time() - cpu0             # every thread of this worker
     kern = {}
     for name, kid in KERNEL_SLOTS():
         tot = dict(ms=0.0, launches=0, bytes=0.0, flops=0.0, ideal_ms=0.0)
@@ -658,6 +732,17 @@ def main():
     # time).  The worker processes have to be started before this process initialises the GPU; they sleep until the
     # main measurement is over.  `value` stays the one-fit-at-a-time figure.
     side_job = None
+    # this process's L3 domain is chosen first, the worker processes' domains next (all the others to choose from: the
+    # affinity mask is put back for that, and the workers inherit the full mask), then this process pins itself
+    early_pin, full_mask = None, None
+    if cfg != 4 and not (args.procs and args.procs > 1):
+        try:
+            full_mask = os.sched_getaffinity(0)
+        except (AttributeError, OSError):
+            full_mask = None
+        early_pin = pin_to_l3_domain(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
+        if early_pin is not None and full_mask is not None:
+            os.sched_setaffinity(0, full_mask)
     if (cfg == 2 and world == 1 and rank == 0 and not args.procs and not args.no_throughput and not args.mode
             and os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') != '1'):
         # worker processes next to this one, which fits along as one more (six processes on the GPU at most, this one
@@ -670,9 +755,12 @@ def main():
                 import multiprocessing as mp
                 ctx_mp = mp.get_context('spawn')
                 gate, start_b, done_q = ctx_mp.Event(), ctx_mp.Barrier(side_procs + 1), ctx_mp.Queue()
+                side_domains = quiet_l3_domains(side_procs, avoid=early_pin, near=gpu_numa_cpus(local))
+                side_domains += [None] * (side_procs - len(side_domains))
                 side_workers = [ctx_mp.Process(target=fits_worker, daemon=True,
                                                args=(cfg, k + 1, side_procs + 1, local, [k + 1],
-                                                     args.rows or CONFIGS[cfg]['rows'], SIDE_FITS, 1, start_b, done_q, gate))
+                                                     args.rows or CONFIGS[cfg]['rows'], SIDE_FITS, 1, start_b, done_q, gate,
+                                                     side_domains[k]))
                                 for k in range(side_procs)]
                 for w in side_workers:
                     w.start()
@@ -680,6 +768,11 @@ def main():
             except Exception as exc:                          # never let the extra cost the main measurement
                 print(f"bench.py: throughput side measurement not started: {exc}", file=sys.stderr)
                 side_job = None
+    if early_pin is not None:
+        try:
+            os.sched_setaffinity(0, early_pin)              # the workers are on their way: now this process's own domain
+        except OSError:
+            pass
     if cfg == 4:
         procs = args.procs if args.procs else max(1, min(4, int(engine._cpu_budget() // 4)))
         procs = max(1, min(procs, args.fits_per_step or 8))
@@ -703,7 +796,8 @@ def main():
         for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '2'), ('FOKL_SPECTRAL_THREADS', '2')):
             os.environ.setdefault(name, val)
     else:
-        pinned = pin_to_l3_domain(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
+        pinned = early_pin if early_pin is not None else pin_to_l3_domain(
+            local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     mode = args.mode or ('candidates' if cfg == 3 else 'fits')
     one_fit_for_all = mode in ('rows', 'candidates')
     fits_per_step = (args.fits_per_step or 8) if cfg == 4 else 1
@@ -951,7 +1045,7 @@ def main():
                 chain_mode=os.environ.get('FOKL_CHAIN', 'auto'),
                 worker_s_per_fit={key: sum(r['stats'].get(key, 0.0) for r in side_res) / max(1, side_procs * SIDE_FITS)
                                   for key in ('t_eigh', 't_chain', 'pool_noise_s', 'pool_spectral_s', 'noise_verdict_wait_s',
-                                              'noise_queue_wait_s', 'seconds')},
+                                              'noise_queue_wait_s', 'seconds', 'cpu_s')},
                 worker_elapsed_s=[r['elapsed'] for r in side_res])
         except Exception as exc:
             print(f"bench.py: throughput side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)

@@ -622,6 +622,7 @@ class DeviceChainJob:
 
 class DeviceChainEngine:
     """include/fokl_hip.h: fokl_dchain_* -- finishing of the polar normals and the Gibbs recursion on the GPU."""
+    max_columns = 768                   # one wavefront per chain, up to 12 eigen-directions per lane
 
     def __init__(self, device=0, slots=96):
         self._lib = load()

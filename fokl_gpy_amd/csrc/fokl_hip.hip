@@ -315,6 +315,14 @@ extern "C" int fokl_ctx_create(int device, fokl_ctx **out)
         return fail(nullptr, FOKL_ERR_ARG, "fokl_ctx_create: device index out of range");
     fokl_ctx *ctx = new fokl_ctx();
     ctx->device = device;
+    // FOKL_SYNC=blocking: host threads that wait for the device sleep instead of spinning -- for many processes sharing one
+    // GPU under a CPU quota (bench.py's throughput workers), where the spinning of one is CPU the others do not get.
+    // Must come before the runtime creates the device's context; an error (context exists already) is not fatal.
+    if (const char *mode = std::getenv("FOKL_SYNC"))
+        if (std::strcmp(mode, "blocking") == 0) {
+            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+            (void)hipGetLastError();
+        }
     HIP_TRY(nullptr, hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));

@@ -1092,7 +1092,8 @@ class ForwardSelection:
         spec, idx, _, dtd, _ = pending
         if noise_job is None:
             noise_job = self._tape_for(idx.shape[0], model=not test)
-        if test and self.chain_engine is not None and not (self._prechain is not None and self._prechain[0] is noise_job):
+        if (test and self.chain_engine is not None and idx.shape[0] <= getattr(self.chain_engine, 'max_columns', 768)
+                and not (self._prechain is not None and self._prechain[0] is noise_job)):
             job = self.host.chain_device(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job, stat_first)
             if job is not None:
                 self.stats['device_chains'] += 1
