@@ -119,8 +119,11 @@ def load():
         raise FoklNativeError(-1, f"{LIB_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; "
                                   f"g.build()'` or `make -C fokl_gpy_amd/csrc` (there is no CPU fallback)")
     lib = ctypes.CDLL(LIB_PATH)
+    host_only = os.environ.get('FOKL_HOST_ONLY_LIBRARY', '0') == '1'      # sanitizer builds of the host side (csrc/Makefile)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None) if host_only else getattr(lib, name)
+        if fn is None:
+            continue
         fn.restype = res
         fn.argtypes = args
     _lib = lib

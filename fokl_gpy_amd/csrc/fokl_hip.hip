@@ -47,6 +47,7 @@ struct PendingEvent {
 
 struct fokl_ctx {
     int device = 0;
+    int cus = 0;                 // compute units of the device
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -331,7 +332,10 @@ extern "C" int fokl_ctx_create(int device, fokl_ctx **out)
         delete ctx;
         return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: device is " + arch + ", this library is built for gfx950 only");
     }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+    const int total_cus = prop.multiProcessorCount;
+    ctx->cus = total_cus;
+    const hipError_t made = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (made != hipSuccess ||
         hipEventCreateWithFlags(&ctx->args_free, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->gram_done, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
@@ -489,15 +493,8 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
 // K1 launch planning
 // ---------------------------------------------------------------------------------------------------------
 
-static int cu_count(fokl_ctx *ctx)
-{
-    static int cached = 0;
-    if (cached) return cached;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) cached = prop.multiProcessorCount;
-    if (cached <= 0) cached = 256;
-    return cached;
-}
+// Compute units of the device: every launch plan sizes its grid for this number.
+static int cu_count(fokl_ctx *ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 
 // LDS available to one workgroup of the basis kernel; the factor table takes 4 KB per distinct factor.
 static constexpr size_t K1_LDS_BUDGET = 144 * 1024;

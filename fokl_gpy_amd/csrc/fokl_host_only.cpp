@@ -1,0 +1,34 @@
+// Host-only stand-ins for what the host translation units (sampler, thread pool, vector log, integrator) expect from
+// fokl_hip.hip: the error plumbing and the version call.  Linked into the sanitizer builds of the host side
+// (`make host-tsan host-asan`, tools/sanitize_host.sh) -- GPU sanitizers are not available on this pool, and the
+// hand-rolled lock-free pipeline of fokl_hostpool.cpp is exactly the part that wants a race detector.  Device entry
+// points are absent from those libraries: _capi.load() skips them when FOKL_HOST_ONLY_LIBRARY=1.
+#include <mutex>
+#include <string>
+
+#include "../../include/fokl_hip.h"
+
+static std::mutex g_err_mutex;
+static std::string g_err;
+
+void fokl_set_global_error(const std::string &msg)
+{
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    g_err = msg;
+}
+
+extern "C" int fokl_version(void) { return 100; }
+
+extern "C" const char *fokl_last_error(const fokl_ctx *)
+{
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+extern "C" int fokl_device_count(int *count)
+{
+    if (count) *count = 0;
+    return FOKL_ERR_HIP;
+}

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_kernel(
     const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr,
     DerivSpec deriv)
 {
+    __builtin_amdgcn_s_setprio(3);   // ahead of the single-wavefront chain kernels that may share the CU (fokl_chain_device.inc)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
     const int *fac_input = arr;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
     const BasisPlan *__restrict__ plan, const int *__restrict__ arr, double *const *__restrict__ slot_ptr,
     DerivSpec deriv)
 {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int U = plan->n_fac, T = plan->n_terms, NS = plan->n_slabs;
     const int *fac_input = arr;
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(GV_THREADS) void gram_valu_kernel(double *const *__
                                                                const int *__restrict__ col_slots, int nc, int64_t n,
                                                                double *__restrict__ slab, int nr_pad, int nc_pad)
 {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double red[GV_THREADS / WAVE][GV_TI * GV_TJ];
     const int tid = threadIdx.x;
     const int i0 = blockIdx.z * GV_TI, j0 = blockIdx.y * GV_TJ;
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
                                                                 const double *__restrict__ zero_col,
                                                                 const double *__restrict__ base)
 {
+    __builtin_amdgcn_s_setprio(3);
     static_assert(KS == 1 || NT == 1, "k-split teams hold one tile");
     extern __shared__ __attribute__((aligned(16))) double gt_tile[];
     const int rb = 1 << rb_shift, R = 32 << rb_shift, pitch = R + 2;
@@ -894,6 +898,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
                                                                        int nr_pad, int nc_pad,
                                                                        const double *__restrict__ base, uint32_t zero_units)
 {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(1024))) double gd_tile[];
     constexpr int R = 32, pitch = R + 2;
     const GramGroup &g = groups[blockIdx.y];
@@ -1389,6 +1394,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
                                                            const double *__restrict__ y, int64_t n,
                                                            double *__restrict__ slab)
 {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) ResidCol cols[RS_BATCH];
     __shared__ double red[RS_THREADS / WAVE][2];
     const int tid = threadIdx.x;
@@ -1547,6 +1553,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_terms_kernel(
     const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
     const double *__restrict__ y, double *__restrict__ slab)
 {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     __shared__ double red[RS_THREADS / WAVE][2];
     const int T = hdr->n_terms, G = hdr->n_groups;
@@ -1721,6 +1728,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_terms_lds_kernel(
     const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
     const double *__restrict__ y, double *__restrict__ slab)
 {
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     __shared__ double red[RS_THREADS / WAVE][2];
     const int U = hdr->n_fac, T = hdr->n_terms, G = hdr->n_groups;

@@ -108,6 +108,10 @@ CASES = {
     # configs[3] family (M = 16, 3-way, stages capped at 3) at the largest N / draws the oracle finishes in ~1/2 h:
     # its O(P^3) products per Gibbs iteration (FR:1521-1528) on 585-column models are what bounds it
     'cfg3': lambda: run_case('cfg3_n1e5_m16_way3', 3, rows=100_000, burnin=30, draws=30),
+    # ... and at the benchmark's own N = 1e6 with the same shortened chains (the oracle's cost at this size is the 900
+    # Gram matrices of up to 586 columns over a million rows and the column builds, about 1.5 h on 6 cores; with the
+    # configuration's 1000 + 1000 draws the O(P^3) products per Gibbs iteration would add days)
+    'cfg3big': lambda: run_case('cfg3_n1e6_m16_way3', 3, rows=1_000_000, burnin=30, draws=30),
 }
 
 if __name__ == '__main__':
