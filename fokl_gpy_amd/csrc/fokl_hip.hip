@@ -496,6 +496,8 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
 // Compute units of the device: every launch plan sizes its grid for this number.
 static int cu_count(fokl_ctx *ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 
+static int env_int(const char *name, int fallback);
+
 // LDS available to one workgroup of the basis kernel; the factor table takes 4 KB per distinct factor.
 static constexpr size_t K1_LDS_BUDGET = 144 * 1024;
 
@@ -595,7 +597,8 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
 
     const int64_t tile_rows = (int64_t)threads * K1_ROWS_PER_THREAD;
     const int64_t n_tiles = (ctx->n + tile_rows - 1) / tile_rows;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(reg_table ? 5 : 16, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(reg_table ? 5 : 16, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
+    per_cu = std::min(per_cu, std::max(1, env_int("FOKL_K1_WGS", per_cu)));
     const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cu_count(ctx) * per_cu);
     const BasisPlan *d_plan = reinterpret_cast<const BasisPlan *>(ctx->d_args);
     const int *d_arr = reinterpret_cast<const int *>(ctx->d_args + plan_bytes);
@@ -732,6 +735,7 @@ static int blocks_per_cu(F fn, int threads, size_t dyn_lds)
     return std::min(nb, 8);
 }
 
+#ifdef FOKL_DEV_KERNELS
 // One instantiation per tile configuration; the dispatcher below picks the smallest that covers the block.
 typedef void (*gram_mfma_fn)(double *const *, const int *, int, const int *, int, int64_t, double *, int, int,
                              const double *);
@@ -772,6 +776,8 @@ static gram_mfma_fn jsplit_kernel(int ti, int tj)
     return gram_mfma_kernel<2, 3, false>;
 }
 
+#endif  // FOKL_DEV_KERNELS
+
 // ---- tile-list Gram (gram_tiles_kernel): launch planning ---------------------------------------------------
 
 struct GramPlan {
@@ -797,8 +803,13 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
 {
     pl.kind = kind;
     pl.waves = 4;
+#ifdef FOKL_DEV_KERNELS
     const int nt_max = kind == 1 ? G4S_MAX_NT : GT_MAX_NT;
     const int ct_max = kind == 1 ? G4S_MAX_CT : GT_MAX_CT;
+#else
+    const int nt_max = GT_MAX_NT, ct_max = GT_MAX_CT;
+    (void)kind;
+#endif
     pl.icols.assign(row_slots, row_slots + nr);
     pl.perm.resize(nc);
     {
@@ -989,6 +1000,7 @@ static gram_tiles_fn tiles_kernel(int nt, int passes, int depth, int ks)
     }
 }
 
+#ifdef FOKL_DEV_KERNELS
 typedef void (*gram_tiles4_fn)(double *const *, const int *, int, const GramGroup *, int, int64_t, double *, int, int,
                                const double *, const double *);
 
@@ -1010,6 +1022,8 @@ static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
         default: return tiles4s_kernel_n<4>(passes);
     }
 }
+
+#endif  // FOKL_DEV_KERNELS
 
 typedef void (*gram_dma_fn)(const GramGroup *, int, int, int64_t, double *, int, int, const double *, uint32_t);
 
@@ -1036,13 +1050,20 @@ static gram_dma_fn tiles_dma_kernel_b(int nt8, bool half)
 
 static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf, bool half)
 {
-    return nbuf == 3 ? tiles_dma_kernel_b<3>(nt8, half) : tiles_dma_kernel_b<2>(nt8, half);
+#ifdef FOKL_DEV_KERNELS
+    if (nbuf == 3) return tiles_dma_kernel_b<3>(nt8, half);
+#endif
+    (void)nbuf;
+    return tiles_dma_kernel_b<2>(nt8, half);
 }
 
 // Half-tile slots need the LDS-DMA kernel: asked for only where it runs every block (the default), FOKL_GRAM_HALF=0 for A/B
 static bool half_slots_wanted()
 {
-    return env_int("FOKL_GRAM_DMA", 2) == 2 && env_int("FOKL_GRAM_MFMA4", 0) != 2 && env_int("FOKL_GRAM_HALF", 1) != 0;
+#ifdef FOKL_DEV_KERNELS
+    if (env_int("FOKL_GRAM_MFMA4", 0) == 2) return false;
+#endif
+    return env_int("FOKL_GRAM_DMA", 2) == 2 && env_int("FOKL_GRAM_HALF", 1) != 0;
 }
 
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
@@ -1050,6 +1071,9 @@ extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *c
 {
     if (!row_slots || !col_slots || !info || nr <= 0 || nc <= 0 || kind < 0 || kind > 1)
         return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_plan: bad argument");
+#ifndef FOKL_DEV_KERNELS
+    if (kind == 1) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_plan: kind 1 (4x4x4 tile lists) needs a development build");
+#endif
     GramPlan pl;
     plan_gram(row_slots, nr, col_slots, nc, kind, pl, half_slots_wanted());
     const int32_t head[10] = {pl.nci, pl.it, pl.jt, (int32_t)pl.groups.size(), pl.nt, pl.ct, pl.rb_shift, pl.ks, pl.depth,
@@ -1121,7 +1145,11 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
     if (path == 2) {
         // tile lists over the internal column order; tiles below the diagonal of the row-side x row-side part skipped
         // FOKL_GRAM_MFMA4=2: the 4x4x4 form of the fp64 MFMA instruction (A/B runs; slower beyond the smallest blocks)
+#ifdef FOKL_DEV_KERNELS
         const int kind = env_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
+#else
+        const int kind = 0;
+#endif
         GramPlan pl;
         plan_gram(row_slots, nr, col_slots, nc, kind, pl, half_slots_wanted());
         // column addresses for the groups' descriptors (distances on the 256-byte slot grid)
@@ -1167,6 +1195,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         // partial block the reduction has to read back (FOKL_GRAM_WGS caps it)
         const int wgs_cap = std::max(1, env_int("FOKL_GRAM_WGS", 3));
         int S;
+#ifdef FOKL_DEV_KERNELS
         if (kind == 1) {
             const int P = pl.ct <= 2 ? 2 : pl.ct <= 4 ? 4 : pl.ct <= 6 ? 6 : 8;
             gram_tiles4_fn fn = tiles4s_kernel(pl.nt, pl.ct);
@@ -1183,14 +1212,19 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(G4S_THREADS), lds, ctx->stream,
                                ctx->d_slot_ptr, d_icols, pl.nci, d_groups, pl.ct, ctx->n, ctx->d_slab, nr_pad, nc_pad,
                                ctx->d_zero, grid_base);
-        } else if (pl.ks == 1 && (env_int("FOKL_GRAM_DMA", 2) == 2 ||
+        } else
+#endif
+        if (pl.ks == 1 && (env_int("FOKL_GRAM_DMA", 2) == 2 ||
                                   (env_int("FOKL_GRAM_DMA", 2) == 1 && gram_slot == FOKL_K_GRAM_MFMA))) {
             // LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers: every block of three tiles or more
             // (FOKL_GRAM_DMA=1: only the launches the matrix pipe bounds, 0: gram_tiles_kernel for everything)
             const int pieces = (pl.ct * 16 * 34 * 8 + 1023) / 1024;
             // three LDS buffers (a chunk's pieces in flight across the barrier) where they fit, FOKL_GRAM_BUFS to force
-            int nbuf = env_int("FOKL_GRAM_BUFS", 2);
+            int nbuf = 2;
+#ifdef FOKL_DEV_KERNELS
+            nbuf = env_int("FOKL_GRAM_BUFS", 2);
             if (nbuf == 3 && 3 * (size_t)pieces * 1024 > 160 * 1024) nbuf = 2;
+#endif
             gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half);
             const size_t lds = (size_t)nbuf * pieces * 1024;
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
@@ -1243,6 +1277,10 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int *d_cols = d_rows + nr;
         int S, nr_pad, nc_pad;
         dim3 grid;
+#ifndef FOKL_DEV_KERNELS
+        if (path == 3) return fail(ctx, FOKL_ERR_ARG, "fokl_gram: path 3 (round-1 panel kernel) needs a development build");
+        {
+#else
         gram_mfma_fn mfma_fn = nullptr;
         if (path == 3) {                                     // rectangular panels, one i-tile or j-tile set per wavefront
             int BI, BJ;
@@ -1271,6 +1309,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             grid = dim3(S, gy, gz);
         } else {
+#endif
             const int gz = (nr + GV_TI - 1) / GV_TI, gy = (nc + GV_TJ - 1) / GV_TJ;
             nr_pad = gz * GV_TI;
             nc_pad = gy * GV_TJ;
@@ -1283,10 +1322,13 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         if (rc) return rc;
         {
             TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
+#ifdef FOKL_DEV_KERNELS
             if (path == 3) {
                 hipLaunchKernelGGL(mfma_fn, grid, dim3(GM_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows, nr, d_cols,
                                    nc, ctx->n, ctx->d_slab, nr_pad, nc_pad, ctx->d_zero);
-            } else {
+            } else
+#endif
+            {
                 hipLaunchKernelGGL(gram_valu_kernel, grid, dim3(GV_THREADS), 0, ctx->stream, ctx->d_slot_ptr, d_rows,
                                    nr, d_cols, nc, ctx->n, ctx->d_slab, nr_pad, nc_pad);
             }

@@ -509,6 +509,9 @@ __global__ __launch_bounds__(RD_THREADS) void reduce_slabs_kernel(const double *
     }
 }
 
+// Retired paths (round-1 panel kernel: `path` 3; the 4x4x4 form of the tile lists: FOKL_GRAM_MFMA4=2; a third LDS-DMA
+// buffer: FOKL_GRAM_BUFS=3) are kept for A/B runs but compiled only into development builds (make DEV=1).
+#ifdef FOKL_DEV_KERNELS
 // ---------------------------------------------------------------------------------------------------------
 // K2b: Gram block on fp64 MFMA tiles (v_mfma_f64_16x16x4_f64)
 // ---------------------------------------------------------------------------------------------------------
@@ -649,6 +652,8 @@ __global__ __launch_bounds__(GM_THREADS) void gram_mfma_kernel(double *const *__
                 out[(size_t)gi * nc_pad + gj] = acc[i][j][v];
             }
 }
+
+#endif  // FOKL_DEV_KERNELS
 
 // ---------------------------------------------------------------------------------------------------------
 // K2c: Gram block as lists of 16 x 16 MFMA tiles (round 2; the default MFMA path)
@@ -1168,6 +1173,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     }
 }
 
+#ifdef FOKL_DEV_KERNELS
 // ---------------------------------------------------------------------------------------------------------
 // K2d: the same tile lists on v_mfma_f64_4x4x4_4b_f64 (opt-in: FOKL_GRAM_MFMA4=2)
 // ---------------------------------------------------------------------------------------------------------
@@ -1326,6 +1332,8 @@ __global__ __launch_bounds__(G4S_THREADS, 2) void gram_tiles4s_kernel(double *co
             }
     }
 }
+
+#endif  // FOKL_DEV_KERNELS
 
 // reduce_slabs_kernel for gram_tiles_kernel's slabs: element (i, j) of the caller's block sits at internal column
 // perm[j]; a position in a tile below the diagonal of the internal tile grid was not computed and is read from its
