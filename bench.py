@@ -438,11 +438,11 @@ def kernel_report(kern, n, m, cfg):
             if kernels[name]:
                 kernels[name]['all_gram_launches'] = gram_all
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/pmc_r02.json, produced by tools/profile_r02.sh: separate
+    # rocprofv3 --pmc passes over this same command (profiles/pmc_r03.json, produced by tools/profile_r03.sh: separate
     # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
     # was recorded for exactly this workload.
     traffic_source = None
-    for cand in ('pmc_r02.json', 'pmc_r01.json'):
+    for cand in ('pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         pmc_path = os.path.join(ROOT, 'profiles', cand)
         if not os.path.exists(pmc_path):
             continue
@@ -1113,6 +1113,18 @@ def main():
         'basis_build_sustained': hot,
         'device_sustains': sustained,
         'throughput_mode': throughput_mode,
+        # G3 on the device: one wavefront per chain on streams of their own, concurrent with everything above and with
+        # each other -- not on the context's stream, so not among `kernels`; per-kernel durations are in the committed
+        # rocprofv3 summary (profiles/rocprof_r03_summary.md: ~1.0 ms per chain of 2000 iterations at up to 64 columns).
+        # A chain is a recursion of 2000 dependent iterations: bound by dependent-instruction latency (three long fp64
+        # operations + a cross-lane sum per iteration), neither by HBM nor by the matrix pipe; it occupies 1 of the
+        # chip's ~8000 wavefront slots, which is why summed kernel durations say nothing about what bounds the device.
+        'device_chains': {'chains_per_step': host['device_chains'] / max(args.steps, 1),
+                          'guessed_decisions_per_step': host['guessed'] / max(args.steps, 1),
+                          'guesses_confirmed_per_step': host['guesses_verified'] / max(args.steps, 1),
+                          'searches_repeated': host['searches_repeated'],
+                          'dispatcher_cpu_s_per_step': host['dchain_dispatch_s'] / max(args.steps, 1),
+                          'bound': 'latency (serial recursion, one wavefront per chain)'},
     }
     if not args.no_cpu_baseline:
         line.update(cpu_baselines(fits[0][2], fits[0][3], spec0))

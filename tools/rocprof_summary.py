@@ -25,7 +25,7 @@ def short(name):
     for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_tiles_dma_kernel', 'gram_tiles4s_kernel', 'gram_tiles_kernel',
                 'gram_mfma_kernel', 'gram_valu_kernel',
                 'resid_terms_lds_kernel', 'resid_terms_kernel', 'resid_kernel', 'reduce_slabs_sym_kernel', 'reduce_slabs_kernel',
-                'transpose_inputs_kernel', 'predict_mfma_kernel', 'predict_kernel'):
+                'transpose_inputs_kernel', 'predict_mfma_kernel', 'predict_kernel', 'gibbs_chain_kernel', 'tape_gather_kernel'):
         if key in name:
             tag = ''
             if '<' in name:
@@ -83,7 +83,7 @@ def family(name):
                      ('gram_tiles_dma_kernel', 'gram'), ('gram_tiles4s_kernel', 'gram'), ('gram_tiles_kernel', 'gram'),
                      ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
                      ('resid_terms_lds_kernel', 'resid_matrix_free'), ('resid_terms_kernel', 'resid_matrix_free'),
-                     ('resid_kernel', 'resid')):
+                     ('resid_kernel', 'resid'), ('gibbs_chain_kernel', 'gibbs_chain'), ('tape_gather_kernel', 'tape_gather')):
         if key in name:
             return fam
     return None
