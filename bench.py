@@ -633,6 +633,44 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
                      'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
 
+    # N > 1, independent fits (the weak-scaling default of configs[2]): north_star's own split measured in the same run --
+    # every rank uploads the SAME dataset (unit 0) and the ranks fit it together, candidate models dealt over the ranks with
+    # one RCCL all-gather per window of candidates -- so that a scaling run records both curves.  Secondary: `value` stays the
+    # replica figure.
+    sharded_line = None
+    if world > 1 and mode == 'fits' and cfg in (1, 2) and comm_kind == 'RCCL' and not args.no_throughput:
+        try:
+            xs, ys, sp = config_workload(cfg, 0, args.rows)
+            kernel, phis, _ = kernel_and_phis(sp)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                joint = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp['fit'])
+                joint._backend_override = backends[0]
+                joint._prepare_fit(xs, ys, dict(clean=True))
+
+                def joint_fit():
+                    np.random.seed(sp['seed_fit'])
+                    joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
+                    backends[0].ctx.sync()
+                    return joint.fit_stats
+
+                joint_fit()                                 # warm-up
+                comm.barrier()
+                t0 = time.perf_counter()
+                terms = sum(joint_fit()['terms_logical'] for _ in range(max(1, args.steps)))
+                backends[0].ctx.sync()
+                comm.barrier()
+                t_joint = float(np.max(comm.allgather([time.perf_counter() - t0])[:, 0]))
+            sharded_line = dict(mode='candidates', value=terms / t_joint, unit='candidate-terms/s',
+                                ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
+                                spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
+                                exchanges=int(joint.fit_stats.get('exchanges', 0)),
+                                note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
+                                     'ranks, one RCCL all-gather per window of candidates (north_star\'s split); after the '
+                                     'timed region of the independent fits')
+        except Exception as exc:                            # never let the secondary measurement cost the line
+            print(f"bench.py: candidate-sharded side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
+
     gathered = comm.allgather([elapsed, logical, physical, calls])
     if rank != 0:
         comm.close()
@@ -707,7 +745,7 @@ def main():
                     help='worker PROCESSES per rank, each fitting its share of the rank\'s datasets of a step on its own '
                          'device context, host threads and L3 domain (--config 4 default: one per 4 CPUs of the budget, at most '
                          '4; other configurations: opt-in, a step is then that many independent fits)')
-    ap.add_argument('--mode', choices=('fits', 'rows', 'candidates'), default=None,
+    ap.add_argument('--mode', choices=('fits', 'rows', 'candidates', 'hybrid'), default=None,
                     help="N > 1, see the module docstring; default: candidates for --config 3, fits otherwise")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-microbench', action='store_true',
@@ -798,8 +836,10 @@ def main():
     else:
         pinned = early_pin if early_pin is not None else pin_to_l3_domain(
             local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
-    mode = args.mode or ('candidates' if cfg == 3 else 'fits')
-    one_fit_for_all = mode in ('rows', 'candidates')
+    # configs[3] at N > 1: rows AND candidates sharded (the device work and the eigen-decompositions are both divided by N);
+    # on one GPU the two splits are empty and the mode is the plain fit through the candidate-exchange code path
+    mode = args.mode or (('hybrid' if world > 1 else 'candidates') if cfg == 3 else 'fits')
+    one_fit_for_all = mode in ('rows', 'candidates', 'hybrid')
     fits_per_step = (args.fits_per_step or 8) if cfg == 4 else 1
     if one_fit_for_all and fits_per_step != 1:
         print("bench.py: --config 4 runs in --mode fits", file=sys.stderr)
@@ -827,7 +867,7 @@ def main():
             hypers = {}
             clean_kw = dict(clean=True)
             n_local = spec['rows']
-            if mode == 'rows':
+            if mode in ('rows', 'hybrid'):
                 # rank r holds rows [lo, hi) of the one dataset; the data-driven defaults of b / btau (FR:1322-1348)
                 # need the global mean and variance of y: one all-gather.  A shard must not be rescaled by its own
                 # min / max: the synthetic inputs are U[0,1) already.
@@ -883,6 +923,9 @@ def main():
             np.random.seed(spec['seed_fit'])
             if mode == 'rows':
                 model._search(backend, n_local, m, n_global=spec['rows'], row_sharded=True)
+            elif mode == 'hybrid':
+                model._search(backend, n_local, m, n_global=spec['rows'], row_sharded=True, comm=comm,
+                              candidate_sharded=use_rccl)
             elif mode == 'candidates' and use_rccl:
                 model._search(backend, n_local, m, comm=comm, candidate_sharded=True)
             else:
@@ -1073,7 +1116,8 @@ def main():
     if world > 1:
         parallelism = {'fits': f'independent fits x{world}', 'rows': f'rows sharded x{world}, RCCL all-reduce of Gram '
                        f'blocks', 'candidates': f'candidate models sharded x{world}, RCCL all-gather of per-candidate '
-                       f'BIC + spectral factors'}[mode]
+                       f'BIC + spectral factors', 'hybrid': f'rows sharded x{world} (RCCL all-reduce of Gram blocks on the '
+                       f'device) + candidate models dealt over the ranks (RCCL all-gather of BIC + spectral factors)'}[mode]
     line = {
         'metric': 'candidate-terms/sec (basis build + Gibbs + BIC)',
         'value': tot_logical / t_max,
@@ -1113,6 +1157,7 @@ def main():
         'basis_build_sustained': hot,
         'device_sustains': sustained,
         'throughput_mode': throughput_mode,
+        'candidate_sharded': sharded_line,
         # G3 on the device: one wavefront per chain on streams of their own, concurrent with everything above and with
         # each other -- not on the context's stream, so not among `kernels`; per-kernel durations are in the committed
         # rocprofv3 summary (profiles/rocprof_r03_summary.md: ~1.0 ms per chain of 2000 iterations at up to 64 columns).

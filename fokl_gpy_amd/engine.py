@@ -859,8 +859,10 @@ class ForwardSelection:
         # candidates -- is computed by one rank each and all-gathered (HostPipeline._exchange)
         self.candidate_sharded = bool(candidate_sharded) and comm is not None and (
             comm.world > 1 or os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1')
-        if self.candidate_sharded and row_sharded:
-            raise ValueError("a search shards either its rows or its candidates over the ranks, not both")
+        # Both at once is the hybrid split: every rank holds N / G rows (K1, K2, K3 on its rows, the small Gram blocks and
+        # residual moments all-reduced on the device -- the DEVICE work is divided by G) and the replicated search deals its
+        # eigen-decompositions over the ranks as well (the HOST work that bounds configs[3] is divided by G too).  The Gram
+        # is identical on every rank after the all-reduce, so the owner of a spectral job computes what any rank would.
         self.sigsqd0 = b / (1 + a)          # FR:1371
         self.tausqd0 = btau / (1 + atau)    # FR:1372
         self.pool = SlotPool(backend)

@@ -132,6 +132,27 @@ def main():
     digest = comm.allgather([float(np.sum(cb)), float(np.sum(ce)), float(cm.sum())])
     res['cand_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
 
+    # 5. hybrid: rows AND candidates sharded (each rank holds half of the rows of section 4's dataset: its device work is
+    #    halved; the eigen-decompositions of the replicated search are dealt over the ranks on top)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        lo, hi = dist.shard_range(n, rank, world)
+        hyb = FoKLRoutines.FoKL(b=single.b, btau=single.btau, **hy3)
+        backend = ShardedOracleBackend(comm)
+        hyb.inputs, hyb.data = single.inputs[lo:hi], single.data[lo:hi]
+        hyb._upload(backend, hyb.inputs, hyb.data)
+        np.random.seed(9)
+        hb, hm, he = hyb._search(backend, hi - lo, m, n_global=n, row_sharded=True, comm=comm, candidate_sharded=True)
+        hyb_state = np.random.get_state()
+    res['hybrid_mtx_equal'] = bool(hm.shape == sm.shape and np.array_equal(hm, sm))
+    res['hybrid_evs_err'] = float(np.max(np.abs(he - se) / np.abs(se))) if len(he) == len(se) else 1.0
+    res['hybrid_betas_err'] = float(np.max(np.abs(hb - sb) / np.max(np.abs(sb), axis=0))) if hb.shape == sb.shape else 1.0
+    res['hybrid_calls_equal'] = [t['cols'] for t in hyb.fit_trace] == [t['cols'] for t in single.fit_trace]
+    res['hybrid_stream_equal'] = bool(np.array_equal(single_state[1], hyb_state[1]) and single_state[2:] == hyb_state[2:])
+    res['hybrid_remote'] = int(hyb.fit_stats['spectral_remote'])
+    digest = comm.allgather([float(np.sum(hb)), float(np.sum(he)), float(hm.sum())])
+    res['hybrid_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
+
     comm.barrier()
     with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as fh:
         json.dump(res, fh)

@@ -35,6 +35,10 @@ def test_two_rank_collectives_rowshard_and_replicas(tmp_path):
         assert res['cand_evs_err'] < 1e-10 and res['cand_betas_err'] < 1e-8
         assert res['cand_ranks_bitwise_equal']
         assert res['cand_exchanges'] > 0 and res['cand_remote'] >= res['cand_gibbs_calls'] // 2 - 2
+        # hybrid (rows + candidates): same model, calls and stream; sums differ in association only
+        assert res['hybrid_mtx_equal'] and res['hybrid_calls_equal'] and res['hybrid_stream_equal']
+        assert res['hybrid_evs_err'] < 1e-10 and res['hybrid_betas_err'] < 1e-8
+        assert res['hybrid_ranks_bitwise_equal'] and res['hybrid_remote'] > 0
     # throughput mode: every rank sees all ranks' counters after the single all-gather
     assert results[0]['replica_terms'] == results[1]['replica_terms']
     assert results[0]['replica_terms'][0] == results[0]['replica_own_terms']
