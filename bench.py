@@ -633,44 +633,6 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
                      'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
 
-    # N > 1, independent fits (the weak-scaling default of configs[2]): north_star's own split measured in the same run --
-    # every rank uploads the SAME dataset (unit 0) and the ranks fit it together, candidate models dealt over the ranks with
-    # one RCCL all-gather per window of candidates -- so that a scaling run records both curves.  Secondary: `value` stays the
-    # replica figure.
-    sharded_line = None
-    if world > 1 and mode == 'fits' and cfg in (1, 2) and comm_kind == 'RCCL' and not args.no_throughput:
-        try:
-            xs, ys, sp = config_workload(cfg, 0, args.rows)
-            kernel, phis, _ = kernel_and_phis(sp)
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                joint = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp['fit'])
-                joint._backend_override = backends[0]
-                joint._prepare_fit(xs, ys, dict(clean=True))
-
-                def joint_fit():
-                    np.random.seed(sp['seed_fit'])
-                    joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
-                    backends[0].ctx.sync()
-                    return joint.fit_stats
-
-                joint_fit()                                 # warm-up
-                comm.barrier()
-                t0 = time.perf_counter()
-                terms = sum(joint_fit()['terms_logical'] for _ in range(max(1, args.steps)))
-                backends[0].ctx.sync()
-                comm.barrier()
-                t_joint = float(np.max(comm.allgather([time.perf_counter() - t0])[:, 0]))
-            sharded_line = dict(mode='candidates', value=terms / t_joint, unit='candidate-terms/s',
-                                ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
-                                spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
-                                exchanges=int(joint.fit_stats.get('exchanges', 0)),
-                                note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
-                                     'ranks, one RCCL all-gather per window of candidates (north_star\'s split); after the '
-                                     'timed region of the independent fits')
-        except Exception as exc:                            # never let the secondary measurement cost the line
-            print(f"bench.py: candidate-sharded side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
-
     gathered = comm.allgather([elapsed, logical, physical, calls])
     if rank != 0:
         comm.close()
@@ -1097,6 +1059,44 @@ def main():
                 w.join(5)
                 if w.is_alive():
                     w.terminate()
+
+    # N > 1, independent fits (the weak-scaling default of configs[2]): north_star's own split measured in the same run --
+    # every rank uploads the SAME dataset (unit 0) and the ranks fit it together, candidate models dealt over the ranks with
+    # one RCCL all-gather per window of candidates -- so that a scaling run records both curves.  Secondary: `value` stays the
+    # replica figure.
+    sharded_line = None
+    if world > 1 and mode == 'fits' and cfg in (1, 2) and comm_kind == 'RCCL' and not args.no_throughput:
+        try:
+            xs, ys, sp = config_workload(cfg, 0, args.rows)
+            kernel, phis, _ = kernel_and_phis(sp)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                joint = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp['fit'])
+                joint._backend_override = backends[0]
+                joint._prepare_fit(xs, ys, dict(clean=True))
+
+                def joint_fit():
+                    np.random.seed(sp['seed_fit'])
+                    joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
+                    backends[0].ctx.sync()
+                    return joint.fit_stats
+
+                joint_fit()                                 # warm-up
+                comm.barrier()
+                t0 = time.perf_counter()
+                terms = sum(joint_fit()['terms_logical'] for _ in range(max(1, args.steps)))
+                backends[0].ctx.sync()
+                comm.barrier()
+                t_joint = float(np.max(comm.allgather([time.perf_counter() - t0])[:, 0]))
+            sharded_line = dict(mode='candidates', value=terms / t_joint, unit='candidate-terms/s',
+                                ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
+                                spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
+                                exchanges=int(joint.fit_stats.get('exchanges', 0)),
+                                note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
+                                     'ranks, one RCCL all-gather per window of candidates (north_star\'s split); after the '
+                                     'timed region of the independent fits')
+        except Exception as exc:                            # never let the secondary measurement cost the line
+            print(f"bench.py: candidate-sharded side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
 
     gathered = comm.allgather([elapsed, logical, physical, calls])
     if rank != 0:
