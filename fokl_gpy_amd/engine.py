@@ -917,6 +917,10 @@ class ForwardSelection:
         # Misprediction and the search is repeated without guessing -- results never depend on a guess.
         self.allow_device_chains = True
         self.chain_engine = None
+        # ... for models of up to this many columns.  Beyond, the chain stays on the host threads: a 585-column tape is 14 MB
+        # of page-locked memory and dozens of them are alive at a time (configs[3]: 1.74 s per fit with device chains,
+        # 1.49 s with host chains -- and the eigen-decompositions, not the chains, are what that fit waits for)
+        self.device_chain_columns = int(os.environ.get('FOKL_DCHAIN_MAX_COLUMNS', '256'))
         self.guess_margin = float(os.environ.get('FOKL_GUESS_MARGIN', '0.02'))
         self._flip_guess = int(os.environ.get('FOKL_GUESS_TEST_FLIP', '0'))   # tests: the n-th guess is taken wrong
         self._unverified = collections.deque()   # (device-chained outcome, half0) whose checks are open, oldest first
@@ -1094,7 +1098,7 @@ class ForwardSelection:
         spec, idx, _, dtd, _ = pending
         if noise_job is None:
             noise_job = self._tape_for(idx.shape[0], model=not test)
-        if (test and self.chain_engine is not None and idx.shape[0] <= getattr(self.chain_engine, 'max_columns', 768)
+        if (test and self.chain_engine is not None and idx.shape[0] <= self.device_chain_columns
                 and not (self._prechain is not None and self._prechain[0] is noise_job)):
             job = self.host.chain_device(spec, self.b, self.btau, dtd, self.sigsqd0, self.tausqd0, noise_job, stat_first)
             if job is not None:
@@ -1479,6 +1483,9 @@ class ForwardSelection:
                 # it, one that guesses would stop on a misprediction alone and leave the others in a collective
                 if self.allow_device_chains and not self.allreduce and not self.candidate_sharded:
                     self.chain_engine = chain_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
+                    if self.chain_engine is not None:
+                        self.device_chain_columns = min(self.device_chain_columns,
+                                                        getattr(self.chain_engine, 'max_columns', 768))
                     self._dchain_stats0 = self.chain_engine.stats() if self.chain_engine is not None else {}
                 self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None,
                                          chain_engine=self.chain_engine)
