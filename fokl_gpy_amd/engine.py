@@ -1006,7 +1006,8 @@ class ForwardSelection:
         False: for a kill-test candidate, whose chain runs on the device when there is an engine (the tape stays raw)."""
         astar = self.a + 1 + self.n / 2 + p1 / 2                     # FR:1508 (mmtx + 1 == p1)
         atau_star = self.atau + (p1 - 1) / 2                         # FR:1510
-        return self.host.request(p1, astar, atau_star, tentative, finish=model or self.chain_engine is None)
+        on_device = not model and self.chain_engine is not None and p1 <= self.device_chain_columns
+        return self.host.request(p1, astar, atau_star, tentative, finish=not on_device)
 
     # Tapes on order.  A tape's content depends on nothing but the model size and the position of the stream, so the
     # driver keeps the noise thread supplied with the sizes the search will PROBABLY ask for next -- several deep, across
