@@ -34,8 +34,12 @@ def fit(x, y, kw, seed, oracle):
     np.random.seed(seed + 11)
     b, mtx, evs = model.fit(x, y, clean=True)
     st = np.random.get_state()
+    if not oracle:
+        for key in TALLY:
+            TALLY[key] += model.fit_stats.get(key, 0)
     return b, mtx, evs, hashlib.sha256(st[1].tobytes()).hexdigest() + str(st[2:])
 
+TALLY = dict(device_chains=0, guessed=0, guesses_verified=0, guess_waits=0, searches_repeated=0, kill_tests=0)
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     x, y, kw = problem(seed)
@@ -48,4 +52,4 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         bad += 1
     print(seed, 'rows', x.shape, 'kernel', kw['kernel'], 'terms', ref[1].shape[0], got[1].shape[0], 'OK' if ok else 'MISMATCH',
           '(outgrown)' if grown else '', flush=True)
-print('mismatches', bad)
+print('mismatches', bad, 'device path:', TALLY)
