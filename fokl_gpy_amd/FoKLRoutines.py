@@ -27,6 +27,7 @@ import numpy as np
 from . import getKernels
 from . import _capi
 from . import engine as _engine
+from . import update as _update
 
 
 def _column_min_max(a):
@@ -1113,7 +1114,7 @@ class FoKL:
             # priors from the previous posterior (gibbs_Xin_update cases 2 / 3): host samplers on device-built Grams,
             # drawing from numpy's global generator call for call as the reference does
             with _host_blas_threads():
-                betas, mtx, evs, stats, trace = _engine.fit_update_next(
+                betas, mtx, evs, stats, trace = _update.fit_update_next(
                     backend, n, m, len(self.phis), self.betas, self.burn, self.a, self.b, self.atau, self.btau,
                     self.tolerance, self.burnin + self.draws, self.gimmie, self.aic, self.sigsqd0,
                     console=self.ConsoleOutput)
@@ -1124,7 +1125,7 @@ class FoKL:
         stream = _capi.LegacyStream()
         try:
             with _host_blas_threads():
-                betas, mtx, evs, built, stats, trace = _engine.fit_update_first(
+                betas, mtx, evs, built, stats, trace = _update.fit_update_first(
                     backend, n, m, len(self.phis), self.a, self.b, self.atau, self.btau, self.tolerance,
                     self.burnin + self.draws, self.gimmie, self.aic, self.sigsqd0, stream,
                     console=self.ConsoleOutput)

@@ -218,7 +218,7 @@ class StandInChainJob(_capi.DeviceChainJob):
 
 
 class StandInChainEngine:
-    """CPU stand-in for _capi.DeviceChainEngine (tests only; installed through engine._chain_engine_factory): the same
+    """CPU stand-in for _capi.DeviceChainEngine (tests only; installed through host_pipeline._chain_engine_factory): the same
     interface, the chain computed by the host sampler on a worker thread after `delay` seconds -- late enough for the
     search to take its kill-test decisions from guesses, as it does with a real device."""
     wants_pinned_tapes = False

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN, FIT_CASES, OracleBackend, load_case, UNITS_PATH
-from fokl_gpy_amd import FoKLRoutines, engine, _capi, getKernels
+from fokl_gpy_amd import FoKLRoutines, engine, host_pipeline, _capi, getKernels
 from oracle import fokl_oracle as O
 
 
@@ -415,18 +415,18 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     monkeypatch.delenv('FOKL_FINISH_LOG', raising=False)
     cases = ((16, (2, 1, 4)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 0, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
     for budget, plan in cases:
-        monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
-        assert engine._thread_plan() == plan
+        monkeypatch.setattr(host_pipeline, '_cpu_budget', lambda b=budget: b)
+        assert host_pipeline._thread_plan() == plan
     monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')                  # libm's scalar log: finishing needs three threads
     for budget, plan in ((16, (2, 3, 4)), (7.5, (1, 2, 3))):
-        monkeypatch.setattr(engine, '_cpu_budget', lambda b=budget: b)
-        assert engine._thread_plan() == plan
+        monkeypatch.setattr(host_pipeline, '_cpu_budget', lambda b=budget: b)
+        assert host_pipeline._thread_plan() == plan
     monkeypatch.delenv('FOKL_FINISH_LOG')
-    monkeypatch.setattr(engine, '_cpu_budget', lambda: 2)
+    monkeypatch.setattr(host_pipeline, '_cpu_budget', lambda: 2)
     monkeypatch.setenv('FOKL_FINISH_THREADS', '5')
-    assert engine._thread_plan() == (1, 5, 1)
+    assert host_pipeline._thread_plan() == (1, 5, 1)
     monkeypatch.undo()
-    assert engine._cpu_budget() >= 1
+    assert host_pipeline._cpu_budget() >= 1
 
 
 def _search_with_pipeline(monkeypatch, draws=40):
@@ -615,7 +615,7 @@ def test_search_with_device_chains_equals_the_inline_search(monkeypatch, seed):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
-        monkeypatch.setattr(engine, '_chain_engine_factory', factory_)
+        monkeypatch.setattr(host_pipeline, '_chain_engine_factory', factory_)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model = FoKLRoutines.FoKL(**kw)
