@@ -154,3 +154,59 @@ def check(entry, draws, s_ref):
     scale = np.max(np.abs(want), axis=0)
     assert flag[0] == 0 and np.max(np.abs(w - want) / scale) < 1e-13
     assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+
+
+@pytest.mark.parametrize('draws', [1, 2, 7, 8, 9, 17, 129])
+def test_short_chains_and_ring_boundaries(engine, exact_engine, draws, monkeypatch):
+    """Fewer iterations than the prefetch ring holds, one more than it holds, one more than a staged block of gammas:
+    the clamped row indices of the ring and the gamma blocks must not leak into the results."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(draws)
+    for p1 in (3, 70):
+        lamb, qty = model(p1, rng)
+        tape = host_tape(p1, draws, 5 * draws + p1)
+        args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
+        want, _ = _capi.gibbs_chain_from_tape(*args, tape)
+        for eng in (engine, exact_engine):
+            w, mean_w, negative = _capi.gibbs_chain_device(eng, *args, tape, stat_first=draws // 2)
+            scale = np.max(np.abs(want), axis=0)
+            assert not negative and np.max(np.abs(w - want) / scale) < 1e-13
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+
+
+def test_largest_model_and_beyond(engine, monkeypatch):
+    """768 columns is what one wavefront holds (12 eigen-directions per lane); beyond that the engine says so and the
+    search keeps such chains on the host threads (engine.ForwardSelection.device_chain_columns)."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(768)
+    lamb, qty = model(768, rng)
+    tape = host_tape(768, 40, 768)
+    args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
+    want, _ = _capi.gibbs_chain_from_tape(*args, tape)
+    w, _, negative = _capi.gibbs_chain_device(engine, *args, tape)
+    assert not negative and np.max(np.abs(w - want) / np.max(np.abs(want), axis=0)) < 1e-13
+    lamb, qty = model(769, rng)
+    with pytest.raises(_capi.FoklNativeError) as err:
+        engine.submit(lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9, host_tape(769, 10, 1), follow=False)
+    assert err.value.code == -2 and '768' in str(err.value)
+
+
+def test_tapes_in_ordinary_memory_are_staged(engine, monkeypatch):
+    """A tape in page-locked memory (fokl_host_alloc) is read by the device in place; one in ordinary memory goes through
+    copy calls and a device staging buffer: same draws either way."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    rng = np.random.default_rng(11)
+    p1, draws = 45, 300
+    lamb, qty = model(p1, rng)
+    args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
+    np.random.seed(5)
+    s1, s2 = _capi.LegacyStream(), _capi.LegacyStream()
+    plain = _capi.noise_tape(p1, draws, 500.0, 26.0, s1)
+    need = _capi.NoiseTape.doubles_needed(p1, draws) + 8
+    pinned = _capi.record_noise_tape(_capi.NoiseTape(p1, draws, _capi.pinned_empty(need)), 500.0, 26.0, s2)
+    before = engine.stats()['staged']
+    w_plain, _, _ = _capi.gibbs_chain_device(engine, *args, plain)
+    assert engine.stats()['staged'] == before + 1
+    w_pinned, _, _ = _capi.gibbs_chain_device(engine, *args, pinned)
+    assert engine.stats()['staged'] == before + 1
+    assert np.array_equal(w_plain, w_pinned)
