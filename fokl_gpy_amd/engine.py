@@ -890,6 +890,10 @@ class ForwardSelection:
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
         _mark('pool_up')
+        # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
+        # one for the normals finished on the host, host threads or the device for the kill tests' chains
+        self.stats['finish_log'] = os.environ.get('FOKL_FINISH_LOG', 'fast')
+        self.stats['chain_mode'] = 'device' if self.chain_engine is not None else 'host'
         t_up = time.perf_counter()
         try:
             return self._run()
