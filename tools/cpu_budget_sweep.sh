@@ -10,7 +10,7 @@ for c in 2 3 4 6 8 16; do
 import json
 d=json.load(open('/tmp/sweep_$c.json')); h=d['host_main_thread_s_per_step']
 cpu=h['pool_noise_s']+h['pool_chain_s']+h['pool_finish_s']+h['pool_spectral_s']
-print('cpus $c  ms/fit %.1f  terms/s %.0f  pool CPU-s/fit %.3f (noise %.3f chain %.3f finish %.3f spectral %.3f)' % (d['ms_per_step'], d['value'], cpu, h['pool_noise_s'], h['pool_chain_s'], h['pool_finish_s'], h['pool_spectral_s']))
+print('cpus $c  ms/fit %.1f  terms/s %.0f  process CPU-s/fit %.3f  pool busy-s/fit %.3f (noise %.3f chain %.3f finish %.3f spectral %.3f)  chains on %s' % (d['ms_per_step'], d['value'], d.get('cpu_seconds_per_step', float('nan')), cpu, h['pool_noise_s'], h['pool_chain_s'], h['pool_finish_s'], h['pool_spectral_s'], 'device' if h.get('device_chains') else 'host'))
 PY
 done
 cat $out
