@@ -913,7 +913,8 @@ def main():
                     pool_finish_s=0.0, pool_spectral_s=0.0, tapes_rewound=0, forecasts_used=0, spectral_remote=0,
                     exchanges=0, chains_skipped=0, spectral_submitted=0, resid_matrix_free=0, bic_from_gram=0,
                     noise_queue_wait_s=0.0, noise_verdict_wait_s=0.0, device_chains=0, chains_fetched=0, guessed=0,
-                    guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0, t_final_verify=0.0,
+                    guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0, dchain_kernel_s=0.0,
+                    dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0)
         for _ in range(args.steps):
             for st in one_step():
@@ -1176,6 +1177,9 @@ def main():
                           'guesses_confirmed_per_step': host['guesses_verified'] / max(args.steps, 1),
                           'searches_repeated': host['searches_repeated'],
                           'dispatcher_cpu_s_per_step': host['dchain_dispatch_s'] / max(args.steps, 1),
+                          # by the recursion kernel's own clock, over the chains whose statistics the search read
+                          'avg_chain_kernel_ms': 1e3 * host['dchain_kernel_s'] / max(host['dchain_timed'], 1),
+                          'chains_timed_per_step': host['dchain_timed'] / max(args.steps, 1),
                           'bound': 'latency (serial recursion, one wavefront per chain)'},
     }
     if not args.no_cpu_baseline:

@@ -565,7 +565,7 @@ class DeviceChainJob:
         self._area = self._flag = None
         self._mark = float(ticket) if ticket is not None else 0.0
         if stats_address:
-            self._area = np.ctypeslib.as_array((ctypes.c_double * (5 + p1)).from_address(stats_address))
+            self._area = np.ctypeslib.as_array((ctypes.c_double * (6 + p1)).from_address(stats_address))
             self._flag = ctypes.c_double.from_address(stats_address + 8 * (4 + p1))
 
     def resolve(self, commit):
@@ -593,6 +593,13 @@ class DeviceChainJob:
                 _check(self._engine._lib.fokl_dchain_wait(self._engine._h, self._ticket, _ptr(buf)))
                 self._stats = buf
         return self._stats[4:], np.array([int(self._stats[0])], dtype=np.int32)
+
+    @property
+    def kernel_seconds(self):
+        """How long the chain's wavefront ran, by the kernel's own clock (0.0 if not known)."""
+        if self._area is not None and self._ran():
+            return float(self._area[5 + self.p1])
+        return 0.0
 
     @property
     def last_state(self):

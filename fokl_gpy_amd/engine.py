@@ -328,7 +328,7 @@ class ForwardSelection:
                           t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, bic_from_gram=0,
                           bic_gram_max_rel=0.0, tapes_rewound=0, tapes_wasted=0, chains_ahead=0, chains_ahead_unused=0, forecasts_used=0, resid_matrix_free=0, chains_skipped=0,
                           spectral_submitted=0, device_chains=0, chains_fetched=0, guessed=0, guess_waits=0,
-                          guesses_verified=0)
+                          guesses_verified=0, dchain_kernel_s=0.0, dchain_timed=0)
 
     # -- one model evaluation (G1-G4) -------------------------------------------------------------------
     def _same_model_same_ev(self, idx, ev):

@@ -560,6 +560,8 @@ class GibbsOutcome:
             t0 = time.perf_counter()
             mean_w, negative = self._chain_job.wait()
             o.stats['t_chain'] += time.perf_counter() - t0
+            o.stats['dchain_kernel_s'] += getattr(self._chain_job, 'kernel_seconds', 0.0)
+            o.stats['dchain_timed'] += 1
             if negative[0]:
                 raise RuntimeError("bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
                                    "cannot reproduce the reference's skipped draw (FR:1538-1539)")

@@ -420,7 +420,8 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
  * w [draws, p1] (betas = w Q') to the host; fokl_dchain_release frees the slot (idempotent).
  * `stats_area` (may be NULL) receives the address of the job's statistics in page-locked host memory: the five + p1
  * doubles the recursion kernel writes -- the four + p1 of fokl_dchain_wait, then the job's ticket (as a double),
- * stored last with system-wide release semantics: a caller may poll that word instead of calling fokl_dchain_poll.
+ * stored last with system-wide release semantics: a caller may poll that word instead of calling fokl_dchain_poll;
+ * one more double behind it holds the seconds the chain's wavefront ran (the kernel's own clock).
  * The area belongs to the job's slot: valid until the job is released.
  * Errors: FOKL_ERR_STATE when every slot is taken (the caller runs that chain on the host). */
 typedef struct fokl_dchain fokl_dchain;
