@@ -589,11 +589,12 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
     backend = FoKLRoutines.device_backend(device_of(local))
     ctx = backend.ctx
     comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=False)
-    comm.barrier()
+    control = getattr(comm, 'control', None) or comm        # independent fits: barriers and gathers over the control plane
+    control.barrier()
     start.wait(timeout=1800)                                # every worker has prepared and warmed up: go
     t0 = time.perf_counter()
     results = [done.get(timeout=3600) for _ in workers]
-    comm.barrier()
+    control.barrier()
     elapsed = time.perf_counter() - t0
     for w in workers:
         w.join(60)
@@ -634,7 +635,7 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
         sustained = {'unit': 'GB/s and TFLOP/s', 'hbm_read_GBps': ctx.probe(0) / 1e9, 'hbm_write_GBps': ctx.probe(1) / 1e9,
                      'hbm_1_read_7_writes_GBps': ctx.probe(2) / 1e9, 'mfma_f64_TFLOPs': ctx.probe(3) / 1e12}
 
-    gathered = comm.allgather([elapsed, logical, physical, calls])
+    gathered = control.allgather([elapsed, logical, physical, calls])
     if rank != 0:
         comm.close()
         return
@@ -815,6 +816,9 @@ def main():
         backends.append(engine.HipBackend(_capi.DeviceContext(device_of(local))))
     ctx = backends[0].ctx
     comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=one_fit_for_all)
+    # barriers and the gathers of timing figures go over the TCP control plane when there is one (N > 1): a launch of
+    # independent fits then runs no RCCL collective at all, RCCL carries the data path of the sharded modes only
+    control = getattr(comm, 'control', None) or comm
 
     units = [0] if one_fit_for_all else [rank * fits_per_step + i for i in range(fits_per_step)]
     fits = []                                                 # (model, backend, x, y, spec, n_local)
@@ -837,7 +841,7 @@ def main():
                 lo, hi = dist.shard_range(spec['rows'], rank, world)
                 x, y = x[lo:hi], y[lo:hi]
                 n_local = hi - lo
-                mom = comm.allgather([n_local, float(np.sum(y)), float(np.sum(y * y))])
+                mom = control.allgather([n_local, float(np.sum(y)), float(np.sum(y * y))])
                 mean = float(np.sum(mom[:, 1]) / spec['rows'])
                 var = float(np.sum(mom[:, 2]) / spec['rows'] - mean * mean)
                 hypers = dict(b=var * (4 + 1), btau=abs(mean) / var * (4 + 1))
@@ -904,7 +908,7 @@ def main():
         for _, backend, *_ in fits:
             backend.ctx.timing_enable(True)
             backend.ctx.timing_reset()
-        comm.barrier()
+        control.barrier()
         ctx.sync()
         cpu0 = time.process_time()                            # all threads of this process (pool, dispatcher, driver)
         t0 = time.perf_counter()
@@ -924,7 +928,7 @@ def main():
                 for key in host:
                     host[key] += st.get(key, 0)
         ctx.sync()
-        comm.barrier()
+        control.barrier()
         elapsed = time.perf_counter() - t0
         cpu_s = time.process_time() - cpu0
         end_state = np.random.get_state()
@@ -1068,47 +1072,93 @@ def main():
                 if w.is_alive():
                     w.terminate()
 
+    # the figures of the timed region, over the control plane: safe before anything below can go wrong
+    gathered = control.allgather([elapsed, logical, physical, calls])
+
     # N > 1, independent fits (the weak-scaling default of configs[2]): north_star's own split measured in the same run --
     # every rank uploads the SAME dataset (unit 0) and the ranks fit it together, candidate models dealt over the ranks with
     # one RCCL all-gather per window of candidates -- so that a scaling run records both curves.  Secondary: `value` stays the
-    # replica figure.
-    sharded_line = None
-    if world > 1 and mode == 'fits' and cfg in (1, 2) and comm_kind == 'RCCL' and not args.no_throughput:
-        try:
-            xs, ys, sp = config_workload(cfg, 0, args.rows)
-            kernel, phis, _ = kernel_and_phis(sp)
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                joint = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp['fit'])
-                joint._backend_override = backends[0]
-                joint._prepare_fit(xs, ys, dict(clean=True))
+    # replica figure, and the measurement runs on a helper thread under a deadline (FOKL_BENCH_SHARDED_TIMEOUT seconds from
+    # the moment every rank is ready): these are the first RCCL collectives of the launch, and one that never returns must
+    # cost the side figure, not the line.  The ranks agree over the control plane whether it finished everywhere; if not,
+    # nothing touches the device or the communicator afterwards and the process leaves through os._exit.
+    sharded_line, wedged = None, False
+    # (launcher rehearsals on a box where RCCL cannot come up: FOKL_BENCH_SHARDED_OVER_TCP=1 runs the same measurement with
+    # the windows gathered over the control plane; FOKL_BENCH_SHARDED_TEST_HANG=<rank> makes that rank never come back)
+    joint_transport_ok = comm_kind == 'RCCL' or os.environ.get('FOKL_BENCH_SHARDED_OVER_TCP', '0') == '1'
+    if world > 1 and mode == 'fits' and cfg in (1, 2) and joint_transport_ok and not args.no_throughput:
+        import threading
+        box = {}
 
-                def joint_fit():
-                    np.random.seed(sp['seed_fit'])
-                    joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
+        def joint_measurement():
+            try:
+                if os.environ.get('FOKL_BENCH_SHARDED_TEST_HANG', '') == str(rank):
+                    time.sleep(3600)
+                xs, ys, sp = config_workload(cfg, 0, args.rows)
+                kernel, phis, _ = kernel_and_phis(sp)
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    joint = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp['fit'])
+                    joint._backend_override = backends[0]
+                    joint._prepare_fit(xs, ys, dict(clean=True))
+
+                    def joint_fit():
+                        np.random.seed(sp['seed_fit'])
+                        joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
+                        backends[0].ctx.sync()
+                        return joint.fit_stats
+
+                    joint_fit()                             # warm-up
+                    comm.barrier()
+                    t0 = time.perf_counter()
+                    terms = sum(joint_fit()['terms_logical'] for _ in range(max(1, args.steps)))
                     backends[0].ctx.sync()
-                    return joint.fit_stats
+                    comm.barrier()
+                    box['seconds'] = time.perf_counter() - t0
+                box.update(terms=terms, spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
+                           exchanges=int(joint.fit_stats.get('exchanges', 0)))
+            except BaseException as exc:                    # noqa: BLE001 -- reported below, never costs the line
+                box['error'] = f'{type(exc).__name__} {exc}'
 
-                joint_fit()                                 # warm-up
-                comm.barrier()
-                t0 = time.perf_counter()
-                terms = sum(joint_fit()['terms_logical'] for _ in range(max(1, args.steps)))
-                backends[0].ctx.sync()
-                comm.barrier()
-                t_joint = float(np.max(comm.allgather([time.perf_counter() - t0])[:, 0]))
-            sharded_line = dict(mode='candidates', value=terms / t_joint, unit='candidate-terms/s',
+        state_before = np.random.get_state()
+        control.barrier()                                   # rank 0 arrives last (its side measurements above)
+        worker = threading.Thread(target=joint_measurement, name='fokl-bench-joint', daemon=True)
+        worker.start()
+        worker.join(float(os.environ.get('FOKL_BENCH_SHARDED_TIMEOUT', '180')))
+        finished = not worker.is_alive()                    # decided once
+        if not finished:
+            box.setdefault('error', 'did not finish before the deadline (an RCCL collective that never returned?)')
+        report = control.allgather([1.0 if finished else 0.0, 1.0 if 'error' in box else 0.0, box.get('seconds', 0.0)])
+        wedged = float(np.min(report[:, 0])) < 1.0
+        if wedged or float(np.max(report[:, 1])) > 0.0:
+            why = box.get('error', 'failed on another rank')
+            print(f"bench.py: rank {rank}: candidate-sharded side measurement failed: {why}", file=sys.stderr)
+            sharded_line = dict(mode='candidates', value=None, error=why)
+        else:
+            t_joint = float(np.max(report[:, 2]))
+            sharded_line = dict(mode='candidates', value=box['terms'] / t_joint, unit='candidate-terms/s',
                                 ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
-                                spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
-                                exchanges=int(joint.fit_stats.get('exchanges', 0)),
+                                spectral_remote=box['spectral_remote'], exchanges=box['exchanges'],
+                                transport='RCCL' if comm_kind == 'RCCL' else 'TCP control plane (launcher rehearsal)',
                                 note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
-                                     'ranks, one RCCL all-gather per window of candidates (north_star\'s split); after the '
+                                     'ranks, one all-gather per window of candidates (north_star\'s split); after the '
                                      'timed region of the independent fits')
-        except Exception as exc:                            # never let the secondary measurement cost the line
-            print(f"bench.py: candidate-sharded side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
+        if finished:
+            np.random.set_state(state_before)
 
-    gathered = comm.allgather([elapsed, logical, physical, calls])
-    if rank != 0:
+    def leave(code=0):
+        """End of the process.  After a collective that never returned: no communicator or device teardown (they would
+        wait for it), streams flushed, hard exit."""
+        if wedged:
+            control.close()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            dist.flush_c_streams()
+            os._exit(code)
         comm.close()
+
+    if rank != 0:
+        leave()
         return
     t_max = float(np.max(gathered[:, 0]))
     if one_fit_for_all:                                     # every rank ran the same search: count it once
@@ -1184,13 +1234,18 @@ def main():
     }
     if not args.no_cpu_baseline:
         line.update(cpu_baselines(fits[0][2], fits[0][3], spec0))
-    comm.close()
+    if not wedged:
+        comm.close()
     dist.flush_c_streams()
     sys.stderr.flush()
     print(json.dumps(line), flush=True)          # the ONE JSON line, last thing on stdout
     if parity_checked and not parity['ok']:
         print(f"bench.py: PARITY MISMATCH against {parity['golden']}: {parity}", file=sys.stderr)
+        if wedged:
+            leave(3)
         sys.exit(3)
+    if wedged:
+        leave(0)
 
 
 if __name__ == '__main__':

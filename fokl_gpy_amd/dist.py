@@ -155,6 +155,7 @@ class RcclComm:
     def __init__(self, ctx, rank, world, unique_id=None, _pending=None):
         self.rank, self.world = int(rank), int(world)
         self.ctx, self._id_file = None, None
+        self.control = None                                   # bring_up: the TCP control plane that came up before RCCL
         self._pending = _pending
         if _pending is None:
             pending = RcclComm.initialise(ctx.device, rank, world, ctx.comm_unique_id, unique_id)
@@ -207,11 +208,16 @@ class RcclComm:
         self.ctx.allreduce_sum(np.zeros(1))
         self.ctx.sync()
 
-    def close(self):
-        if self.ctx is not None:
+    def close(self, destroy=True):
+        """destroy=False: leave the communicator alone (a collective on it never returned: ncclCommDestroy would wait)."""
+        if self.control is not None:
+            self.control.close()
+            self.control = None
+        if self.ctx is not None and destroy:
             self.ctx.comm_destroy()
-            self.ctx = None
-        self.drop()
+        self.ctx = None
+        if destroy:
+            self.drop()
         flush_c_streams()
 
 
@@ -376,7 +382,9 @@ def bring_up(ctx, rank, world, need_rccl, timeout_s=180.0, log=None):
     everywhere = float(np.min(tcp.allgather([ok])[:, 0])) == 1.0
     if everywhere:
         comm = pending.attach(ctx)
-        tcp.close()
+        # the control plane stays up next to RCCL: barriers and the gathers of a few timing figures need no device
+        # collective, and a launch whose data path has no exchange must not depend on one (RcclComm.close closes it)
+        comm.control = tcp
         return comm, 'RCCL'
     if pending is not None:
         pending.drop()                                        # came up here but not everywhere: nothing stays attached

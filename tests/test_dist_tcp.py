@@ -81,6 +81,11 @@ def _worker(rank, world, port, behaviours, need_rccl, out):
             if not isinstance(comm, dist.RcclComm):
                 res['after'] = comm.allgather([rank + 0.5]).tolist()
                 comm.barrier()
+            else:
+                # the control plane stays up beside RCCL: barriers and timing gathers of a launch need no device collective
+                res['control'] = comm.control.allgather([rank + 0.25]).tolist()
+                comm.control.barrier()
+                comm.control.close()
             comm.close()
         except RuntimeError as exc:
             res['raised'] = str(exc)
@@ -140,6 +145,7 @@ def test_modes_that_need_rccl_fail_everywhere_instead_of_hanging():
 def test_rccl_is_used_when_it_comes_up_everywhere():
     res = _launch(['ok', 'ok'], need_rccl=True)
     assert all(one.get('kind') == 'RCCL' for one in res), res
+    assert all(one.get('control') == [[0.25], [1.25]] for one in res), res
 
 
 def test_a_communicator_that_is_not_used_everywhere_is_dropped_and_a_late_one_never_reaches_the_context():
