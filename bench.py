@@ -1104,7 +1104,8 @@ def main():
 
                     def joint_fit():
                         np.random.seed(sp['seed_fit'])
-                        joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm, candidate_sharded=True)
+                        box['result'] = joint._search(backends[0], sp['rows'], sp['inputs'], comm=comm,
+                                                      candidate_sharded=True)
                         backends[0].ctx.sync()
                         return joint.fit_stats
 
@@ -1117,6 +1118,15 @@ def main():
                     box['seconds'] = time.perf_counter() - t0
                 box.update(terms=terms, spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
                            exchanges=int(joint.fit_stats.get('exchanges', 0)))
+                # the joint fit against the same golden as the timed fit (every rank checks its own copy of the result)
+                key = (cfg, 0, sp['rows'])
+                if key in GOLDENS and not GOLDENS[key][1] and not args.inputs and \
+                        os.path.exists(os.path.join(ROOT, 'tests', 'golden', GOLDENS[key][0] + '.npz')):
+                    jb, jm, je = box['result']
+                    check = compare_with_golden(GOLDENS[key][0], joint, jb, jm, je, np.random.get_state())
+                    box['parity'] = {k: check.get(k) for k in ('golden', 'ok', 'mtx_equal', 'gibbs_calls_equal',
+                                                               'max_rel_bic', 'max_draw_err_over_scale',
+                                                               'numpy_stream_equal')}
             except BaseException as exc:                    # noqa: BLE001 -- reported below, never costs the line
                 box['error'] = f'{type(exc).__name__} {exc}'
 
@@ -1128,7 +1138,9 @@ def main():
         finished = not worker.is_alive()                    # decided once
         if not finished:
             box.setdefault('error', 'did not finish before the deadline (an RCCL collective that never returned?)')
-        report = control.allgather([1.0 if finished else 0.0, 1.0 if 'error' in box else 0.0, box.get('seconds', 0.0)])
+        parity_flag = -1.0 if 'parity' not in box else (1.0 if box['parity']['ok'] else 0.0)
+        report = control.allgather([1.0 if finished else 0.0, 1.0 if 'error' in box else 0.0, box.get('seconds', 0.0),
+                                    parity_flag])
         wedged = float(np.min(report[:, 0])) < 1.0
         if wedged or float(np.max(report[:, 1])) > 0.0:
             why = box.get('error', 'failed on another rank')
@@ -1139,6 +1151,9 @@ def main():
             sharded_line = dict(mode='candidates', value=box['terms'] / t_joint, unit='candidate-terms/s',
                                 ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
                                 spectral_remote=box['spectral_remote'], exchanges=box['exchanges'],
+                                parity=box.get('parity'),
+                                parity_ok_on_every_rank=None if float(np.max(report[:, 3])) < 0.0
+                                else bool(float(np.min(report[:, 3])) == 1.0),
                                 transport='RCCL' if comm_kind == 'RCCL' else 'TCP control plane (launcher rehearsal)',
                                 note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
                                      'ranks, one all-gather per window of candidates (north_star\'s split); after the '
