@@ -964,7 +964,7 @@ def main():
         elif cfg == 3 and not args.inputs and world == 1:
             # no oracle can run configs[3] with 2000 Gibbs iterations on 585-column models (O(P^3) products per
             # iteration): the golden is the benchmark's own dataset -- N = 1e6, stages capped at 3 -- with chains of
-            # burnin 30 + draws 30 (round 3; 1.5 h of oracle), or, should that file be missing, the N = 1e5 variant --
+            # burnin 30 + draws 30 (round 3; 3.5 h of oracle), or, should that file be missing, the N = 1e5 variant --
             # fitted here, untimed
             big = GOLDENS[(3, 0, 1_000_000)]
             rows_checked = n if (n == 1_000_000 and os.path.exists(

@@ -109,8 +109,9 @@ CASES = {
     # its O(P^3) products per Gibbs iteration (FR:1521-1528) on 585-column models are what bounds it
     'cfg3': lambda: run_case('cfg3_n1e5_m16_way3', 3, rows=100_000, burnin=30, draws=30),
     # ... and at the benchmark's own N = 1e6 with the same shortened chains (the oracle's cost at this size is the 900
-    # Gram matrices of up to 586 columns over a million rows and the column builds, about 1.5 h on 6 cores; with the
-    # configuration's 1000 + 1000 draws the O(P^3) products per Gibbs iteration would add days)
+    # Gram matrices of up to 586 columns over a million rows and the column builds: 3.5 h here, most of it page faults
+    # on the 4.7 GB design matrices the restatement copies per evaluation; with the configuration's 1000 + 1000 draws
+    # the O(P^3) products per Gibbs iteration would add days)
     'cfg3big': lambda: run_case('cfg3_n1e6_m16_way3', 3, rows=1_000_000, burnin=30, draws=30),
 }
 
