@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void write_columns(d2 *dst, size_t rows2, int 
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const size_t cap = (size_t)8 << 30;
+    const bool rows_sweep = argc > 1;                          // any argument: K1's shape against the number of rows only
+    const size_t cap = rows_sweep ? (size_t)24 << 30 : (size_t)8 << 30;
     char *buf;
     if (hipMalloc(&buf, cap) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
     hipEvent_t e0, e1;
@@ -81,6 +82,18 @@ int main()
         const d2 v = {1.0, 2.0};
         const double b = timeit((double)bytes, 4, [&] { write_stream<d2, true><<<256 * per_cu, 256>>>((d2 *)buf, bytes / 16, v); });
         printf("%3d per CU  %7.0f\n", per_cu, b);
+    }
+    if (rows_sweep) {
+        printf("# K1's shape against the number of rows: T = 56 columns side by side, 5 workgroups per CU, one launch each; GB/s plain | nt\n");
+        for (size_t n : {(size_t)1000000, (size_t)4000000, (size_t)10000000, (size_t)20000000, (size_t)50000000}) {
+            const size_t rows2 = n / 2;
+            const double bytes = 56.0 * rows2 * 16;
+            const int reps = n >= 10000000 ? 2 : 6;
+            const double a = timeit(bytes, reps, [&] { write_columns<false><<<256 * 5, 256>>>((d2 *)buf, rows2, 56); });
+            const double b = timeit(bytes, reps, [&] { write_columns<true><<<256 * 5, 256>>>((d2 *)buf, rows2, 56); });
+            printf("N = %9zu (%6.0f MB per launch)  %7.0f | %7.0f\n", n, bytes / 1e6, a, b);
+        }
+        return 0;
     }
     printf("# K1's shape: N = 1e6 rows (8 MB per column), T columns written side by side, 5 workgroups per CU; GB/s plain | nt\n");
     for (int streams : {1, 8, 28, 56, 112, 224}) {
