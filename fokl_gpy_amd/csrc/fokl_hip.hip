@@ -1230,7 +1230,12 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
-            const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, GD_THREADS, lds));
+            // The row cut decides which rows meet in which partial sum, i.e. the last bits of the block: it must not move
+            // when a compiler or an edit changes the kernel's register count.  Pinned to what these kernels could host
+            // when the goldens' margins were measured (three workgroups per CU for one tile per wavefront, two beyond),
+            // under the LDS limit the occupancy query reports; resident or queued, every workgroup has the same work.
+            const int by_registers = (pl.nt + 1) / 2 == 1 ? 3 : 2;
+            const int per_cu = std::min({wgs_cap, blocks_per_cu(fn, GD_THREADS, lds), by_registers});
             const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);

@@ -913,9 +913,13 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int64_t n_chunks = (n + R - 1) / R;
     const int64_t stride = gridDim.x;
 
-    // this lane's part in the pieces its wavefront issues (piece wave, wave + 8, ...): source column and row pair
-    uint32_t units[GD_MAX_PIECES];
-    int rowoff[GD_MAX_PIECES];                                  // first of its two rows within a chunk; -1: no row advance
+    // This lane's part in the pieces its wavefront issues (piece wave, wave + 8, ...): the address it reads next.  The
+    // addresses are formed once and then only advance -- every workgroup walks down the rows in steps of gridDim.x chunks,
+    // padding lanes walk down the zero column alongside -- so a piece costs ONE 64-bit add per chunk.  It used to cost eight
+    // VALU instructions (distance -> address, row offset, the padding select), and a matrix wavefront's VALU instructions
+    // are not free: gfx950 issues the fp64 MFMA through the SIMD's vector datapath, and two integer adds per MFMA take a
+    // sixth off its rate (tools/mfma_f64_issue.hip, profiles/mfma_f64_issue_r03.txt).
+    const double *src[GD_MAX_PIECES];
 #pragma unroll
     for (int i = 0; i < GD_MAX_PIECES; ++i) {
         const int piece = wave + 8 * i;
@@ -924,23 +928,21 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
         uint32_t u = 0x80000000u;                              // (flag: padding, the zero column)
         if (piece < pieces && col < 16 * ct_count) u = g.col_units[col >> 4][col & 15];
         const bool pad = (u >> 31) || within >= 8 * R;
-        units[i] = pad ? zero_units : u;
-        rowoff[i] = pad ? -1 : within / 8;
+        src[i] = base + ((size_t)(pad ? zero_units : u) << 5) + (pad ? 0 : within / 8) + (int64_t)blockIdx.x * R;
     }
-#define FOKL_GD_ISSUE_PIECE(i, row0, buf)                                                                   \
+    const int64_t src_step = stride * R;                        // rows between two chunks of this workgroup
+#define FOKL_GD_ISSUE_PIECE(i, row0, buf)                      /* (row0: where src[i] points by construction) */     \
     do {                                                                                                   \
         if (wave + 8 * (i) < pieces) {                         /* wave-uniform */                          \
-            uint32_t u_ = units[i];                                                                        \
-            asm volatile("" : "+v"(u_));                                                                   \
-            const double *src_ = base + ((size_t)u_ << 5) + (rowoff[i] < 0 ? 0 : (row0) + rowoff[i]);      \
-            __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src_,                                       \
+            __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src[i],                                     \
                                              (lds_void_ptr)(gd_tile + (buf) * buf_doubles + 128 * (wave + 8 * (i))), 16, 0, 0); \
+            src[i] += src_step;                                                                            \
         }                                                                                                  \
     } while (0)
-    auto issue = [&](int64_t chunk, int buf) {
-        const int64_t row0 = chunk * R;
+    auto issue = [&](int64_t chunk, int buf) {                  // (chunk: the one the addresses point at)
+        (void)chunk;
 #pragma unroll
-        for (int i = 0; i < GD_MAX_PIECES; ++i) FOKL_GD_ISSUE_PIECE(i, row0, buf);
+        for (int i = 0; i < GD_MAX_PIECES; ++i) FOKL_GD_ISSUE_PIECE(i, chunk * R, buf);
     };
 
     // tiles: list w & 3 of the group, every other entry

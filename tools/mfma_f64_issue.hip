@@ -75,6 +75,22 @@ __global__ __launch_bounds__(256) void spin(double *out, int iters)
                          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
                          "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
                          "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");
+        // MODE 7 / 8 / 9 / 10: D = C in vector registers with other VALU work of the same wavefront between the MFMAs --
+        // two 32-bit integer adds, four of them, two fp64 FMAs, four fp64 FMAs per MFMA (all independent of the MFMAs):
+        // does the matrix instruction share the SIMD's vector datapath with them or run beside it?
+#define CLOB ::: "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+                         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", \
+                         "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+                         "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
+                         "v68", "v69", "v70", "v71", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87"
+#define I2 "v_add_u32 v76, v76, v77\n v_add_u32 v78, v78, v77\n"
+#define F2 "v_fma_f64 v[80:81], v[80:81], v[82:83], v[82:83]\n v_fma_f64 v[84:85], v[84:85], v[86:87], v[86:87]\n"
+#define EIGHT(X) M("v[8:15]", "v[8:15]") X M("v[16:23]", "v[16:23]") X M("v[24:31]", "v[24:31]") X M("v[32:39]", "v[32:39]") X \
+                 M("v[40:47]", "v[40:47]") X M("v[48:55]", "v[48:55]") X M("v[56:63]", "v[56:63]") X M("v[64:71]", "v[64:71]") X
+        if (MODE == 7) asm volatile(EIGHT(I2) CLOB);
+        if (MODE == 8) asm volatile(EIGHT(I2 I2) CLOB);
+        if (MODE == 9) asm volatile(EIGHT(F2) CLOB);
+        if (MODE == 10) asm volatile(EIGHT(F2 F2) CLOB);
     }
     if (out && iters < 0) out[threadIdx.x] = 1.0;
 }
@@ -110,6 +126,10 @@ int main()
         run<4>("A, B in the same banks, D = C:", w);
         run<5>("operands from LDS every time:", w);
         run<6>("... in the Gram fragment pattern:", w);
+        run<7>("+ 2 integer adds per MFMA:", w);
+        run<8>("+ 4 integer adds per MFMA:", w);
+        run<9>("+ 2 fp64 FMAs per MFMA:", w);
+        run<10>("+ 4 fp64 FMAs per MFMA:", w);
     }
     return 0;
 }
