@@ -1027,34 +1027,36 @@ static gram_tiles4_fn tiles4s_kernel(int nt, int passes)
 
 typedef void (*gram_dma_fn)(const GramGroup *, int, int, int64_t, double *, int, int, const double *, uint32_t);
 
-// nt8: ordinary tiles per wavefront (1 .. 5; with half-tile slots 1 .. 4 + the slot)
-template <int NBUF>
+// nt8: ordinary tiles per wavefront (1 .. 5; with half-tile slots 1 .. 4 + the slot); LW: loader wavefronts (0, 2, 4)
+template <int NBUF, int LW>
 static gram_dma_fn tiles_dma_kernel_b(int nt8, bool half)
 {
     if (half) {
         switch (nt8) {
-            case 1: return gram_tiles_dma_kernel<1, NBUF, true>;
-            case 2: return gram_tiles_dma_kernel<2, NBUF, true>;
-            case 3: return gram_tiles_dma_kernel<3, NBUF, true>;
-            default: return gram_tiles_dma_kernel<4, NBUF, true>;
+            case 1: return gram_tiles_dma_kernel<1, NBUF, true, LW>;
+            case 2: return gram_tiles_dma_kernel<2, NBUF, true, LW>;
+            case 3: return gram_tiles_dma_kernel<3, NBUF, true, LW>;
+            default: return gram_tiles_dma_kernel<4, NBUF, true, LW>;
         }
     }
     switch (nt8) {
-        case 1: return gram_tiles_dma_kernel<1, NBUF, false>;
-        case 2: return gram_tiles_dma_kernel<2, NBUF, false>;
-        case 3: return gram_tiles_dma_kernel<3, NBUF, false>;
-        case 4: return gram_tiles_dma_kernel<4, NBUF, false>;
-        default: return gram_tiles_dma_kernel<5, NBUF, false>;
+        case 1: return gram_tiles_dma_kernel<1, NBUF, false, LW>;
+        case 2: return gram_tiles_dma_kernel<2, NBUF, false, LW>;
+        case 3: return gram_tiles_dma_kernel<3, NBUF, false, LW>;
+        case 4: return gram_tiles_dma_kernel<4, NBUF, false, LW>;
+        default: return gram_tiles_dma_kernel<5, NBUF, false, LW>;
     }
 }
 
-static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf, bool half)
+static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf, bool half, int loaders = 0)
 {
 #ifdef FOKL_DEV_KERNELS
-    if (nbuf == 3) return tiles_dma_kernel_b<3>(nt8, half);
+    if (nbuf == 3) return tiles_dma_kernel_b<3, 0>(nt8, half);
 #endif
     (void)nbuf;
-    return tiles_dma_kernel_b<2>(nt8, half);
+    if (loaders == 2) return tiles_dma_kernel_b<2, 2>(nt8, half);
+    if (loaders == 4) return tiles_dma_kernel_b<2, 4>(nt8, half);
+    return tiles_dma_kernel_b<2, 0>(nt8, half);
 }
 
 // Half-tile slots need the LDS-DMA kernel: asked for only where it runs every block (the default), FOKL_GRAM_HALF=0 for A/B
@@ -1225,9 +1227,9 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             nbuf = env_int("FOKL_GRAM_BUFS", 2);
             if (nbuf == 3 && 3 * (size_t)pieces * 1024 > 160 * 1024) nbuf = 2;
 #endif
-            gram_dma_fn fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half);
+            gram_dma_fn plain_fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half);
             const size_t lds = (size_t)nbuf * pieces * 1024;
-            rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
+            rc = raise_lds_limit(reinterpret_cast<const void *>(plain_fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
             // The row cut decides which rows meet in which partial sum, i.e. the last bits of the block: it must not move
@@ -1235,15 +1237,31 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             // when the goldens' margins were measured (three workgroups per CU for one tile per wavefront, two beyond),
             // under the LDS limit the occupancy query reports; resident or queued, every workgroup has the same work.
             const int by_registers = (pl.nt + 1) / 2 == 1 ? 3 : 2;
-            const int per_cu = std::min({wgs_cap, blocks_per_cu(fn, GD_THREADS, lds), by_registers});
+            const int per_cu = std::min({wgs_cap, blocks_per_cu(plain_fn, GD_THREADS, lds), by_registers});
+            // Four loader wavefronts issue the LDS-DMA pieces instead of the matrix wavefronts (gram_tiles_dma_kernel<.., 4>)
+            // wherever a CU can host as many of the larger workgroups as the row cut puts on it -- fewer resident
+            // workgroups cost more than the loaders bring (56 x 98: 195 -> 216 us).  FOKL_GRAM_LOADERS=0: never.  Same tiles,
+            // same order of summation: the block's bits do not depend on it.
+            int loaders = nbuf == 2 ? env_int("FOKL_GRAM_LOADERS", 4) : 0;
+            if (loaders != 2 && loaders != 4) loaders = 0;
+            gram_dma_fn fn = plain_fn;
+            if (loaders) {
+                gram_dma_fn with = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half, loaders);
+                rc = raise_lds_limit(reinterpret_cast<const void *>(with), lds);
+                if (rc) return rc;
+                if (blocks_per_cu(with, GD_THREADS + 64 * loaders, lds) >= per_cu)
+                    fn = with;
+                else
+                    loaders = 0;
+            }
             const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
             const uint32_t zero_units = (uint32_t)((reinterpret_cast<uintptr_t>(ctx->d_zero) - reinterpret_cast<uintptr_t>(grid_base)) >> 8);
             TimedRegion timed(ctx, gram_slot, bytes, flops);      // brackets the Gram kernel only
-            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GD_THREADS), lds, ctx->stream, d_groups,
-                               pl.ct, pieces, ctx->n, ctx->d_slab, nr_pad, nc_pad, grid_base, zero_units);
+            hipLaunchKernelGGL(fn, dim3(S, (unsigned)pl.groups.size()), dim3(GD_THREADS + 64 * loaders), lds, ctx->stream,
+                               d_groups, pl.ct, pieces, ctx->n, ctx->d_slab, nr_pad, nc_pad, grid_base, zero_units);
         } else {
             gram_tiles_fn fn = tiles_kernel(pl.nt, pl.ct << pl.rb_shift, pl.depth, pl.ks);
             const int R = 32 << pl.rb_shift;

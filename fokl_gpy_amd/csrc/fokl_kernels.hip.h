@@ -897,11 +897,17 @@ typedef __attribute__((address_space(1))) const void *global_cvoid_ptr;
 #endif
 
 
-template <int NT, int NBUF, bool HALF>
-__global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count,
-                                                                       int pieces, int64_t n, double *__restrict__ slab,
-                                                                       int nr_pad, int nc_pad,
-                                                                       const double *__restrict__ base, uint32_t zero_units)
+// LW > 0: LW LOADER wavefronts next to the eight matrix wavefronts (blockDim = 512 + 64 LW).  A wavefront issues in
+// order, and an LDS-DMA load whose requests find the memory pipeline backed up holds its wavefront at that instruction --
+// a matrix wavefront then issues no MFMA either (the "200 cycles per piece" of the phase stamps; compiled out, the pieces
+// are worth 15 % of a flop-bound launch although the instruction itself costs the matrix stream nothing:
+// profiles/k2_where_the_rest_goes_r03.txt, profiles/mfma_f64_issue_r03.txt).  The loaders issue ALL pieces of the next
+// chunk, wait for them and meet the others at the chunk barrier; the matrix wavefronts never touch vector memory.
+template <int NT, int NBUF, bool HALF, int LW = 0>
+__global__ __launch_bounds__(GD_THREADS + LW * WAVE, LW && NT >= 4 ? 1 : 2)
+void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, int pieces, int64_t n,
+                           double *__restrict__ slab, int nr_pad, int nc_pad, const double *__restrict__ base,
+                           uint32_t zero_units)
 {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(1024))) double gd_tile[];
@@ -912,6 +918,47 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int buf_doubles = pieces * 128;                       // whole KiB pieces per buffer
     const int64_t n_chunks = (n + R - 1) / R;
     const int64_t stride = gridDim.x;
+
+    if (LW > 0 && wave >= GD_THREADS / WAVE) {
+        static_assert(LW == 0 || NBUF == 2, "the loaders follow the two-buffer schedule");
+        constexpr int LWD = LW > 0 ? LW : 1;
+        constexpr int MAXP = (8 * GD_MAX_PIECES + LWD - 1) / LWD;          // pieces of one loader
+        const int lw = wave - GD_THREADS / WAVE;
+        const double *from[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int piece = lw + LWD * i;
+            const int byte = 1024 * piece + 16 * lane;
+            const int col = byte / (8 * pitch), within = byte % (8 * pitch);
+            uint32_t u = 0x80000000u;
+            if (piece < pieces && col < 16 * ct_count) u = g.col_units[col >> 4][col & 15];
+            const bool pad = (u >> 31) || within >= 8 * R;
+            from[i] = base + ((size_t)(pad ? zero_units : u) << 5) + (pad ? 0 : within / 8) + (int64_t)blockIdx.x * R;
+        }
+        const int64_t step = stride * R;
+        const int mine = __builtin_amdgcn_readfirstlane(lw < pieces ? (pieces - lw + LWD - 1) / LWD : 0);
+        auto issue_all = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i)
+                if (i < mine) {                                 // wave-uniform
+                    __builtin_amdgcn_global_load_lds((global_cvoid_ptr)from[i],
+                                                     (lds_void_ptr)(gd_tile + buf * buf_doubles + 128 * (lw + LWD * i)), 16, 0, 0);
+                    from[i] += step;
+                }
+        };
+        int64_t chunk = blockIdx.x;
+        if (chunk < n_chunks) issue_all(0);
+        __syncthreads();                                        // (vmcnt(0), then the barrier)
+        int buf = 0;
+        while (chunk < n_chunks) {
+            if (chunk + stride < n_chunks) issue_all(buf ^ 1);
+            if (chunk == n_chunks - 1 && n % R != 0) __syncthreads();      // (the matrix wavefronts trim the last chunk)
+            __syncthreads();
+            chunk += stride;
+            buf ^= 1;
+        }
+        return;
+    }
 
     // This lane's part in the pieces its wavefront issues (piece wave, wave + 8, ...): the address it reads next.  The
     // addresses are formed once and then only advance -- every workgroup walks down the rows in steps of gridDim.x chunks,
@@ -933,7 +980,7 @@ __global__ __launch_bounds__(GD_THREADS, 2) void gram_tiles_dma_kernel(const Gra
     const int64_t src_step = stride * R;                        // rows between two chunks of this workgroup
 #define FOKL_GD_ISSUE_PIECE(i, row0, buf)                      /* (row0: where src[i] points by construction) */     \
     do {                                                                                                   \
-        if (wave + 8 * (i) < pieces) {                         /* wave-uniform */                          \
+        if (LW == 0 && wave + 8 * (i) < pieces) {              /* wave-uniform; LW: the loaders' job */    \
             __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src[i],                                     \
                                              (lds_void_ptr)(gd_tile + (buf) * buf_doubles + 128 * (wave + 8 * (i))), 16, 0, 0); \
             src[i] += src_step;                                                                            \

@@ -8,16 +8,20 @@
 #define M(D, C) "v_mfma_f64_16x16x4_f64 " D ", v[0:1], v[2:3], " C "\n"
 
 template <int MODE>
-__global__ __launch_bounds__(256) void spin(double *out, int iters)
+__global__ __launch_bounds__(256) void spin(double *out, int iters, const char *gbuf = nullptr)
 {
     __shared__ double lds_buf[4096];
+    // MODE 11+: this lane's 16 bytes of a 1 KiB piece (an L2-resident source), landing in this wavefront's KiB of LDS
+    const char *gsrc = gbuf + (size_t)(blockIdx.x % 256) * 4096 + (threadIdx.x / 64) * 1024 + (threadIdx.x & 63) * 16;
+    const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)((unsigned)(size_t)(__attribute__((address_space(3))) double *)lds_buf + 16384 + (threadIdx.x / 64) * 1024));
     lds_buf[threadIdx.x] = 1.0 + threadIdx.x;
     lds_buf[threadIdx.x + 256] = 2.0;
     __syncthreads();
     // MODE 5: lane-contiguous reads; MODE 6: the Gram kernel's fragment pattern (column lane & 15 of a [column][34] tile, row lane >> 4)
     const unsigned lane = threadIdx.x & 63;
     const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds_buf +
-                              (MODE == 6 ? 8 * ((lane & 15) * 34 + (lane >> 4)) : 8 * lane);
+                              (MODE == 6 || MODE >= 14 ? 8 * ((lane & 15) * 34 + (lane >> 4)) : 8 * lane);
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0)
             asm volatile(M("v[8:15]", "v[8:15]") M("v[16:23]", "v[16:23]") M("v[24:31]", "v[24:31]") M("v[32:39]", "v[32:39]")
@@ -91,6 +95,46 @@ __global__ __launch_bounds__(256) void spin(double *out, int iters)
         if (MODE == 8) asm volatile(EIGHT(I2 I2) CLOB);
         if (MODE == 9) asm volatile(EIGHT(F2) CLOB);
         if (MODE == 10) asm volatile(EIGHT(F2 F2) CLOB);
+        // MODE 11 / 12 / 13: one / two / four LDS-DMA loads (global_load_lds_dwordx4, 64-bit per-lane addresses, data from L2)
+        // per eight MFMAs: what a piece of the Gram kernel's staging costs the matrix stream of its SIMD
+#define DMA1 "s_mov_b32 m0, %1\n s_nop 0\n global_load_lds_dwordx4 %0, off\n"
+        if (MODE == 11)
+            asm volatile(DMA1 M("v[8:15]", "v[8:15]") M("v[16:23]", "v[16:23]") M("v[24:31]", "v[24:31]") M("v[32:39]", "v[32:39]")
+                         M("v[40:47]", "v[40:47]") M("v[48:55]", "v[48:55]") M("v[56:63]", "v[56:63]") M("v[64:71]", "v[64:71]")
+                         "s_waitcnt vmcnt(0)\n" :: "v"(gsrc), "s"(lds_dst) : "memory", "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+                         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                         "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                         "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
+                         "v68", "v69", "v70", "v71");
+        if (MODE == 12)
+            asm volatile(DMA1 M("v[8:15]", "v[8:15]") M("v[16:23]", "v[16:23]") M("v[24:31]", "v[24:31]") M("v[32:39]", "v[32:39]")
+                         DMA1 M("v[40:47]", "v[40:47]") M("v[48:55]", "v[48:55]") M("v[56:63]", "v[56:63]") M("v[64:71]", "v[64:71]")
+                         "s_waitcnt vmcnt(0)\n" :: "v"(gsrc), "s"(lds_dst) : "memory", "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+                         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                         "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                         "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
+                         "v68", "v69", "v70", "v71");
+        if (MODE == 13)
+            asm volatile(DMA1 M("v[8:15]", "v[8:15]") M("v[16:23]", "v[16:23]") DMA1 M("v[24:31]", "v[24:31]") M("v[32:39]", "v[32:39]")
+                         DMA1 M("v[40:47]", "v[40:47]") M("v[48:55]", "v[48:55]") DMA1 M("v[56:63]", "v[56:63]") M("v[64:71]", "v[64:71]")
+                         "s_waitcnt vmcnt(0)\n" :: "v"(gsrc), "s"(lds_dst) : "memory", "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+                         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                         "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                         "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
+                         "v68", "v69", "v70", "v71");
+        // MODE 14 / 15: the Gram fragment pattern (operands from LDS before every MFMA) WITH two / four LDS-DMA loads per eight
+        // MFMAs landing in the same LDS: do the arriving pieces get in the way of the fragment reads?
+#define LM(D, A, B, OA, OB) "ds_read_b64 " A ", %2 offset:" OA "\n ds_read_b64 " B ", %2 offset:" OB "\n s_waitcnt lgkmcnt(2)\n v_mfma_f64_16x16x4_f64 " D ", " B ", " A ", " D "\n"
+        if (MODE == 14)
+            asm volatile(DMA1 LM("v[8:15]", "v[0:1]", "v[2:3]", "0", "512") LM("v[16:23]", "v[72:73]", "v[74:75]", "1024", "1536")
+                         LM("v[24:31]", "v[0:1]", "v[2:3]", "2048", "2560") LM("v[32:39]", "v[72:73]", "v[74:75]", "3072", "3584")
+                         DMA1 LM("v[40:47]", "v[0:1]", "v[2:3]", "4096", "4608") LM("v[48:55]", "v[72:73]", "v[74:75]", "5120", "5632")
+                         LM("v[56:63]", "v[0:1]", "v[2:3]", "6144", "6656") LM("v[64:71]", "v[72:73]", "v[74:75]", "7168", "7680")
+                         "s_waitcnt vmcnt(0)\n" :: "v"(gsrc), "s"(lds_dst), "v"(lds_addr) : "memory", "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+                         "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                         "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                         "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",
+                         "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75");
     }
     if (out && iters < 0) out[threadIdx.x] = 1.0;
 }
@@ -104,9 +148,11 @@ void run(const char *what, int waves_per_simd)
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int warm = 0; warm < 5; ++warm) spin<MODE><<<blocks, 256>>>(nullptr, iters);
+    static char *gbuf = nullptr;
+    if (!gbuf) (void)hipMalloc(&gbuf, 2 << 20);
+    for (int warm = 0; warm < 5; ++warm) spin<MODE><<<blocks, 256>>>(nullptr, iters, gbuf);
     (void)hipEventRecord(e0);
-    spin<MODE><<<blocks, 256>>>(nullptr, iters);
+    spin<MODE><<<blocks, 256>>>(nullptr, iters, gbuf);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -130,6 +176,10 @@ int main()
         run<8>("+ 4 integer adds per MFMA:", w);
         run<9>("+ 2 fp64 FMAs per MFMA:", w);
         run<10>("+ 4 fp64 FMAs per MFMA:", w);
+        run<11>("+ 1 LDS-DMA load per 8 MFMAs:", w);
+        run<12>("+ 2 LDS-DMA loads per 8 MFMAs:", w);
+        run<13>("+ 4 LDS-DMA loads per 8 MFMAs:", w);
+        run<14>("LDS operands + 2 LDS-DMA per 8:", w);
     }
     return 0;
 }
