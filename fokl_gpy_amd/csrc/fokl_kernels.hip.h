@@ -1049,7 +1049,9 @@ void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, i
 #ifndef FOKL_GD_AHEAD
 #define FOKL_GD_AHEAD 3
 #endif
-        constexpr int AHEAD = FOKL_GD_AHEAD;
+        // (three-tile kernels with loaders read two fragment pairs ahead instead of three: the six registers are what
+        // lets a CU host two of their 12-wavefront workgroups)
+        constexpr int AHEAD = LW > 0 && NT == 3 ? 2 : FOKL_GD_AHEAD;
         double af[AHEAD], bf[AHEAD], cf[HALF ? AHEAD : 1];
 #define FOKL_GD_FETCH(u)                                                                                   \
     do {                                                                                                   \
