@@ -37,7 +37,7 @@ for trial in range(trials):
     want = full[:, rs].T @ full[:, cs]
     pl = _capi.gram_plan(rs, cs)
     halves += int(pl['half'].sum())
-    for path in (2, 3):
+    for path in ((2, 3) if os.environ.get('K2_STRESS_PANELS') else (2,)):     # path 3: development builds only
         got = ctx.gram(rs, cs, path=path)
         if not np.array_equal(got, want):
             bad += 1
