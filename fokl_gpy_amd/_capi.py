@@ -19,7 +19,7 @@ RESID_TERMS_MAX_FACTORS = 48
 RESID_TERMS_MAX_ORDER = 8
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
 
-c_int, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+c_int, c_i32, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); mirrors include/fokl_hip.h one to one (tests/test_capi_symbols.py checks it)
 SIGNATURES = {
@@ -56,10 +56,10 @@ SIGNATURES = {
                                 c_vp]),
     'fokl_gibbs_chain_from_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_destroy': (None, [c_vp]),
-    'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
-                                       c_vp, c_int, c_vp]),
+    'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                       c_vp, c_int, c_int, c_vp]),
     'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -69,6 +69,19 @@ SIGNATURES = {
     'fokl_pool_wait': (c_int, [c_vp]),
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_noise_waits': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_pool_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_create': (c_int, [c_vp, c_i32, c_i32, c_dbl, c_int, c_vp]),
+    'fokl_stream_destroy': (None, [c_vp]),
+    'fokl_stream_walk': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_tell': (c_int, [c_vp, c_vp]),
+    'fokl_stream_seek': (c_int, [c_vp, c_vp]),
+    'fokl_stream_hold': (c_int, [c_vp, c_vp]),
+    'fokl_stream_release': (c_int, [c_vp, ctypes.c_uint64]),
+    'fokl_stream_advance_floor': (c_int, [c_vp]),
+    'fokl_stream_state': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_expand': (c_int, [c_vp, c_int, c_dbl, c_dbl, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
     'fokl_finish_tape_blocks': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'fokl_gibbs_chain_from_finished_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp,
                                                     c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -233,7 +246,7 @@ class NoiseTape:
     ``progress[0]`` counts the iterations recorded so far (-1 = the producer failed); ``block_done`` are the flags of
     fokl_finish_tape_blocks (blocks of BLOCK iterations).
     One allocation, carved up by address: a tape is made for every model evaluation on the search's critical thread."""
-    __slots__ = ('p1', 'draws', 'finishing_requested', '_buf', '_addr', '_off', '_ints')
+    __slots__ = ('p1', 'draws', 'finishing_requested', 'materialised_by_pool', '_buf', '_addr', '_off', '_ints')
     BLOCK = 16                                                # = FOKL_TAPE_BLOCK
 
     @classmethod
@@ -246,7 +259,10 @@ class NoiseTape:
         off = [0]
         for count in (d * p1 + 16, d * half + 8, d, d):     # slack: the recorder stores whole vectors (see the header)
             off.append(off[-1] + pad(count))
-        return tuple(off), ints, off[4] + pad((ints[1] + d + 1) // 2) + 8
+        # behind the int32 area: the tape as the pool's walker leaves it (fokl_tape_row [d]: 4 x uint64 each)
+        rows = off[4] + pad((ints[1] + d + 1) // 2) + 8
+        off.append(rows)
+        return tuple(off), ints, rows + 4 * d + 8
 
     @classmethod
     def doubles_needed(cls, p1, draws):
@@ -267,6 +283,7 @@ class NoiseTape:
         self._addr = self._buf.__array_interface__['data'][0]
         self._buf[off[4]:off[4] + ints[1] // 2] = 0.0         # progress and block flags start at zero
         self.finishing_requested = False                      # HostPool.submit_noise(..., finish=True) was given this tape
+        self.materialised_by_pool = False                     # block_done flags: set by the pool's finish threads
 
     def _int_area(self):
         return self._buf[self._off[4]:].view(np.int32)
@@ -288,6 +305,12 @@ class NoiseTape:
     def progress_pointer(self):
         return self._addr + 8 * self._off[4]
 
+    def rows_pointer(self):
+        return self._addr + 8 * self._off[5]
+
+    rows = property(lambda self: self._buf[self._off[5]:self._off[5] + 4 * self.draws].view(np.uint64)
+                    .reshape(self.draws, 4))
+
     def block_done_pointer(self):
         return self._addr + 8 * self._off[4] + 4 * self._ints[0]
 
@@ -305,6 +328,78 @@ def record_noise_tape(tape, astar, atau_star, stream):
 
 def noise_tape(p1, draws, astar, atau_star, stream):
     return record_noise_tape(NoiseTape(p1, draws), astar, atau_star, stream)
+
+
+class _StreamCursor(ctypes.Structure):
+    _fields_ = [('position', ctypes.c_uint64), ('gauss_source', ctypes.c_uint64), ('has_gauss', ctypes.c_int32)]
+
+
+class StreamEngine:
+    """include/fokl_hip.h: fokl_stream_* -- the random stream as bulk threads + one serial walk, outside a HostPool
+    (tests, tools; a fit's engine lives inside its pool).  ``walk`` fills a NoiseTape's rows, ``expand`` turns them into
+    the numbers fokl_noise_tape records; the part of the stream a tape covers is held from its walk until ``release``."""
+
+    def __init__(self, stream, bulk_threads=2):
+        self._lib = load()
+        self._h = None
+        self.stream = stream
+        h = c_vp(0)
+        _check(self._lib.fokl_stream_create(_ptr(stream.key), stream.pos, stream.has_gauss, stream.cache,
+                                            int(bulk_threads), ctypes.byref(h)))
+        self._h = h
+
+    def close(self, write_back=True):
+        """Stops the bulk threads; the walker's position goes back to ``stream`` as numpy's state tuple."""
+        if self._h:
+            if write_back:
+                _check(self._lib.fokl_stream_state(self._h, *self.stream.args()))
+            self._lib.fokl_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close(write_back=False)
+
+    def walk(self, tape, astar, atau_star):
+        """One model evaluation's draws: -> the hold that keeps the tape's part of the stream readable."""
+        hold = ctypes.c_uint64(0)
+        _check(self._lib.fokl_stream_hold(self._h, ctypes.byref(hold)))
+        a = tape._addr
+        rc = self._lib.fokl_stream_walk(self._h, tape.p1, tape.draws, float(astar), float(atau_star), tape.rows_pointer(),
+                                        a + 8 * tape._off[2], a + 8 * tape._off[3], tape.progress_pointer())
+        if rc:
+            self._lib.fokl_stream_release(self._h, hold)
+        _check(rc)
+        _check(self._lib.fokl_stream_advance_floor(self._h))
+        return hold.value
+
+    def expand(self, tape, astar, atau_star, first=0, last=None):
+        ptr = tape.pointers()
+        _check(self._lib.fokl_stream_expand(self._h, tape.p1, float(astar), float(atau_star), tape.rows_pointer(),
+                                            int(first), tape.draws if last is None else int(last), ptr[0], ptr[1], ptr[2],
+                                            ptr[3], ptr[4]))
+        return tape
+
+    def release(self, hold):
+        _check(self._lib.fokl_stream_release(self._h, ctypes.c_uint64(hold)))
+
+    def tell(self):
+        cur = _StreamCursor()
+        _check(self._lib.fokl_stream_tell(self._h, ctypes.byref(cur)))
+        return cur
+
+    def seek(self, cursor):
+        _check(self._lib.fokl_stream_seek(self._h, ctypes.byref(cursor)))
+
+    def numpy_state(self):
+        st = LegacyStream(self.stream.as_numpy_state())
+        _check(self._lib.fokl_stream_state(self._h, *st.args()))
+        return st.as_numpy_state()
+
+    def stats(self):
+        b, w, seg, ga, ge = c_dbl(0), c_dbl(0), c_i64(0), c_i64(0), c_i64(0)
+        _check(self._lib.fokl_stream_stats(self._h, *[ctypes.byref(x) for x in (b, w, seg, ga, ge)]))
+        return dict(bulk_s=b.value, walker_wait_s=w.value, segments=seg.value, gamma_attempts=ga.value,
+                    gamma_attempts_exact=ge.value)
 
 
 def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_sig_tau=False, follow=False):
@@ -432,15 +527,15 @@ class HostPool:
     """include/fokl_hip.h: fokl_pool_* -- the noise thread (owns ``stream`` until close()), chain threads and
     spectral threads of one fit."""
 
-    def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1):
+    def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1, bulk_threads=2):
         self._lib = load()
         self.stream = stream
         self._h = None
         h = c_vp(0)
         fn = _scipy_dsyevr_address() if spectral_threads > 0 else None
         self.finish_threads = int(finish_threads)
-        _check(self._lib.fokl_pool_create(int(chain_threads), self.finish_threads, int(spectral_threads), int(noise_cpu),
-                                          c_vp(fn),
+        _check(self._lib.fokl_pool_create(int(chain_threads), self.finish_threads, int(spectral_threads),
+                                          max(1, int(bulk_threads)), int(noise_cpu), c_vp(fn),
                                           *stream.args(),
                                           ctypes.byref(h)))
         self._h = h
@@ -459,10 +554,11 @@ class HostPool:
         h = c_vp(0)
         finish = bool(finish) and self.finish_threads > 0
         _check(self._lib.fokl_pool_submit_noise(self._h, tape.p1, tape.draws, float(astar), float(atau_star),
-                                                *tape.pointers(), tape.progress_pointer(), int(bool(tentative)),
-                                                tape.block_done_pointer() if finish else None, tape.BLOCK,
+                                                tape.rows_pointer(), *tape.pointers(), tape.progress_pointer(),
+                                                int(bool(tentative)), tape.block_done_pointer(), tape.BLOCK, int(finish),
                                                 ctypes.byref(h)))
         tape.finishing_requested = finish
+        tape.materialised_by_pool = True
         return PoolJob(h, (tape,), tape, tentative)
 
     def submit_chain(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, w_raw=None):
@@ -479,8 +575,7 @@ class HostPool:
         h = c_vp(0)
         _check(self._lib.fokl_pool_submit_chain(self._h, _ptr(lamb), _ptr(qty), p1, float(b), float(btau), float(dtd),
                                                 float(sigsqd0), float(tausqd0), tape.draws, *tape.pointers(),
-                                                tape.progress_pointer(),
-                                                tape.block_done_pointer() if self.finish_threads else None,
+                                                tape.progress_pointer(), tape.block_done_pointer(),
                                                 tape.BLOCK, int(tape.finishing_requested), _ptr(w), _ptr(flag),
                                                 ctypes.byref(h)))
         return PoolJob(h, (lamb, qty, tape, w, flag), (w, flag))
@@ -499,8 +594,11 @@ class HostPool:
         _check(self._lib.fokl_pool_busy_seconds(self._h, *[ctypes.byref(x) for x in v]))
         w = [c_dbl(0), c_dbl(0)]
         _check(self._lib.fokl_pool_noise_waits(self._h, ctypes.byref(w[0]), ctypes.byref(w[1])))
+        b, ww, seg, ga, ge = c_dbl(0), c_dbl(0), c_i64(0), c_i64(0), c_i64(0)
+        _check(self._lib.fokl_pool_stream_stats(self._h, *[ctypes.byref(x) for x in (b, ww, seg, ga, ge)]))
         return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value,
-                    noise_queue_wait=w[0].value, noise_verdict_wait=w[1].value)
+                    noise_queue_wait=w[0].value, noise_verdict_wait=w[1].value, bulk=b.value, walker_wait=ww.value,
+                    stream_segments=seg.value, gamma_attempts=ga.value, gamma_attempts_exact=ge.value)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -662,7 +760,8 @@ class DeviceChainEngine:
         _check(self._lib.fokl_dchain_submit(self._h, p1, tape.draws, _ptr(lamb), _ptr(qty), float(b), float(btau),
                                             float(dtd), float(sigsqd0), float(tausqd0), ptr[0], ptr[2], ptr[3], ptr[4],
                                             tape.progress_pointer() if follow else None,
-                                            tape.block_done_pointer() if finished else None, tape.BLOCK, int(finished),
+                                            tape.block_done_pointer() if finished or tape.materialised_by_pool else None,
+                                            tape.BLOCK, int(finished),
                                             int(stat_first), ctypes.byref(ticket), ctypes.byref(area)))
         return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape,), area.value)
 

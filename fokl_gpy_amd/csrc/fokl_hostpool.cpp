@@ -1,10 +1,14 @@
 // Host threads of one fit (G2/G3 of SURVEY 8(a) are N-independent and latency bound, so they stay on the host; this
 // file keeps them off the Python driver thread).  Four kinds of work, each on its own queue(s):
 //
-//   noise    ONE thread that owns the numpy legacy random stream for the lifetime of the pool and records noise
-//            tapes strictly in submission order (fokl_noise_tape) -- the stream is serial by definition;
-//   finish   threads that complete the normals of a tape in place (the log / sqrt half of the polar method), all of
-//            them on every tape, block-interleaved, while it is still being recorded;
+//   noise    ONE thread that walks the numpy legacy random stream for the lifetime of the pool and records noise tapes
+//            strictly in submission order -- since round 4 as ROWS OF POSITIONS (fokl_stream_walk): the stream's words,
+//            doubles and accept flags come from the stream's bulk threads (csrc/fokl_stream.cpp), the walk only counts
+//            flags and decides the two gamma draws per iteration;
+//   finish   threads that turn a tape's rows into its numbers (fokl_stream_expand: the accepted pairs, the leading and
+//            trailing normals, the gamma variates) and, where a host chain will read it, complete the normals in place
+//            (the log / sqrt half of the polar method) -- all of them on every tape, block-interleaved, while it is still
+//            being walked;
 //   chain    threads that turn a tape into the draws of one candidate (the sequential recursion FR:1521-1548),
 //            following the finished blocks;
 //   spectral threads that diagonalise a candidate's XtX sub-block: LAPACK dsyevr exactly as scipy.linalg.eigh calls
@@ -37,6 +41,14 @@
 #include "../../include/fokl_hip.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
+
+// fokl_sampler.cpp (library-internal)
+extern "C" __attribute__((visibility("hidden"))) void fokl_finish_tape_rows(int p1, double *normals, const double *pair_r2,
+                                                                            const int32_t *lead, int k0, int k1);
+extern "C" __attribute__((visibility("hidden"))) int fokl_gibbs_chain_from_raw_blocks(
+    const double *lamb, const double *qty, int p1, double b, double btau, double dtd, double sigsqd0, double tausqd0,
+    int draws, const double *normals, const double *pair_r2, const int32_t *lead, const double *gam_sig,
+    const double *gam_tau, const int32_t *block_done, int block, double *w_out, int32_t *bstar_negative);
 
 namespace {
 
@@ -72,6 +84,10 @@ struct fokl_host_job {
     // noise / chain
     int p1 = 0, draws = 0;
     double astar = 0, atau_star = 0;
+    fokl_tape_row *rows = nullptr;          // noise / finish: the tape as the walk leaves it
+    uint64_t hold = 0;                      // noise: the stream is kept readable from here on until the job settles
+    bool held = false;
+    bool finish_normals = false;            // finish: complete the normals in place after expanding them
     double *normals = nullptr, *pair_r2 = nullptr, *gam_sig = nullptr, *gam_tau = nullptr;
     int32_t *lead = nullptr, *progress = nullptr;
     // chain
@@ -80,6 +96,7 @@ struct fokl_host_job {
     double *w_out = nullptr;
     int32_t *bstar_negative = nullptr;
     // finish (internal, freed by the thread that ran it) and chain on a tape finished by those
+    const int32_t *raw_block_done = nullptr; // chain on a tape whose blocks are expanded, not finished, by the finish threads
     int32_t *block_done = nullptr;
     int block = 0, part = 0, parts = 0;
     bool self_owned = false;
@@ -95,7 +112,9 @@ struct fokl_host_pool {
     std::deque<Queue> finish_q;             // one per finish thread: every tape is split over all of them
     std::vector<std::thread> threads;
     dsyevr_fn dsyevr = nullptr;
-    // the random stream (caller-owned storage, updated in place by the noise thread only)
+    // the random stream: walked by the noise thread, produced by the stream's own bulk threads; the caller's state
+    // (mt_key ...) is read at creation and written back when the pool is destroyed
+    fokl_stream *stream = nullptr;
     uint32_t *mt_key = nullptr;
     int32_t *mt_pos = nullptr, *has_gauss = nullptr;
     double *gauss_cache = nullptr;
@@ -222,6 +241,42 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
 
 void settle(fokl_host_job *job);
 
+// A finish thread's share of one tape: blocks part, part + parts, ... of `block` rows, each as soon as the walk has
+// passed it -- rows -> numbers (fokl_stream_expand), then, for tapes a host chain reads, the normals completed in place;
+// block_done[blk] = 1 (release) after each, -1 for every block still open when the tape is sent back.
+int expand_tape_blocks(fokl_host_pool *pool, fokl_host_job *job)
+{
+    const int nblocks = (job->draws + job->block - 1) / job->block;
+    int32_t ready = 0;
+    for (int blk = job->part; blk < nblocks; blk += job->parts) {
+        const int k0 = blk * job->block, k1 = std::min(job->draws, k0 + job->block);
+        int rc = FOKL_OK;
+        for (int spins = 0; ready < k1;) {
+            ready = __atomic_load_n(job->progress, __ATOMIC_ACQUIRE);
+            if (ready < 0) break;
+            if (ready < k1) {
+                if (++spins < 2000)
+                    _mm_pause();
+                else
+                    std::this_thread::sleep_for(std::chrono::microseconds(10));
+            }
+        }
+        if (ready >= 0) {
+            rc = fokl_stream_expand(pool->stream, job->p1, job->astar, job->atau_star, job->rows, k0, k1, job->normals,
+                                    job->pair_r2, job->lead, job->gam_sig, job->gam_tau);
+            if (rc == FOKL_OK && job->finish_normals)
+                fokl_finish_tape_rows(job->p1, job->normals, job->pair_r2, job->lead, k0, k1);
+        }
+        if (ready < 0 || rc != FOKL_OK) {
+            for (int later = blk; later < nblocks; later += job->parts)
+                __atomic_store_n(job->block_done + later, -1, __ATOMIC_RELEASE);
+            return ready < 0 ? FOKL_ERR_STATE : rc;
+        }
+        __atomic_store_n(job->block_done + blk, 1, __ATOMIC_RELEASE);
+    }
+    return FOKL_OK;
+}
+
 void run(fokl_host_pool *pool, fokl_host_job *job)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -232,8 +287,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
     case Kind::noise:
         break;                                              // the noise thread has its own loop (noise_worker)
     case Kind::finish:
-        rc = fokl_finish_tape_blocks(job->p1, job->draws, job->normals, job->pair_r2, job->lead, job->progress,
-                                     job->part, job->parts, job->block, job->block_done);
+        rc = expand_tape_blocks(pool, job);
         busy = &pool->finish_busy_ns;
         break;
     case Kind::chain:
@@ -246,10 +300,10 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
             busy = &pool->chain_busy_ns;
             break;
         }
-        rc = fokl_gibbs_chain_from_tape(job->lamb, job->qty, job->p1, job->b, job->btau, job->dtd, job->sigsqd0,
-                                        job->tausqd0, job->draws, job->normals, job->pair_r2, job->lead, job->gam_sig,
-                                        job->gam_tau, job->w_out, nullptr, nullptr, job->bstar_negative,
-                                        job->progress);
+        rc = fokl_gibbs_chain_from_raw_blocks(job->lamb, job->qty, job->p1, job->b, job->btau, job->dtd, job->sigsqd0,
+                                              job->tausqd0, job->draws, job->normals, job->pair_r2, job->lead,
+                                              job->gam_sig, job->gam_tau, job->raw_block_done, job->block, job->w_out,
+                                              job->bstar_negative);
         if (rc != FOKL_OK) err = "chain: invalid arguments or the tape producer failed";
         busy = &pool->chain_busy_ns;
         break;
@@ -292,34 +346,12 @@ void worker(fokl_host_pool *pool, Queue *queue)
 // it final; an abort of the oldest puts the stream back where it began and takes every younger one with it (the caller
 // resolves those to "abort" as well: their content no longer is what the stream serves there); an abort of the youngest
 // rewinds just that one.  A plain (non-tentative) request waits until nothing speculative is left.
-struct StreamState {
-    uint32_t key[624];
-    int32_t pos, has_gauss;
-    double cache;
-};
-
 struct Speculation {
     fokl_host_job *job;
-    StreamState at_start;
+    fokl_stream_cursor at_start;            // a rewind moves the walker; the stream's bulk data stays where it is
 };
 
 constexpr size_t kMaxSpeculation = 16;
-
-void save_stream(const fokl_host_pool *pool, StreamState &s)
-{
-    std::memcpy(s.key, pool->mt_key, sizeof(s.key));
-    s.pos = *pool->mt_pos;
-    s.has_gauss = *pool->has_gauss;
-    s.cache = *pool->gauss_cache;
-}
-
-void restore_stream(fokl_host_pool *pool, const StreamState &s)
-{
-    std::memcpy(pool->mt_key, s.key, sizeof(s.key));
-    *pool->mt_pos = s.pos;
-    *pool->has_gauss = s.has_gauss;
-    *pool->gauss_cache = s.cache;
-}
 
 void trace_noise(fokl_host_pool *pool, fokl_host_job *job, int64_t verdict_seen)
 {
@@ -332,6 +364,10 @@ void settle(fokl_host_job *job)                            // status / error wer
 {
     if (job->pending.fetch_sub(1, std::memory_order_acq_rel) != 1) return;      // somebody is still on the tape
     fokl_host_pool *pool = job->pool;                       // the job may be freed by its waiter right after `done`
+    if (job->held) {                                        // nobody reads this tape's part of the stream any more
+        job->held = false;
+        fokl_stream_release(pool->stream, job->hold);
+    }
     {
         std::lock_guard<std::mutex> lock(pool->done_m);
         job->done.store(1, std::memory_order_release);
@@ -343,13 +379,41 @@ void record_tape(fokl_host_pool *pool, fokl_host_job *job)
 {
     const auto t0 = std::chrono::steady_clock::now();
     job->t_start = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
-    const int rc = fokl_noise_tape(job->p1, job->draws, job->astar, job->atau_star, pool->mt_key, pool->mt_pos,
-                                   pool->has_gauss, pool->gauss_cache, job->normals, job->pair_r2, job->lead,
-                                   job->gam_sig, job->gam_tau, job->progress);
+    int rc = fokl_stream_hold(pool->stream, &job->hold);
+    job->held = rc == FOKL_OK;
+    if (rc == FOKL_OK && !pool->finish_q.empty()) {
+        // the finish threads follow `progress` and turn the rows into numbers
+        rc = fokl_stream_walk(pool->stream, job->p1, job->draws, job->astar, job->atau_star, job->rows, job->gam_sig,
+                              job->gam_tau, job->progress);
+    } else if (rc == FOKL_OK) {
+        // no finish threads in this pool: this thread materialises each block itself
+        const int block = job->block > 0 ? job->block : FOKL_TAPE_BLOCK;
+        for (int k0 = 0; k0 < job->draws && rc == FOKL_OK; k0 += block) {
+            const int k1 = std::min(job->draws, k0 + block);
+            rc = fokl_stream_walk(pool->stream, job->p1, k1 - k0, job->astar, job->atau_star, job->rows + k0,
+                                  job->gam_sig + k0, job->gam_tau + k0, nullptr);
+            if (rc == FOKL_OK)
+                rc = fokl_stream_expand(pool->stream, job->p1, job->astar, job->atau_star, job->rows, k0, k1, job->normals,
+                                        job->pair_r2, job->lead, job->gam_sig, job->gam_tau);
+            if (rc != FOKL_OK) break;
+            if (job->block_done) __atomic_store_n(job->block_done + k0 / block, 1, __ATOMIC_RELEASE);
+            __atomic_store_n(job->progress, k1, __ATOMIC_RELEASE);
+        }
+        if (rc != FOKL_OK) {
+            if (job->block_done)
+                for (int blk = 0; blk < (job->draws + block - 1) / block; ++blk) {
+                    int32_t open = 0;
+                    __atomic_compare_exchange_n(job->block_done + blk, &open, -1, false, __ATOMIC_ACQ_REL,
+                                                __ATOMIC_ACQUIRE);
+                }
+            __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);
+        }
+    }
     if (rc != FOKL_OK) {
         job->status = rc;
-        job->error = "noise tape: invalid arguments or gamma shape";
+        job->error = "noise tape: invalid arguments, gamma shape or the stream's producers failed";
     }
+    fokl_stream_advance_floor(pool->stream);                // what is still needed behind the walker is held by its tape
     const auto t1 = std::chrono::steady_clock::now();
     job->t_recorded = std::chrono::duration_cast<std::chrono::nanoseconds>(t1.time_since_epoch()).count();
     pool->noise_busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(),
@@ -380,7 +444,7 @@ void noise_worker(fokl_host_pool *pool)
         }
         const size_t cut = first_aborted();
         if (cut < open.size()) {
-            restore_stream(pool, open[cut].at_start);
+            fokl_stream_seek(pool->stream, &open[cut].at_start);
             for (size_t k = cut; k < open.size(); ++k) aborted(open[k].job);
             open.erase(open.begin() + (std::ptrdiff_t)cut, open.end());
         }
@@ -453,7 +517,7 @@ void noise_worker(fokl_host_pool *pool)
                 continue;
             }
             open.push_back({job, {}});
-            save_stream(pool, open.back().at_start);
+            fokl_stream_tell(pool->stream, &open.back().at_start);
             record_tape(pool, job);
         } else {
             record_tape(pool, job);
@@ -483,11 +547,11 @@ void stop(Queue &queue)
 
 }  // namespace
 
-extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int noise_cpu, void *dsyevr,
-                                uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
-                                fokl_host_pool **out)
+extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads,
+                                int noise_cpu, void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss,
+                                double *gauss_cache, fokl_host_pool **out)
 {
-    if (!out || chain_threads < 1 || spectral_threads < 0 || chain_threads > 64 || spectral_threads > 64 ||
+    if (!out || chain_threads < 1 || bulk_threads < 1 || bulk_threads > 16 || spectral_threads < 0 || chain_threads > 64 || spectral_threads > 64 ||
         finish_threads < 0 || finish_threads > 64 || !mt_key ||
         !mt_pos || !has_gauss || !gauss_cache || (spectral_threads > 0 && !dsyevr)) {
         fokl_set_global_error("fokl_pool_create: bad thread counts, null RNG state or missing dsyevr");
@@ -498,6 +562,10 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
         return FOKL_ERR_ARG;
     }
     auto *pool = new fokl_host_pool();
+    if (fokl_stream_create(mt_key, *mt_pos, *has_gauss, *gauss_cache, bulk_threads, &pool->stream) != FOKL_OK) {
+        delete pool;
+        return FOKL_ERR_STATE;
+    }
     pool->dsyevr = reinterpret_cast<dsyevr_fn>(dsyevr);
     pool->mt_key = mt_key;
     pool->mt_pos = mt_pos;
@@ -525,6 +593,7 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
         stop(pool->spectral_q);
         for (auto &q : pool->finish_q) stop(q);
         for (auto &t : pool->threads) t.join();
+        fokl_stream_destroy(pool->stream);
         delete pool;
         fokl_set_global_error(std::string("fokl_pool_create: ") + e.what());
         return FOKL_ERR_STATE;
@@ -542,6 +611,9 @@ extern "C" void fokl_pool_destroy(fokl_host_pool *pool)
     stop(pool->spectral_q);
     for (auto &q : pool->finish_q) stop(q);
     for (auto &t : pool->threads) t.join();
+    // the stream goes back to its owner where the walker stands: numpy's state tuple after everything that was walked
+    fokl_stream_state(pool->stream, pool->mt_key, pool->mt_pos, pool->has_gauss, pool->gauss_cache);
+    fokl_stream_destroy(pool->stream);
     if (!pool->trace_path.empty()) {
         if (FILE *f = std::fopen(pool->trace_path.c_str(), "a")) {
             for (const auto &r : pool->trace)
@@ -553,24 +625,29 @@ extern "C" void fokl_pool_destroy(fokl_host_pool *pool)
     delete pool;
 }
 
-static void submit_finish_jobs(fokl_host_pool *pool, fokl_host_job *parent, int p1, int draws, double *normals,
-                               double *pair_r2, int32_t *lead, int32_t *progress, int32_t *block_done, int block)
+static void submit_finish_jobs(fokl_host_pool *pool, fokl_host_job *parent, bool finish_normals)
 {
     const int parts = (int)pool->finish_q.size();
-    for (int part = 0; part < parts; ++part) {             // the tape is completed in place by all finish threads
+    for (int part = 0; part < parts; ++part) {             // the tape is materialised by all finish threads
         auto *fin = new fokl_host_job();
         fin->pool = pool;
         fin->kind = Kind::finish;
         fin->self_owned = true;
         fin->parent = parent;
-        fin->p1 = p1;
-        fin->draws = draws;
-        fin->normals = normals;
-        fin->pair_r2 = pair_r2;
-        fin->lead = lead;
-        fin->progress = progress;
-        fin->block_done = block_done;
-        fin->block = block;
+        fin->p1 = parent->p1;
+        fin->draws = parent->draws;
+        fin->astar = parent->astar;
+        fin->atau_star = parent->atau_star;
+        fin->rows = parent->rows;
+        fin->normals = parent->normals;
+        fin->pair_r2 = parent->pair_r2;
+        fin->lead = parent->lead;
+        fin->gam_sig = parent->gam_sig;
+        fin->gam_tau = parent->gam_tau;
+        fin->progress = parent->progress;
+        fin->block_done = parent->block_done;
+        fin->block = parent->block;
+        fin->finish_normals = finish_normals;
         fin->part = part;
         fin->parts = parts;
         submit(pool->finish_q[(size_t)part], fin);
@@ -578,13 +655,13 @@ static void submit_finish_jobs(fokl_host_pool *pool, fokl_host_job *parent, int 
 }
 
 extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star,
-                                      double *normals, double *pair_r2, int32_t *lead, double *gam_sig,
-                                      double *gam_tau, int32_t *progress, int tentative, int32_t *block_done,
-                                      int block, fokl_host_job **out)
+                                      fokl_tape_row *rows, double *normals, double *pair_r2, int32_t *lead,
+                                      double *gam_sig, double *gam_tau, int32_t *progress, int tentative,
+                                      int32_t *block_done, int block, int finish, fokl_host_job **out)
 {
-    if (!pool || !out || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau || !progress ||
-        (block_done && block < 1)) {
-        fokl_set_global_error("fokl_pool_submit_noise: null pointer or empty model");
+    if (!pool || !out || p1 <= 0 || draws < 0 || !rows || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau ||
+        !progress || !block_done || block < 1) {
+        fokl_set_global_error("fokl_pool_submit_noise: null pointer, empty model or bad block size");
         return FOKL_ERR_ARG;
     }
     auto *job = new fokl_host_job();
@@ -594,20 +671,23 @@ extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, d
     job->draws = draws;
     job->astar = astar;
     job->atau_star = atau_star;
+    job->rows = rows;
     job->normals = normals;
     job->pair_r2 = pair_r2;
     job->lead = lead;
     job->gam_sig = gam_sig;
     job->gam_tau = gam_tau;
     job->progress = progress;
+    job->block_done = block_done;
+    job->block = block;
     job->tentative = tentative != 0;
     if (!pool->trace_path.empty()) job->t_submit = now_ns();
     *out = job;
-    if (block_done && !pool->finish_q.empty()) {
-        // the finishing half follows the recorder whether or not a chain has been asked for yet (a tape recorded ahead
-        // of the decision that it is needed is complete when its chain comes); an aborted tape ends these jobs too
+    if (!pool->finish_q.empty()) {
+        // the finish threads follow the walk whether or not a chain has been asked for yet (a tape walked ahead of the
+        // decision that it is needed is complete when its chain comes); a tape that is sent back ends these jobs too
         job->pending.store(1 + (int)pool->finish_q.size(), std::memory_order_relaxed);
-        submit_finish_jobs(pool, job, p1, draws, normals, pair_r2, lead, progress, block_done, block);
+        submit_finish_jobs(pool, job, finish != 0);
     }
     submit(pool->noise_q, job);
     return FOKL_OK;
@@ -621,14 +701,10 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
                                       int32_t *bstar_negative, fokl_host_job **out)
 {
     if (!pool || !out || !lamb || !qty || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig ||
-        !gam_tau || !progress || !w_out || !bstar_negative || (block_done && block < 1)) {
+        !gam_tau || !progress || !w_out || !bstar_negative || !block_done || block < 1) {
         fokl_set_global_error("fokl_pool_submit_chain: null pointer or empty model");
         return FOKL_ERR_ARG;
     }
-    const int parts = block_done ? (int)pool->finish_q.size() : 0;
-    if (parts > 0 && !finishing_requested)
-        submit_finish_jobs(pool, nullptr, p1, draws, const_cast<double *>(normals), const_cast<double *>(pair_r2),
-                           const_cast<int32_t *>(lead), const_cast<int32_t *>(progress), block_done, block);
     auto *job = new fokl_host_job();
     job->pool = pool;
     job->kind = Kind::chain;
@@ -649,10 +725,11 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
     job->progress = const_cast<int32_t *>(progress);
     job->w_out = w_out;
     job->bstar_negative = bstar_negative;
-    if (parts > 0) {
-        job->block_done = block_done;
-        job->block = block;
-    }
+    job->block = block;
+    if (finishing_requested)
+        job->block_done = block_done;                       // the finish threads complete the normals in place
+    else
+        job->raw_block_done = block_done;                   // ... or only expand them: the chain completes each row
     *out = job;
     submit(pool->chain_q, job);
     return FOKL_OK;
@@ -745,6 +822,18 @@ extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise,
     if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
     if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
     return FOKL_OK;
+}
+
+// The pool's random stream (fokl_stream_stats): CPU seconds of its bulk threads, seconds the walker waited for them,
+// segments produced, gamma attempts walked and how many of them needed the exact expressions.
+extern "C" int fokl_pool_stream_stats(const fokl_host_pool *pool, double *bulk_busy_s, double *walker_wait_s,
+                                      int64_t *segments, int64_t *gamma_attempts, int64_t *gamma_attempts_exact)
+{
+    if (!pool) {
+        fokl_set_global_error("fokl_pool_stream_stats: null pool");
+        return FOKL_ERR_ARG;
+    }
+    return fokl_stream_stats(pool->stream, bulk_busy_s, walker_wait_s, segments, gamma_attempts, gamma_attempts_exact);
 }
 
 // Where the noise thread -- the serial resource of a fit -- was not recording: waiting for the next request with an

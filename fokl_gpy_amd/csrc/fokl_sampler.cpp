@@ -861,6 +861,53 @@ extern "C" int fokl_finish_tape_blocks(int p1, int draws, double *normals, const
     return FOKL_OK;
 }
 
+// Rows k0 .. k1 - 1 of a raw tape completed in place (the pool's expanders: fokl_stream_expand leaves raw pairs).
+FOKL_INTERNAL void fokl_finish_tape_rows(int p1, double *normals, const double *pair_r2, const int32_t *lead, int k0, int k1)
+{
+    const size_t half = (size_t)p1 / 2 + 1;
+    std::vector<double> fbuf(half);
+    const bool fast = fast_finish_requested();
+    for (int k = k0; k < k1; ++k) {
+        double *row = normals + (size_t)k * p1;
+        finish_normals(row, pair_r2 + (size_t)k * half, lead[k], p1, row, fbuf.data(), fast);
+    }
+}
+
+// fokl_gibbs_chain_from_tape for a tape whose blocks are materialised by other threads: waits on block_done (as
+// fokl_gibbs_chain_from_finished_tape does) and completes each row's normals itself.
+FOKL_INTERNAL int fokl_gibbs_chain_from_raw_blocks(const double *lamb, const double *qty, int p1, double b, double btau,
+                                                   double dtd, double sigsqd0, double tausqd0, int draws,
+                                                   const double *normals, const double *pair_r2, const int32_t *lead,
+                                                   const double *gam_sig, const double *gam_tau,
+                                                   const int32_t *block_done, int block, double *w_out,
+                                                   int32_t *bstar_negative)
+{
+    ChainState st{sigsqd0, tausqd0};
+    const size_t half = (size_t)p1 / 2 + 1;
+    std::vector<double> vec((size_t)p1), fbuf(half);
+    const bool fast = fast_finish_requested();
+    int ready_block = -1;
+    for (int k = 0; k < draws; ++k) {
+        if (k / block > ready_block) {
+            const int blk = k / block;
+            for (int spins = 0;;) {
+                const int32_t flag = __atomic_load_n(block_done + blk, __ATOMIC_ACQUIRE);
+                if (flag > 0) break;
+                if (flag < 0) {
+                    fokl_set_global_error("chain: the tape producer failed or the tape was sent back");
+                    return FOKL_ERR_STATE;
+                }
+                follow_wait(spins);
+            }
+            ready_block = blk;
+        }
+        finish_normals(normals + (size_t)k * p1, pair_r2 + (size_t)k * half, lead[k], p1, vec.data(), fbuf.data(), fast);
+        chain_step(lamb, qty, p1, b, btau, dtd, vec.data(), gam_sig[k], gam_tau[k], w_out + (size_t)k * p1, st);
+    }
+    if (bstar_negative) *bstar_negative = st.flagged;
+    return FOKL_OK;
+}
+
 extern "C" int fokl_gibbs_chain_from_finished_tape(const double *lamb, const double *qty, int p1, double b,
                                                    double btau, double dtd, double sigsqd0, double tausqd0, int draws,
                                                    const double *normals, const double *gam_sig,

@@ -1,0 +1,1335 @@
+// The numpy-legacy random stream of a fit, split into a BULK phase and a serial WALK (round 4).
+//
+// What the reference consumes (FoKLRoutines.py:1527, 1541, 1547: np.random.normal / np.random.gamma, three calls per Gibbs
+// iteration on numpy's global legacy RandomState) is one MT19937 word stream read as 53-bit doubles, paired up by the
+// polar method (one-value cache shared by normal and gamma) and by Marsaglia-Tsang's gamma (fokl_sampler.cpp restates the
+// published algorithm and is pinned against numpy bit for bit).  Up to round 3 one thread produced all of it, draw by
+// draw: 31 + 0.93 p1 ns per Gibbs iteration, 70 ms of an 80 ms fit.  Only a sliver of that is sequential:
+//
+//   * the WORDS are a linear recurrence, w[g] = w[g - 227] ^ twist(w[g - 624], w[g - 623]), whose shortest dependency is
+//     227 words long: over a flat array it is a plain vector loop;
+//   * tempering, the conversion to doubles, x = 2 d - 1, x^2 and the ACCEPT FLAG of the polar attempt that STARTS at each
+//     double (0 < x_d^2 + x_{d+1}^2 < 1) are element-wise.  A uniform drawn by a gamma shifts the pairing of the doubles
+//     by one, so the flags are kept for both alignments (attempts starting at even and at odd doubles), as two bit masks;
+//   * what is left for the walk: "advance over ceil((p1 - cached) / 2) accepted attempts" -- popcounts over the mask
+//     of the current alignment -- and the two gamma draws of the iteration (one normal, one uniform and a data-independent
+//     accept test each).  The normals of an iteration are not touched by the walk at all: a tape row is (where the scan
+//     began, the leading cached normal, the trailing half pair, the two gammas) -- 40 bytes instead of 12 p1.
+//
+// Bulk threads produce SEGMENTS of the stream (256 MT19937 blocks: 79 872 doubles) ahead of the walker: the recurrence of
+// a segment runs under a token (it continues the previous segment's last block: 0.15 cycles per word), everything else
+// of the segment -- tempering in place, flags -- runs outside it, so several threads overlap.  Consumers turn tape rows
+// back into normals (fokl_stream_expand: any thread, any time while the tape's segments are held): the mask says which
+// attempts were accepted, the tempered words give (x2, x1).
+//
+// Exactness: every double, every flag and every draw of the walk is computed with the operations fokl_sampler.cpp's
+// LegacyRng uses (the conversion and x = 2 d - 1 are exact; x^2 and the sum are one rounding each, no contraction: this
+// file is compiled with -ffp-contract=off), so positions, consumption and values are numpy's bit for bit
+// (tests/test_stream_engine.py: against the one-thread recorder, against numpy itself, odd word positions, rewinds).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <immintrin.h>
+
+#include "../../include/fokl_hip.h"
+
+extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
+
+namespace {
+
+constexpr int MT_N = 624, MT_SHIFT = 227;                   // 227 = 624 - 397
+constexpr int kSegBlocks = 256;
+constexpr int kSegWords = kSegBlocks * MT_N;                // 159 744 words
+constexpr int kSegDoubles = kSegWords / 2;                  // 79 872 doubles (attempts may start at each of them)
+constexpr int kSegSlots = kSegDoubles / 2;                  // 39 936 attempts per alignment
+constexpr int kSegMaskWords = kSegSlots / 64;               // 624 mask words per alignment
+constexpr int kSegTail = 32;                                // words of the next segment kept behind this one's
+constexpr int kTable = 8192;                                // segments that can be alive at a time (524 M doubles)
+constexpr int kAhead = 6;                                   // segments produced ahead of the walker
+constexpr uint64_t kLeadBit = 1ull << 63;                   // fokl_tape_row.start: the row opens with the cached normal
+constexpr uint64_t kCachedHalf = 1ull << 63;                // a normal's source: the x1 half of the attempt (else x2)
+constexpr uint64_t kGivenGauss = (1ull << 62) - 1;          // source position: the cached value of the state handed over
+constexpr uint64_t kFinalValue = ~0ull;                     // fokl_tape_row.gamma[j]: the walker stored the variate itself
+
+static_assert(kSegSlots % 64 == 0, "mask words must not straddle segments");
+
+#define FOKL_WIDE_TARGET __attribute__((target("avx512f,avx512dq,avx512vl,avx512bw,bmi,bmi2,popcnt,lzcnt")))
+
+inline bool cpu_is_wide()
+{
+    static const bool wide = [] {
+        const char *isa = std::getenv("FOKL_SAMPLER_ISA");            // "base" forces the portable loops (tests)
+        if (isa && std::strcmp(isa, "base") == 0) return false;
+        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&
+               __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
+               __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
+    }();
+    return wide;
+}
+
+// One segment: [previous block, raw | the segment's words | the first words of the next segment], contiguous because the
+// recurrence reads up to 624 words back; the words are raw while the token holder generates them and tempered from
+// `ready` on.  mask[a] bit q: the polar attempt on doubles (2 q + a, 2 q + a + 1) of this segment is accepted.
+struct alignas(64) Segment {
+    uint32_t buf[MT_N + kSegWords + kSegTail];
+    alignas(64) uint64_t mask[2][kSegMaskWords];
+    int64_t index;
+    std::atomic<int> ready;
+
+    uint32_t *words() { return buf + MT_N; }
+    const uint32_t *words() const { return buf + MT_N; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// the bulk phase
+// ---------------------------------------------------------------------------------------------------------------
+
+inline uint32_t twist(uint32_t a, uint32_t b)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+
+// buf[g] for g in [from, to): the MT19937 recurrence over the flat array (block b + 1 follows block b in memory)
+void recurrence_portable(uint32_t *buf, int from, int to)
+{
+    for (int g = from; g < to; ++g) buf[g] = buf[g - MT_SHIFT] ^ twist(buf[g - MT_N], buf[g - MT_N + 1]);
+}
+
+FOKL_WIDE_TARGET void recurrence_wide(uint32_t *buf, int from, int to)
+{
+    const __m512i upper = _mm512_set1_epi32((int)0x80000000u), mag = _mm512_set1_epi32((int)0x9908b0dfu);
+    const __m512i one = _mm512_set1_epi32(1);
+    int g = from;
+    for (; g + 16 <= to; g += 16) {                         // 16 <= 227: no lane reads what this step writes
+        const __m512i a = _mm512_loadu_si512(buf + g - MT_N), b = _mm512_loadu_si512(buf + g - MT_N + 1);
+        const __m512i c = _mm512_loadu_si512(buf + g - MT_SHIFT);
+        const __m512i y = _mm512_ternarylogic_epi32(upper, a, b, 0xca);       // upper ? a : b
+        const __mmask16 odd = _mm512_test_epi32_mask(y, one);
+        __m512i r = _mm512_xor_si512(c, _mm512_srli_epi32(y, 1));
+        r = _mm512_mask_xor_epi32(r, odd, r, mag);
+        _mm512_storeu_si512(buf + g, r);
+    }
+    for (; g < to; ++g) buf[g] = buf[g - MT_SHIFT] ^ twist(buf[g - MT_N], buf[g - MT_N + 1]);
+}
+
+inline uint32_t temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// numpy's 53-bit double from two tempered words, and the polar coordinate 2 d - 1 (both exact)
+inline double to_double(uint32_t wa, uint32_t wb)
+{
+    const int32_t a = (int32_t)(wa >> 5), b = (int32_t)(wb >> 6);
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);   // a power of two: the product is numpy's quotient
+}
+
+// Tempering in place and the accept flags of a segment; `o` = parity of the word position the doubles pair up from
+// (double l of the segment <-> words o + 2 l, o + 2 l + 1).
+void finish_segment_portable(Segment *seg, int o)
+{
+    uint32_t *w = seg->words();
+    for (int i = 0; i < kSegWords + kSegTail; ++i) w[i] = temper(w[i]);
+    std::vector<double> sq((size_t)kSegDoubles + 1);
+    for (int l = 0; l <= kSegDoubles; ++l) {
+        const double x = 2.0 * to_double(w[o + 2 * l], w[o + 2 * l + 1]) - 1.0;
+        sq[(size_t)l] = x * x;
+    }
+    std::memset(seg->mask, 0, sizeof(seg->mask));
+    for (int l = 0; l < kSegDoubles; ++l) {
+        const double r2 = sq[(size_t)l] + sq[(size_t)l + 1];
+        const uint64_t ok = (uint64_t)((r2 < 1.0) & (r2 != 0.0));
+        seg->mask[l & 1][(l >> 1) >> 6] |= ok << ((l >> 1) & 63);
+    }
+}
+
+FOKL_WIDE_TARGET inline __m512d polar_squares(const uint32_t *p)
+{
+    // eight doubles from sixteen tempered words: lane = wa | wb << 32; v = (wa >> 5) 2^26 + (wb >> 6) < 2^53;
+    // x = 2 v / 2^53 - 1 = (v - 2^52) / 2^52 (exact either way); x^2 is the one rounding numpy's x * x makes
+    const __m512i lanes = _mm512_loadu_si512(p);
+    const __m512i a = _mm512_srli_epi64(_mm512_and_si512(lanes, _mm512_set1_epi64(0xffffffffll)), 5);
+    const __m512i b = _mm512_srli_epi64(lanes, 38);
+    const __m512i v = _mm512_add_epi64(_mm512_slli_epi64(a, 26), b);
+    const __m512d x = _mm512_mul_pd(_mm512_cvtepi64_pd(_mm512_sub_epi64(v, _mm512_set1_epi64(1ll << 52))),
+                                    _mm512_set1_pd(1.0 / 4503599627370496.0));
+    return _mm512_mul_pd(x, x);
+}
+
+FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o)
+{
+    uint32_t *w = seg->words();
+    const __m512i m7 = _mm512_set1_epi32((int)0x9d2c5680u), m15 = _mm512_set1_epi32((int)0xefc60000u);
+    for (int i = 0; i < kSegWords + kSegTail; i += 16) {
+        __m512i y = _mm512_loadu_si512(w + i);
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), m7));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), m15));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+        _mm512_storeu_si512(w + i, y);
+    }
+    const __m512d one = _mm512_set1_pd(1.0), zero = _mm512_setzero_pd();
+    const uint32_t *p = w + o;
+    __m512d cur = polar_squares(p);
+    uint64_t *m0 = seg->mask[0], *m1 = seg->mask[1];
+    for (int word = 0; word < kSegMaskWords; ++word) {      // 128 doubles -> one mask word per alignment
+        uint64_t even = 0, odd = 0;
+        for (int half = 0; half < 2; ++half) {
+            uint64_t bits = 0;
+            for (int j = 0; j < 8; ++j) {
+                p += 16;
+                const __m512d nxt = polar_squares(p);
+                // r2 of the attempt starting at double l = sq[l] + sq[l + 1]
+                const __m512d shifted = _mm512_castsi512_pd(
+                    _mm512_alignr_epi64(_mm512_castpd_si512(nxt), _mm512_castpd_si512(cur), 1));
+                const __m512d r2 = _mm512_add_pd(cur, shifted);
+                const unsigned m = _mm512_cmp_pd_mask(r2, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(r2, zero, _CMP_NEQ_OQ);
+                bits |= (uint64_t)m << (8 * j);
+                cur = nxt;
+            }
+            even |= _pext_u64(bits, 0x5555555555555555ull) << (32 * half);
+            odd |= _pext_u64(bits, 0xaaaaaaaaaaaaaaaaull) << (32 * half);
+        }
+        m0[word] = even;
+        m1[word] = odd;
+    }
+}
+
+// process-wide spare segments: a fit uses a few dozen and the next fit wants them mapped and warm
+std::mutex g_spare_m;
+std::vector<Segment *> g_spares;
+constexpr size_t kSpareMax = 192;                           // 123 MB
+
+Segment *take_segment()
+{
+    {
+        std::lock_guard<std::mutex> lock(g_spare_m);
+        if (!g_spares.empty()) {
+            Segment *s = g_spares.back();
+            g_spares.pop_back();
+            return s;
+        }
+    }
+    void *mem = nullptr;
+    if (posix_memalign(&mem, 64, sizeof(Segment)) != 0) return nullptr;
+    return new (mem) Segment();
+}
+
+void give_segment(Segment *s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lock(g_spare_m);
+        if (g_spares.size() < kSpareMax) {
+            g_spares.push_back(s);
+            return;
+        }
+    }
+    s->~Segment();
+    std::free(s);
+}
+
+}  // namespace
+
+struct fokl_stream {
+    // the stream as it was handed over (numpy's get_state()): block 0 is mt_key, the first unread word is pos0
+    uint32_t key0[MT_N];
+    int pos0 = 0;
+    int o = 0;                                              // pos0 & 1: double D <-> words o + 2 D, o + 2 D + 1
+    // producer side
+    std::mutex token_m;                                     // holder runs the recurrence of segment next_raw
+    // producers with nothing to do sleep here; the walker (raising `limit`) and whoever moves `low_water` wake them.  Not
+    // token_m: the walker must never wait for a recurrence to finish
+    std::mutex room_m;
+    std::condition_variable room_cv;
+    uint32_t carry[MT_N];                                   // last raw block generated so far
+    int64_t next_raw = 0;                                   // next segment to be generated
+    int64_t oldest_alive = 0;                               // segments below were given back
+    std::atomic<int64_t> limit{kAhead};                     // segments < limit may be produced
+    std::atomic<int64_t> low_water{0};                      // segments < low_water will not be read again
+    bool stop = false;
+    std::atomic<bool> stop_flag{false};
+    std::vector<std::thread> threads;
+    std::atomic<Segment *> table[kTable];
+    std::atomic<int64_t> bulk_busy_ns{0}, segments_made{0};
+    // holds: positions (doubles) somebody may still read from -- open tapes, expansions in flight
+    std::mutex hold_m;
+    std::multiset<uint64_t> holds;
+    uint64_t walker_floor = 0;
+    // the walker (one thread at a time)
+    uint64_t D = 0;
+    int has_gauss = 0;
+    uint64_t gauss_src = 0;                                 // the attempt whose x1 half is the cached normal, or kGivenGauss
+    double gauss0 = 0.0;                                    // the cached normal the state handed over held (kGivenGauss)
+    std::atomic<int64_t> walker_wait_ns{0};
+    std::atomic<int64_t> exact_draws{0}, gamma_draws{0};    // gamma attempts that needed libm / all of them
+    std::atomic<int64_t> rollbacks{0};                      // iterations the wide walk had to redo draw by draw
+    bool wide = false;
+    std::string error;
+};
+
+namespace {
+
+inline int64_t now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+void update_low_water(fokl_stream *e)                       // hold_m held
+{
+    uint64_t d = e->walker_floor;
+    if (!e->holds.empty()) d = std::min(d, *e->holds.begin());
+    e->low_water.store((int64_t)(d / kSegDoubles), std::memory_order_release);
+}
+
+// The token holder's part of segment `index`: its raw words (and the first words of the next segment behind them).
+void generate_raw(fokl_stream *e, Segment *seg, int64_t index)
+{
+    uint32_t *buf = seg->buf;
+    int from = MT_N;
+    if (index == 0) {
+        std::memset(buf, 0, MT_N * sizeof(uint32_t));
+        std::memcpy(buf + MT_N, e->key0, MT_N * sizeof(uint32_t));      // block 0 is given
+        from = 2 * MT_N;
+    } else {
+        std::memcpy(buf, e->carry, MT_N * sizeof(uint32_t));
+    }
+    const int to = MT_N + kSegWords + kSegTail;
+    if (e->wide)
+        recurrence_wide(buf, from, to);
+    else
+        recurrence_portable(buf, from, to);
+    std::memcpy(e->carry, buf + kSegWords, MT_N * sizeof(uint32_t));    // the segment's last block, raw
+}
+
+void bulk_worker(fokl_stream *e)
+{
+    for (;;) {
+        Segment *seg = nullptr;
+        int64_t index = 0;
+        std::vector<Segment *> retired;
+        {
+            std::unique_lock<std::mutex> lock(e->token_m);
+            for (;;) {
+                if (e->stop) return;
+                const int64_t low = e->low_water.load(std::memory_order_acquire);
+                if (e->next_raw < e->limit.load(std::memory_order_acquire) && e->next_raw - low < kTable - 2) break;
+                const int64_t next = e->next_raw;
+                lock.unlock();
+                {
+                    std::unique_lock<std::mutex> room(e->room_m);
+                    e->room_cv.wait(room, [&] {
+                        return e->stop_flag.load(std::memory_order_acquire) ||
+                               (next < e->limit.load(std::memory_order_acquire) &&
+                                next - e->low_water.load(std::memory_order_acquire) < kTable - 2);
+                    });
+                }
+                lock.lock();
+            }
+            // segments nobody will read again go back first (their table entries are about to be reused)
+            const int64_t low = e->low_water.load(std::memory_order_acquire);
+            while (e->oldest_alive < low && e->oldest_alive < e->next_raw) {
+                retired.push_back(e->table[e->oldest_alive % kTable].exchange(nullptr, std::memory_order_acq_rel));
+                ++e->oldest_alive;
+            }
+            index = e->next_raw;
+            seg = nullptr;
+            if (!retired.empty()) {
+                seg = retired.back();
+                retired.pop_back();
+            }
+            if (!seg) seg = take_segment();
+            if (!seg) {
+                e->error = "fokl_stream: out of memory";
+                e->stop = true;
+                e->stop_flag.store(true, std::memory_order_release);
+                e->room_cv.notify_all();
+                return;
+            }
+            seg->index = index;
+            seg->ready.store(0, std::memory_order_relaxed);
+            const int64_t t0 = now_ns();
+            generate_raw(e, seg, index);
+            e->bulk_busy_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+            ++e->next_raw;
+        }
+        for (Segment *s : retired) give_segment(s);
+        const int64_t t0 = now_ns();
+        if (e->wide)
+            finish_segment_wide(seg, e->o);
+        else
+            finish_segment_portable(seg, e->o);
+        seg->ready.store(1, std::memory_order_release);
+        e->table[index % kTable].store(seg, std::memory_order_release);
+        e->segments_made.fetch_add(1, std::memory_order_relaxed);
+        e->bulk_busy_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    }
+}
+
+// The segment that owns double D (blocks until a bulk thread has published it).  Callers hold a position <= D.
+Segment *segment_of(fokl_stream *e, uint64_t D, bool walker)
+{
+    const int64_t index = (int64_t)(D / kSegDoubles);
+    Segment *seg = e->table[index % kTable].load(std::memory_order_acquire);
+    if (seg && seg->index == index) return seg;
+    if (walker && index + kAhead > e->limit.load(std::memory_order_relaxed)) {
+        {
+            std::lock_guard<std::mutex> lock(e->room_m);
+            e->limit.store(index + kAhead, std::memory_order_release);
+        }
+        e->room_cv.notify_all();
+    }
+    const int64_t t0 = now_ns();
+    for (int spins = 0;; ++spins) {
+        seg = e->table[index % kTable].load(std::memory_order_acquire);
+        if (seg && seg->index == index) break;
+        if (spins < 4000)
+            _mm_pause();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(5));
+        if ((spins & 1023) == 1023 && e->stop_flag.load(std::memory_order_acquire)) return nullptr;
+    }
+    if (walker) e->walker_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    return seg;
+}
+
+// A reader's view of the stream: the segment under the cursor is cached, crossing into the next one is the rare path.
+struct Reader {
+    fokl_stream *e;
+    bool walker;
+    int o;
+    Segment *seg = nullptr;
+    uint64_t lo = 1, hi = 0;                                // doubles [lo, hi) belong to seg
+    bool failed = false;
+
+    Reader(fokl_stream *engine, bool is_walker) : e(engine), walker(is_walker), o(engine->o) {}
+
+    __attribute__((always_inline)) inline bool locate(uint64_t D)
+    {
+        if (D - lo < (uint64_t)kSegDoubles && seg) return true;
+        return relocate(D);
+    }
+
+    __attribute__((noinline)) bool relocate(uint64_t D)
+    {
+        Segment *s = segment_of(e, D, walker);
+        if (!s) {
+            failed = true;
+            return false;
+        }
+        seg = s;
+        lo = (D / kSegDoubles) * kSegDoubles;
+        hi = lo + kSegDoubles;
+        if (walker) {
+            // keep the producers kAhead segments in front of this one
+            const int64_t want = (int64_t)(D / kSegDoubles) + 1 + kAhead;
+            if (want > e->limit.load(std::memory_order_relaxed)) {
+                {
+                    std::lock_guard<std::mutex> lock(e->room_m);
+                    e->limit.store(want, std::memory_order_release);
+                }
+                e->room_cv.notify_all();
+            }
+        }
+        return true;
+    }
+
+    // the words of the doubles at D (a gamma draw's attempt and its uniform: 24 bytes), if they belong to the segment under
+    // the cursor: they were written by another core a moment ago
+    __attribute__((always_inline)) inline void prefetch_words(uint64_t D) const
+    {
+        if (D - lo >= (uint64_t)kSegDoubles) return;
+        const char *p = reinterpret_cast<const char *>(seg->words() + o + 2 * (D - lo));
+        __builtin_prefetch(p);
+        __builtin_prefetch(p + 24);
+    }
+
+    // the flag words two cache lines ahead of double D (called when the scan enters a new line of flags)
+    __attribute__((always_inline)) inline void prefetch_flags(uint64_t D) const
+    {
+        const uint64_t word = ((D - lo) >> 7) + 16;
+        if (word < (uint64_t)kSegMaskWords) {
+            __builtin_prefetch(&seg->mask[0][word]);
+            __builtin_prefetch(&seg->mask[1][word]);
+        }
+    }
+
+    // value of double D
+    __attribute__((always_inline)) inline double dbl(uint64_t D)
+    {
+        if (!locate(D)) return 0.5;
+        const uint32_t *w = seg->words() + o + 2 * (D - lo);
+        return to_double(w[0], w[1]);
+    }
+
+    // polar coordinates of the attempt starting at double D (its second double may be the first of the next segment:
+    // the tail words cover it)
+    __attribute__((always_inline)) inline void pair(uint64_t D, double &x1, double &x2)
+    {
+        if (!locate(D)) {
+            x1 = x2 = 0.5;
+            return;
+        }
+        const uint32_t *w = seg->words() + o + 2 * (D - lo);
+        x1 = 2.0 * to_double(w[0], w[1]) - 1.0;
+        x2 = 2.0 * to_double(w[2], w[3]) - 1.0;
+    }
+
+    // start of the first accepted attempt at or after D, same alignment
+    __attribute__((always_inline)) inline uint64_t next_accepted(uint64_t D)
+    {
+        const int a = (int)(D & 1);
+        for (;;) {
+            if (!locate(D)) return D;
+            const uint64_t q = (D - lo) >> 1;
+            int word = (int)(q >> 6);
+            uint64_t m = seg->mask[a][word] & (~0ull << (q & 63));
+            while (!m && ++word < kSegMaskWords) m = seg->mask[a][word];
+            if (m) return lo + 2 * ((uint64_t)word * 64 + (uint64_t)__builtin_ctzll(m)) + (uint64_t)a;
+            D = hi + (uint64_t)a;
+        }
+    }
+};
+
+inline uint64_t select_bit_portable(uint64_t m, int k)     // position of the k-th (0-based) set bit
+{
+    for (int i = 0; i < k; ++i) m &= m - 1;
+    return (uint64_t)__builtin_ctzll(m);
+}
+
+FOKL_WIDE_TARGET inline uint64_t select_bit_wide(uint64_t m, int k)
+{
+    return (uint64_t)_tzcnt_u64(_pdep_u64(1ull << k, m));
+}
+
+// Position behind the k-th accepted attempt at or after D (same alignment), k >= 1.
+template <bool WIDE>
+static inline __attribute__((always_inline)) uint64_t skip_accepted(Reader &r, uint64_t D, int k)
+{
+    const int a = (int)(D & 1);
+    for (;;) {
+        if (!r.locate(D)) return D;
+        const uint64_t q = (D - r.lo) >> 1;
+        int word = (int)(q >> 6);
+        const uint64_t *mask = r.seg->mask[a];
+        uint64_t m = mask[word] & (~0ull << (q & 63));
+        int c = __builtin_popcountll(m);
+        while (c < k) {
+            k -= c;
+            if (++word == kSegMaskWords) break;
+            m = mask[word];
+            c = __builtin_popcountll(m);
+        }
+        if (word < kSegMaskWords) {
+            const uint64_t bit = WIDE ? select_bit_wide(m, k - 1) : select_bit_portable(m, k - 1);
+            return r.lo + 2 * ((uint64_t)word * 64 + bit + 1) + (uint64_t)a;
+        }
+        D = r.hi + (uint64_t)a;                             // the rest lies in the next segment
+    }
+}
+
+// ln(y) for normal y > 0 to within 2e-6 (absolute): exponent + atanh series on [1/sqrt 2, sqrt 2).  The walker decides
+// the squeeze test of a gamma draw from BOUNDS built on this (kLnSlack is far above its error) and evaluates the exact
+// expressions -- libm's log, numpy's order of operations -- only where the bounds do not decide.
+constexpr double kLnSlack = 1e-4;
+
+inline double fast_ln(double y)
+{
+    uint64_t bits;
+    std::memcpy(&bits, &y, sizeof(bits));
+    int e = (int)(bits >> 52) - 1023;
+    bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    std::memcpy(&m, &bits, sizeof(m));
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+    return e * 0.6931471805599453 + 2.0 * s * (1.0 + s2 * (1.0 / 3.0 + s2 * (0.2 + s2 * (1.0 / 7.0))));
+}
+
+// The walk: numpy's legacy draws on top of the reader, positions only.  A normal is known by its SOURCE -- the accepted
+// attempt it comes from and which half of it -- and never formed here unless a gamma draw's accept test needs its value.
+struct Walk {
+    Reader r;
+    fokl_stream *e;
+    uint64_t D;
+    int has_gauss;
+    uint64_t gauss_src;
+    int64_t exact = 0, gammas = 0;
+
+    Walk(fokl_stream *engine) : r(engine, true), e(engine), D(engine->D), has_gauss(engine->has_gauss),
+                                gauss_src(engine->gauss_src) {}
+
+    __attribute__((always_inline)) inline double next_double()
+    {
+        const double d = r.dbl(D);
+        D += 1;
+        return d;
+    }
+
+    // source of the next gauss(): the cached half, or the x2 half of the next accepted attempt (whose x1 half is cached)
+    __attribute__((always_inline)) inline uint64_t gauss_source()
+    {
+        if (has_gauss) {
+            has_gauss = 0;
+            return gauss_src | kCachedHalf;
+        }
+        const uint64_t at = r.next_accepted(D);
+        gauss_src = at;
+        has_gauss = 1;
+        D = at + 2;
+        return at;
+    }
+
+    // the normal itself: numpy's operations, libm's log
+    inline double value_of(uint64_t source)
+    {
+        const uint64_t at = source & ~kCachedHalf;
+        if (at == kGivenGauss) return e->gauss0;
+        double x1, x2;
+        r.pair(at, x1, x2);
+        const double r2 = x1 * x1 + x2 * x2;
+        const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+        return (source & kCachedHalf) ? f * x1 : f * x2;
+    }
+
+    inline double std_exponential() { return -std::log(1.0 - next_double()); }
+
+    // numpy's shape > 1 branch (b = shape - 1/3, c = 1 / sqrt(9 b)): -> the source of the X the accepted attempt used
+    __attribute__((always_inline)) inline uint64_t marsaglia_tsang(const double b, const double c)
+    {
+        for (;;) {
+            ++gammas;
+            uint64_t source;
+            double X = 0.0, V = 0.0, x2_hi = 0.0;
+            bool formed = false, positive = true;
+            for (;;) {                                      // do { X = gauss(); V = 1 + c X; } while (V <= 0)
+                source = gauss_source();
+                formed = false;
+                const uint64_t at = source & ~kCachedHalf;
+                if (at != kGivenGauss) {
+                    double x1, x2;
+                    r.pair(at, x1, x2);
+                    const double xh = (source & kCachedHalf) ? x1 : x2;
+                    const double r2 = x1 * x1 + x2 * x2;
+                    // X^2 = -2 ln(r2) xh^2 / r2, from above
+                    x2_hi = 2.0 * (kLnSlack - fast_ln(r2)) * (xh * xh / r2) * (1.0 + 1e-12);
+                    positive = xh >= 0.0;
+                    if (positive || x2_hi * (c * c) < 0.81) break;              // V = 1 + c X > 0 for sure
+                }
+                X = value_of(source);
+                V = 1.0 + c * X;
+                formed = true;
+                if (V > 0.0) break;
+            }
+            const double U = next_double();
+            if (!formed) {
+                // U < 1 - 0.0331 X^4 for sure?
+                if (U < 1.0 - 0.0331 * (x2_hi * x2_hi) - 1e-13) return source;
+                // ln U < X^2 / 2 + b (1 - V + ln V) for sure?  With t = c X and 9 b c^2 = 1 the right-hand side is
+                // b h(t), h(t) = 3 (ln(1 + t) - t + t^2 / 2 - t^3 / 3) = 3 sum_{n >= 4} (-1)^(n+1) t^n / n:
+                // h >= -0.75 t^4 for t >= 0 (alternating, decreasing terms), h >= -0.75 t^4 / (1 - |t|) for -1 < t < 0
+                // (all terms negative, geometric bound); ln U <= U - 1.  The slack covers what numpy's own evaluation
+                // of the right-hand side loses to cancellation (b times a few ulp of 1 - V + ln V).
+                const double t2 = x2_hi * (c * c);
+                if (t2 < 0.81) {
+                    const double bound = 0.75 * b * (t2 * t2) / (positive ? 1.0 : 1.0 - std::sqrt(t2));
+                    if (1.0 - U > 1.001 * bound + 1e-12 + 1e-14 * b * (1.0 + x2_hi)) return source;
+                }
+                X = value_of(source);
+                V = 1.0 + c * X;
+            }
+            ++exact;
+            V = V * V * V;
+            if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return source;
+            if (std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V))) return source;
+        }
+    }
+
+    double std_gamma_small(double shape)                    // numpy's legacy_standard_gamma for shape <= 1
+    {
+        if (shape == 1.0) return std_exponential();
+        if (shape == 0.0) return 0.0;
+        for (;;) {
+            const double U = next_double();
+            const double V = std_exponential();
+            if (U <= 1.0 - shape) {
+                const double X = std::pow(U, 1.0 / shape);
+                if (X <= V) return X;
+            } else {
+                const double Y = -std::log((1 - U) / shape);
+                const double X = std::pow(1.0 - shape + shape * Y, 1.0 / shape);
+                if (X <= (V + Y)) return X;
+            }
+        }
+    }
+};
+
+// The body is inlined into two entry points: one compiled for AVX-512 / BMI2 / POPCNT machines (the counting and
+// selecting of flags become popcnt / pdep / tzcnt), one for any x86-64.
+template <bool WIDE>
+static inline __attribute__((always_inline)) int walk_body(fokl_stream *e, int p1, int draws, double astar,
+                                                            double atau_star, fokl_tape_row *rows, double *gam_sig,
+                                                            double *gam_tau, int32_t *progress)
+{
+    Walk w(e);
+    const bool fast_sig = astar > 1.0, fast_tau = atau_star > 1.0;
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
+    for (int k0 = 0; k0 < draws; k0 += FOKL_TAPE_BLOCK) {
+        const int k1 = std::min(draws, k0 + FOKL_TAPE_BLOCK);
+        for (int k = k0; k < k1; ++k) {
+            // np.random.normal(0, 1, (p1, 1)): p1 successive gauss draws -- the cached normal if there is one, then
+            // accepted attempts two normals each; an odd one out leaves its other half in the cache
+            fokl_tape_row row;
+            const int lead = w.has_gauss ? 1 : 0;
+            row.lead_source = lead ? w.gauss_src : 0;
+            w.has_gauss = 0;
+            const uint64_t begin = w.D;
+            row.start = begin | (lead ? kLeadBit : 0);
+            const int rest = p1 - lead, attempts = (rest + 1) >> 1;
+            if (attempts > 0) w.D = skip_accepted<WIDE>(w.r, w.D, attempts);
+            if (rest & 1) {
+                w.gauss_src = w.D - 2;                      // the last of them: its x2 half closes the row
+                w.has_gauss = 1;
+            }
+            const uint64_t site = w.D;                       // the gamma draws begin here
+            if (fast_sig) {
+                row.gamma[0] = w.marsaglia_tsang(b_sig, c_sig);
+            } else {
+                row.gamma[0] = kFinalValue;
+                gam_sig[k] = w.std_gamma_small(astar);
+            }
+            if (fast_tau) {
+                row.gamma[1] = w.marsaglia_tsang(b_tau, c_tau);
+            } else {
+                row.gamma[1] = kFinalValue;
+                gam_tau[k] = w.std_gamma_small(atau_star);
+            }
+            rows[k] = row;
+            if (((site - w.r.lo) >> 10) != ((begin - w.r.lo) >> 10)) w.r.prefetch_flags(site);
+        }
+        if (w.r.failed) break;
+        if (progress) __atomic_store_n(progress, k1, __ATOMIC_RELEASE);
+    }
+    e->exact_draws.fetch_add(w.exact, std::memory_order_relaxed);
+    e->gamma_draws.fetch_add(w.gammas, std::memory_order_relaxed);
+    if (w.r.failed) {
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        fokl_set_global_error("fokl_stream_walk: the stream's producers stopped (" + e->error + ")");
+        return FOKL_ERR_STATE;
+    }
+    e->D = w.D;
+    e->has_gauss = w.has_gauss;
+    e->gauss_src = w.gauss_src;
+    return FOKL_OK;
+}
+
+// ---- the AVX-512 walk: positions first, accept tests eight at a time ----------------------------------------------
+// A gamma draw nearly always accepts its first attempt, so where the walk goes hardly ever depends on the VALUES of the
+// draws.  The wide walk therefore runs a block of FOKL_TAPE_BLOCK iterations on positions alone -- every gamma draw taken
+// to be one normal + one uniform -- and then checks all of the block's 2 x 16 accept tests together: the bounds of
+// Walk::marsaglia_tsang evaluated in vector registers.  A test the bounds do not decide is evaluated exactly (libm,
+// numpy's order of operations); if it turns out REJECTED (or V <= 0), the block is rolled back to the start of that
+// iteration, which is then walked by the scalar code above, and the positions-only pass resumes behind it.  Rows are
+// those of the scalar walk bit for bit (tests/test_stream_engine.py compares the two and fokl_noise_tape).
+
+struct IterationStart {
+    uint64_t D, gauss_src;
+    int has_gauss;
+};
+
+// x = 2 d - 1 of eight doubles given as lanes wa | wb << 32 of tempered words
+FOKL_WIDE_TARGET inline __m512d lanes_to_x(__m512i lanes)
+{
+    const __m512i a = _mm512_srli_epi64(_mm512_and_si512(lanes, _mm512_set1_epi64(0xffffffffll)), 5);
+    const __m512i b = _mm512_srli_epi64(lanes, 38);
+    const __m512i v = _mm512_add_epi64(_mm512_slli_epi64(a, 26), b);
+    return _mm512_mul_pd(_mm512_cvtepi64_pd(_mm512_sub_epi64(v, _mm512_set1_epi64(1ll << 52))),
+                         _mm512_set1_pd(1.0 / 4503599627370496.0));
+}
+
+// ln(y), 0 < y < 1, to within 2e-5: exponent + atanh series of the mantissa in [1, 2)
+FOKL_WIDE_TARGET inline __m512d fast_ln8(__m512d y)
+{
+    const __m512d m = _mm512_getmant_pd(y, _MM_MANT_NORM_1_2, _MM_MANT_SIGN_zero);
+    const __m512d ex = _mm512_getexp_pd(y);
+    const __m512d one = _mm512_set1_pd(1.0);
+    const __m512d s = _mm512_div_pd(_mm512_sub_pd(m, one), _mm512_add_pd(m, one));
+    const __m512d s2 = _mm512_mul_pd(s, s);
+    __m512d poly = _mm512_set1_pd(1.0 / 9.0);
+    poly = _mm512_add_pd(_mm512_mul_pd(poly, s2), _mm512_set1_pd(1.0 / 7.0));
+    poly = _mm512_add_pd(_mm512_mul_pd(poly, s2), _mm512_set1_pd(0.2));
+    poly = _mm512_add_pd(_mm512_mul_pd(poly, s2), _mm512_set1_pd(1.0 / 3.0));
+    poly = _mm512_add_pd(_mm512_mul_pd(poly, s2), one);
+    return _mm512_add_pd(_mm512_mul_pd(ex, _mm512_set1_pd(0.6931471805599453)),
+                         _mm512_mul_pd(_mm512_add_pd(s, s), poly));
+}
+
+// bit i set: gamma draw i of the eight surely accepts its first attempt (Walk::marsaglia_tsang's two bounds)
+FOKL_WIDE_TARGET inline unsigned sure_accepts8(__m512i first, __m512i second, __m512i uniform, __mmask8 cached,
+                                               __m512d b, __m512d c)
+{
+    const __m512d x1 = lanes_to_x(first), x2 = lanes_to_x(second);
+    const __m512d r2 = _mm512_add_pd(_mm512_mul_pd(x1, x1), _mm512_mul_pd(x2, x2));
+    const __m512d xh = _mm512_mask_blend_pd(cached, x2, x1);
+    const __m512d ln = fast_ln8(r2);
+    const __m512d one = _mm512_set1_pd(1.0);
+    __m512d x2_hi = _mm512_mul_pd(_mm512_sub_pd(_mm512_set1_pd(kLnSlack), ln), _mm512_div_pd(_mm512_mul_pd(xh, xh), r2));
+    x2_hi = _mm512_mul_pd(x2_hi, _mm512_set1_pd(2.0 * (1.0 + 1e-12)));
+    // U = v / 2^53
+    const __m512i ua = _mm512_srli_epi64(_mm512_and_si512(uniform, _mm512_set1_epi64(0xffffffffll)), 5);
+    const __m512i ub = _mm512_srli_epi64(uniform, 38);
+    const __m512d U = _mm512_mul_pd(_mm512_cvtepi64_pd(_mm512_add_epi64(_mm512_slli_epi64(ua, 26), ub)),
+                                    _mm512_set1_pd(1.0 / 9007199254740992.0));
+    const __mmask8 positive = _mm512_cmp_pd_mask(xh, _mm512_setzero_pd(), _CMP_GE_OQ);
+    const __m512d t2 = _mm512_mul_pd(x2_hi, _mm512_mul_pd(c, c));
+    const __mmask8 small = _mm512_cmp_pd_mask(t2, _mm512_set1_pd(0.81), _CMP_LT_OQ);
+    // U < 1 - 0.0331 X^4 for sure
+    const __m512d thr = _mm512_sub_pd(_mm512_sub_pd(one, _mm512_mul_pd(_mm512_set1_pd(0.0331), _mm512_mul_pd(x2_hi, x2_hi))),
+                                      _mm512_set1_pd(1e-13));
+    const __mmask8 squeeze = _mm512_cmp_pd_mask(U, thr, _CMP_LT_OQ);
+    // ln U < X^2 / 2 + b (1 - V + ln V) for sure (see Walk::marsaglia_tsang)
+    const __m512d denom = _mm512_mask_blend_pd(positive, _mm512_sub_pd(one, _mm512_sqrt_pd(t2)), one);
+    const __m512d bound = _mm512_div_pd(_mm512_mul_pd(_mm512_mul_pd(_mm512_set1_pd(0.75), b), _mm512_mul_pd(t2, t2)), denom);
+    const __m512d need = _mm512_add_pd(_mm512_add_pd(_mm512_mul_pd(_mm512_set1_pd(1.001), bound), _mm512_set1_pd(1e-12)),
+                                       _mm512_mul_pd(_mm512_mul_pd(_mm512_set1_pd(1e-14), b), _mm512_add_pd(one, x2_hi)));
+    const __mmask8 second_test = small & _mm512_cmp_pd_mask(_mm512_sub_pd(one, U), need, _CMP_GT_OQ);
+    return (unsigned)((positive | small) & (squeeze | second_test));
+}
+
+// one iteration of the scalar walk (the body of walk_body's loop for shapes > 1)
+template <bool WIDE>
+static inline __attribute__((always_inline)) void walk_iteration(Walk &w, int p1, double b_sig, double c_sig,
+                                                                 double b_tau, double c_tau, fokl_tape_row &row)
+{
+    const int lead = w.has_gauss ? 1 : 0;
+    row.lead_source = lead ? w.gauss_src : 0;
+    w.has_gauss = 0;
+    row.start = w.D | (lead ? kLeadBit : 0);
+    const int rest = p1 - lead, attempts = (rest + 1) >> 1;
+    if (attempts > 0) w.D = skip_accepted<WIDE>(w.r, w.D, attempts);
+    if (rest & 1) {
+        w.gauss_src = w.D - 2;
+        w.has_gauss = 1;
+    }
+    row.gamma[0] = w.marsaglia_tsang(b_sig, c_sig);
+    row.gamma[1] = w.marsaglia_tsang(b_tau, c_tau);
+}
+
+FOKL_WIDE_TARGET int walk_tape_wide(fokl_stream *e, int p1, int draws, double astar, double atau_star,
+                                    fokl_tape_row *rows, double *gam_sig, double *gam_tau, int32_t *progress)
+{
+    if (!(astar > 1.0) || !(atau_star > 1.0) || std::getenv("FOKL_STREAM_SCALAR_WALK"))
+        return walk_body<true>(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress);
+    constexpr int B = FOKL_TAPE_BLOCK;
+    Walk w(e);
+    Walk checker(e);                                        // its reader serves the values of the accept tests
+    checker.r.walker = false;
+    Reader &rv = checker.r;
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
+    const __m512d bvec = _mm512_setr_pd(b_sig, b_tau, b_sig, b_tau, b_sig, b_tau, b_sig, b_tau);
+    const __m512d cvec = _mm512_setr_pd(c_sig, c_tau, c_sig, c_tau, c_sig, c_tau, c_sig, c_tau);
+    const int o = e->o;
+    int64_t exact = 0, rolled_back = 0;
+    IterationStart at_start[B];
+    uint64_t source[2 * B], upos[2 * B];
+    alignas(64) uint64_t first[2 * B], second[2 * B], uniform[2 * B];
+    for (int k0 = 0; k0 < draws; k0 += B) {
+        const int k1 = std::min(draws, k0 + B);
+        int k = k0;
+        while (k < k1) {
+            // positions of iterations k .. k1 - 1, every gamma draw taken to accept its first attempt
+            const int count = k1 - k;
+            for (int i = 0; i < count; ++i) {
+                at_start[i] = {w.D, w.gauss_src, w.has_gauss};
+                fokl_tape_row &row = rows[k + i];
+                const int lead = w.has_gauss ? 1 : 0;
+                row.lead_source = lead ? w.gauss_src : 0;
+                w.has_gauss = 0;
+                const uint64_t begin = w.D;
+                row.start = begin | (lead ? kLeadBit : 0);
+                const int rest = p1 - lead, attempts = (rest + 1) >> 1;
+                if (attempts > 0) w.D = skip_accepted<true>(w.r, w.D, attempts);
+                if (rest & 1) {
+                    w.gauss_src = w.D - 2;
+                    w.has_gauss = 1;
+                }
+                // the words the accept tests will read (after the block's positions are known) can be on their way
+                const uint64_t site = w.D;
+                for (int j = 0; j < 2; ++j) {
+                    const uint64_t src = w.gauss_source();
+                    source[2 * i + j] = row.gamma[j] = src;
+                    w.r.prefetch_words(src & ~kCachedHalf);
+                    upos[2 * i + j] = w.D;
+                    w.D += 1;
+                }
+                if (((site - w.r.lo) >> 10) != ((begin - w.r.lo) >> 10)) w.r.prefetch_flags(site);
+            }
+            if (w.r.failed) break;
+            // the words behind the 2 * count accept tests
+            const int tests = 2 * count;
+            unsigned given = 0;
+            for (int n = 0; n < tests; ++n) {
+                const uint64_t src = source[n] & ~kCachedHalf;
+                if (src == kGivenGauss) {                   // the cached value handed over with the state: no words
+                    given |= 1u << n;
+                    first[n] = second[n] = uniform[n] = 0x0400000004000000ull;
+                    continue;
+                }
+                if (!rv.locate(src)) break;
+                const uint32_t *p = rv.seg->words() + o + 2 * (src - rv.lo);
+                std::memcpy(&first[n], p, 8);
+                std::memcpy(&second[n], p + 2, 8);
+                if (!rv.locate(upos[n])) break;
+                std::memcpy(&uniform[n], rv.seg->words() + o + 2 * (upos[n] - rv.lo), 8);
+            }
+            if (rv.failed) {
+                w.r.failed = true;
+                break;
+            }
+            for (int n = tests; n < ((tests + 7) & ~7); ++n) {
+                first[n] = first[0];
+                second[n] = second[0];
+                uniform[n] = uniform[0];
+                source[n] = source[0];
+            }
+            unsigned sure = 0;
+            for (int v = 0; v < tests; v += 8) {
+                unsigned cached = 0;
+                for (int l = 0; l < 8; ++l) cached |= (unsigned)((source[v + l] >> 63) & 1) << l;
+                sure |= sure_accepts8(_mm512_load_si512(first + v), _mm512_load_si512(second + v),
+                                      _mm512_load_si512(uniform + v), (__mmask8)cached, bvec, cvec)
+                        << v;
+            }
+            sure &= ~given;
+            unsigned open = ~sure & (tests >= 32 ? 0xffffffffu : ((1u << tests) - 1u));
+            int redo = -1;                                  // iteration (relative to k) whose draw did not accept
+            while (open) {
+                const int n = __builtin_ctz(open);
+                open &= open - 1;
+                ++exact;
+                const double b = (n & 1) ? b_tau : b_sig, c = (n & 1) ? c_tau : c_sig;
+                const double X = checker.value_of(source[n]);
+                double V = 1.0 + c * X;
+                bool accepted = false;
+                if (V > 0.0) {
+                    const double U = rv.dbl(upos[n]);
+                    V = V * V * V;
+                    accepted = U < 1.0 - 0.0331 * (X * X) * (X * X) ||
+                               std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V));
+                }
+                if (!accepted) {
+                    redo = n >> 1;
+                    break;
+                }
+            }
+            if (rv.failed) {
+                w.r.failed = true;
+                break;
+            }
+            if (redo < 0) {
+                k = k1;
+                continue;
+            }
+            // iterations k .. k + redo - 1 stand; iteration k + redo is walked draw by draw from where it began
+            ++rolled_back;
+            w.D = at_start[redo].D;
+            w.gauss_src = at_start[redo].gauss_src;
+            w.has_gauss = at_start[redo].has_gauss;
+            walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k + redo]);
+            k += redo + 1;
+        }
+        if (w.r.failed) break;
+        if (progress) __atomic_store_n(progress, k1, __ATOMIC_RELEASE);
+    }
+    e->exact_draws.fetch_add(exact + w.exact, std::memory_order_relaxed);
+    e->gamma_draws.fetch_add(2 * (int64_t)draws, std::memory_order_relaxed);
+    e->rollbacks.fetch_add(rolled_back, std::memory_order_relaxed);
+    if (w.r.failed) {
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        fokl_set_global_error("fokl_stream_walk: the stream's producers stopped (" + e->error + ")");
+        return FOKL_ERR_STATE;
+    }
+    e->D = w.D;
+    e->has_gauss = w.has_gauss;
+    e->gauss_src = w.gauss_src;
+    return FOKL_OK;
+}
+
+int walk_tape_base(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                   double *gam_sig, double *gam_tau, int32_t *progress)
+{
+    return walk_body<false>(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress);
+}
+
+// what the walker may still read: everything from its position on, and the attempt its cached normal comes from
+inline uint64_t walker_reach(const fokl_stream *e)
+{
+    return e->has_gauss && e->gauss_src != kGivenGauss ? std::min(e->D, e->gauss_src) : e->D;
+}
+
+}  // namespace
+
+extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_t has_gauss, double gauss_cache,
+                                  int bulk_threads, fokl_stream **out)
+{
+    if (!out || !mt_key || mt_pos < 0 || mt_pos > MT_N || bulk_threads < 1 || bulk_threads > 16) {
+        fokl_set_global_error("fokl_stream_create: null pointer, invalid MT19937 position or thread count");
+        return FOKL_ERR_ARG;
+    }
+    auto *e = new fokl_stream();
+    std::memcpy(e->key0, mt_key, sizeof(e->key0));
+    e->pos0 = mt_pos;
+    e->o = mt_pos & 1;
+    e->D = (uint64_t)(mt_pos >> 1);
+    e->walker_floor = e->D;
+    e->has_gauss = has_gauss ? 1 : 0;
+    e->gauss_src = kGivenGauss;
+    e->gauss0 = gauss_cache;
+    e->wide = cpu_is_wide();
+    for (auto &t : e->table) t.store(nullptr, std::memory_order_relaxed);
+    try {
+        for (int i = 0; i < bulk_threads; ++i) e->threads.emplace_back(bulk_worker, e);
+    } catch (const std::exception &ex) {
+        {
+            std::lock_guard<std::mutex> lock(e->token_m);
+            e->stop = true;
+        }
+        {
+            std::lock_guard<std::mutex> room(e->room_m);
+            e->stop_flag.store(true, std::memory_order_release);
+        }
+        e->room_cv.notify_all();
+        for (auto &t : e->threads) t.join();
+        delete e;
+        fokl_set_global_error(std::string("fokl_stream_create: ") + ex.what());
+        return FOKL_ERR_STATE;
+    }
+    *out = e;
+    return FOKL_OK;
+}
+
+extern "C" void fokl_stream_destroy(fokl_stream *e)
+{
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lock(e->token_m);
+        e->stop = true;
+    }
+    {
+        std::lock_guard<std::mutex> room(e->room_m);
+        e->stop_flag.store(true, std::memory_order_release);
+    }
+    e->room_cv.notify_all();
+    for (auto &t : e->threads) t.join();
+    for (auto &t : e->table) give_segment(t.exchange(nullptr));
+    delete e;
+}
+
+extern "C" int fokl_stream_walk(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                                double *gam_sig, double *gam_tau, int32_t *progress)
+{
+    if (!e || p1 <= 0 || draws < 0 || !rows || !gam_sig || !gam_tau) {
+        fokl_set_global_error("fokl_stream_walk: null pointer or empty model");
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        return FOKL_ERR_ARG;
+    }
+    if (!(astar >= 0.0) || !(atau_star >= 0.0)) {
+        fokl_set_global_error("fokl_stream_walk: gamma shape parameter is negative or NaN");
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        return FOKL_ERR_NUMERIC;
+    }
+    return e->wide ? walk_tape_wide(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress)
+                   : walk_tape_base(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress);
+}
+
+extern "C" int fokl_stream_tell(const fokl_stream *e, fokl_stream_cursor *out)
+{
+    if (!e || !out) {
+        fokl_set_global_error("fokl_stream_tell: null pointer");
+        return FOKL_ERR_ARG;
+    }
+    out->position = e->D;
+    out->has_gauss = e->has_gauss;
+    out->gauss_source = e->gauss_src;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_stream_seek(fokl_stream *e, const fokl_stream_cursor *at)
+{
+    if (!e || !at) {
+        fokl_set_global_error("fokl_stream_seek: null pointer");
+        return FOKL_ERR_ARG;
+    }
+    {
+        std::lock_guard<std::mutex> lock(e->hold_m);
+        const uint64_t reach = at->has_gauss && at->gauss_source != kGivenGauss ? std::min(at->position, at->gauss_source)
+                                                                                 : at->position;
+        if ((int64_t)(reach / kSegDoubles) < e->low_water.load(std::memory_order_acquire)) {
+            fokl_set_global_error("fokl_stream_seek: that part of the stream was not held and is gone");
+            return FOKL_ERR_STATE;
+        }
+        e->walker_floor = std::min(e->walker_floor, reach);
+        update_low_water(e);
+    }
+    e->D = at->position;
+    e->has_gauss = at->has_gauss ? 1 : 0;
+    e->gauss_src = at->gauss_source;
+    return FOKL_OK;
+}
+
+// Keep the stream readable from the walker's present position on (a tape that begins here; the attempt its cached normal
+// comes from included) until fokl_stream_release.
+extern "C" int fokl_stream_hold(fokl_stream *e, uint64_t *position_out)
+{
+    if (!e || !position_out) {
+        fokl_set_global_error("fokl_stream_hold: null pointer");
+        return FOKL_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(e->hold_m);
+    const uint64_t reach = walker_reach(e);
+    e->holds.insert(reach);
+    *position_out = reach;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_stream_release(fokl_stream *e, uint64_t position)
+{
+    if (!e) {
+        fokl_set_global_error("fokl_stream_release: null stream");
+        return FOKL_ERR_ARG;
+    }
+    bool moved = false;
+    {
+        std::lock_guard<std::mutex> lock(e->hold_m);
+        auto it = e->holds.find(position);
+        if (it == e->holds.end()) {
+            fokl_set_global_error("fokl_stream_release: no such hold");
+            return FOKL_ERR_ARG;
+        }
+        e->holds.erase(it);
+        const int64_t before = e->low_water.load(std::memory_order_relaxed);
+        update_low_water(e);
+        moved = e->low_water.load(std::memory_order_relaxed) != before;
+    }
+    if (moved) {                                            // producers may have been waiting for table entries
+        { std::lock_guard<std::mutex> room(e->room_m); }
+        e->room_cv.notify_all();
+    }
+    return FOKL_OK;
+}
+
+// The walker lets go of everything behind its present position (between tapes: what is still needed is held).
+extern "C" int fokl_stream_advance_floor(fokl_stream *e)
+{
+    if (!e) {
+        fokl_set_global_error("fokl_stream_advance_floor: null stream");
+        return FOKL_ERR_ARG;
+    }
+    bool moved = false;
+    {
+        std::lock_guard<std::mutex> lock(e->hold_m);
+        e->walker_floor = walker_reach(e);
+        const int64_t before = e->low_water.load(std::memory_order_relaxed);
+        update_low_water(e);
+        moved = e->low_water.load(std::memory_order_relaxed) != before;
+    }
+    if (moved) {
+        { std::lock_guard<std::mutex> room(e->room_m); }
+        e->room_cv.notify_all();
+    }
+    return FOKL_OK;
+}
+
+// numpy's state tuple at the walker's position: the block that holds the next unread word, raw, and its index there
+// (pos = 624 with the block before it when the position is a block boundary: numpy refills lazily).
+extern "C" int fokl_stream_state(fokl_stream *e, uint32_t *key_out, int32_t *pos_out, int32_t *has_gauss_out,
+                                 double *gauss_out)
+{
+    if (!e || !key_out || !pos_out || !has_gauss_out || !gauss_out) {
+        fokl_set_global_error("fokl_stream_state: null pointer");
+        return FOKL_ERR_ARG;
+    }
+    const uint64_t g = (uint64_t)e->o + 2 * e->D;           // next unread word
+    *has_gauss_out = e->has_gauss;
+    *gauss_out = 0.0;
+    if (e->has_gauss) {
+        Walk w(e);
+        *gauss_out = w.value_of(e->gauss_src | kCachedHalf);
+        if (w.r.failed) {
+            fokl_set_global_error("fokl_stream_state: the stream's producers stopped");
+            return FOKL_ERR_STATE;
+        }
+    }
+    if (g == (uint64_t)e->pos0) {                           // nothing was drawn
+        std::memcpy(key_out, e->key0, sizeof(e->key0));
+        *pos_out = e->pos0;
+        return FOKL_OK;
+    }
+    // the raw block to hand back: the one that holds word g, or -- g on a block boundary -- the one before it
+    const int64_t target = g % MT_N ? (int64_t)(g / MT_N) : (int64_t)(g / MT_N) - 1;
+    *pos_out = g % MT_N ? (int)(g % MT_N) : MT_N;
+    if (target == 0) {
+        std::memcpy(key_out, e->key0, sizeof(e->key0));
+        return FOKL_OK;
+    }
+    // The segment under the walker is alive (everything from its floor on is); the target block lies in it or is the raw
+    // block kept in front of it.  Tempering overwrote the segment's raw words: regenerate from that block.
+    const int64_t index = (int64_t)(e->D / kSegDoubles);
+    Segment *seg = segment_of(e, e->D, true);
+    if (!seg) {
+        fokl_set_global_error("fokl_stream_state: the stream's producers stopped");
+        return FOKL_ERR_STATE;
+    }
+    const int64_t local = target - index * kSegBlocks;      // -1: the block in front of the segment
+    if (local < -1 || local >= kSegBlocks) {
+        fokl_set_global_error("fokl_stream_state: internal error (block outside the walker's segment)");
+        return FOKL_ERR_STATE;
+    }
+    if (local == -1) {
+        std::memcpy(key_out, seg->buf, MT_N * sizeof(uint32_t));
+        return FOKL_OK;
+    }
+    std::vector<uint32_t> buf((size_t)MT_N * (size_t)(local + 2));
+    int from = MT_N;
+    if (index == 0) {
+        std::memset(buf.data(), 0, MT_N * sizeof(uint32_t));
+        std::memcpy(buf.data() + MT_N, e->key0, MT_N * sizeof(uint32_t));
+        from = 2 * MT_N;
+    } else {
+        std::memcpy(buf.data(), seg->buf, MT_N * sizeof(uint32_t));
+    }
+    recurrence_portable(buf.data(), from, MT_N * (int)(local + 2));
+    std::memcpy(key_out, buf.data() + (size_t)MT_N * (size_t)(local + 1), MT_N * sizeof(uint32_t));
+    return FOKL_OK;
+}
+
+// Tape rows k0 .. k1 - 1 back into the layout fokl_noise_tape records (include/fokl_hip.h): row k of normals_out
+// [draws, p1] = lead_out[k] finished values, (p1 - lead) / 2 accepted pairs as (x2, x1) with r2 in row k of pair_r2_out
+// [draws, p1 / 2 + 1], and one more finished value if p1 - lead is odd; gam_sig_out / gam_tau_out [draws] = the two
+// standard gammas of the row (b V^3 of the normal the accepted attempt used; astar / atau_star as given to the walk).
+// Finished values and gammas are formed with libm's log in numpy's order of operations: numpy's bits.  Any thread; the
+// rows' part of the stream must be held.  pair_r2_out may be NULL (consumers that re-form r2 from the pair).
+extern "C" int fokl_stream_expand(fokl_stream *e, int p1, double astar, double atau_star, const fokl_tape_row *rows,
+                                  int k0, int k1, double *normals_out, double *pair_r2_out, int32_t *lead_out,
+                                  double *gam_sig_out, double *gam_tau_out)
+{
+    if (!e || !rows || !normals_out || !lead_out || !gam_sig_out || !gam_tau_out || p1 <= 0 || k0 < 0 || k1 < k0) {
+        fokl_set_global_error("fokl_stream_expand: null pointer, empty model or bad row range");
+        return FOKL_ERR_ARG;
+    }
+    Walk w(e);                                              // only its reader and value_of are used
+    w.r.walker = false;
+    Reader &r = w.r;
+    const size_t half = (size_t)p1 / 2 + 1;
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
+    for (int k = k0; k < k1; ++k) {
+        const fokl_tape_row &row = rows[k];
+        const int lead = (row.start & kLeadBit) ? 1 : 0;
+        uint64_t D = row.start & ~kLeadBit;
+        double *out = normals_out + (size_t)k * p1;
+        double *r2 = pair_r2_out ? pair_r2_out + (size_t)k * half : nullptr;
+        lead_out[k] = lead;
+        if (lead) out[0] = w.value_of(row.lead_source | kCachedHalf);
+        const int rest = p1 - lead, pairs = rest >> 1, attempts = (rest + 1) >> 1;
+        const int a = (int)(D & 1);
+        int have = 0;
+        while (have < attempts) {
+            if (!r.locate(D)) break;
+            // accepted attempts of this alignment from D to the end of the segment, a mask word at a time
+            const uint64_t q = (D - r.lo) >> 1;
+            int word = (int)(q >> 6);
+            uint64_t m = r.seg->mask[a][word] & (~0ull << (q & 63));
+            const uint32_t *wd = r.seg->words() + r.o + a * 2;         // attempt s of the alignment starts at word 4 s
+            for (;;) {
+                while (m && have < pairs) {
+                    const uint64_t s = (uint64_t)word * 64 + (uint64_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t *p = wd + 4 * s;
+                    const double x1 = 2.0 * to_double(p[0], p[1]) - 1.0, x2 = 2.0 * to_double(p[2], p[3]) - 1.0;
+                    out[lead + 2 * have] = x2;
+                    out[lead + 2 * have + 1] = x1;
+                    if (r2) r2[have] = x1 * x1 + x2 * x2;
+                    ++have;
+                }
+                if (m && have == pairs && have < attempts) {
+                    // the odd one out: its x2 half closes the row (final), its x1 half went to the cache
+                    const uint64_t s = (uint64_t)word * 64 + (uint64_t)__builtin_ctzll(m);
+                    out[p1 - 1] = w.value_of(r.lo + 2 * s + (uint64_t)a);
+                    ++have;
+                }
+                if (have == attempts || ++word == kSegMaskWords) break;
+                m = r.seg->mask[a][word];
+            }
+            D = r.hi + (uint64_t)a;
+        }
+        if (row.gamma[0] != kFinalValue) {
+            const double X = w.value_of(row.gamma[0]);
+            double V = 1.0 + c_sig * X;
+            V = V * V * V;
+            gam_sig_out[k] = b_sig * V;
+        }
+        if (row.gamma[1] != kFinalValue) {
+            const double X = w.value_of(row.gamma[1]);
+            double V = 1.0 + c_tau * X;
+            V = V * V * V;
+            gam_tau_out[k] = b_tau * V;
+        }
+        if (r.failed) {
+            fokl_set_global_error("fokl_stream_expand: the stream's producers stopped");
+            return FOKL_ERR_STATE;
+        }
+    }
+    return FOKL_OK;
+}
+
+extern "C" int fokl_stream_stats(const fokl_stream *e, double *bulk_busy_s, double *walker_wait_s, int64_t *segments,
+                                 int64_t *gamma_attempts, int64_t *gamma_attempts_exact)
+{
+    if (!e) {
+        fokl_set_global_error("fokl_stream_stats: null stream");
+        return FOKL_ERR_ARG;
+    }
+    if (bulk_busy_s) *bulk_busy_s = 1e-9 * (double)e->bulk_busy_ns.load();
+    if (walker_wait_s) *walker_wait_s = 1e-9 * (double)e->walker_wait_ns.load();
+    if (segments) *segments = e->segments_made.load();
+    if (gamma_attempts) *gamma_attempts = e->gamma_draws.load();
+    if (gamma_attempts_exact) *gamma_attempts_exact = e->exact_draws.load();
+    return FOKL_OK;
+}
+
+// |fast_ln(y) - log(y)| over n values spread over (0, 1) (tests: the bound the walker's squeeze decisions rest on)
+extern "C" double fokl_stream_fast_ln_error(int64_t n)
+{
+    double worst = 0.0;
+    for (int64_t i = 1; i <= n; ++i) {
+        const double u = (double)i / (double)(n + 1);
+        for (const double y : {u, u * u * u * 1e-3, std::ldexp(u, -104 + (int)(i % 100))}) {
+            if (!(y > 0.0) || y >= 1.0) continue;
+            worst = std::max(worst, std::fabs(fast_ln(y) - std::log(y)));
+        }
+    }
+    return worst;
+}

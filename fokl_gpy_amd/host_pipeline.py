@@ -100,6 +100,15 @@ def _cpu_budget():
     return budget
 
 
+def _bulk_threads(budget=None):
+    """Threads that produce the random stream ahead of the noise thread's walk (csrc/fokl_stream.cpp): the walk consumes a
+    segment of 79 872 doubles in 10-30 us, a bulk thread makes one in 20-40 us (AVX-512).  FOKL_BULK_THREADS overrides."""
+    if budget is None:
+        budget = _cpu_budget()
+    default = 3 if budget >= 12 else (2 if budget >= 5 else 1)
+    return max(1, int(os.environ.get('FOKL_BULK_THREADS', str(default))))
+
+
 def _thread_plan():
     """(chain, finish, spectral) thread counts of the host pipeline for the CPU budget of this process; the driver and
     the noise thread come on top.  FOKL_CHAIN_THREADS / FOKL_FINISH_THREADS / FOKL_SPECTRAL_THREADS override."""
@@ -242,7 +251,7 @@ class HostPipeline:
             self._saved_affinity, noise_cpu = _place_host_threads()
         chain, finish, spectral = _thread_plan()
         try:
-            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu)
+            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads())
         except BaseException:
             self._restore_affinity()        # the caller may carry on in line: not pinned to one L3 domain
             raise

@@ -306,6 +306,67 @@ int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, doubl
                     double shape, double scale, int64_t n, double *out);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* The random stream in two phases: bulk threads + one serial walk (round 4; csrc/fokl_stream.cpp).          */
+/* Call sites replaced: np.random.normal FR:1527, np.random.gamma FR:1541 / FR:1547.                         */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * The stream of fokl_noise_tape, produced by `bulk_threads` threads ahead of ONE walking thread.  The bulk threads
+ * continue MT19937 from the state handed to fokl_stream_create (np.random.get_state()), temper the words and flag, for
+ * every double of the stream, whether the polar attempt that STARTS there is accepted (both pairings of the doubles: a
+ * gamma's uniform shifts the pairing by one).  fokl_stream_walk advances over one model evaluation's draws exactly
+ * as fokl_noise_tape does -- same positions, same consumption, same cached value -- but touches only what is serial: per
+ * Gibbs iteration it steps over ceil((p1 - lead) / 2) accepted attempts by counting flags and makes the two gamma draws
+ * -- and those from BOUNDS where they decide (a normal is known by its source, the accepted attempt it comes from and
+ * which half; its value is formed, with libm's log, only when a gamma's accept test is too close to call: 1 in 10).  A
+ * tape row is 32 bytes of positions:
+ *     start        double index where the iteration's attempts begin; bit 63 = the row opens with the cached normal
+ *     lead_source  the attempt whose x1 half that cached normal is
+ *     gamma[2]     source of the normal X the accepted attempt of each gamma draw used (bit 63 = the x1 half): the
+ *                  variate is b (1 + c X)^3; all ones = the walker stored the variate itself (shapes <= 1)
+ * fokl_stream_expand turns rows back into fokl_noise_tape's layout (raw pairs (x2, x1), r2, lead, final lead / tail
+ * values, the two gamma variates) on any thread -- values identical to fokl_noise_tape's; the part of the stream a tape
+ * covers must be HELD from before its walk until its last expansion: fokl_stream_hold (on the walking thread, at the
+ * position the tape starts from) / fokl_stream_release (any thread).  The walker itself keeps everything from its floor
+ * on; fokl_stream_advance_floor moves the floor to its present position (between tapes).
+ * fokl_stream_tell / fokl_stream_seek save and restore the walker (tentative tapes: a rewind is three words, the
+ * bulk data does not move).  fokl_stream_state writes numpy's state tuple at the walker's position.
+ * One thread at a time may walk / seek / tell / ask for the state; expand, hold-release and stats are thread-safe.
+ */
+typedef struct fokl_stream fokl_stream;
+typedef struct fokl_tape_row {
+    uint64_t start;
+    uint64_t lead_source;
+    uint64_t gamma[2];
+} fokl_tape_row;
+typedef struct fokl_stream_cursor {
+    uint64_t position;
+    uint64_t gauss_source;
+    int32_t has_gauss;
+} fokl_stream_cursor;
+int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_t has_gauss, double gauss_cache, int bulk_threads,
+                       fokl_stream **out);
+void fokl_stream_destroy(fokl_stream *stream);
+int fokl_stream_walk(fokl_stream *stream, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                     double *gam_sig, double *gam_tau, int32_t *progress);
+int fokl_stream_tell(const fokl_stream *stream, fokl_stream_cursor *out);
+int fokl_stream_seek(fokl_stream *stream, const fokl_stream_cursor *at);
+int fokl_stream_hold(fokl_stream *stream, uint64_t *position_out);
+int fokl_stream_release(fokl_stream *stream, uint64_t position);
+int fokl_stream_advance_floor(fokl_stream *stream);
+int fokl_stream_state(fokl_stream *stream, uint32_t *key_out, int32_t *pos_out, int32_t *has_gauss_out,
+                      double *gauss_out);
+int fokl_stream_expand(fokl_stream *stream, int p1, double astar, double atau_star, const fokl_tape_row *rows, int k0,
+                       int k1, double *normals_out, double *pair_r2_out, int32_t *lead_out, double *gam_sig_out,
+                       double *gam_tau_out);
+/* seconds the bulk threads worked, seconds the walker waited for them, segments (79 872 doubles each) produced, gamma
+ * attempts walked and how many of them needed the exact expressions */
+int fokl_stream_stats(const fokl_stream *stream, double *bulk_busy_s, double *walker_wait_s, int64_t *segments,
+                      int64_t *gamma_attempts, int64_t *gamma_attempts_exact);
+/* max |fast_ln(y) - log(y)| over a sweep of (0, 1): the approximation the walker's bounds are built on (tests) */
+double fokl_stream_fast_ln_error(int64_t n);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* Host threads of one fit: the work of G2/G3 that must not sit on the Python driver thread.                */
 /* ------------------------------------------------------------------------------------------------------ */
 
@@ -313,44 +374,47 @@ typedef struct fokl_host_pool fokl_host_pool;
 typedef struct fokl_host_job fokl_host_job;
 
 /*
- * One noise thread (owns the random stream mt_key / mt_pos / has_gauss / gauss_cache -- caller storage, updated in
- * place -- and records tapes strictly in submission order), `finish_threads` threads that complete the normals of
- * each tape (all of them on every tape; 0 = the chain threads do it), `chain_threads` threads that run the chain
- * recursions and `spectral_threads` threads that diagonalise XtX sub-blocks.  `dsyevr` is the address of LAPACK's dsyevr with the
- * Fortran calling convention and 32-bit integers (the Python side passes scipy's own:
- * scipy.linalg.cython_lapack.__pyx_capi__['dsyevr']), so that eigenpairs are those of the reference's
+ * One noise thread that walks the random stream (fokl_stream_*: created here from mt_key / mt_pos / has_gauss / gauss_cache
+ * -- caller storage, read now and WRITTEN BACK by fokl_pool_destroy with numpy's state after everything that was walked --
+ * and produced by `bulk_threads` threads of its own) and records tapes strictly in submission order, `finish_threads`
+ * threads that materialise each tape (all of them on every tape; 0 = the noise thread does it, block by block),
+ * `chain_threads` threads that run the chain recursions and `spectral_threads` threads that diagonalise XtX sub-blocks.
+ * `dsyevr` is the address of LAPACK's dsyevr with the Fortran calling convention and 32-bit integers (the Python side
+ * passes scipy's own: scipy.linalg.cython_lapack.__pyx_capi__['dsyevr']), so that eigenpairs are those of the reference's
  * scipy.linalg.eigh call (FR:1499) bit for bit; NULL is allowed with spectral_threads == 0.
  * The threads inherit the CPU affinity of the caller, except that the noise thread is pinned to logical CPU
- * `noise_cpu` if that is >= 0 (the caller then keeps its other threads off that core).  Every buffer handed to a submit call must stay alive until
- * fokl_pool_wait has returned for that job.  fokl_pool_destroy first runs everything still queued.
+ * `noise_cpu` if that is >= 0 (the caller then keeps its other threads off that core).  Every buffer handed to a submit
+ * call must stay alive until fokl_pool_wait has returned for that job.  fokl_pool_destroy first runs everything still queued.
  */
-int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int noise_cpu, void *dsyevr,
-                     uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
+int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads, int noise_cpu,
+                     void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      fokl_host_pool **out);
 void fokl_pool_destroy(fokl_host_pool *pool);
 /*
- * fokl_noise_tape on the noise thread (arguments as there; progress must be given and start at 0).
- * tentative != 0: the tape is recorded ahead of the decision that it is needed, and fokl_pool_resolve(job, commit) is
+ * One model evaluation's tape on the noise thread: fokl_stream_walk into rows [draws] (progress must be given and start
+ * at 0: rows walked so far), materialised into fokl_noise_tape's layout (normals / pair_r2 / lead / gam_sig / gam_tau:
+ * identical numbers) by the finish threads, block by block of `block` rows behind the walk: block_done [ceil(draws /
+ * block)] (zero-initialised) receives 1 (release) per block, -1 if the tape is sent back.  finish != 0: the normals of
+ * each block are also completed IN PLACE (the log / sqrt half of the polar method: tapes a host chain reads); the job
+ * counts as run only when the finish threads have left the tape too.
+ * tentative != 0: the tape is walked ahead of the decision that it is needed, and fokl_pool_resolve(job, commit) is
  * its verdict -- commit keeps the tape (identical to a plain submission at that point of the stream), otherwise the
- * stream is rewound to where the tape began and `progress` is set to -1.  Tentative tapes may be NESTED: up to 16 can be
- * on record without a verdict, the noise thread goes on recording behind them.  A commit of the oldest makes it final;
+ * walker is put back where the tape began and `progress` is set to -1.  Tentative tapes may be NESTED: up to 16 can be
+ * on record without a verdict, the noise thread goes on walking behind them.  A commit of the oldest makes it final;
  * an abort takes every younger tentative tape with it (the caller resolves those to "abort" as well: what they hold is
  * no longer what the stream serves there); an abort of the youngest rewinds just that one.  A plain request waits until
  * nothing tentative is left.  Every tentative job MUST be resolved, or the noise thread (and fokl_pool_destroy) waits
  * for ever.
- * block_done [ceil(draws / block)] (zero-initialised; may be NULL): with finish threads in the pool, the tape is
- * completed IN PLACE (fokl_finish_tape_blocks) while it is recorded, whether or not a chain has been asked for yet;
- * the job then counts as run only when those threads have left the tape too.
  */
-int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, double *normals,
-                           double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau, int32_t *progress,
-                           int tentative, int32_t *block_done, int block, fokl_host_job **out);
+int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                           double *normals, double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau,
+                           int32_t *progress, int tentative, int32_t *block_done, int block, int finish,
+                           fokl_host_job **out);
 int fokl_pool_resolve(fokl_host_job *job, int commit);
 /*
- * The draws of one candidate from its tape (whose noise job must have been submitted): with finish threads and
- * block_done given, the recursion follows the finish threads' flags -- the tape is completed by them IN PLACE, started
- * here unless the noise job was submitted with the same block_done (finishing_requested != 0); otherwise
- * fokl_gibbs_chain_from_tape runs on a chain thread, following `progress`.
+ * The draws of one candidate from its tape (whose noise job must have been submitted with the same block_done): the
+ * recursion follows the flags of the finish threads -- on normals they completed in place (finishing_requested != 0:
+ * the tape was submitted with finish != 0) or completing each row itself.
  */
 int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b, double btau,
                            double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
@@ -375,6 +439,9 @@ int fokl_pool_wait(fokl_host_job *job);
 /* Accumulated time (s) the kinds of thread spent inside jobs (including their waits on the tape producer). */
 int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise, double *chain, double *finish,
                            double *spectral);
+/* The pool's random stream: fokl_stream_stats of it. */
+int fokl_pool_stream_stats(const fokl_host_pool *pool, double *bulk_busy_s, double *walker_wait_s, int64_t *segments,
+                           int64_t *gamma_attempts, int64_t *gamma_attempts_exact);
 /* Seconds the noise thread spent waiting: with an empty queue, and for the verdict on tentative tapes. */
 int fokl_pool_noise_waits(const fokl_host_pool *pool, double *queue_wait, double *verdict_wait);
 
@@ -410,9 +477,9 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
  *
  * fokl_dchain_submit queues a chain and returns at once.  The tape may still be on record: `progress` (may be
  * NULL: the tape is complete) is polled by the dispatcher until it reaches `draws`; a negative value fails the
- * job.  `finished` != 0: the normals are final already (host finish threads; `block_done` / `block` as for
- * fokl_gibbs_chain_from_finished_tape, polled the same way), else they are raw pairs + `lead` as fokl_noise_tape
- * leaves them.  lamb / qty are copied at submit; the tape's arrays must stay valid until fokl_dchain_poll
+ * job; `block_done` / `block` (may be NULL: the arrays are filled as soon as `progress` says so) are the flags of the
+ * threads that materialise the tape (fokl_pool_submit_noise), polled the same way.  `finished` != 0: the normals are
+ * final already (host finish threads), else they are raw pairs + `lead` as fokl_noise_tape leaves them.  lamb / qty are copied at submit; the tape's arrays must stay valid until fokl_dchain_poll
  * reports 1 or fokl_dchain_wait / fokl_dchain_release has returned.
  * fokl_dchain_wait sleeps until the chain has run and returns stats_out[4 + p1] = {bstar < 0 seen, last sigma^2,
  * last tau^2, rows averaged, mean over rows stat_first .. draws - 1 of w} -- what the kill tests look at
