@@ -82,6 +82,33 @@ SIGNATURES = {
     'fokl_stream_expand': (c_int, [c_vp, c_int, c_dbl, c_dbl, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
+    'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'fokl_search_destroy': (None, [c_vp]),
+    'fokl_search_error': (ctypes.c_char_p, [c_vp]),
+    'fokl_search_mispredicted': (c_int, [c_vp]),
+    'fokl_search_set_substage': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_search_speculate': (c_int, [c_vp, c_vp, c_vp, c_int]),
+    'fokl_search_drop_speculation': (c_int, [c_vp]),
+    'fokl_search_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
+    'fokl_spectrum_done': (c_int, [c_vp]),
+    'fokl_spectrum_wait': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'fokl_spectrum_release': (None, [c_vp, c_vp]),
+    'fokl_search_model_begin': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_vp]),
+    'fokl_search_score': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp]),
+    'fokl_outcome_info': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_outcome_chain_ready': (c_int, [c_vp]),
+    'fokl_outcome_draws': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_outcome_intercept_scale': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_outcome_release': (None, [c_vp, c_vp]),
+    'fokl_outcome_drop': (None, [c_vp, c_vp]),
+    'fokl_search_verify': (c_int, [c_vp, c_int]),
+    'fokl_search_register_forecast': (c_int, [c_vp, c_vp, c_int, c_vp, c_dbl]),
+    'fokl_search_clear_forecasts': (None, [c_vp]),
+    'fokl_search_likely_first_tests': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp]),
+    'fokl_search_stats': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_search_trace': (c_i64, [c_vp, c_vp, c_i64]),
+    'fokl_search_kill_tests': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_finish_tape_blocks': (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'fokl_gibbs_chain_from_finished_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp,
                                                     c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -599,6 +626,253 @@ class HostPool:
         return dict(noise=v[0].value, chain=v[1].value, finish=v[2].value, spectral=v[3].value,
                     noise_queue_wait=w[0].value, noise_verdict_wait=w[1].value, bulk=b.value, walker_wait=ww.value,
                     stream_segments=seg.value, gamma_attempts=ga.value, gamma_attempts_exact=ge.value)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the native half of a search (include/fokl_hip.h: fokl_search_*)
+# ---------------------------------------------------------------------------------------------------------
+
+class _SearchParams(ctypes.Structure):
+    _fields_ = [('n', c_i64), ('a', c_dbl), ('b', c_dbl), ('atau', c_dbl), ('btau', c_dbl), ('threshav', c_dbl),
+                ('threshstda', c_dbl), ('threshstdb', c_dbl), ('guess_margin', c_dbl), ('draws', c_i32), ('half0', c_i32),
+                ('aic', c_i32), ('lookahead', c_i32), ('foresight', c_i32), ('speculation_max', c_i32),
+                ('tentative_tapes', c_i32), ('test_rewinds', c_i32), ('device_chain_columns', c_i32),
+                ('finish_threads', c_i32), ('flip_guess', c_i32)]
+
+
+class _OutcomeView(ctypes.Structure):
+    _fields_ = [('spectrum', c_vp), ('idx', c_vp), ('ev', c_dbl), ('siglik', c_dbl), ('intercept_scale', c_dbl),
+                ('p1', c_i32), ('on_device', c_i32)]
+
+
+_FORESEE_CB = ctypes.CFUNCTYPE(None, c_vp, ctypes.POINTER(c_i32), c_int)
+_IDLE_CB = ctypes.CFUNCTYPE(c_int, c_vp)
+_RESIDUAL_CB = ctypes.CFUNCTYPE(c_int, c_vp, ctypes.POINTER(c_i32), c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl),
+                                ctypes.POINTER(c_dbl))
+
+
+class _KillTestsArgs(ctypes.Structure):
+    _fields_ = [('gram', c_vp), ('columns', c_vp), ('mean_abs', c_vp), ('rel_std', c_vp), ('slots', c_vp), ('best', c_vp),
+                ('ahead_keys', c_vp), ('ahead_offsets', c_vp), ('ahead_spectra', c_vp), ('user', c_vp),
+                ('foresee', _FORESEE_CB), ('idle_work', _IDLE_CB), ('residual', _RESIDUAL_CB), ('active', c_i32),
+                ('proposals', c_i32), ('n_prev', c_i32), ('vm_next', c_i32), ('ahead_count', c_i32)]
+
+
+class _KillTestsResult(ctypes.Structure):
+    _fields_ = [('killed', c_vp), ('best', c_vp), ('evmin', c_dbl), ('killed_count', c_i32), ('best_is_new', c_i32)]
+
+
+SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain', 'chains_materialised', 'bic_from_gram',
+                'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
+                'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
+                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop')
+
+
+class NativeSearch:
+    """include/fokl_hip.h: fokl_search_* -- the tapes on order, G2 jobs, chains and the kill-test loop of one fit, next to
+    its HostPool.  Handles (spectra, tapes, outcomes) are plain integers; engine.NativeOutcome wraps the last kind."""
+
+    def __init__(self, pool, dchain, **params):
+        self._lib = load()
+        self._h = None
+        self._pool, self._dchain = pool, dchain             # keep them alive: the search uses them until close()
+        prm = _SearchParams(**params)
+        h = c_vp(0)
+        _check(self._lib.fokl_search_create(pool._h, dchain._h if dchain is not None else None, ctypes.byref(prm),
+                                            ctypes.byref(h)))
+        self._h = h
+        self.draws = int(params['draws'])
+
+    def close(self):
+        if self._h:
+            self._lib.fokl_search_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _checked(self, rc):
+        if rc:
+            if self._lib.fokl_search_mispredicted(self._h):
+                from .host_pipeline import Misprediction
+                raise Misprediction(self._lib.fokl_search_error(self._h).decode())
+            _check(rc)
+
+    def set_substage(self, term_ids):
+        ids = np.ascontiguousarray(term_ids, dtype=np.int64)
+        self._checked(self._lib.fokl_search_set_substage(self._h, _ptr(ids), ids.shape[0]))
+
+    def speculate(self, sizes):
+        """sizes: [(columns, is_model)] the stream will probably serve next, in order."""
+        n = len(sizes)
+        cols = np.array([s for s, _ in sizes], dtype=np.int32)
+        model = np.array([int(m) for _, m in sizes], dtype=np.int32)
+        self._checked(self._lib.fokl_search_speculate(self._h, _ptr(cols), _ptr(model), n))
+
+    def drop_speculation(self):
+        self._checked(self._lib.fokl_search_drop_speculation(self._h))
+
+    def spectral(self, gram, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        h = c_vp(0)
+        self._checked(self._lib.fokl_search_spectral(self._h, _ptr(gram), gram.shape[1], _ptr(idx), idx.shape[0],
+                                                     ctypes.byref(h)))
+        return h.value
+
+    def spectrum_done(self, spectrum):
+        return bool(self._lib.fokl_spectrum_done(c_vp(spectrum)))
+
+    def spectrum_view(self, spectrum):
+        """-> SpectralResult over the search's own buffer (valid while the spectrum is referenced)."""
+        buf, p1 = c_vp(0), c_int(0)
+        self._checked(self._lib.fokl_spectrum_wait(self._h, c_vp(spectrum), ctypes.byref(buf), ctypes.byref(p1)))
+        n = p1.value
+        arr = np.ctypeslib.as_array((ctypes.c_double * SpectralResult.doubles(n)).from_address(buf.value))
+        return SpectralResult(n, arr)
+
+    def spectrum_release(self, spectrum):
+        if self._h:
+            self._lib.fokl_spectrum_release(self._h, c_vp(spectrum))
+
+    def model_begin(self, gram, idx, given, then):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        cols = np.array([s for s, _ in then], dtype=np.int32)
+        model = np.array([int(m) for _, m in then], dtype=np.int32)
+        sp, tape = c_vp(0), c_vp(0)
+        self._checked(self._lib.fokl_search_model_begin(self._h, _ptr(gram), gram.shape[1], _ptr(idx), idx.shape[0],
+                                                        c_vp(given) if given else None, _ptr(cols), _ptr(model),
+                                                        len(then), ctypes.byref(sp), ctypes.byref(tape)))
+        return sp.value, tape.value
+
+    def model_commit(self, spectrum, tape, dtd):
+        out = c_vp(0)
+        self._checked(self._lib.fokl_search_model_commit(self._h, c_vp(spectrum), c_vp(tape), float(dtd),
+                                                         ctypes.byref(out)))
+        return out.value
+
+    def score(self, outcome, s1, s2, n_prev, kill):
+        ev = c_dbl(0)
+        self._checked(self._lib.fokl_search_score(self._h, c_vp(outcome), float(s1), float(s2), int(n_prev), int(kill),
+                                                  ctypes.byref(ev)))
+        return ev.value
+
+    def outcome_info(self, outcome):
+        view = _OutcomeView()
+        self._checked(self._lib.fokl_outcome_info(self._h, c_vp(outcome), ctypes.byref(view)))
+        return view
+
+    def outcome_chain_ready(self, outcome):
+        return bool(self._lib.fokl_outcome_chain_ready(c_vp(outcome)))
+
+    def outcome_draws(self, outcome, p1):
+        w = c_vp(0)
+        self._checked(self._lib.fokl_outcome_draws(self._h, c_vp(outcome), ctypes.byref(w)))
+        return np.ctypeslib.as_array((ctypes.c_double * (self.draws * p1)).from_address(w.value)).reshape(self.draws, p1)
+
+    def outcome_intercept_scale(self, outcome):
+        v = c_dbl(0)
+        self._checked(self._lib.fokl_outcome_intercept_scale(self._h, c_vp(outcome), ctypes.byref(v)))
+        return v.value
+
+    def outcome_release(self, outcome):
+        if self._h:
+            self._lib.fokl_outcome_release(self._h, c_vp(outcome))
+
+    def outcome_drop(self, outcome):
+        if self._h:
+            self._lib.fokl_outcome_drop(self._h, c_vp(outcome))
+
+    def verify(self, block=False):
+        self._checked(self._lib.fokl_search_verify(self._h, int(bool(block))))
+
+    def register_forecast(self, key, spectrum, dtd):
+        key = np.ascontiguousarray(key, dtype=np.int32)
+        self._checked(self._lib.fokl_search_register_forecast(self._h, _ptr(key), key.shape[0], c_vp(spectrum), float(dtd)))
+
+    def clear_forecasts(self):
+        self._lib.fokl_search_clear_forecasts(self._h)
+
+    def likely_first_tests(self, spectrum, n_new, siglik=None):
+        out = np.empty(max(1, int(n_new)), dtype=np.int32)
+        count = c_int(0)
+        self._checked(self._lib.fokl_search_likely_first_tests(self._h, c_vp(spectrum), int(n_new),
+                                                               float('nan') if siglik is None else float(siglik),
+                                                               _ptr(out), ctypes.byref(count)))
+        return [int(c) for c in out[:count.value]]
+
+    def stats(self):
+        v = np.zeros(len(SEARCH_STATS) + 8)
+        n = self._lib.fokl_search_stats(self._h, _ptr(v), v.shape[0])
+        if n != len(SEARCH_STATS):
+            raise FoklNativeError(-3, "fokl_search_stats: the library's counters do not match SEARCH_STATS")
+        return dict(zip(SEARCH_STATS, v[:n].tolist()))
+
+    def trace(self):
+        n = self._lib.fokl_search_trace(self._h, None, 0)
+        rec = np.zeros((max(1, n), 4))
+        self._lib.fokl_search_trace(self._h, _ptr(rec), n)
+        return [dict(cols=int(r[0]), built=int(r[1]), ev=float(r[2]), kill=bool(r[3])) for r in rec[:n]]
+
+    def kill_tests(self, gram, columns, mean_abs, rel_std, slots, best, n_prev, vm_next, ahead, foresee=None,
+                   idle_work=None, residual=None):
+        """fokl_search_kill_tests.  ahead: {frozenset of active columns: spectrum handle}; the callbacks are Python
+        callables -- foresee(list of killed columns), idle_work(), residual(idx, betahat) -> (s1, s2) -- whose exceptions
+        are re-raised here after the native loop has returned.  -> (killed columns, evmin, best handle, best_is_new)."""
+        A = int(gram.shape[0]) - 1
+        vm = int(columns.shape[0])
+        columns = np.ascontiguousarray(columns, dtype=np.int32)
+        mean_abs = np.ascontiguousarray(mean_abs, dtype=np.float64)
+        rel_std = np.ascontiguousarray(rel_std, dtype=np.float64)
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        keys, offsets, handles = [], [0], []
+        for key, h in ahead.items():
+            keys.extend(sorted(key))
+            offsets.append(len(keys))
+            handles.append(h)
+        keys = np.array(keys if keys else [0], dtype=np.int32)
+        offsets = np.array(offsets, dtype=np.int32)
+        handle_arr = (c_vp * max(1, len(handles)))(*handles)
+        raised = []
+
+        def guard(fn, *args):
+            try:
+                return fn(*args)
+            except BaseException as exc:                     # noqa: B902 -- carried over the native frame
+                raised.append(exc)
+                return None
+
+        def cb_foresee(_user, killed, count):
+            if not raised:
+                guard(foresee, [int(killed[i]) for i in range(count)])
+
+        def cb_idle(_user):
+            if not raised:
+                guard(idle_work)
+            return -3 if raised else 0
+
+        def cb_residual(_user, idx, p1, betahat, s1, s2):
+            if not raised:
+                got = guard(residual, np.array([idx[i] for i in range(p1)], dtype=np.int32),
+                            np.array([betahat[i] for i in range(p1)]))
+                if got is not None:
+                    s1[0], s2[0] = float(got[0]), float(got[1])
+            return -3 if raised else 0
+
+        killed = np.zeros(max(1, vm), dtype=np.int32)
+        args = _KillTestsArgs(
+            gram=_ptr(gram), columns=_ptr(columns), mean_abs=_ptr(mean_abs), rel_std=_ptr(rel_std),
+            slots=_ptr(slots), best=best, ahead_keys=_ptr(keys), ahead_offsets=_ptr(offsets),
+            ahead_spectra=ctypes.cast(handle_arr, c_vp).value, user=None,
+            foresee=_FORESEE_CB(cb_foresee) if foresee is not None else _FORESEE_CB(),
+            idle_work=_IDLE_CB(cb_idle) if idle_work is not None else _IDLE_CB(),
+            residual=_RESIDUAL_CB(cb_residual) if residual is not None else _RESIDUAL_CB(),
+            active=A, proposals=vm, n_prev=int(n_prev), vm_next=-1 if vm_next is None else int(vm_next),
+            ahead_count=len(handles))
+        res = _KillTestsResult(killed=_ptr(killed))
+        rc = self._lib.fokl_search_kill_tests(self._h, ctypes.byref(args), ctypes.byref(res))
+        if raised:
+            raise raised[0]
+        self._checked(rc)
+        return [int(c) for c in killed[:res.killed_count]], float(res.evmin), res.best, bool(res.best_is_new)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -32,3 +32,22 @@ extern "C" int fokl_device_count(int *count)
     if (count) *count = 0;
     return FOKL_ERR_HIP;
 }
+
+// The device chain engine and page-locked memory do not exist in these builds: the native search (fokl_search.cpp) is
+// then created without an engine and falls back to ordinary memory for its tapes.
+extern "C" int fokl_host_alloc(size_t, void **out)
+{
+    if (out) *out = nullptr;
+    return FOKL_ERR_HIP;
+}
+extern "C" int fokl_host_free(void *) { return FOKL_ERR_HIP; }
+extern "C" int fokl_dchain_submit(fokl_dchain *, int, int, const double *, const double *, double, double, double, double,
+                                  double, const double *, const int32_t *, const double *, const double *, const int32_t *,
+                                  const int32_t *, int, int, int, int64_t *, const double **)
+{
+    return FOKL_ERR_HIP;
+}
+extern "C" int fokl_dchain_wait(fokl_dchain *, int64_t, double *) { return FOKL_ERR_HIP; }
+extern "C" int fokl_dchain_fetch_w(fokl_dchain *, int64_t, double *) { return FOKL_ERR_HIP; }
+extern "C" int fokl_dchain_release(fokl_dchain *, int64_t) { return FOKL_ERR_HIP; }
+extern "C" int fokl_dchain_try_release(fokl_dchain *, int64_t) { return 1; }

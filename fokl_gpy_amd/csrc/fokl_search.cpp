@@ -1,0 +1,1494 @@
+// The sequential kill tests of one sub-stage, and what they share with the rest of a search, off the Python thread
+// (round 4).  Restates engine.ForwardSelection._kill_tests_pipelined and the pieces of host_pipeline.py it drives -- the
+// tapes on order, the eigen-decompositions submitted ahead, the chains on host threads or on the device, the decisions
+// taken from guessed intercept scales and confirmed afterwards -- as native code next to the thread pool: the reference's
+// loop FoKLRoutines.py:1666-1690, same tests, same order, same consumption of the random stream.  The Python driver took
+// ~200 us per kill test (365 of them per benchmark fit: a 60-65 ms floor under the fit); one turn of this loop is a few
+// microseconds of bookkeeping between waits for threads that are doing the work.
+//
+// What stays in Python (engine.ForwardSelection, a dozen calls per fit): the sequence of sub-stages, the K1 / K2 / K3
+// launches, the statistics that order a sub-stage's proposals, the stop rule.  It shares with this file, through the
+// fokl_search_* calls, the objects both sides handle:
+//
+//   tapes      one model evaluation's noise (rows walked by the pool's noise thread, materialised by its finish threads
+//              into buffers from a size-class free list here -- page-locked when a device chain engine may read them);
+//              the queue of tapes ON ORDER ahead of the decisions that they are needed (fokl_search_speculate /
+//              tape_for: a tape is committed when the evaluation that comes has its size, else everything on order is
+//              sent back and the walker rewound);
+//   spectra    G2 jobs on the pool's spectral threads, result buffers owned here, reference counted;
+//   outcomes   a model evaluation: its spectrum, BIC, tape and chain (host chain thread or device engine).
+//
+// Everything in a fokl_search is touched by ONE thread (the driver); the pool's and the device engine's own threads are
+// reached through their C ABI only.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <immintrin.h>
+
+#include "../../include/fokl_hip.h"
+
+extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
+
+// fokl_sampler.cpp (library-internal): the chain of a tape whose blocks are materialised (not finished) by other threads
+extern "C" __attribute__((visibility("hidden"))) int fokl_gibbs_chain_from_raw_blocks(
+    const double *lamb, const double *qty, int p1, double b, double btau, double dtd, double sigsqd0, double tausqd0,
+    int draws, const double *normals, const double *pair_r2, const int32_t *lead, const double *gam_sig,
+    const double *gam_tau, const int32_t *block_done, int block, double *w_out, int32_t *bstar_negative);
+
+namespace {
+
+inline double now_s()
+{
+    return 1e-9 * (double)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                      std::chrono::steady_clock::now().time_since_epoch())
+                      .count();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// buffers: size classes of 64 K doubles, kept from fit to fit (fresh allocations would be page-faulted in by the pool's
+// threads; page-locking costs milliseconds)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t kClassDoubles = 65536;
+
+struct BufferStore {
+    std::mutex m;
+    std::map<size_t, std::vector<double *>> free_plain, free_pinned;    // class -> blocks
+    size_t kept = 0, limit = (size_t)2048 * 131072;                     // doubles kept (FOKL_HOST_POOL_MB)
+    BufferStore()
+    {
+        if (const char *mb = std::getenv("FOKL_HOST_POOL_MB")) limit = (size_t)(std::atof(mb) * 131072.0);
+    }
+};
+
+BufferStore &store()
+{
+    static BufferStore s;
+    return s;
+}
+
+double *take_buffer(size_t doubles, bool pinned, size_t *classes, bool *got_pinned)
+{
+    const size_t cls = (doubles + kClassDoubles - 1) / kClassDoubles;
+    *classes = cls;
+    BufferStore &s = store();
+    {
+        std::lock_guard<std::mutex> lock(s.m);
+        auto &lists = pinned ? s.free_pinned : s.free_plain;
+        auto it = lists.find(cls);
+        if (it != lists.end() && !it->second.empty()) {
+            double *p = it->second.back();
+            it->second.pop_back();
+            s.kept -= cls * kClassDoubles;
+            *got_pinned = pinned;
+            return p;
+        }
+    }
+    if (pinned) {
+        void *p = nullptr;
+        if (fokl_host_alloc(cls * kClassDoubles * sizeof(double), &p) == FOKL_OK && p) {
+            *got_pinned = true;
+            return static_cast<double *>(p);
+        }
+    }
+    void *p = nullptr;
+    if (posix_memalign(&p, 64, cls * kClassDoubles * sizeof(double)) != 0) return nullptr;
+    *got_pinned = false;
+    return static_cast<double *>(p);
+}
+
+void give_buffer(double *p, size_t classes, bool pinned)
+{
+    if (!p) return;
+    BufferStore &s = store();
+    {
+        std::lock_guard<std::mutex> lock(s.m);
+        if (s.kept + classes * kClassDoubles <= s.limit) {
+            (pinned ? s.free_pinned : s.free_plain)[classes].push_back(p);
+            s.kept += classes * kClassDoubles;
+            return;
+        }
+    }
+    if (pinned)
+        (void)fokl_host_free(p);
+    else
+        std::free(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the objects of a search
+// ---------------------------------------------------------------------------------------------------------------
+
+struct Tape {
+    int p1 = 0, draws = 0;
+    bool model = false;                     // ordered for a sub-stage's model (finished by host threads as it is walked)
+    bool tentative = false, resolved = false, abandoned = false;
+    double *mem = nullptr;
+    size_t classes = 0;
+    bool pinned = false;
+    // carved out of mem (the layout of _capi.NoiseTape)
+    double *normals = nullptr, *pair_r2 = nullptr, *gam_sig = nullptr, *gam_tau = nullptr;
+    int32_t *progress = nullptr, *block_done = nullptr, *lead = nullptr;
+    fokl_tape_row *rows = nullptr;
+    bool finishing = false;                 // the finish threads complete the normals in place
+    fokl_host_job *noise = nullptr;         // freed (fokl_pool_wait) when the tape goes
+    int refs = 1;
+    std::vector<fokl_host_job *> readers;   // host chains given up while they may still be reading the tape
+};
+
+struct Spectrum {
+    int p1 = 0;
+    std::vector<int32_t> idx;
+    double *buf = nullptr;                  // lamb | qty | betahat | Qt | moments
+    fokl_host_job *job = nullptr;
+    int status = FOKL_OK;
+    int refs = 1;
+    double *lamb() const { return buf; }
+    double *qty() const { return buf + p1; }
+    double *betahat() const { return buf + 2 * p1; }
+    double *Qt() const { return buf + 3 * p1; }
+    double *moments() const { return buf + 3 * p1 + (size_t)p1 * p1; }
+};
+
+struct Check {
+    double value;
+    bool decision;
+};
+
+struct Outcome {
+    Spectrum *spec = nullptr;
+    Tape *tape = nullptr;
+    double ev = 0, siglik = 0, dtd = NAN;
+    // host chain
+    fokl_host_job *chain = nullptr;
+    double *w = nullptr;
+    size_t w_classes = 0;
+    bool w_pinned = false;
+    int32_t *flag = nullptr;                // bstar < 0 seen (written by the chain thread)
+    bool chain_waited = false;
+    int chain_status = FOKL_OK;
+    // device chain
+    bool on_device = false;
+    int64_t ticket = 0;
+    const double *stats_area = nullptr;     // page-locked: [flag, sig, tau, rows, mean w [p1], ticket, seconds]
+    bool device_released = false;
+    double intercept_scale = NAN;
+    std::vector<Check> checks;
+    bool release_wanted = false, released = false;
+    int refs = 1;                           // Python handle + the search's own lists
+};
+
+struct Forecast {
+    std::vector<int32_t> key;               // device slots of the surviving model columns
+    Spectrum *spec;
+    int columns;
+    double dtd;
+};
+
+enum Stat {
+    S_GIBBS_CALLS, S_KILL_TESTS, S_TERMS_LOGICAL, S_T_EIGH, S_T_CHAIN, S_CHAINS_MATERIALISED, S_BIC_FROM_GRAM,
+    S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
+    S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
+    S_T_RESID, S_T_KILL_LOOP, S_COUNT
+};
+
+}  // namespace
+
+struct fokl_search {
+    fokl_host_pool *pool = nullptr;
+    fokl_dchain *dchain = nullptr;
+    fokl_search_params prm{};
+    double sigsqd0 = 0, tausqd0 = 0;
+    int speculation = 0;
+    int flip_guess = 0;
+    bool pinned_tapes = false;
+    // tapes on order, in stream order, no verdict yet
+    std::deque<Tape *> spec;
+    struct {
+        Tape *tape = nullptr;
+        Spectrum *spec = nullptr;
+        fokl_host_job *job = nullptr;
+        double *w = nullptr;
+        size_t w_classes = 0;
+        bool w_pinned = false;
+        int32_t *flag = nullptr;
+    } prechain;
+    std::map<std::vector<int64_t>, double> ev_cache;
+    std::vector<int64_t> active_ids;        // term id of every active column of the sub-stage (column 0: the intercept)
+    std::deque<Outcome *> unverified;
+    std::deque<Outcome *> zombies;          // device chains nobody will look at: slots go back once they have run
+    std::vector<Outcome *> device_outcomes;  // every device-chained outcome alive (all released when the search ends)
+    std::vector<Forecast> forecasts;
+    // what waits for threads before its memory can go
+    std::vector<Tape *> tape_limbo;
+    struct WLimbo {                         // a host chain nobody looks at: what it reads and writes lives until it has run
+        fokl_host_job *job;
+        double *w;
+        size_t classes;
+        bool pinned;
+        Tape *tape;
+        int32_t *flag;
+        Spectrum *spec;
+    };
+    std::vector<WLimbo> chain_limbo;
+    double stats[S_COUNT] = {};
+    std::vector<double> trace;              // 4 per evaluation: columns, built, ev, kill
+    double last_siglik = 0;
+    std::string error;
+    bool mispredicted = false;
+};
+
+namespace {
+
+int fail(fokl_search *s, int code, const std::string &msg)
+{
+    if (s) s->error = msg;
+    fokl_set_global_error(msg);
+    return code;
+}
+
+// ---- tapes ----------------------------------------------------------------------------------------------------
+
+size_t pad8(size_t count) { return (count + 7) / 8 * 8; }
+
+void carve(Tape *t)
+{
+    const size_t d = (size_t)t->draws, p1 = (size_t)t->p1, half = p1 / 2 + 1;
+    const size_t nblocks = (d + FOKL_TAPE_BLOCK - 1) / FOKL_TAPE_BLOCK;
+    const size_t ints0 = 16, ints1 = 16 + (nblocks + 15) / 16 * 16;
+    size_t off[5];
+    off[0] = 0;
+    off[1] = off[0] + pad8(d * p1 + 16);
+    off[2] = off[1] + pad8(d * half + 8);
+    off[3] = off[2] + pad8(d);
+    off[4] = off[3] + pad8(d);
+    const size_t rows_at = off[4] + pad8((ints1 + d + 1) / 2) + 8;
+    t->normals = t->mem;
+    t->pair_r2 = t->mem + off[1];
+    t->gam_sig = t->mem + off[2];
+    t->gam_tau = t->mem + off[3];
+    int32_t *ints = reinterpret_cast<int32_t *>(t->mem + off[4]);
+    t->progress = ints;
+    t->block_done = ints + ints0;
+    t->lead = ints + ints1;
+    t->rows = reinterpret_cast<fokl_tape_row *>(t->mem + rows_at);
+    std::memset(ints, 0, ints1 * sizeof(int32_t));          // progress and block flags start at zero
+}
+
+size_t tape_doubles(int p1, int draws)
+{
+    const size_t d = (size_t)draws, half = (size_t)p1 / 2 + 1;
+    const size_t nblocks = (d + FOKL_TAPE_BLOCK - 1) / FOKL_TAPE_BLOCK;
+    const size_t ints1 = 16 + (nblocks + 15) / 16 * 16;
+    return pad8(d * (size_t)p1 + 16) + pad8(d * half + 8) + 2 * pad8(d) + pad8((ints1 + d + 1) / 2) + 8 + 4 * d + 8;
+}
+
+void reap(fokl_search *s, bool block);
+
+Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
+{
+    auto *t = new Tape();
+    t->p1 = p1;
+    t->draws = s->prm.draws;
+    t->model = model;
+    t->tentative = tentative;
+    t->mem = take_buffer(tape_doubles(p1, t->draws), s->pinned_tapes, &t->classes, &t->pinned);
+    if (!t->mem) {
+        delete t;
+        fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a noise tape");
+        return nullptr;
+    }
+    carve(t);
+    const double astar = s->prm.a + 1 + s->prm.n / 2.0 + p1 / 2.0;      // FR:1508 (mmtx + 1 == p1)
+    const double atau_star = s->prm.atau + (p1 - 1) / 2.0;            // FR:1510
+    // a kill test's chain runs on the device when there is an engine: its tape stays raw (the device finishes it);
+    // a model's tape is finished by host threads while it is walked (its statistics order the tests: latency matters)
+    const bool on_device = !model && s->dchain && p1 <= s->prm.device_chain_columns;
+    t->finishing = !on_device && s->prm.finish_threads > 0;
+    const int rc = fokl_pool_submit_noise(s->pool, p1, t->draws, astar, atau_star, t->rows, t->normals, t->pair_r2,
+                                          t->lead, t->gam_sig, t->gam_tau, t->progress, tentative ? 1 : 0,
+                                          t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, &t->noise);
+    if (rc != FOKL_OK) {
+        give_buffer(t->mem, t->classes, t->pinned);
+        delete t;
+        s->error = "fokl_search: the pool refused a noise tape";
+        return nullptr;
+    }
+    return t;
+}
+
+void unref(fokl_search *s, Tape *t)
+{
+    if (t && --t->refs == 0) s->tape_limbo.push_back(t);
+}
+
+void resolve(Tape *t, bool commit)
+{
+    if (t->tentative && !t->resolved) {
+        t->resolved = true;
+        (void)fokl_pool_resolve(t->noise, commit ? 1 : 0);
+    }
+}
+
+// ---- spectra --------------------------------------------------------------------------------------------------
+
+Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1)
+{
+    auto *sp = new Spectrum();
+    sp->p1 = p1;
+    sp->idx.assign(idx, idx + p1);
+    sp->buf = static_cast<double *>(std::malloc(((size_t)p1 * (p1 + 3) + 2) * sizeof(double)));
+    if (!sp->buf ||
+        fokl_pool_submit_spectral(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, sp->lamb(), sp->Qt(), sp->qty(),
+                                  sp->betahat(), sp->moments(), &sp->job) != FOKL_OK) {
+        std::free(sp->buf);
+        delete sp;
+        s->error = "fokl_search: the pool refused a spectral job";
+        return nullptr;
+    }
+    s->stats[S_SPECTRAL_SUBMITTED] += 1;
+    return sp;
+}
+
+bool spectrum_done(Spectrum *sp) { return !sp->job || fokl_pool_poll(sp->job) != 0; }
+
+int wait_spectrum(fokl_search *s, Spectrum *sp)
+{
+    if (sp->job) {
+        const double t0 = now_s();
+        sp->status = fokl_pool_wait(sp->job);
+        sp->job = nullptr;
+        s->stats[S_T_EIGH] += now_s() - t0;
+    }
+    return sp->status;
+}
+
+void unref(fokl_search *s, Spectrum *sp)
+{
+    if (!sp || --sp->refs > 0) return;
+    if (sp->job) (void)fokl_pool_wait(sp->job);             // its buffers are written until it has run
+    std::free(sp->buf);
+    delete sp;
+}
+
+// ---- chains and outcomes ----------------------------------------------------------------------------------------
+
+double *take_w(fokl_search *s, int p1, size_t *classes, bool *pinned)
+{
+    return take_buffer((size_t)s->prm.draws * (size_t)p1, false, classes, pinned);
+}
+
+void drop_prechain(fokl_search *s)
+{
+    auto &pc = s->prechain;
+    if (!pc.tape) return;
+    // a chain started ahead that nobody will look at: its buffer goes back when it has run, and the tape it reads is
+    // not reused before that (the chain's reference on the tape passes to the limbo entry)
+    s->chain_limbo.push_back({pc.job, pc.w, pc.w_classes, pc.w_pinned, pc.tape, pc.flag, pc.spec});
+    pc = {};
+    s->stats[S_CHAINS_AHEAD_UNUSED] += 1;
+}
+
+fokl_host_job *submit_host_chain(fokl_search *s, Spectrum *sp, Tape *t, double dtd, double *w, int32_t *flag)
+{
+    fokl_host_job *job = nullptr;
+    const int rc = fokl_pool_submit_chain(s->pool, sp->lamb(), sp->qty(), sp->p1, s->prm.b, s->prm.btau, dtd, s->sigsqd0,
+                                          s->tausqd0, t->draws, t->normals, t->pair_r2, t->lead, t->gam_sig, t->gam_tau,
+                                          t->progress, t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, w, flag, &job);
+    return rc == FOKL_OK ? job : nullptr;
+}
+
+// Start the chain of the evaluation expected next -- G2 `sp`, p1 columns -- if its G2 has run and its tape is the oldest on
+// order (engine.ForwardSelection._chain_ahead).
+void chain_ahead(fokl_search *s, Spectrum *sp, int p1, double dtd)
+{
+    if (s->spec.empty() || s->spec.front()->p1 != p1 || !spectrum_done(sp)) return;
+    Tape *t = s->spec.front();
+    if (s->dchain && !t->model) return;                     // a kill test's chain: submitted to the device at commit
+    if (wait_spectrum(s, sp) != FOKL_OK) return;
+    auto &pc = s->prechain;
+    if (pc.tape) {
+        if (pc.tape == t && pc.spec == sp) return;
+        drop_prechain(s);
+    }
+    size_t classes;
+    bool pinned;
+    double *w = take_w(s, p1, &classes, &pinned);
+    if (!w) return;
+    auto *flag = new int32_t(0);
+    fokl_host_job *job = submit_host_chain(s, sp, t, dtd, w, flag);
+    if (!job) {
+        give_buffer(w, classes, pinned);
+        delete flag;
+        return;
+    }
+    sp->refs += 1;
+    t->refs += 1;                                           // the chain reads the tape whatever becomes of the order
+    pc.tape = t;
+    pc.spec = sp;
+    pc.job = job;
+    pc.w = w;
+    pc.w_classes = classes;
+    pc.w_pinned = pinned;
+    pc.flag = flag;
+    s->stats[S_CHAINS_AHEAD] += 1;
+}
+
+// engine.ForwardSelection._drop_speculation: send back the tapes on order beyond the first `keep`
+void drop_speculation(fokl_search *s, size_t keep)
+{
+    while (s->spec.size() > keep) {
+        Tape *t = s->spec.back();                           // youngest first
+        s->spec.pop_back();
+        if (s->prechain.tape == t) drop_prechain(s);
+        const bool begun = __atomic_load_n(t->progress, __ATOMIC_ACQUIRE) > 0;
+        resolve(t, false);
+        unref(s, t);
+        s->stats[S_TAPES_REWOUND] += 1;
+        if (begun) {
+            s->stats[S_TAPES_WASTED] += 1;
+            s->speculation = std::max(1, s->speculation - 2);
+        }
+    }
+}
+
+// engine.ForwardSelection._tape_for: the tape of the model evaluation that happens now
+Tape *tape_for(fokl_search *s, int p1, bool model)
+{
+    if (!s->spec.empty()) {
+        Tape *t = s->spec.front();
+        if (t->p1 == p1) {
+            s->spec.pop_front();
+            resolve(t, true);
+            s->speculation = std::min(s->prm.speculation_max, s->speculation + 1);
+            return t;
+        }
+        drop_speculation(s, 0);
+    }
+    return request_tape(s, p1, false, model);
+}
+
+// engine.ForwardSelection._speculate: orders that agree with `sizes` stay, the others are sent back, missing ones are
+// placed until s->speculation tapes are on order
+void speculate(fokl_search *s, const std::vector<std::pair<int, bool>> &sizes)
+{
+    if (!s->prm.tentative_tapes) return;
+    size_t k = 0;
+    while (k < s->spec.size() && k < sizes.size() && s->spec[k]->p1 == sizes[k].first) ++k;
+    if (k < s->spec.size()) drop_speculation(s, k);
+    const size_t upto = std::max(k, (size_t)s->speculation);
+    for (size_t i = k; i < sizes.size() && i < upto; ++i) {
+        if (s->prm.test_rewinds) {                          // tests: a recorded tape that is then discarded
+            Tape *bogus = request_tape(s, sizes[i].first + 1, true, true);
+            if (bogus) {
+                while (__atomic_load_n(bogus->progress, __ATOMIC_ACQUIRE) < bogus->draws) std::this_thread::yield();
+                resolve(bogus, false);
+                unref(s, bogus);
+                s->stats[S_TAPES_REWOUND] += 1;
+            }
+        }
+        Tape *t = request_tape(s, sizes[i].first, true, sizes[i].second);
+        if (!t) return;
+        s->spec.push_back(t);
+    }
+}
+
+bool chain_done(Outcome *o)
+{
+    if (o->on_device) {
+        if (o->device_released) return true;
+        double seen;
+        __atomic_load(o->stats_area + 4 + o->spec->p1, &seen, __ATOMIC_ACQUIRE);
+        return seen == (double)o->ticket;
+    }
+    return o->chain_waited || !o->chain || fokl_pool_poll(o->chain) != 0;
+}
+
+int wait_host_chain(fokl_search *s, Outcome *o)
+{
+    if (!o->chain_waited) {
+        const double t0 = now_s();
+        o->chain_status = o->chain ? fokl_pool_wait(o->chain) : FOKL_OK;
+        o->chain = nullptr;
+        o->chain_waited = true;
+        s->stats[S_T_CHAIN] += now_s() - t0;
+        s->stats[S_CHAINS_MATERIALISED] += 1;
+        if (o->chain_status == FOKL_OK && o->flag && *o->flag)
+            o->chain_status = fail(s, FOKL_ERR_NUMERIC,
+                                   "bstar < 0 inside the Gibbs chain (only possible with b <= 0): the noise tape "
+                                   "cannot reproduce the reference's skipped draw (FR:1538-1539)");
+    }
+    return o->chain_status;
+}
+
+// mean over the rows from `first_row` on of the intercept draws (betas[:, 0] = w Q[0, :]')
+int mean_intercept_draw(fokl_search *s, Outcome *o, int first_row, double *out)
+{
+    const int p1 = o->spec->p1;
+    const double *q0 = o->spec->Qt();                       // Qt[j][0] at j * p1
+    if (o->on_device) {
+        std::vector<double> st((size_t)4 + p1);
+        const double t0 = now_s();
+        const int rc = fokl_dchain_wait(s->dchain, o->ticket, st.data());
+        s->stats[S_T_CHAIN] += now_s() - t0;
+        if (rc != FOKL_OK) return rc;
+        s->stats[S_DCHAIN_KERNEL_S] += o->stats_area[5 + p1];
+        s->stats[S_DCHAIN_TIMED] += 1;
+        if (st[0] != 0.0)
+            return fail(s, FOKL_ERR_NUMERIC, "bstar < 0 inside the Gibbs chain (only possible with b <= 0)");
+        double acc = 0.0;
+        for (int j = 0; j < p1; ++j) acc += st[(size_t)4 + j] * q0[(size_t)j * p1];
+        *out = acc;
+        return FOKL_OK;
+    }
+    const int rc = wait_host_chain(s, o);
+    if (rc != FOKL_OK) return rc;
+    const int draws = s->prm.draws;
+    double total = 0.0;
+    for (int k = first_row; k < draws; ++k) {
+        const double *row = o->w + (size_t)k * p1;
+        double acc = 0.0;
+        for (int j = 0; j < p1; ++j) acc += row[j] * q0[(size_t)j * p1];
+        total += acc;
+    }
+    *out = draws > first_row ? total / (double)(draws - first_row) : NAN;
+    return FOKL_OK;
+}
+
+int intercept_scale(fokl_search *s, Outcome *o, double *out)
+{
+    if (std::isnan(o->intercept_scale)) {
+        double m;
+        const int rc = mean_intercept_draw(s, o, s->prm.half0, &m);
+        if (rc != FOKL_OK) return rc;
+        o->intercept_scale = std::fabs(m);
+    }
+    *out = o->intercept_scale;
+    return FOKL_OK;
+}
+
+void release_device_job(fokl_search *s, Outcome *o)
+{
+    if (o->device_released) return;
+    if (fokl_dchain_try_release(s->dchain, o->ticket)) {
+        o->device_released = true;
+        unref(s, o->tape);                                  // the device job was the tape's last reader
+        o->tape = nullptr;
+    } else {
+        o->refs += 1;
+        s->zombies.push_back(o);
+    }
+}
+
+void destroy_outcome(fokl_search *s, Outcome *o)
+{
+    if (o->on_device) {
+        if (!o->device_released) {
+            (void)fokl_dchain_release(s->dchain, o->ticket);          // waits until the chain has run
+            o->device_released = true;
+        }
+    } else if (o->w) {
+        if (o->chain && !o->chain_waited) {                 // still running: buffers, tape and spectrum go when it has
+            o->spec->refs += 1;
+            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec});
+            o->tape = nullptr;
+        } else {
+            give_buffer(o->w, o->w_classes, o->w_pinned);
+            delete o->flag;
+        }
+        o->w = nullptr;
+        o->flag = nullptr;
+    } else {
+        delete o->flag;
+    }
+    unref(s, o->spec);
+    unref(s, o->tape);
+    delete o;
+}
+
+void unref(fokl_search *s, Outcome *o)
+{
+    if (o && --o->refs == 0) destroy_outcome(s, o);
+}
+
+// GibbsOutcome.release: the draws of this model can no longer be looked at
+void release_outcome(fokl_search *s, Outcome *o)
+{
+    if (o->released) return;
+    if (o->on_device) {
+        if (!o->checks.empty()) {                           // its statistics still have to confirm guessed decisions
+            o->release_wanted = true;
+            return;
+        }
+        o->released = true;
+        release_device_job(s, o);
+        return;
+    }
+    o->released = true;
+    if (o->w) {
+        if (o->chain_waited || !o->chain) {
+            give_buffer(o->w, o->w_classes, o->w_pinned);
+            delete o->flag;
+            unref(s, o->tape);
+        } else {
+            o->spec->refs += 1;
+            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec});
+            o->chain = nullptr;
+            o->chain_waited = true;
+            o->chain_status = FOKL_ERR_STATE;
+        }
+        o->flag = nullptr;
+        o->tape = nullptr;
+        o->w = nullptr;
+    }
+}
+
+// What has been waiting for pool threads: tapes whose noise job (walk + materialisation) has run and that no chain reads
+// any more, chains nobody looks at.
+void reap(fokl_search *s, bool block)
+{
+    for (size_t i = 0; i < s->chain_limbo.size();) {
+        auto &c = s->chain_limbo[i];
+        if (block || fokl_pool_poll(c.job)) {
+            (void)fokl_pool_wait(c.job);
+            give_buffer(c.w, c.classes, c.pinned);
+            delete c.flag;
+            Tape *t = c.tape;
+            Spectrum *sp = c.spec;
+            s->chain_limbo[i] = s->chain_limbo.back();
+            s->chain_limbo.pop_back();
+            unref(s, t);
+            unref(s, sp);
+        } else {
+            ++i;
+        }
+    }
+    for (size_t i = 0; i < s->tape_limbo.size();) {
+        Tape *t = s->tape_limbo[i];
+        if (block || fokl_pool_poll(t->noise)) {
+            (void)fokl_pool_wait(t->noise);
+            give_buffer(t->mem, t->classes, t->pinned);
+            delete t;
+            s->tape_limbo[i] = s->tape_limbo.back();
+            s->tape_limbo.pop_back();
+        } else {
+            ++i;
+        }
+    }
+}
+
+// ---- BIC ------------------------------------------------------------------------------------------------------
+
+double ev_from_moments(fokl_search *s, double s1, double s2, int p1)
+{
+    const double n = (double)s->prm.n;
+    const double siglik = s2 / n - (s1 / n) * (s1 / n);     // np.var(y - X betahat), FR:1551
+    s->last_siglik = siglik;
+    const double lik = siglik > 0 ? -(n / 2) * std::log(siglik) - (n - 1) / 2 : NAN;
+    double ev = p1 * std::log(n) - 2 * lik;                 // FR:1553-1554
+    if (s->prm.aic) ev = ev + (2 - std::log(n)) * p1;       // FR:1653-1654 / FR:1684-1685
+    return ev;
+}
+
+// engine.ForwardSelection._same_model_same_ev: the first score of a model is the score of every later evaluation of it
+double same_model_same_ev(fokl_search *s, const int32_t *idx, int p1, double ev)
+{
+    std::vector<int64_t> key((size_t)p1);
+    for (int i = 0; i < p1; ++i) key[(size_t)i] = s->active_ids[(size_t)idx[i]];
+    std::sort(key.begin(), key.end());
+    return s->ev_cache.emplace(std::move(key), ev).first->second;
+}
+
+void record(fokl_search *s, int p1, int n_prev, double ev, bool kill)
+{
+    s->stats[S_GIBBS_CALLS] += 1;
+    s->stats[S_KILL_TESTS] += kill ? 1 : 0;
+    s->stats[S_TERMS_LOGICAL] += p1 - n_prev;
+    s->trace.insert(s->trace.end(), {(double)p1, (double)(p1 - n_prev), ev, kill ? 1.0 : 0.0});
+}
+
+// engine.ForwardSelection._commit: the chain of the evaluation (spectrum, tape) -- device engine for a kill test's
+// candidate if there is one, else a host chain thread (the one started ahead if it is this one)
+Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
+{
+    auto *o = new Outcome();
+    o->spec = sp;
+    sp->refs += 1;
+    o->tape = t;                                            // takes over the caller's reference
+    const int p1 = sp->p1;
+    if (test && s->dchain && p1 <= s->prm.device_chain_columns && s->prechain.tape != t) {
+        const int rc = fokl_dchain_submit(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
+                                          s->sigsqd0, s->tausqd0, t->normals, t->lead, t->gam_sig, t->gam_tau, t->progress,
+                                          t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, s->prm.half0, &o->ticket,
+                                          &o->stats_area);
+        if (rc == FOKL_OK) {
+            o->on_device = true;
+            o->refs += 1;
+            s->device_outcomes.push_back(o);
+            s->stats[S_DEVICE_CHAINS] += 1;
+            return o;
+        }
+        if (rc != FOKL_ERR_STATE) {                         // FOKL_ERR_STATE: every slot is alive -> the host chain
+            destroy_outcome(s, o);
+            return nullptr;
+        }
+    }
+    auto &pc = s->prechain;
+    if (pc.tape) {
+        if (pc.tape == t && pc.spec == sp) {                // the chain started ahead is the model's chain
+            o->chain = pc.job;
+            o->w = pc.w;
+            o->w_classes = pc.w_classes;
+            o->w_pinned = pc.w_pinned;
+            o->flag = pc.flag;
+            unref(s, pc.spec);
+            unref(s, pc.tape);                              // the chain's reference: the outcome holds the tape now
+            pc = {};
+            return o;
+        }
+        drop_prechain(s);
+    }
+    o->w = take_w(s, p1, &o->w_classes, &o->w_pinned);
+    o->flag = new int32_t(0);
+    if (!o->w) {
+        destroy_outcome(s, o);
+        fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a chain's draws");
+        return nullptr;
+    }
+    o->chain = submit_host_chain(s, sp, t, dtd, o->w, o->flag);
+    if (!o->chain) {
+        o->chain_waited = true;
+        destroy_outcome(s, o);
+        return nullptr;
+    }
+    return o;
+}
+
+// engine.ForwardSelection._second_clause_now: `value < threshav * |mean intercept draw of o|` if it can be had without
+// waiting for a chain.  -> 1 / 0, -1: the caller has to wait for the chain, < -1: error (-2 + FOKL_ERR_*)
+int second_clause_now(fokl_search *s, Outcome *o, double value)
+{
+    if (!std::isnan(o->intercept_scale) || chain_done(o)) {
+        double scale;
+        const int rc = intercept_scale(s, o, &scale);
+        if (rc != FOKL_OK) return -2 + rc;
+        return value < s->prm.threshav * scale ? 1 : 0;
+    }
+    if (!o->on_device) return -1;
+    const double threshold = s->prm.threshav * std::fabs(o->spec->betahat()[0]);
+    if (!(threshold > 0.0) || !std::isfinite(threshold) ||
+        std::fabs(value - threshold) <= s->prm.guess_margin * threshold) {
+        // too close to call from the guess, and the device's answer is milliseconds away: the chain once more, in line on
+        // this thread (same tape, same arithmetic up to the last bit of log()).  The tape is still there: the device job
+        // is its reader until it has run.
+        if (std::isnan(o->dtd) || !o->tape) return -1;
+        s->stats[S_GUESS_WAITS] += 1;
+        const double t0 = now_s();
+        Tape *t = o->tape;
+        const int p1 = o->spec->p1;
+        size_t classes;
+        bool pinned;
+        double *w = take_w(s, p1, &classes, &pinned);
+        if (!w) return -2 + FOKL_ERR_STATE;
+        int32_t negative = 0;
+        int rc;
+        if (t->finishing)
+            rc = fokl_gibbs_chain_from_finished_tape(o->spec->lamb(), o->spec->qty(), p1, s->prm.b, s->prm.btau, o->dtd,
+                                                     s->sigsqd0, s->tausqd0, t->draws, t->normals, t->gam_sig, t->gam_tau,
+                                                     t->block_done, FOKL_TAPE_BLOCK, w, nullptr, nullptr, &negative);
+        else
+            rc = fokl_gibbs_chain_from_raw_blocks(o->spec->lamb(), o->spec->qty(), p1, s->prm.b, s->prm.btau, o->dtd,
+                                                  s->sigsqd0, s->tausqd0, t->draws, t->normals, t->pair_r2, t->lead,
+                                                  t->gam_sig, t->gam_tau, t->block_done, FOKL_TAPE_BLOCK, w, &negative);
+        if (rc == FOKL_OK && negative) rc = fail(s, FOKL_ERR_NUMERIC, "bstar < 0 inside the Gibbs chain");
+        if (rc == FOKL_OK) {
+            const double *q0 = o->spec->Qt();
+            double total = 0.0;
+            for (int k = s->prm.half0; k < t->draws; ++k) {
+                double acc = 0.0;
+                for (int j = 0; j < p1; ++j) acc += w[(size_t)k * p1 + j] * q0[(size_t)j * p1];
+                total += acc;
+            }
+            o->intercept_scale = std::fabs(total / (double)(t->draws - s->prm.half0));
+        }
+        give_buffer(w, classes, pinned);
+        s->stats[S_T_CHAIN] += now_s() - t0;
+        if (rc != FOKL_OK) return -2 + rc;
+        return value < s->prm.threshav * o->intercept_scale ? 1 : 0;
+    }
+    bool decision = value < threshold;
+    s->stats[S_GUESSED] += 1;
+    if (s->flip_guess && (int)s->stats[S_GUESSED] == s->flip_guess) decision = !decision;      // tests
+    if (o->checks.empty()) {
+        o->refs += 1;
+        s->unverified.push_back(o);
+    }
+    o->checks.push_back({value, decision});
+    return decision ? 1 : 0;
+}
+
+// engine.ForwardSelection._verify: confirm the decisions taken from guessed intercept scales against the chains' own
+// statistics -- those that have arrived, or (block) all of them.  FOKL_ERR_STATE + s->mispredicted if one does not hold.
+int verify(fokl_search *s, bool block)
+{
+    while (!s->zombies.empty()) {
+        Outcome *z = s->zombies.front();
+        if (!z->device_released) {
+            if (fokl_dchain_try_release(s->dchain, z->ticket)) {
+                z->device_released = true;
+            } else if (block) {
+                (void)fokl_dchain_release(s->dchain, z->ticket);
+                z->device_released = true;
+            } else {
+                break;
+            }
+            unref(s, z->tape);
+            z->tape = nullptr;
+        }
+        s->zombies.pop_front();
+        unref(s, z);
+    }
+    while (!s->unverified.empty() && (block || chain_done(s->unverified.front()))) {
+        Outcome *o = s->unverified.front();
+        s->unverified.pop_front();
+        double scale;
+        const int rc = intercept_scale(s, o, &scale);
+        if (rc != FOKL_OK) {
+            unref(s, o);
+            return rc;
+        }
+        for (const Check &c : o->checks) {
+            if ((c.value < s->prm.threshav * scale) != c.decision) {
+                s->mispredicted = true;
+                unref(s, o);
+                return fail(s, FOKL_ERR_STATE,
+                            "kill test decided from a guessed intercept scale that its chain does not confirm");
+            }
+            s->stats[S_GUESSES_VERIFIED] += 1;
+        }
+        o->checks.clear();
+        if (o->release_wanted) release_outcome(s, o);
+        unref(s, o);
+    }
+    return FOKL_OK;
+}
+
+std::vector<int32_t> columns_without(int A, const std::vector<int32_t> &removed /* sorted */)
+{
+    std::vector<int32_t> idx;
+    idx.reserve((size_t)A);
+    size_t r = 0;
+    for (int c = 0; c < A; ++c) {
+        if (r < removed.size() && removed[r] == c) {
+            ++r;
+            continue;
+        }
+        idx.push_back(c);
+    }
+    return idx;
+}
+
+std::vector<int32_t> with_column(const std::vector<int32_t> &set, int32_t c)
+{
+    std::vector<int32_t> out(set);
+    out.insert(std::upper_bound(out.begin(), out.end(), c), c);
+    return out;
+}
+
+// engine.ForwardSelection._likely_first_tests: the kill tests a sub-stage will probably run, guessed from the
+// least-squares fit of its model (its last n_new columns are new).  -> active-column indices in testing order
+std::vector<int32_t> likely_first_tests(fokl_search *s, const Spectrum *sp, int n_new, double siglik)
+{
+    const int A = sp->p1;
+    std::vector<std::pair<double, int32_t>> order;
+    std::vector<double> guess_std((size_t)n_new);
+    const double *Qt = sp->Qt(), *lamb = sp->lamb(), *bh = sp->betahat();
+    for (int j = 0; j < n_new; ++j) {
+        const int col = A - n_new + j;
+        double acc = 0.0;
+        for (int e = 0; e < A; ++e) acc += Qt[(size_t)e * A + col] * Qt[(size_t)e * A + col] / lamb[e];
+        guess_std[(size_t)j] = std::sqrt(std::max(siglik, 0.0) * acc);
+        order.push_back({std::fabs(bh[col]), (int32_t)j});
+    }
+    std::stable_sort(order.begin(), order.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    const double floor = std::min(s->prm.threshstda, s->prm.threshstdb);
+    std::vector<int32_t> out;
+    for (const auto &e : order)
+        if (guess_std[(size_t)e.second] > floor * e.first) out.push_back(A - n_new + e.second);
+    return out;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_search_params *params,
+                                  fokl_search **out)
+{
+    if (!pool || !params || !out || params->draws < 1 || params->n < 1 || params->speculation_max < 1)
+        return fail(nullptr, FOKL_ERR_ARG, "fokl_search_create: null pointer or bad parameters");
+    auto *s = new fokl_search();
+    s->pool = pool;
+    s->dchain = dchain;
+    s->prm = *params;
+    s->sigsqd0 = params->b / (1 + params->a);               // FR:1371
+    s->tausqd0 = params->btau / (1 + params->atau);         // FR:1372
+    s->speculation = params->speculation_max;
+    s->flip_guess = params->flip_guess;
+    s->pinned_tapes = dchain != nullptr;
+    *out = s;
+    return FOKL_OK;
+}
+
+// Everything still on order is sent back, everything still running is waited for, every buffer goes back to the store.
+extern "C" void fokl_search_destroy(fokl_search *s)
+{
+    if (!s) return;
+    drop_speculation(s, 0);
+    if (s->prechain.tape) drop_prechain(s);
+    for (auto &f : s->forecasts) unref(s, f.spec);
+    s->forecasts.clear();
+    while (!s->unverified.empty()) {
+        Outcome *o = s->unverified.front();
+        s->unverified.pop_front();
+        o->checks.clear();
+        unref(s, o);
+    }
+    (void)verify(s, true);                                  // zombies
+    for (Outcome *o : s->device_outcomes) {
+        if (!o->device_released) {
+            (void)fokl_dchain_release(s->dchain, o->ticket);
+            o->device_released = true;
+        }
+        unref(s, o);
+    }
+    s->device_outcomes.clear();
+    reap(s, true);
+    reap(s, true);                                          // tapes released by the chains of the first pass
+    delete s;
+}
+
+extern "C" const char *fokl_search_error(const fokl_search *s) { return s ? s->error.c_str() : ""; }
+
+extern "C" int fokl_search_mispredicted(const fokl_search *s) { return s && s->mispredicted ? 1 : 0; }
+
+extern "C" int fokl_search_set_substage(fokl_search *s, const int64_t *term_ids, int columns)
+{
+    if (!s || !term_ids || columns < 1) return fail(s, FOKL_ERR_ARG, "fokl_search_set_substage: bad arguments");
+    s->active_ids.assign(term_ids, term_ids + columns);
+    reap(s, false);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_search_speculate(fokl_search *s, const int32_t *sizes, const int32_t *is_model, int count)
+{
+    if (!s || (count > 0 && (!sizes || !is_model))) return fail(s, FOKL_ERR_ARG, "fokl_search_speculate: bad arguments");
+    std::vector<std::pair<int, bool>> want;
+    for (int i = 0; i < count; ++i) want.push_back({sizes[i], is_model[i] != 0});
+    speculate(s, want);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_search_drop_speculation(fokl_search *s)
+{
+    if (!s) return fail(s, FOKL_ERR_ARG, "fokl_search_drop_speculation: null search");
+    drop_speculation(s, 0);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_search_spectral(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1,
+                                    fokl_spectrum **out)
+{
+    if (!s || !gram || !idx || !out || p1 < 1 || ld < 2) return fail(s, FOKL_ERR_ARG, "fokl_search_spectral: bad arguments");
+    Spectrum *sp = submit_spectrum(s, gram, ld, idx, p1);
+    if (!sp) return FOKL_ERR_STATE;
+    *out = reinterpret_cast<fokl_spectrum *>(sp);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_spectrum_done(fokl_spectrum *h) { return h && spectrum_done(reinterpret_cast<Spectrum *>(h)) ? 1 : 0; }
+
+// lamb [p1] | qty [p1] | betahat [p1] | Qt [p1, p1] (row j = eigenvector j) | moments [2]
+extern "C" int fokl_spectrum_wait(fokl_search *s, fokl_spectrum *h, const double **buffer, int *p1)
+{
+    if (!s || !h) return fail(s, FOKL_ERR_ARG, "fokl_spectrum_wait: null pointer");
+    Spectrum *sp = reinterpret_cast<Spectrum *>(h);
+    const int rc = wait_spectrum(s, sp);
+    if (buffer) *buffer = sp->buf;
+    if (p1) *p1 = sp->p1;
+    return rc;
+}
+
+extern "C" void fokl_spectrum_release(fokl_search *s, fokl_spectrum *h)
+{
+    if (s && h) unref(s, reinterpret_cast<Spectrum *>(h));
+}
+
+// A sub-stage's MODEL in two halves around the driver's K3 launch: begin = its tape (committed from the order, or
+// requested), the tapes on order after it (`then`), G2 waited for; commit = its chain.  The BIC comes from the driver
+// (fokl_search_score: residual moments of the device pass).
+extern "C" int fokl_search_model_begin(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1,
+                                       fokl_spectrum *given, const int32_t *then_sizes, const int32_t *then_model,
+                                       int then_count, fokl_spectrum **spectrum_out, fokl_tape **tape_out)
+{
+    if (!s || !gram || !idx || p1 < 1 || !spectrum_out || !tape_out)
+        return fail(s, FOKL_ERR_ARG, "fokl_search_model_begin: bad arguments");
+    Tape *t = tape_for(s, p1, true);                        // requested first: it is walked while G2 runs
+    if (!t) return FOKL_ERR_STATE;
+    std::vector<std::pair<int, bool>> want;
+    for (int i = 0; i < then_count; ++i) want.push_back({then_sizes[i], then_model[i] != 0});
+    speculate(s, want);
+    Spectrum *sp = reinterpret_cast<Spectrum *>(given);
+    if (sp)
+        sp->refs += 1;
+    else
+        sp = submit_spectrum(s, gram, ld, idx, p1);
+    if (!sp) {
+        unref(s, t);
+        return FOKL_ERR_STATE;
+    }
+    const int rc = wait_spectrum(s, sp);
+    if (rc != FOKL_OK) {
+        unref(s, sp);
+        unref(s, t);
+        return rc;
+    }
+    *spectrum_out = reinterpret_cast<fokl_spectrum *>(sp);
+    *tape_out = reinterpret_cast<fokl_tape *>(t);
+    return FOKL_OK;
+}
+
+extern "C" int fokl_search_model_commit(fokl_search *s, fokl_spectrum *spectrum, fokl_tape *tape, double dtd,
+                                        fokl_outcome **out)
+{
+    if (!s || !spectrum || !tape || !out) return fail(s, FOKL_ERR_ARG, "fokl_search_model_commit: null pointer");
+    Spectrum *sp = reinterpret_cast<Spectrum *>(spectrum);
+    Outcome *o = commit(s, sp, reinterpret_cast<Tape *>(tape), dtd, false);
+    unref(s, sp);                                           // model_begin's reference: the outcome holds its own
+    if (!o) return FOKL_ERR_STATE;
+    *out = reinterpret_cast<fokl_outcome *>(o);
+    return FOKL_OK;
+}
+
+// BIC of an evaluation from the residual moments (sum r, sum r^2) the driver measured; identical models score
+// identically (the first score of a model stands); the evaluation is recorded in the trace.
+extern "C" int fokl_search_score(fokl_search *s, fokl_outcome *h, double s1, double s2, int n_prev, int kill, double *ev)
+{
+    if (!s || !h || !ev) return fail(s, FOKL_ERR_ARG, "fokl_search_score: null pointer");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    const int p1 = o->spec->p1;
+    o->ev = same_model_same_ev(s, o->spec->idx.data(), p1, ev_from_moments(s, s1, s2, p1));
+    o->siglik = s->last_siglik;
+    record(s, p1, n_prev, o->ev, kill != 0);
+    *ev = o->ev;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_outcome_info(fokl_search *s, fokl_outcome *h, fokl_outcome_view *view)
+{
+    if (!s || !h || !view) return fail(s, FOKL_ERR_ARG, "fokl_outcome_info: null pointer");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    view->p1 = o->spec->p1;
+    view->on_device = o->on_device ? 1 : 0;
+    view->ev = o->ev;
+    view->siglik = o->siglik;
+    view->intercept_scale = o->intercept_scale;
+    view->spectrum = o->spec->buf;
+    view->idx = o->spec->idx.data();
+    return FOKL_OK;
+}
+
+extern "C" int fokl_outcome_chain_ready(fokl_outcome *h) { return h && chain_done(reinterpret_cast<Outcome *>(h)) ? 1 : 0; }
+
+// The draws in the eigenbasis, w [draws, p1] (betas = w Q'): waits for the chain; a device chain's draws are copied to
+// the host (only models that are returned get here).  The memory belongs to the outcome.
+extern "C" int fokl_outcome_draws(fokl_search *s, fokl_outcome *h, const double **w)
+{
+    if (!s || !h || !w) return fail(s, FOKL_ERR_ARG, "fokl_outcome_draws: null pointer");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    if (o->released) return fail(s, FOKL_ERR_STATE, "fokl_outcome_draws: the outcome's draws were released");
+    if (o->on_device) {
+        if (!o->w) {
+            o->w = take_w(s, o->spec->p1, &o->w_classes, &o->w_pinned);
+            if (!o->w) return fail(s, FOKL_ERR_STATE, "fokl_outcome_draws: out of memory");
+            const double t0 = now_s();
+            std::vector<double> st((size_t)4 + o->spec->p1);
+            int rc = fokl_dchain_wait(s->dchain, o->ticket, st.data());
+            if (rc == FOKL_OK && st[0] != 0.0) rc = fail(s, FOKL_ERR_NUMERIC, "bstar < 0 inside the Gibbs chain");
+            if (rc == FOKL_OK) rc = fokl_dchain_fetch_w(s->dchain, o->ticket, o->w);
+            s->stats[S_T_CHAIN] += now_s() - t0;
+            if (rc != FOKL_OK) return rc;
+            s->stats[S_CHAINS_FETCHED] += 1;
+            s->stats[S_CHAINS_MATERIALISED] += 1;
+        }
+        *w = o->w;
+        return FOKL_OK;
+    }
+    const int rc = wait_host_chain(s, o);
+    if (rc != FOKL_OK) return rc;
+    *w = o->w;
+    return FOKL_OK;
+}
+
+extern "C" int fokl_outcome_intercept_scale(fokl_search *s, fokl_outcome *h, double *scale)
+{
+    if (!s || !h || !scale) return fail(s, FOKL_ERR_ARG, "fokl_outcome_intercept_scale: null pointer");
+    return intercept_scale(s, reinterpret_cast<Outcome *>(h), scale);
+}
+
+// The search will not look at this model's draws again (idempotent); the handle stays valid until fokl_outcome_drop.
+extern "C" void fokl_outcome_release(fokl_search *s, fokl_outcome *h)
+{
+    if (s && h) release_outcome(s, reinterpret_cast<Outcome *>(h));
+}
+
+extern "C" void fokl_outcome_drop(fokl_search *s, fokl_outcome *h)
+{
+    if (!s || !h) return;
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    if (o->on_device && !o->released) {
+        o->checks.clear();
+        release_outcome(s, o);
+    }
+    unref(s, o);
+}
+
+extern "C" int fokl_search_verify(fokl_search *s, int block)
+{
+    if (!s) return fail(s, FOKL_ERR_ARG, "fokl_search_verify: null search");
+    return verify(s, block != 0);
+}
+
+// G2 of the coming sub-stage's model for one predicted set of survivors (key = their device slots): lets the kill-test
+// loop order that model's first tests' tapes and start its chain across the sub-stage boundary.
+extern "C" int fokl_search_register_forecast(fokl_search *s, const int32_t *key, int key_count, fokl_spectrum *spectrum,
+                                             double dtd)
+{
+    if (!s || (key_count > 0 && !key) || !spectrum) return fail(s, FOKL_ERR_ARG, "fokl_search_register_forecast: bad arguments");
+    Spectrum *sp = reinterpret_cast<Spectrum *>(spectrum);
+    sp->refs += 1;
+    s->forecasts.push_back({std::vector<int32_t>(key, key + key_count), sp, sp->p1, dtd});
+    return FOKL_OK;
+}
+
+extern "C" void fokl_search_clear_forecasts(fokl_search *s)
+{
+    if (!s) return;
+    for (auto &f : s->forecasts) unref(s, f.spec);
+    s->forecasts.clear();
+}
+
+extern "C" int fokl_search_likely_first_tests(fokl_search *s, fokl_spectrum *spectrum, int n_new, double siglik,
+                                              int32_t *columns_out, int *count)
+{
+    if (!s || !spectrum || !columns_out || !count) return fail(s, FOKL_ERR_ARG, "fokl_search_likely_first_tests: null pointer");
+    Spectrum *sp = reinterpret_cast<Spectrum *>(spectrum);
+    const int rc = wait_spectrum(s, sp);
+    if (rc != FOKL_OK) return rc;
+    if (std::isnan(siglik)) siglik = sp->moments()[1] / s->prm.n - (sp->moments()[0] / s->prm.n) * (sp->moments()[0] / s->prm.n);
+    const auto cols = likely_first_tests(s, sp, n_new, siglik);
+    for (size_t i = 0; i < cols.size(); ++i) columns_out[i] = cols[i];
+    *count = (int)cols.size();
+    return FOKL_OK;
+}
+
+extern "C" int fokl_search_stats(const fokl_search *s, double *values, int count)
+{
+    if (!s || !values || count < S_COUNT) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_stats: bad arguments");
+    std::memcpy(values, s->stats, sizeof(double) * S_COUNT);
+    return S_COUNT;
+}
+
+extern "C" int64_t fokl_search_trace(const fokl_search *s, double *records, int64_t capacity)
+{
+    if (!s) return 0;
+    const int64_t have = (int64_t)s->trace.size() / 4;
+    if (records) std::memcpy(records, s->trace.data(), sizeof(double) * 4 * (size_t)std::min(have, capacity));
+    return have;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kill tests of one sub-stage (FR:1666-1690)
+// ---------------------------------------------------------------------------------------------------------------
+
+extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args *a, fokl_kill_tests_result *res)
+{
+    if (!s || !a || !res || !a->gram || !a->columns || !a->mean_abs || !a->rel_std || !a->slots || !a->best ||
+        !res->killed)
+        return fail(s, FOKL_ERR_ARG, "fokl_search_kill_tests: null pointer");
+    const double t_begin = now_s();
+    const int A = a->active, ld = A + 1, vm = a->proposals;
+    const double *gram = a->gram;
+    const double dtd = gram[(size_t)A * ld + A];
+    const double threshav = s->prm.threshav;
+    Outcome *best = reinterpret_cast<Outcome *>(a->best);
+    best->refs += 1;                                        // this loop's own reference
+    std::vector<char> clause1((size_t)vm);
+    std::vector<int> proposal;
+    for (int j = 0; j < vm; ++j) {
+        clause1[(size_t)j] = a->rel_std[j] > s->prm.threshstdb;
+        if (clause1[(size_t)j] || a->rel_std[j] > s->prm.threshstda) proposal.push_back(j);   // the others cannot pass FR:1670
+    }
+    // guess at "mean_abs < threshav * |mean intercept draw|" for proposals further down the list: the posterior mean of
+    // the intercept is close to its least-squares value, and it barely moves from one accepted model to the next
+    double scale_guess = std::fabs(best->spec->betahat()[0]);
+    std::vector<int32_t> killed;                            // sorted active-column indices
+    double evmin = best->ev;
+    bool last_accepted = true;                              // predictor: proposals go the way the last went
+    std::map<std::vector<int32_t>, Spectrum *> ahead;       // trial set -> G2 submitted ahead
+    for (int i = 0; i < a->ahead_count; ++i) {
+        Spectrum *sp = reinterpret_cast<Spectrum *>(a->ahead_spectra[i]);
+        std::vector<int32_t> key(a->ahead_keys + a->ahead_offsets[i], a->ahead_keys + a->ahead_offsets[i + 1]);
+        std::sort(key.begin(), key.end());
+        sp->refs += 1;
+        if (!ahead.emplace(std::move(key), sp).second) unref(s, sp);
+    }
+    bool idle_pending = a->idle_work != nullptr;
+    int rc = FOKL_OK;
+
+    auto likely = [&](int j) { return clause1[(size_t)j] || a->mean_abs[j] < threshav * scale_guess; };
+    auto survivors_key = [&](const std::vector<int32_t> &pred) {
+        std::vector<int32_t> key;
+        size_t r = 0;
+        for (int c = 1; c < A; ++c) {
+            if (r < pred.size() && pred[r] < c) ++r;
+            while (r < pred.size() && pred[r] < c) ++r;
+            if (r < pred.size() && pred[r] == c) continue;
+            key.push_back(a->slots[c]);
+        }
+        return key;
+    };
+    auto find_forecast = [&](const std::vector<int32_t> &pred) -> Forecast * {
+        const auto key = survivors_key(pred);
+        for (auto &f : s->forecasts)
+            if (f.key == key) return &f;
+        return nullptr;
+    };
+    auto forecast = [&](size_t pos) {
+        // the kill set at the end of the loop if every remaining test that looks likely runs and is accepted
+        if (!a->foresee) return;
+        std::vector<int32_t> pred(killed);
+        int rest = 0;
+        for (size_t q = pos; q < proposal.size(); ++q)
+            if (likely(proposal[q])) {
+                pred = with_column(pred, a->columns[proposal[q]]);
+                ++rest;
+            }
+        if (rest <= s->prm.foresight) a->foresee(a->user, pred.data(), (int)pred.size());
+    };
+    auto order_tapes = [&](size_t pos) {
+        // the tapes of what the stream serves next if the search goes on as predicted (see engine.py order_tapes)
+        std::vector<std::pair<int, bool>> sizes;
+        std::vector<int32_t> pred(killed);
+        bool through = true;
+        for (size_t q = pos; q < proposal.size(); ++q) {
+            if ((int)sizes.size() >= s->prm.speculation_max) {
+                through = false;
+                break;
+            }
+            const int j = proposal[q];
+            if (likely(j)) {
+                sizes.push_back({A - (int)pred.size() - 1, false});
+                if (last_accepted) pred = with_column(pred, a->columns[j]);
+            }
+        }
+        if (through && a->vm_next >= 0) {
+            // across the boundary: the coming model, its first test (every first test is one column smaller whichever
+            // proposal it removes) -- or, if G2 of that model is there already, all the tests its least-squares fit
+            // makes likely
+            int tests = std::min(a->vm_next, 1);
+            if (Forecast *f = find_forecast(pred))
+                if (spectrum_done(f->spec) && wait_spectrum(s, f->spec) == FOKL_OK) {
+                    const double n = (double)s->prm.n;
+                    const double *m = f->spec->moments();
+                    tests = (int)likely_first_tests(s, f->spec, a->vm_next, m[1] / n - (m[0] / n) * (m[0] / n)).size();
+                }
+            const int coming = A - (int)pred.size() + a->vm_next;
+            sizes.push_back({coming, true});
+            for (int t = 1; t <= tests; ++t) sizes.push_back({coming - t, false});
+        }
+        speculate(s, sizes);
+        // ... and the chain of the very next evaluation, if its G2 is there
+        int nxt = -1;
+        for (size_t q = pos; q < proposal.size(); ++q)
+            if (likely(proposal[q])) {
+                nxt = proposal[q];
+                break;
+            }
+        if (nxt >= 0) {
+            auto it = ahead.find(with_column(killed, a->columns[nxt]));
+            if (it != ahead.end()) chain_ahead(s, it->second, A - (int)killed.size() - 1, dtd);
+        } else if (a->vm_next >= 0) {
+            if (Forecast *f = find_forecast(killed)) chain_ahead(s, f->spec, A - (int)killed.size() + a->vm_next, f->dtd);
+        }
+    };
+
+    forecast(0);
+    order_tapes(0);
+    for (size_t pos = 0; pos < proposal.size() && rc == FOKL_OK; ++pos) {
+        const int i = proposal[pos];
+        bool decided = clause1[(size_t)i];
+        if ((rc = verify(s, false)) != FOKL_OK) break;
+        if (!decided) {
+            // the second clause without a wait: from the chain of `best` if it has run, from its least-squares intercept
+            // (confirmed later) if that is a device chain and the proposal is not a borderline case
+            const int quick = second_clause_now(s, best, a->mean_abs[i]);
+            if (quick < -1) {
+                rc = quick + 2;
+                break;
+            }
+            if (quick == 0) continue;
+            if (quick == 1) {
+                decided = true;
+                if (!std::isnan(best->intercept_scale)) scale_guess = best->intercept_scale;
+            }
+        }
+        if (!decided && (!std::isnan(best->intercept_scale) || !likely(i))) {
+            // second clause without G2 of a model that will probably not be needed: from the known scale, or -- the test
+            // looks unlikely -- after waiting for the chain of `best`
+            if ((rc = intercept_scale(s, best, &scale_guess)) != FOKL_OK) break;
+            if (!(a->mean_abs[i] < threshav * scale_guess)) continue;
+            decided = true;
+        }
+        // G2 of the models on the predicted path, `lookahead` tests deep (a wrong guess costs latency only)
+        {
+            std::vector<int32_t> cur(killed);
+            int deep = 0;
+            for (size_t q = pos; q < proposal.size() && deep <= s->prm.lookahead; ++q) {
+                const int j = proposal[q];
+                if (q > pos && !likely(j)) continue;
+                ++deep;
+                auto key = with_column(cur, a->columns[j]);
+                if (ahead.find(key) == ahead.end()) {
+                    const auto idx = columns_without(A, key);
+                    Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size());
+                    if (!sp) {
+                        rc = FOKL_ERR_STATE;
+                        break;
+                    }
+                    ahead.emplace(key, sp);
+                }
+                if (last_accepted) cur = std::move(key);
+            }
+            if (rc != FOKL_OK) break;
+        }
+        const auto trial = with_column(killed, a->columns[i]);
+        const int p1 = A - (int)trial.size();
+        // the test runs for sure: its tape is committed (or, not on order after a wrong guess, requested) now, so that
+        // the stream moves on while this thread waits for G2
+        Tape *tape = decided ? tape_for(s, p1, false) : nullptr;
+        if (decided && !tape) {
+            rc = FOKL_ERR_STATE;
+            break;
+        }
+        if (idle_pending) {
+            idle_pending = false;
+            if ((rc = a->idle_work(a->user)) != FOKL_OK) {
+                unref(s, tape);
+                break;
+            }
+        }
+        Spectrum *sp = ahead[trial];
+        ahead.erase(trial);
+        if ((rc = wait_spectrum(s, sp)) != FOKL_OK) {
+            unref(s, sp);
+            unref(s, tape);
+            break;
+        }
+        if (!decided) {
+            if ((rc = intercept_scale(s, best, &scale_guess)) != FOKL_OK) {      // waits for the chain of `best`
+                unref(s, sp);
+                break;
+            }
+            if (!(a->mean_abs[i] < threshav * scale_guess)) {
+                unref(s, sp);
+                continue;
+            }
+            tape = tape_for(s, p1, false);
+            if (!tape) {
+                unref(s, sp);
+                rc = FOKL_ERR_STATE;
+                break;
+            }
+        }
+        // The BIC comes from the Gram and is known now, before anything is spent on the candidate's draws: a rejected
+        // candidate only has to advance the random stream (its tape is walked, never chained -- nobody reads the draws
+        // of a model that loses, FR:1686-1690).  A candidate that (nearly) interpolates the data gets the device's
+        // residual pass after all: y'y - 2 b'Xty + b'XtX b cancels y'y / SSR digits.
+        double s1 = sp->moments()[0], s2 = sp->moments()[1];
+        if (!(s2 > 1e-6 * dtd)) {
+            const double t0 = now_s();
+            if (!a->residual || (rc = a->residual(a->user, sp->idx.data(), p1, sp->betahat(), &s1, &s2)) != FOKL_OK) {
+                if (rc == FOKL_OK) rc = fail(s, FOKL_ERR_STATE, "fokl_search_kill_tests: a residual pass is needed and no callback was given");
+                unref(s, sp);
+                unref(s, tape);
+                break;
+            }
+            s->stats[S_T_RESID] += now_s() - t0;
+        } else {
+            s->stats[S_BIC_FROM_GRAM] += 1;
+        }
+        const double ev = same_model_same_ev(s, sp->idx.data(), p1, ev_from_moments(s, s1, s2, p1));
+        const double siglik = s->last_siglik;
+        Outcome *cand = nullptr;
+        if (ev < evmin) {
+            cand = commit(s, sp, tape, dtd, true);          // takes over the tape's reference
+            if (!cand) {
+                unref(s, sp);
+                rc = FOKL_ERR_STATE;
+                break;
+            }
+        } else {
+            if (s->prechain.tape == tape) drop_prechain(s);
+            unref(s, tape);                                 // walked all the same: the stream advances as the reference's
+            s->stats[S_CHAINS_SKIPPED] += 1;
+        }
+        record(s, p1, a->n_prev, ev, true);
+        last_accepted = ev < evmin;
+        if (last_accepted) {
+            killed = trial;
+            evmin = ev;
+            release_outcome(s, best);                       // the model it replaces: its draws are history
+            unref(s, best);
+            best = cand;
+            best->ev = ev;
+            best->siglik = siglik;
+            best->dtd = dtd;
+            best->refs += 1;                                // this loop's reference (the creation reference is the caller's)
+        }
+        unref(s, sp);
+        forecast(pos + 1);
+        order_tapes(pos + 1);
+        if ((pos & 7) == 7) reap(s, false);
+    }
+    if (rc == FOKL_OK) {
+        order_tapes(proposal.size());                       // the kill set is final
+        if (idle_pending) {
+            rc = a->idle_work(a->user);
+            if (rc == FOKL_OK) forecast(proposal.size());
+        }
+    }
+    for (auto &kv : ahead) unref(s, kv.second);
+    reap(s, false);
+    // the caller's handle on `best`: the outcome it passed in if no test was accepted, else a new one (whose creation
+    // reference becomes the caller's)
+    res->best = reinterpret_cast<fokl_outcome *>(best);
+    res->best_is_new = best != reinterpret_cast<Outcome *>(a->best) ? 1 : 0;
+    best->refs -= 1;                                        // this loop's reference
+    res->killed_count = (int)killed.size();
+    for (size_t k = 0; k < killed.size(); ++k) res->killed[k] = killed[k];
+    res->evmin = evmin;
+    s->stats[S_T_KILL_LOOP] += now_s() - t_begin;
+    return rc;
+}

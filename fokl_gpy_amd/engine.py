@@ -29,7 +29,8 @@ from . import _capi
 
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = _capi.SLOT_ONES, _capi.SLOT_Y, _capi.SLOT_FIRST_FREE
 from .host_pipeline import (  # noqa: F401  (re-exported: tests and tools reach them through this module)
-    HostPipeline, ShardedSpectralJob, GibbsOutcome, EagerOutcome, Misprediction, ModelSize, chain_engine_for,
+    HostPipeline, ShardedSpectralJob, GibbsOutcome, EagerOutcome, NativeOutcome, NativeSpectrum, Misprediction, ModelSize,
+    chain_engine_for,
     close_chain_engines, drop_spare_buffers, _mark, _flush_marks, _cpu_budget, _thread_plan, _thread_spares,
     _place_host_threads, _SPARES)
 
@@ -260,6 +261,12 @@ class ForwardSelection:
         self.tausqd0 = btau / (1 + atau)    # FR:1372
         self.pool = SlotPool(backend)
         self.host = None                    # HostPipeline while run() is active (b > 0 only)
+        # csrc/fokl_search.cpp: the tapes on order, the G2 jobs, the chains and the kill-test loop as native code next to the
+        # pool (_capi.NativeSearch) while run() is active -- single-process searches; FOKL_SEARCH=python keeps this
+        # file's own statement of the same logic (the reference for tests/test_native_search.py, and what searches
+        # replicated over ranks run)
+        self.native = None
+        self._term_ids = {}                 # term -> its number (native BIC cache: identical models score identically)
         self._async_resid = hasattr(backend, 'bic_resid_launch')
         # K3 without the stored columns (fokl_bic_resid_terms_launch): the residual pass re-forms the basis columns from
         # the inputs, 8 N (M_used + 1) bytes instead of 8 N (P + 2).  Decided per sub-stage (every model evaluated in a
@@ -385,9 +392,17 @@ class ForwardSelection:
         else:
             self.backend.bic_resid_launch(cand_slots, betahat)
 
+    def _spectral(self, gram, idx):
+        """Queue G2 for the model made of columns idx of gram (pool job, or the native search's)."""
+        if self.native is not None:
+            return NativeSpectrum(self.native, self.native.spectral(gram, idx), gram)
+        return self.host.spectral(gram, idx)
+
     def _set_active_terms(self, damtx):
         """Terms of the active columns of the sub-stage that begins (column 0 = intercept)."""
         self._active_terms = [()] + list(map(tuple, np.asarray(damtx, dtype=np.int64).tolist()))
+        if self.native is not None:
+            self.native.set_substage([self._term_ids.setdefault(t, len(self._term_ids)) for t in self._active_terms])
         self._terms_arr = None
         if self._matrix_free and damtx.shape[0]:
             arr = np.ascontiguousarray(damtx, dtype=np.int32)
@@ -411,6 +426,9 @@ class ForwardSelection:
         """Send back the tapes on order beyond the first `keep`.  What a wrong guess costs is the recorder's time on
         tapes it had begun: each of those takes two off the depth of the speculation (every tape that is used grows it
         back by one); orders the recorder had not reached yet cost nothing."""
+        if self.native is not None:
+            self.native.drop_speculation()
+            return
         while len(self._spec) > keep:
             _, job = self._spec.pop()                                 # youngest first
             if self._prechain is not None and self._prechain[0] is job:
@@ -444,6 +462,9 @@ class ForwardSelection:
         if not self.tentative_tapes or self.host is None:
             return
         sizes = list(sizes)
+        if self.native is not None:
+            self.native.speculate([(int(size), isinstance(size, ModelSize)) for size in sizes])
+            return
         k = 0
         while k < len(self._spec) and k < len(sizes) and self._spec[k][0] == sizes[k]:
             k += 1
@@ -543,6 +564,34 @@ class ForwardSelection:
         """
         idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
+        if self.native is not None:
+            # the same steps with the tape, G2 and the chain on the native side (fokl_search_model_begin / _commit /
+            # _score); this thread keeps the device's residual pass
+            ns = self.native
+            t0 = time.perf_counter()
+            spectrum, tape = ns.model_begin(gram, idx, spectral_job.h if spectral_job is not None else None,
+                                            [(int(size), isinstance(size, ModelSize)) for size in then])
+            try:
+                betahat = ns.spectrum_view(spectrum).betahat
+                self.stats['t_eigh'] += time.perf_counter() - t0
+                cand_slots = [slots[i] for i in idx]
+                if self._async_resid:
+                    self._launch_resid(cand_slots, idx, betahat)
+                ycol = gram.shape[0] - 1
+                handle = ns.model_commit(spectrum, tape, gram[ycol, ycol])
+            except BaseException:
+                ns.spectrum_release(spectrum)
+                raise
+            t0 = time.perf_counter()
+            if self._async_resid:
+                s1, s2 = self.backend.bic_resid_fetch(self.allreduce)
+            else:
+                s1, s2 = self.backend.bic_resid(cand_slots, np.array(betahat), self.allreduce)
+            self.stats['t_resid'] += time.perf_counter() - t0
+            ns.score(handle, s1, s2, n_prev_cols, kill)
+            outcome = NativeOutcome(self, ns, handle)
+            self._outcomes.append(outcome)
+            return outcome
         if self.host is not None:
             # not speculative: the tape is requested first, so that it is recorded while G2 runs
             noise_job = self._tape_for(p1)
@@ -596,7 +645,7 @@ class ForwardSelection:
         the model the next sub-stage starts from) can no longer be looked at -- their buffers go back to the pool, a
         little later (_release_retired): the noise thread is waiting for the coming sub-stage's orders right now."""
         self._retiring += [o for o in self._outcomes if not any(o is k for k in keep)]
-        self._outcomes = [k for k in keep if isinstance(k, GibbsOutcome)]
+        self._outcomes = [k for k in keep if isinstance(k, (GibbsOutcome, NativeOutcome))]
 
     def _release_retired(self):
         for outcome in self._retiring:
@@ -632,7 +681,7 @@ class ForwardSelection:
         jobs, cur = {}, frozenset()
         for c in likely[:1 + self.lookahead]:
             cur = cur | {c}
-            jobs[cur] = self.host.spectral(gram, self._columns_without(A, cur))
+            jobs[cur] = self._spectral(gram, self._columns_without(A, cur))
         # and their tapes: test t of the sub-stage has A - 1 - t columns if the tests before it were accepted
         sizes = [A - 1 - t for t in range(len(likely))]
         self._speculate(([ModelSize(A)] if before_model else []) + sizes)
@@ -685,6 +734,9 @@ class ForwardSelection:
     def _verify(self, block=False):
         """Confirm the decisions that were taken from guessed intercept scales against the chains' own statistics --
         those that have arrived, or (block) all of them.  Raises Misprediction if one does not hold."""
+        if self.native is not None:
+            self.native.verify(block)
+            return
         # chains complete in the order they were submitted, near enough: only the oldest is polled (one call per turn)
         while self._zombies and (self._zombies[0].try_release() or block):
             self._zombies.popleft().release()
@@ -717,6 +769,17 @@ class ForwardSelection:
         (None: not known yet).  chain_coming(killed set): start the chain of the coming sub-stage's model if this one ends
         with that kill set and G2 of that model is there.
         """
+        if self.native is not None:
+            # csrc/fokl_search.cpp fokl_search_kill_tests: this loop as native code.  peek / chain_coming are its own (the
+            # forecasts are registered with it by `foresee`)
+            resid = lambda idx, betahat: self.backend.bic_resid([slots[i] for i in idx], betahat, self.allreduce)
+            killed, evmin, handle, is_new = self.native.kill_tests(
+                gram, cand_col, mean_abs, rel_std, slots, best.h, n_prev, vm_next,
+                {key: job.h for key, job in (ahead or {}).items()}, foresee, idle_work, resid)
+            if is_new:
+                best = NativeOutcome(self, self.native, handle)
+                self._outcomes.append(best)
+            return killed, evmin, best
         A = len(slots)
         dtd = gram[A, A]
         vm = cand_col.shape[0]
@@ -889,6 +952,17 @@ class ForwardSelection:
                 import warnings
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
+        if self.host is not None and self._native_wanted():
+            half0 = int(math.ceil(self.draws / 2))
+            self.native = _capi.NativeSearch(
+                self.host.pool, self.chain_engine, n=self.n, a=self.a, b=self.b, atau=self.atau, btau=self.btau,
+                threshav=self.threshav, threshstda=self.threshstda, threshstdb=self.threshstdb,
+                guess_margin=self.guess_margin, draws=self.draws, half0=half0, aic=int(self.aic),
+                lookahead=self.lookahead, foresight=self.foresight, speculation_max=self.speculation_max,
+                tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
+                device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
+                flip_guess=self._flip_guess)
+        self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
         # one for the normals finished on the host, host threads or the device for the kill tests' chains
@@ -901,6 +975,15 @@ class ForwardSelection:
             _mark('run_end')
             t_down = time.perf_counter()
             self.stats['t_search_body'] = t_down - t_up
+            if self.native is not None:
+                # what the native side counted (its evaluations, waits and guesses) joins this side's counters; the
+                # trace of evaluations is its (model evaluations are recorded there too: one sequence)
+                for key, value in self.native.stats().items():
+                    self.stats[key] = self.stats.get(key, 0) + value
+                self.trace = self.native.trace()
+                self._outcomes, self._retiring = [], []
+                self.native.close()         # sends back what is on order, waits for what is in flight
+                self.native = None
             if self.host is not None:
                 # every device chain of this search gives its slot back (the engine outlives the fit); idempotent, and
                 # a chain that has not run yet is waited for -- its tape is committed, so it will
@@ -918,11 +1001,24 @@ class ForwardSelection:
                                   noise_queue_wait_s=busy['noise_queue_wait'],
                                   noise_verdict_wait_s=busy['noise_verdict_wait'],
                                   spectral_remote=self.host.remote_results, exchanges=self.host.exchanges,
-                                  spectral_submitted=self.host.spectral_submitted)
+                                  spectral_submitted=self.stats.get('spectral_submitted', 0) + self.host.spectral_submitted)
                 self.host = None
                 self.stats['t_teardown'] = time.perf_counter() - t_down
                 _mark('pool_down')
                 _flush_marks()
+
+    def _native_wanted(self):
+        """The native search core drives single-process searches whose kill-test BICs come from the Gram; replicated
+        searches (rows or candidates over ranks), FOKL_KILL_BIC=device|check and stand-in chain engines (tests) keep the
+        Python statement of the loop.  FOKL_SEARCH=python forces that one."""
+        from . import host_pipeline
+        if os.environ.get('FOKL_SEARCH', 'native') == 'python':
+            return False
+        if self.allreduce or self.candidate_sharded or self.kill_bic not in ('auto', 'gram'):
+            return False
+        if self.chain_engine is not None and not isinstance(self.chain_engine, _capi.DeviceChainEngine):
+            return False
+        return host_pipeline._chain_engine_factory is None
 
     def _patterns(self):
         """(stage ind, indvec) of every sub-stage in the reference's order (FR:1602-1613, FR:1722-1747)."""
@@ -1017,6 +1113,8 @@ class ForwardSelection:
                 else:
                     gram = self._extend_gram(gram, keep, self._ahead_block(ahead), keep, ahead['over'])
                 self._ahead_block(ahead)                    # a launched block is always fetched
+                if self.native is not None:
+                    self.native.clear_forecasts()           # before their Grams go: waits for G2 jobs nobody else holds
                 ahead, forecasts = None, {}
             else:
                 # K1 + K2: build the new columns once, extend the Gram
@@ -1068,7 +1166,9 @@ class ForwardSelection:
                 key = tuple(active[c] for c in keep_pred[1:])
                 if key not in forecasts:
                     g = self._extend_gram(gram, keep_pred, self._ahead_block(ahead), keep_pred, ahead['over'])
-                    forecasts[key] = (self.host.spectral(g, np.arange(g.shape[0] - 1, dtype=np.int32)), g)
+                    forecasts[key] = (self._spectral(g, np.arange(g.shape[0] - 1, dtype=np.int32)), g)
+                    if self.native is not None:
+                        self.native.register_forecast(key, forecasts[key][0].h, g[-1, -1])
 
             guesses = {}
 
@@ -1159,6 +1259,8 @@ class ForwardSelection:
 
         if self.host is not None:                  # the search stopped: tapes on order for a sub-stage that does not come
             self._drop_speculation()
+        if self.native is not None:
+            self.native.clear_forecasts()
         if ahead is not None:                      # ... and the columns built ahead are not needed
             self._ahead_block(ahead)
             self.pool.give(ahead['slots'])

@@ -616,6 +616,102 @@ class GibbsOutcome:
         return self.w[first_row:] @ self.Qt[:, cols]
 
 
+class NativeSpectrum:
+    """A G2 job of a NativeSearch (fokl_search_spectral): the interface of a pool job -- done(), wait() -> SpectralResult
+    over the search's own buffer -- plus the handle `h`.  Owns one reference; keeps the Gram it was computed from alive."""
+    __slots__ = ('_ns', 'h', '_gram', '_view')
+
+    def __init__(self, ns, handle, gram):
+        self._ns, self.h, self._gram, self._view = ns, handle, gram, None
+
+    def done(self):
+        return self._view is not None or self._ns.spectrum_done(self.h)
+
+    def wait(self):
+        if self._view is None:
+            self._view = self._ns.spectrum_view(self.h)
+        return self._view
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._ns.spectrum_release(self.h)
+        except Exception:                                              # interpreter shutdown
+            pass
+        self.h = None
+
+
+class NativeOutcome:
+    """One model evaluation of a NativeSearch (csrc/fokl_search.cpp): GibbsOutcome's interface over a native handle.  The
+    spectrum, the draws and their buffers belong to the search; the arrays here are views that live as long as this
+    object is not released / dropped."""
+    __slots__ = ('_ns', 'h', 'lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'siglik', 'on_device', '_w', '_betas',
+                 '_scale', '_owner')
+
+    def __init__(self, owner, ns, handle):
+        self._owner, self._ns, self.h = owner, ns, handle
+        view = ns.outcome_info(handle)
+        p1 = view.p1
+        import ctypes
+        buf = np.ctypeslib.as_array((ctypes.c_double * _capi.SpectralResult.doubles(p1)).from_address(view.spectrum))
+        spec = _capi.SpectralResult(p1, buf)
+        self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
+        self.idx = np.array(np.ctypeslib.as_array((ctypes.c_int32 * p1).from_address(view.idx)))
+        self.ev, self.siglik, self.on_device = view.ev, view.siglik, bool(view.on_device)
+        self._w = self._betas = self._scale = None
+
+    @property
+    def intercept_scale(self):
+        if self._scale is None:
+            v = self._ns.outcome_info(self.h).intercept_scale
+            if v == v:
+                self._scale = v
+        return self._scale
+
+    @intercept_scale.setter
+    def intercept_scale(self, value):
+        self._scale = value
+
+    def chain_ready(self):
+        return self._w is not None or self._ns.outcome_chain_ready(self.h)
+
+    def release(self):
+        self._w = None
+        if self.h:
+            self._ns.outcome_release(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._ns.outcome_drop(self.h)
+        except Exception:                                              # interpreter shutdown
+            pass
+        self.h = None
+
+    @property
+    def Q(self):
+        return self.Qt.T
+
+    @property
+    def w(self):
+        if self._w is None:
+            t0 = time.perf_counter()
+            self._w = self._ns.outcome_draws(self.h, self.lamb.shape[0])
+            self._owner.stats['t_chain'] += time.perf_counter() - t0
+        return self._w
+
+    @property
+    def betas(self):
+        if self._betas is None:
+            self._betas = self.w @ self.Qt
+        return self._betas
+
+    def beta_columns(self, cols, first_row=0):
+        if self._betas is not None:
+            return self._betas[first_row:, cols]
+        return self.w[first_row:] @ self.Qt[:, cols]
+
+
 class EagerOutcome:
     """Model evaluation whose chain ran in line (b <= 0: bstar < 0 may skip draws, so no tape can be recorded ahead)."""
     __slots__ = ('w', 'Q', 'betahat', 'ev', 'idx', 'intercept_scale', '_betas')

@@ -446,6 +446,123 @@ int fokl_pool_stream_stats(const fokl_host_pool *pool, double *bulk_busy_s, doub
 int fokl_pool_noise_waits(const fokl_host_pool *pool, double *queue_wait, double *verdict_wait);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* The search's per-evaluation work off the driver thread: tapes on order, G2 ahead, chains, kill tests     */
+/* (csrc/fokl_search.cpp).  Replaces the loop FR:1666-1690 and the bookkeeping around FR:1650 / FR:1681.     */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/*
+ * A fokl_search holds, for ONE fit, what the sequential decisions of the forward selection share: the queue of noise
+ * tapes on order ahead of the decisions that they are needed, the G2 jobs submitted ahead, the chains (pool threads or
+ * the device engine), the decisions taken from guessed intercept scales and their confirmation, the BIC cache of models
+ * scored before, the trace of evaluations.  It is driven by one thread.  The driver (Python: engine.ForwardSelection)
+ * keeps the sequence of sub-stages, the K1 / K2 / K3 launches, the statistics that order a sub-stage's proposals and the
+ * stop rule, and calls
+ *   fokl_search_set_substage        term ids of the active columns (identical models score identically, see
+ *                                   fokl_search_score);
+ *   fokl_search_model_begin/_commit a sub-stage's model (FR:1650) around the driver's residual pass;
+ *   fokl_search_score               BIC (FR:1551-1554, 1653-1654) from residual moments + the trace record;
+ *   fokl_search_kill_tests          FR:1666-1690 for one sub-stage: same tests, same order, same consumption of the
+ *                                   random stream; BIC of the candidates from the sub-stage's Gram.
+ * dchain may be NULL (every chain on pool threads).  fokl_search_destroy sends back what is on order and waits for
+ * everything in flight; the pool must outlive the search.
+ */
+typedef struct fokl_dchain fokl_dchain;         /* the device chain engine, declared further down */
+typedef struct fokl_search fokl_search;
+typedef struct fokl_spectrum fokl_spectrum;     /* one G2 job and its result */
+typedef struct fokl_tape fokl_tape;             /* one model evaluation's noise */
+typedef struct fokl_outcome fokl_outcome;       /* one model evaluation */
+typedef struct fokl_search_params {
+    int64_t n;                                  /* rows of the whole dataset (FR:1508: astar) */
+    double a, b, atau, btau;                    /* FR:1322-1348 */
+    double threshav, threshstda, threshstdb;    /* FR:1670-1671 */
+    double guess_margin;                        /* decisions from the least-squares intercept: relative distance kept */
+    int32_t draws;                              /* burnin + draws: iterations per chain */
+    int32_t half0;                              /* ceil(draws / 2): first row of the intercept statistic (FR:1671) */
+    int32_t aic;                                /* FR:1653-1654 */
+    int32_t lookahead, foresight;               /* G2 jobs ahead of the tests; tests left when the next model is foreseen */
+    int32_t speculation_max;                    /* tapes on order at most */
+    int32_t tentative_tapes, test_rewinds;      /* 0: no tape is ordered ahead; tests: a discarded tape before every order */
+    int32_t device_chain_columns;               /* device chains for models of up to this many columns */
+    int32_t finish_threads;                     /* of the pool (0: chains complete their normals themselves) */
+    int32_t flip_guess;                         /* tests: the n-th guessed decision is taken wrong */
+} fokl_search_params;
+int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_search_params *params, fokl_search **out);
+void fokl_search_destroy(fokl_search *search);
+const char *fokl_search_error(const fokl_search *search);
+/* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */
+int fokl_search_mispredicted(const fokl_search *search);
+int fokl_search_set_substage(fokl_search *search, const int64_t *term_ids, int columns);
+/* the models the stream will probably serve next, in order (sizes in columns; is_model: a sub-stage's model) */
+int fokl_search_speculate(fokl_search *search, const int32_t *sizes, const int32_t *is_model, int count);
+int fokl_search_drop_speculation(fokl_search *search);
+/* G2 (fokl_pool_submit_spectral) with the result buffer owned by the search: lamb [p1] | qty [p1] | betahat [p1] |
+ * Qt [p1, p1] | moments [2]; gram must stay alive until the job has run */
+int fokl_search_spectral(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1, fokl_spectrum **out);
+int fokl_spectrum_done(fokl_spectrum *spectrum);
+int fokl_spectrum_wait(fokl_search *search, fokl_spectrum *spectrum, const double **buffer, int *p1);
+void fokl_spectrum_release(fokl_search *search, fokl_spectrum *spectrum);
+int fokl_search_model_begin(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1,
+                            fokl_spectrum *given, const int32_t *then_sizes, const int32_t *then_model, int then_count,
+                            fokl_spectrum **spectrum_out, fokl_tape **tape_out);
+int fokl_search_model_commit(fokl_search *search, fokl_spectrum *spectrum, fokl_tape *tape, double dtd, fokl_outcome **out);
+int fokl_search_score(fokl_search *search, fokl_outcome *outcome, double sum_r, double sum_r2, int n_prev, int kill,
+                      double *ev);
+typedef struct fokl_outcome_view {
+    const double *spectrum;                     /* lamb | qty | betahat | Qt | moments of the model */
+    const int32_t *idx;                         /* its active-column indices [p1] */
+    double ev, siglik, intercept_scale;         /* intercept_scale: NaN while unknown */
+    int32_t p1, on_device;
+} fokl_outcome_view;
+int fokl_outcome_info(fokl_search *search, fokl_outcome *outcome, fokl_outcome_view *view);
+int fokl_outcome_chain_ready(fokl_outcome *outcome);
+int fokl_outcome_draws(fokl_search *search, fokl_outcome *outcome, const double **w);
+int fokl_outcome_intercept_scale(fokl_search *search, fokl_outcome *outcome, double *scale);
+void fokl_outcome_release(fokl_search *search, fokl_outcome *outcome);
+void fokl_outcome_drop(fokl_search *search, fokl_outcome *outcome);
+int fokl_search_verify(fokl_search *search, int block);
+int fokl_search_register_forecast(fokl_search *search, const int32_t *key, int key_count, fokl_spectrum *spectrum,
+                                  double dtd);
+void fokl_search_clear_forecasts(fokl_search *search);
+int fokl_search_likely_first_tests(fokl_search *search, fokl_spectrum *spectrum, int n_new, double siglik,
+                                   int32_t *columns_out, int *count);
+/* counters / seconds in the order of csrc/fokl_search.cpp's Stat enumeration (-> their number); the trace: 4 doubles per
+ * evaluation (columns, built, ev, kill) */
+int fokl_search_stats(const fokl_search *search, double *values, int count);
+int64_t fokl_search_trace(const fokl_search *search, double *records, int64_t capacity);
+/*
+ * One sub-stage's kill tests.  gram [(active + 1)^2]: Gram of the active columns with y last; columns / mean_abs /
+ * rel_std [proposals]: the new terms in testing order (ascending |mean beta|, FR:1663-1664): active-column index,
+ * |mean beta| (FR:1656), std / |mean| (FR:1657-1658); slots [active]: device slot of every active column (the key of
+ * forecasts); best: the sub-stage's model.  ahead_*: G2 jobs the caller submitted for first trial sets (keys: active
+ * column indices, CSR offsets).  vm_next: columns the coming sub-stage adds (-1: there is none).  Callbacks (may be
+ * NULL) run on the calling thread: foresee(predicted kill set) towards the end of the loop; idle_work once, when the
+ * first test's tape and G2 are under way (or at the end); residual: sum r, sum r^2 of y - X betahat for a candidate
+ * that (nearly) interpolates the data.  killed [>= proposals] receives the kill set (ascending); best: the model the
+ * sub-stage ends on (best_is_new: a new handle the caller owns, else the one passed in).
+ */
+typedef struct fokl_kill_tests_args {
+    const double *gram;
+    const int32_t *columns;
+    const double *mean_abs, *rel_std;
+    const int32_t *slots;
+    fokl_outcome *best;
+    const int32_t *ahead_keys, *ahead_offsets;
+    fokl_spectrum *const *ahead_spectra;
+    void *user;
+    void (*foresee)(void *user, const int32_t *killed, int count);
+    int (*idle_work)(void *user);
+    int (*residual)(void *user, const int32_t *idx, int p1, const double *betahat, double *sum_r, double *sum_r2);
+    int32_t active, proposals, n_prev, vm_next, ahead_count;
+} fokl_kill_tests_args;
+typedef struct fokl_kill_tests_result {
+    int32_t *killed;
+    fokl_outcome *best;
+    double evmin;
+    int32_t killed_count, best_is_new;
+} fokl_kill_tests_result;
+int fokl_search_kill_tests(fokl_search *search, const fokl_kill_tests_args *args, fokl_kill_tests_result *result);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* N4: the consumer of fitted models, GP_Integrate (reference src/FoKL/GP_Integrate.py:5-282)               */
 /* ------------------------------------------------------------------------------------------------------ */
 
@@ -491,7 +608,6 @@ int fokl_gp_integrate(int n_states, int n_other, int64_t n_steps, const double *
  * one more double behind it holds the seconds the chain's wavefront ran (the kernel's own clock).
  * The area belongs to the job's slot: valid until the job is released.
  * Errors: FOKL_ERR_STATE when every slot is taken (the caller runs that chain on the host). */
-typedef struct fokl_dchain fokl_dchain;
 int fokl_dchain_create(int device, int slots, fokl_dchain **out);
 void fokl_dchain_destroy(fokl_dchain *engine);
 int fokl_dchain_submit(fokl_dchain *engine, int p1, int draws, const double *lamb, const double *qty, double b,

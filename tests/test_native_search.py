@@ -1,0 +1,100 @@
+"""The native search core (csrc/fokl_search.cpp: tapes on order, G2 ahead, chains, the kill-test loop FR:1666-1690) against
+engine.py's own statement of the same logic (FOKL_SEARCH=python), on the CPU stand-in backend: same sequence of model
+evaluations (sizes, BICs, kill flags), same selected model, same draws, same consumption of numpy's random stream."""
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import OracleBackend, load_case
+from fokl_gpy_amd import FoKLRoutines, engine, _capi
+
+
+def _fit(monkeypatch, driver, name=None, problem=None, env=(), **hypers):
+    monkeypatch.setenv('FOKL_SEARCH', driver)
+    for key, value in env:
+        monkeypatch.setenv(key, value)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if name is not None:
+            g, hy, kname, kid, phis = load_case(name)
+            model = FoKLRoutines.FoKL(kernel=kname, phis=phis, UserWarnings=False, ConsoleOutput=False, **{**hy, **hypers})
+            x, y, seed = g['raw_inputs'], g['raw_data'], int(g['seed'])
+        else:
+            x, y, seed = problem
+            model = FoKLRoutines.FoKL(kernel=1, UserWarnings=False, ConsoleOutput=False, **hypers)
+        model._backend_override = OracleBackend()
+        np.random.seed(seed)
+        betas, mtx, evs = model.fit(x, y, clean=True)
+    st = np.random.get_state()
+    return model, betas, mtx, evs, (st[1].copy(), st[2], st[3], st[4])
+
+
+def _same(a, b):
+    ma, ba, xa, ea, sa = a
+    mb, bb, xb, eb, sb = b
+    assert ma.fit_stats['search_driver'] == 'native' and mb.fit_stats['search_driver'] == 'python'
+    assert [(t['cols'], t['built'], t['kill']) for t in ma.fit_trace] == \
+           [(t['cols'], t['built'], t['kill']) for t in mb.fit_trace]
+    assert np.allclose([t['ev'] for t in ma.fit_trace], [t['ev'] for t in mb.fit_trace], rtol=1e-12, atol=0)
+    assert np.array_equal(xa, xb)
+    assert np.allclose(ea, eb, rtol=1e-12, atol=0)
+    assert ba.shape == bb.shape and np.max(np.abs(ba - bb)) <= 1e-12 * np.max(np.abs(bb))
+    assert np.array_equal(sa[0], sb[0]) and sa[1:] == sb[1:]             # the stream ends on the same state
+    for key in ('gibbs_calls', 'kill_tests', 'terms_logical', 'substages'):
+        assert ma.fit_stats[key] == mb.fit_stats[key], key
+
+
+@pytest.mark.parametrize('name', ['bern_m1', 'bern_m3', 'bern_m4_way3', 'bern_m6', 'bern_m8_capped', 'splines_m4'])
+def test_native_search_equals_the_python_search_on_the_fixtures(monkeypatch, name):
+    _same(_fit(monkeypatch, 'native', name), _fit(monkeypatch, 'python', name))
+
+
+def _random_problem(seed, n=600, m=5):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.3 * x[:, 3] ** 2 + 0.05 * rng.standard_normal(n)
+    return x, y, 1000 + seed
+
+
+@pytest.mark.parametrize('seed', [3, 10, 29, 53])
+@pytest.mark.parametrize('env', [(), (('FOKL_TENTATIVE_TAPES', 'test'),), (('FOKL_LOOKAHEAD', '0'), ('FOKL_FORESIGHT', '0')),
+                                 (('FOKL_SPECULATION', '2'),), (('FOKL_FINISH_THREADS', '0'),)])
+def test_native_search_equals_the_python_search_whatever_is_ordered_ahead(monkeypatch, seed, env):
+    """Forced rewinds before every order, no look-ahead at all, a short order book, no finish threads: what is prepared
+    ahead differs, what is evaluated does not."""
+    problem = _random_problem(seed)
+    hy = dict(draws=60, burnin=60)
+    _same(_fit(monkeypatch, 'native', problem=problem, env=env, **hy),
+          _fit(monkeypatch, 'python', problem=problem, env=env, **hy))
+
+
+def test_native_objects_are_released(monkeypatch):
+    """A fit leaves no tape on order and nothing in flight: the pool can be torn down and the stream written back (the
+    state compared above); spare buffers are reused by the next fit (same process, no growth in what is kept)."""
+    problem = _random_problem(7)
+    a = _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
+    b = _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])
+    assert a[0].fit_stats['tapes_rewound'] == b[0].fit_stats['tapes_rewound']
+
+
+def test_a_callback_that_raises_surfaces_after_the_native_loop(monkeypatch):
+    problem = _random_problem(3)
+    monkeypatch.setenv('FOKL_SEARCH', 'native')
+    boom = RuntimeError('device gone')
+    real = engine.ForwardSelection._build_ahead
+    calls = []
+
+    def failing(self, indvec, active_slots):
+        calls.append(1)
+        if len(calls) == 3:
+            raise boom
+        return real(self, indvec, active_slots)
+
+    monkeypatch.setattr(engine.ForwardSelection, '_build_ahead', failing)
+    with pytest.raises(RuntimeError, match='device gone'):
+        _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
+    # and the next fit in this process works: nothing was left half torn down
+    monkeypatch.setattr(engine.ForwardSelection, '_build_ahead', real)
+    _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
