@@ -56,10 +56,12 @@ SIGNATURES = {
                                 c_vp]),
     'fokl_gibbs_chain_from_tape': (c_int, [c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'fokl_pool_stream': (c_vp, [c_vp]),
+    'fokl_pool_release_hold': (c_int, [c_vp, ctypes.c_uint64]),
     'fokl_pool_destroy': (None, [c_vp]),
     'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
-                                       c_vp, c_int, c_int, c_vp]),
+                                       c_vp, c_int, c_int, c_vp, c_vp]),
     'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -70,7 +72,9 @@ SIGNATURES = {
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_noise_waits': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_pool_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'fokl_stream_create': (c_int, [c_vp, c_i32, c_i32, c_dbl, c_int, c_vp]),
+    'fokl_stream_create': (c_int, [c_vp, c_i32, c_i32, c_dbl, c_int, c_vp, c_int, c_vp]),
+    'fokl_stream_prestates_published': (c_i64, [c_vp]),
+    'fokl_stream_given_gauss': (c_dbl, [c_vp]),
     'fokl_stream_destroy': (None, [c_vp]),
     'fokl_stream_walk': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_tell': (c_int, [c_vp, c_vp]),
@@ -120,6 +124,11 @@ SIGNATURES = {
     'fokl_dchain_destroy': (None, [c_vp]),
     'fokl_dchain_submit': (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    'fokl_dchain_prestate_ring': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_dchain_bind_stream': (c_int, [c_vp, c_vp]),
+    'fokl_dchain_submit_rows': (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp,
+                                        c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    'fokl_dchain_stream_stats': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_dchain_try_release': (c_int, [c_vp, c_i64]),
     'fokl_dchain_poll': (c_int, [c_vp, c_i64]),
     'fokl_dchain_wait': (c_int, [c_vp, c_i64, c_vp]),
@@ -366,13 +375,16 @@ class StreamEngine:
     (tests, tools; a fit's engine lives inside its pool).  ``walk`` fills a NoiseTape's rows, ``expand`` turns them into
     the numbers fokl_noise_tape records; the part of the stream a tape covers is held from its walk until ``release``."""
 
-    def __init__(self, stream, bulk_threads=2):
+    def __init__(self, stream, bulk_threads=2, prestates=None):
+        """prestates: (address, entries) of DeviceChainEngine.prestate_ring() when a device will expand this stream's
+        tapes from rows."""
         self._lib = load()
         self._h = None
         self.stream = stream
         h = c_vp(0)
         _check(self._lib.fokl_stream_create(_ptr(stream.key), stream.pos, stream.has_gauss, stream.cache,
-                                            int(bulk_threads), ctypes.byref(h)))
+                                            int(bulk_threads), prestates[0] if prestates else None,
+                                            prestates[1] if prestates else 0, ctypes.byref(h)))
         self._h = h
 
     def close(self, write_back=True):
@@ -554,7 +566,10 @@ class HostPool:
     """include/fokl_hip.h: fokl_pool_* -- the noise thread (owns ``stream`` until close()), chain threads and
     spectral threads of one fit."""
 
-    def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1, bulk_threads=2):
+    def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1, bulk_threads=2,
+                 prestates=None):
+        """prestates: (address, entries) of a pre-state ring (DeviceChainEngine.prestate_ring()) for a device that
+        regenerates the stream itself."""
         self._lib = load()
         self.stream = stream
         self._h = None
@@ -563,9 +578,13 @@ class HostPool:
         self.finish_threads = int(finish_threads)
         _check(self._lib.fokl_pool_create(int(chain_threads), self.finish_threads, int(spectral_threads),
                                           max(1, int(bulk_threads)), int(noise_cpu), c_vp(fn),
-                                          *stream.args(),
-                                          ctypes.byref(h)))
+                                          *stream.args(), prestates[0] if prestates else None,
+                                          prestates[1] if prestates else 0, ctypes.byref(h)))
         self._h = h
+
+    def stream_handle(self):
+        """The pool's fokl_stream (for DeviceChainEngine.bind)."""
+        return self._lib.fokl_pool_stream(self._h)
 
     def close(self):
         """Runs everything still queued (each submitted tape advances the stream), then stops the threads."""
@@ -583,7 +602,7 @@ class HostPool:
         _check(self._lib.fokl_pool_submit_noise(self._h, tape.p1, tape.draws, float(astar), float(atau_star),
                                                 tape.rows_pointer(), *tape.pointers(), tape.progress_pointer(),
                                                 int(bool(tentative)), tape.block_done_pointer(), tape.BLOCK, int(finish),
-                                                ctypes.byref(h)))
+                                                None, ctypes.byref(h)))
         tape.finishing_requested = finish
         tape.materialised_by_pool = True
         return PoolJob(h, (tape,), tape, tentative)
@@ -637,7 +656,7 @@ class _SearchParams(ctypes.Structure):
                 ('threshstda', c_dbl), ('threshstdb', c_dbl), ('guess_margin', c_dbl), ('draws', c_i32), ('half0', c_i32),
                 ('aic', c_i32), ('lookahead', c_i32), ('foresight', c_i32), ('speculation_max', c_i32),
                 ('tentative_tapes', c_i32), ('test_rewinds', c_i32), ('device_chain_columns', c_i32),
-                ('finish_threads', c_i32), ('flip_guess', c_i32)]
+                ('finish_threads', c_i32), ('flip_guess', c_i32), ('device_rows', c_i32)]
 
 
 class _OutcomeView(ctypes.Structure):
@@ -665,7 +684,7 @@ class _KillTestsResult(ctypes.Structure):
 SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain', 'chains_materialised', 'bic_from_gram',
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
-                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop')
+                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains')
 
 
 class NativeSearch:
@@ -1038,6 +1057,35 @@ class DeviceChainEngine:
                                             tape.BLOCK, int(finished),
                                             int(stat_first), ctypes.byref(ticket), ctypes.byref(area)))
         return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape,), area.value)
+
+    def prestate_ring(self):
+        """(address, entries) of the page-locked ring a stream's bulk threads leave its pre-states in: hand it to the
+        HostPool / StreamEngine whose tapes this engine will expand from rows, then ``bind`` that stream."""
+        ring, entries = c_vp(0), c_int(0)
+        _check(self._lib.fokl_dchain_prestate_ring(self._h, ctypes.byref(ring), ctypes.byref(entries)))
+        return ring.value, entries.value
+
+    def bind(self, stream_handle):
+        _check(self._lib.fokl_dchain_bind_stream(self._h, stream_handle))
+
+    def submit_rows(self, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, astar, atau_star, tape, span, stat_first=0):
+        """The chain of a tape that exists as rows (``tape.rows``, its gamma arrays and progress word in page-locked
+        memory); span: uint64 [2] as fokl_pool_submit_noise fills it (position held from, position behind the tape)."""
+        lamb = np.ascontiguousarray(lamb, dtype=np.float64)
+        qty = np.ascontiguousarray(qty, dtype=np.float64)
+        p1 = lamb.shape[0]
+        ptr = tape.pointers()
+        ticket, area = c_i64(0), c_vp(0)
+        _check(self._lib.fokl_dchain_submit_rows(self._h, p1, tape.draws, _ptr(lamb), _ptr(qty), float(b), float(btau),
+                                                 float(dtd), float(sigsqd0), float(tausqd0), float(astar), float(atau_star),
+                                                 tape.rows_pointer(), ptr[3], ptr[4], tape.progress_pointer(), _ptr(span),
+                                                 int(stat_first), ctypes.byref(ticket), ctypes.byref(area)))
+        return DeviceChainJob(self, ticket.value, p1, tape.draws, (tape, span), area.value)
+
+    def stream_stats(self):
+        seg, rows = c_i64(0), c_i64(0)
+        _check(self._lib.fokl_dchain_stream_stats(self._h, ctypes.byref(seg), ctypes.byref(rows)))
+        return dict(segments_made=seg.value, rows_jobs=rows.value)
 
     def stats(self):
         busy, issued, launches, staged = c_dbl(0), c_i64(0), c_i64(0), c_i64(0)

@@ -47,6 +47,12 @@ extern "C" int fokl_dchain_submit(fokl_dchain *, int, int, const double *, const
 {
     return FOKL_ERR_HIP;
 }
+extern "C" int fokl_dchain_submit_rows(fokl_dchain *, int, int, const double *, const double *, double, double, double, double,
+                                       double, double, double, const fokl_tape_row *, const double *, const double *,
+                                       const int32_t *, const uint64_t *, int, int64_t *, const double **)
+{
+    return FOKL_ERR_HIP;
+}
 extern "C" int fokl_dchain_wait(fokl_dchain *, int64_t, double *) { return FOKL_ERR_HIP; }
 extern "C" int fokl_dchain_fetch_w(fokl_dchain *, int64_t, double *) { return FOKL_ERR_HIP; }
 extern "C" int fokl_dchain_release(fokl_dchain *, int64_t) { return FOKL_ERR_HIP; }

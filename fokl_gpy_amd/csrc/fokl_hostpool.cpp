@@ -87,6 +87,9 @@ struct fokl_host_job {
     fokl_tape_row *rows = nullptr;          // noise / finish: the tape as the walk leaves it
     uint64_t hold = 0;                      // noise: the stream is kept readable from here on until the job settles
     bool held = false;
+    uint64_t *span_out = nullptr;           // noise: [hold position, walker position behind the tape]; the hold then is
+                                            // the caller's to release (fokl_pool_release_hold)
+    bool rows_only = false;                 // noise: nobody materialises the tape here (the device expands the rows)
     bool finish_normals = false;            // finish: complete the normals in place after expanding them
     double *normals = nullptr, *pair_r2 = nullptr, *gam_sig = nullptr, *gam_tau = nullptr;
     int32_t *lead = nullptr, *progress = nullptr;
@@ -364,7 +367,7 @@ void settle(fokl_host_job *job)                            // status / error wer
 {
     if (job->pending.fetch_sub(1, std::memory_order_acq_rel) != 1) return;      // somebody is still on the tape
     fokl_host_pool *pool = job->pool;                       // the job may be freed by its waiter right after `done`
-    if (job->held) {                                        // nobody reads this tape's part of the stream any more
+    if (job->held && !job->span_out) {                      // nobody reads this tape's part of the stream any more
         job->held = false;
         fokl_stream_release(pool->stream, job->hold);
     }
@@ -381,7 +384,19 @@ void record_tape(fokl_host_pool *pool, fokl_host_job *job)
     job->t_start = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
     int rc = fokl_stream_hold(pool->stream, &job->hold);
     job->held = rc == FOKL_OK;
-    if (rc == FOKL_OK && !pool->finish_q.empty()) {
+    if (job->span_out) job->span_out[0] = job->hold;
+    if (rc == FOKL_OK && job->rows_only) {
+        // the walk writes progress itself; the span must be there before the last block is published
+        int32_t local = 0;
+        rc = fokl_stream_walk(pool->stream, job->p1, job->draws, job->astar, job->atau_star, job->rows, job->gam_sig,
+                              job->gam_tau, &local);
+        if (rc == FOKL_OK) {
+            fokl_stream_cursor at;
+            fokl_stream_tell(pool->stream, &at);
+            if (job->span_out) job->span_out[1] = at.position;
+        }
+        __atomic_store_n(job->progress, rc == FOKL_OK ? job->draws : -1, __ATOMIC_RELEASE);
+    } else if (rc == FOKL_OK && !pool->finish_q.empty()) {
         // the finish threads follow `progress` and turn the rows into numbers
         rc = fokl_stream_walk(pool->stream, job->p1, job->draws, job->astar, job->atau_star, job->rows, job->gam_sig,
                               job->gam_tau, job->progress);
@@ -549,7 +564,7 @@ void stop(Queue &queue)
 
 extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads,
                                 int noise_cpu, void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss,
-                                double *gauss_cache, fokl_host_pool **out)
+                                double *gauss_cache, uint32_t *prestate_ring, int prestate_entries, fokl_host_pool **out)
 {
     if (!out || chain_threads < 1 || bulk_threads < 1 || bulk_threads > 16 || spectral_threads < 0 || chain_threads > 64 || spectral_threads > 64 ||
         finish_threads < 0 || finish_threads > 64 || !mt_key ||
@@ -562,7 +577,8 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
         return FOKL_ERR_ARG;
     }
     auto *pool = new fokl_host_pool();
-    if (fokl_stream_create(mt_key, *mt_pos, *has_gauss, *gauss_cache, bulk_threads, &pool->stream) != FOKL_OK) {
+    if (fokl_stream_create(mt_key, *mt_pos, *has_gauss, *gauss_cache, bulk_threads, prestate_ring, prestate_entries,
+                           &pool->stream) != FOKL_OK) {
         delete pool;
         return FOKL_ERR_STATE;
     }
@@ -657,10 +673,12 @@ static void submit_finish_jobs(fokl_host_pool *pool, fokl_host_job *parent, bool
 extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star,
                                       fokl_tape_row *rows, double *normals, double *pair_r2, int32_t *lead,
                                       double *gam_sig, double *gam_tau, int32_t *progress, int tentative,
-                                      int32_t *block_done, int block, int finish, fokl_host_job **out)
+                                      int32_t *block_done, int block, int finish, uint64_t *span_out,
+                                      fokl_host_job **out)
 {
-    if (!pool || !out || p1 <= 0 || draws < 0 || !rows || !normals || !pair_r2 || !lead || !gam_sig || !gam_tau ||
-        !progress || !block_done || block < 1) {
+    const bool rows_only = finish == 2;
+    if (!pool || !out || p1 <= 0 || draws < 0 || !rows || !gam_sig || !gam_tau || !progress ||
+        (!rows_only && (!normals || !pair_r2 || !lead || !block_done || block < 1)) || (rows_only && !span_out)) {
         fokl_set_global_error("fokl_pool_submit_noise: null pointer, empty model or bad block size");
         return FOKL_ERR_ARG;
     }
@@ -681,13 +699,15 @@ extern "C" int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, d
     job->block_done = block_done;
     job->block = block;
     job->tentative = tentative != 0;
+    job->span_out = span_out;
+    job->rows_only = rows_only;
     if (!pool->trace_path.empty()) job->t_submit = now_ns();
     *out = job;
-    if (!pool->finish_q.empty()) {
+    if (!rows_only && !pool->finish_q.empty()) {
         // the finish threads follow the walk whether or not a chain has been asked for yet (a tape walked ahead of the
         // decision that it is needed is complete when its chain comes); a tape that is sent back ends these jobs too
         job->pending.store(1 + (int)pool->finish_q.size(), std::memory_order_relaxed);
-        submit_finish_jobs(pool, job, finish != 0);
+        submit_finish_jobs(pool, job, finish == 1);
     }
     submit(pool->noise_q, job);
     return FOKL_OK;
@@ -822,6 +842,17 @@ extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise,
     if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
     if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
     return FOKL_OK;
+}
+
+extern "C" fokl_stream *fokl_pool_stream(fokl_host_pool *pool) { return pool ? pool->stream : nullptr; }
+
+extern "C" int fokl_pool_release_hold(fokl_host_pool *pool, uint64_t position)
+{
+    if (!pool) {
+        fokl_set_global_error("fokl_pool_release_hold: null pool");
+        return FOKL_ERR_ARG;
+    }
+    return fokl_stream_release(pool->stream, position);
 }
 
 // The pool's random stream (fokl_stream_stats): CPU seconds of its bulk threads, seconds the walker waited for them,

@@ -140,6 +140,14 @@ struct Tape {
     int32_t *progress = nullptr, *block_done = nullptr, *lead = nullptr;
     fokl_tape_row *rows = nullptr;
     bool finishing = false;                 // the finish threads complete the normals in place
+    // a tape the DEVICE expands (fokl_dchain_submit_rows) exists as rows only: [progress | rows | gam_sig | gam_tau] in a
+    // small page-locked block; materialise() gives it the arrays after all (a host chain has to read it)
+    bool rows_only = false;
+    double *rows_mem = nullptr;
+    size_t rows_classes = 0;
+    uint64_t span[2] = {0, 0};              // [position the stream is held from, position behind the tape]
+    bool holds_stream = false;
+    double astar = 0, atau_star = 0;
     fokl_host_job *noise = nullptr;         // freed (fokl_pool_wait) when the tape goes
     int refs = 1;
     std::vector<fokl_host_job *> readers;   // host chains given up while they may still be reading the tape
@@ -198,7 +206,7 @@ enum Stat {
     S_GIBBS_CALLS, S_KILL_TESTS, S_TERMS_LOGICAL, S_T_EIGH, S_T_CHAIN, S_CHAINS_MATERIALISED, S_BIC_FROM_GRAM,
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
-    S_T_RESID, S_T_KILL_LOOP, S_COUNT
+    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_COUNT
 };
 
 }  // namespace
@@ -301,6 +309,42 @@ Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
     t->draws = s->prm.draws;
     t->model = model;
     t->tentative = tentative;
+    const double astar = s->prm.a + 1 + s->prm.n / 2.0 + p1 / 2.0;      // FR:1508 (mmtx + 1 == p1)
+    const double atau_star = s->prm.atau + (p1 - 1) / 2.0;            // FR:1510
+    t->astar = astar;
+    t->atau_star = atau_star;
+    // a kill test's chain runs on the device when there is an engine: its tape stays raw (the device finishes it) -- or,
+    // with the stream regenerated on the device, is never materialised on the host at all;
+    // a model's tape is finished by host threads while it is walked (its statistics order the tests: latency matters)
+    const bool on_device = !model && s->dchain && p1 <= s->prm.device_chain_columns;
+    if (on_device && s->prm.device_rows && astar > 1.0 && atau_star > 1.0) {
+        const size_t d = (size_t)t->draws;
+        bool pinned = false;
+        t->rows_mem = take_buffer(8 + 6 * d + 8, true, &t->rows_classes, &pinned);
+        if (t->rows_mem && !pinned) {                       // the device reads rows in place: page-locked or not at all
+            give_buffer(t->rows_mem, t->rows_classes, false);
+            t->rows_mem = nullptr;
+        }
+        if (t->rows_mem) {
+            t->rows_only = true;
+            t->progress = reinterpret_cast<int32_t *>(t->rows_mem);
+            std::memset(t->rows_mem, 0, 64);
+            t->rows = reinterpret_cast<fokl_tape_row *>(t->rows_mem + 8);
+            t->gam_sig = t->rows_mem + 8 + 4 * d;
+            t->gam_tau = t->gam_sig + d;
+            const int rc = fokl_pool_submit_noise(s->pool, p1, t->draws, astar, atau_star, t->rows, nullptr, nullptr, nullptr,
+                                                  t->gam_sig, t->gam_tau, t->progress, tentative ? 1 : 0, nullptr,
+                                                  FOKL_TAPE_BLOCK, 2, t->span, &t->noise);
+            if (rc != FOKL_OK) {
+                give_buffer(t->rows_mem, t->rows_classes, true);
+                delete t;
+                s->error = "fokl_search: the pool refused a noise tape";
+                return nullptr;
+            }
+            t->holds_stream = true;
+            return t;
+        }
+    }
     t->mem = take_buffer(tape_doubles(p1, t->draws), s->pinned_tapes, &t->classes, &t->pinned);
     if (!t->mem) {
         delete t;
@@ -308,15 +352,10 @@ Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
         return nullptr;
     }
     carve(t);
-    const double astar = s->prm.a + 1 + s->prm.n / 2.0 + p1 / 2.0;      // FR:1508 (mmtx + 1 == p1)
-    const double atau_star = s->prm.atau + (p1 - 1) / 2.0;            // FR:1510
-    // a kill test's chain runs on the device when there is an engine: its tape stays raw (the device finishes it);
-    // a model's tape is finished by host threads while it is walked (its statistics order the tests: latency matters)
-    const bool on_device = !model && s->dchain && p1 <= s->prm.device_chain_columns;
     t->finishing = !on_device && s->prm.finish_threads > 0;
     const int rc = fokl_pool_submit_noise(s->pool, p1, t->draws, astar, atau_star, t->rows, t->normals, t->pair_r2,
                                           t->lead, t->gam_sig, t->gam_tau, t->progress, tentative ? 1 : 0,
-                                          t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, &t->noise);
+                                          t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, nullptr, &t->noise);
     if (rc != FOKL_OK) {
         give_buffer(t->mem, t->classes, t->pinned);
         delete t;
@@ -324,6 +363,42 @@ Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
         return nullptr;
     }
     return t;
+}
+
+// A rows-only tape gets its arrays after all: a host chain has to read it (no device slot was free, a borderline guess is
+// settled in line, the first row opens with the cached normal of the state handed over).  Waits for the walk.
+int materialise(fokl_search *s, Tape *t)
+{
+    if (!t->rows_only) return FOKL_OK;
+    for (int spins = 0;; ++spins) {
+        const int32_t p = __atomic_load_n(t->progress, __ATOMIC_ACQUIRE);
+        if (p < 0) return fail(s, FOKL_ERR_STATE, "fokl_search: the tape to materialise was sent back");
+        if (p >= t->draws) break;
+        if (spins < 2000)
+            _mm_pause();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+    }
+    t->mem = take_buffer(tape_doubles(t->p1, t->draws), false, &t->classes, &t->pinned);
+    if (!t->mem) return fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a noise tape");
+    const fokl_tape_row *rows = t->rows;
+    const double *gs = t->gam_sig, *gt = t->gam_tau;
+    int32_t *walked = t->progress;
+    carve(t);
+    std::memcpy(t->rows, rows, sizeof(fokl_tape_row) * (size_t)t->draws);
+    std::memcpy(t->gam_sig, gs, sizeof(double) * (size_t)t->draws);       // variates the walker stored itself (shapes <= 1)
+    std::memcpy(t->gam_tau, gt, sizeof(double) * (size_t)t->draws);
+    (void)walked;
+    const int rc = fokl_stream_expand(fokl_pool_stream(s->pool), t->p1, t->astar, t->atau_star, t->rows, 0, t->draws,
+                                      t->normals, t->pair_r2, t->lead, t->gam_sig, t->gam_tau);
+    if (rc != FOKL_OK) return rc;
+    const int nblocks = (t->draws + FOKL_TAPE_BLOCK - 1) / FOKL_TAPE_BLOCK;
+    for (int b = 0; b < nblocks; ++b) t->block_done[b] = 1;
+    __atomic_store_n(t->progress, t->draws, __ATOMIC_RELEASE);
+    t->rows_only = false;
+    t->finishing = false;
+    s->stats[S_TAPES_MATERIALISED] += 1;
+    return FOKL_OK;
 }
 
 void unref(fokl_search *s, Tape *t)
@@ -676,7 +751,9 @@ void reap(fokl_search *s, bool block)
         Tape *t = s->tape_limbo[i];
         if (block || fokl_pool_poll(t->noise)) {
             (void)fokl_pool_wait(t->noise);
+            if (t->holds_stream) (void)fokl_pool_release_hold(s->pool, t->span[0]);   // nobody expands its rows any more
             give_buffer(t->mem, t->classes, t->pinned);
+            give_buffer(t->rows_mem, t->rows_classes, true);
             delete t;
             s->tape_limbo[i] = s->tape_limbo.back();
             s->tape_limbo.pop_back();
@@ -725,7 +802,32 @@ Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
     sp->refs += 1;
     o->tape = t;                                            // takes over the caller's reference
     const int p1 = sp->p1;
-    if (test && s->dchain && p1 <= s->prm.device_chain_columns && s->prechain.tape != t) {
+    if (test && t->rows_only && t->rows[0].lead_source == FOKL_SOURCE_GIVEN && (t->rows[0].start & FOKL_ROW_LEAD) &&
+        __atomic_load_n(t->progress, __ATOMIC_ACQUIRE) > 0) {
+        // (the very first tape of a stream handed over with a cached normal: that value exists on the host only)
+        if (materialise(s, t) != FOKL_OK) {
+            destroy_outcome(s, o);
+            return nullptr;
+        }
+    }
+    if (test && t->rows_only) {
+        const int rc = fokl_dchain_submit_rows(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
+                                               s->sigsqd0, s->tausqd0, t->astar, t->atau_star, t->rows, t->gam_sig,
+                                               t->gam_tau, t->progress, t->span, s->prm.half0, &o->ticket, &o->stats_area);
+        if (rc == FOKL_OK) {
+            o->on_device = true;
+            o->refs += 1;
+            s->device_outcomes.push_back(o);
+            s->stats[S_DEVICE_CHAINS] += 1;
+            s->stats[S_ROWS_CHAINS] += 1;
+            return o;
+        }
+        if (rc != FOKL_ERR_STATE || materialise(s, t) != FOKL_OK) {     // FOKL_ERR_STATE: every slot is alive -> host chain
+            destroy_outcome(s, o);
+            return nullptr;
+        }
+    }
+    if (test && s->dchain && !t->rows_mem && p1 <= s->prm.device_chain_columns && s->prechain.tape != t) {
         const int rc = fokl_dchain_submit(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
                                           s->sigsqd0, s->tausqd0, t->normals, t->lead, t->gam_sig, t->gam_tau, t->progress,
                                           t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, s->prm.half0, &o->ticket,
@@ -795,6 +897,10 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
         const double t0 = now_s();
         Tape *t = o->tape;
         const int p1 = o->spec->p1;
+        if (t->rows_only) {
+            const int rcm = materialise(s, t);
+            if (rcm != FOKL_OK) return -2 + rcm;
+        }
         size_t classes;
         bool pinned;
         double *w = take_w(s, p1, &classes, &pinned);
@@ -1157,10 +1263,9 @@ extern "C" void fokl_outcome_drop(fokl_search *s, fokl_outcome *h)
 {
     if (!s || !h) return;
     Outcome *o = reinterpret_cast<Outcome *>(h);
-    if (o->on_device && !o->released) {
-        o->checks.clear();
-        release_outcome(s, o);
-    }
+    // (a device chain whose statistics still have to confirm guessed decisions keeps its slot until they have: the queue
+    // of unverified outcomes holds a reference of its own)
+    release_outcome(s, o);
     unref(s, o);
 }
 

@@ -49,18 +49,19 @@ extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 namespace {
 
 constexpr int MT_N = 624, MT_SHIFT = 227;                   // 227 = 624 - 397
-constexpr int kSegBlocks = 256;
+constexpr int kSegBlocks = FOKL_SEGMENT_BLOCKS;
 constexpr int kSegWords = kSegBlocks * MT_N;                // 159 744 words
 constexpr int kSegDoubles = kSegWords / 2;                  // 79 872 doubles (attempts may start at each of them)
+static_assert(kSegDoubles == FOKL_SEGMENT_DOUBLES, "include/fokl_hip.h and this file disagree on the segment size");
 constexpr int kSegSlots = kSegDoubles / 2;                  // 39 936 attempts per alignment
 constexpr int kSegMaskWords = kSegSlots / 64;               // 624 mask words per alignment
 constexpr int kSegTail = 32;                                // words of the next segment kept behind this one's
 constexpr int kTable = 8192;                                // segments that can be alive at a time (524 M doubles)
 constexpr int kAhead = 6;                                   // segments produced ahead of the walker
-constexpr uint64_t kLeadBit = 1ull << 63;                   // fokl_tape_row.start: the row opens with the cached normal
-constexpr uint64_t kCachedHalf = 1ull << 63;                // a normal's source: the x1 half of the attempt (else x2)
-constexpr uint64_t kGivenGauss = (1ull << 62) - 1;          // source position: the cached value of the state handed over
-constexpr uint64_t kFinalValue = ~0ull;                     // fokl_tape_row.gamma[j]: the walker stored the variate itself
+constexpr uint64_t kLeadBit = FOKL_ROW_LEAD;                // fokl_tape_row.start: the row opens with the cached normal
+constexpr uint64_t kCachedHalf = FOKL_SOURCE_X1_HALF;       // a normal's source: the x1 half of the attempt (else x2)
+constexpr uint64_t kGivenGauss = FOKL_SOURCE_GIVEN;         // source position: the cached value of the state handed over
+constexpr uint64_t kFinalValue = FOKL_GAMMA_FINAL_VALUE;    // fokl_tape_row.gamma[j]: the walker stored the variate itself
 
 static_assert(kSegSlots % 64 == 0, "mask words must not straddle segments");
 
@@ -274,6 +275,12 @@ struct fokl_stream {
     int64_t oldest_alive = 0;                               // segments below were given back
     std::atomic<int64_t> limit{kAhead};                     // segments < limit may be produced
     std::atomic<int64_t> low_water{0};                      // segments < low_water will not be read again
+    // raw pre-states for a second consumer of the stream (the device regenerates segments from them): entry index %
+    // pre_entries = [624 raw words of the block in front of segment `index` (segment 0: block 0 itself) | index as two
+    // words | 1 if the words ARE block 0 | parity o | padding to FOKL_PRESTATE_WORDS]; written under the token, in order
+    uint32_t *pre_ring = nullptr;
+    int pre_entries = 0;
+    std::atomic<int64_t> pre_published{0};
     bool stop = false;
     std::atomic<bool> stop_flag{false};
     std::vector<std::thread> threads;
@@ -321,6 +328,15 @@ void generate_raw(fokl_stream *e, Segment *seg, int64_t index)
         from = 2 * MT_N;
     } else {
         std::memcpy(buf, e->carry, MT_N * sizeof(uint32_t));
+    }
+    if (e->pre_ring) {
+        uint32_t *entry = e->pre_ring + (size_t)(index % e->pre_entries) * FOKL_PRESTATE_WORDS;
+        std::memcpy(entry, index == 0 ? e->key0 : e->carry, MT_N * sizeof(uint32_t));
+        entry[MT_N] = (uint32_t)((uint64_t)index & 0xffffffffu);
+        entry[MT_N + 1] = (uint32_t)((uint64_t)index >> 32);
+        entry[MT_N + 2] = index == 0 ? 1u : 0u;
+        entry[MT_N + 3] = (uint32_t)e->o;
+        e->pre_published.store(index + 1, std::memory_order_release);
     }
     const int to = MT_N + kSegWords + kSegTail;
     if (e->wide)
@@ -1003,9 +1019,10 @@ inline uint64_t walker_reach(const fokl_stream *e)
 }  // namespace
 
 extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_t has_gauss, double gauss_cache,
-                                  int bulk_threads, fokl_stream **out)
+                                  int bulk_threads, uint32_t *prestate_ring, int prestate_entries, fokl_stream **out)
 {
-    if (!out || !mt_key || mt_pos < 0 || mt_pos > MT_N || bulk_threads < 1 || bulk_threads > 16) {
+    if (!out || !mt_key || mt_pos < 0 || mt_pos > MT_N || bulk_threads < 1 || bulk_threads > 16 ||
+        (prestate_ring && prestate_entries < 4 * kAhead)) {
         fokl_set_global_error("fokl_stream_create: null pointer, invalid MT19937 position or thread count");
         return FOKL_ERR_ARG;
     }
@@ -1018,6 +1035,8 @@ extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_
     e->has_gauss = has_gauss ? 1 : 0;
     e->gauss_src = kGivenGauss;
     e->gauss0 = gauss_cache;
+    e->pre_ring = prestate_ring;
+    e->pre_entries = prestate_ring ? prestate_entries : 0;
     e->wide = cpu_is_wide();
     for (auto &t : e->table) t.store(nullptr, std::memory_order_relaxed);
     try {
@@ -1074,6 +1093,14 @@ extern "C" int fokl_stream_walk(fokl_stream *e, int p1, int draws, double astar,
     return e->wide ? walk_tape_wide(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress)
                    : walk_tape_base(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress);
 }
+
+// segments whose pre-states have been written to the ring so far (they are written in order)
+extern "C" int64_t fokl_stream_prestates_published(const fokl_stream *e)
+{
+    return e ? e->pre_published.load(std::memory_order_acquire) : 0;
+}
+
+extern "C" double fokl_stream_given_gauss(const fokl_stream *e) { return e ? e->gauss0 : 0.0; }
 
 extern "C" int fokl_stream_tell(const fokl_stream *e, fokl_stream_cursor *out)
 {

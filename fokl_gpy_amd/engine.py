@@ -572,8 +572,7 @@ class ForwardSelection:
             spectrum, tape = ns.model_begin(gram, idx, spectral_job.h if spectral_job is not None else None,
                                             [(int(size), isinstance(size, ModelSize)) for size in then])
             try:
-                betahat = ns.spectrum_view(spectrum).betahat
-                self.stats['t_eigh'] += time.perf_counter() - t0
+                betahat = ns.spectrum_view(spectrum).betahat        # (the wait for G2 is counted by the native side)
                 cand_slots = [slots[i] for i in idx]
                 if self._async_resid:
                     self._launch_resid(cand_slots, idx, betahat)
@@ -961,7 +960,7 @@ class ForwardSelection:
                 lookahead=self.lookahead, foresight=self.foresight, speculation_max=self.speculation_max,
                 tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
                 device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
-                flip_guess=self._flip_guess)
+                flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
@@ -996,7 +995,10 @@ class ForwardSelection:
                     now = self.chain_engine.stats()               # the engine outlives the fit: this fit's share
                     self.stats.update({'dchain_' + k: v - self._dchain_stats0.get(k, 0) for k, v in now.items()})
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
-                self.stats.update(pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
+                self.stats.update(pool_bulk_s=busy.get('bulk', 0.0), walker_wait_s=busy.get('walker_wait', 0.0),
+                                  stream_segments=busy.get('stream_segments', 0),
+                                  gamma_attempts_exact=busy.get('gamma_attempts_exact', 0),
+                                  pool_noise_s=busy['noise'], pool_chain_s=busy['chain'],
                                   pool_finish_s=busy['finish'], pool_spectral_s=busy['spectral'],
                                   noise_queue_wait_s=busy['noise_queue_wait'],
                                   noise_verdict_wait_s=busy['noise_verdict_wait'],

@@ -250,8 +250,23 @@ class HostPipeline:
         if os.environ.get('FOKL_PIN_L3', '1') != '0':
             self._saved_affinity, noise_cpu = _place_host_threads()
         chain, finish, spectral = _thread_plan()
+        # With a device chain engine the stream's bulk threads leave every segment's pre-state in the engine's page-locked
+        # ring: the device regenerates the segments a tape covers and expands the tape from its 32-byte rows
+        # (fokl_dchain_submit_rows) -- the native search then never materialises a kill test's tape on the host.
+        # FOKL_DCHAIN_ROWS=0: tapes are materialised by the finish threads and read over the bus, as in round 3.
+        self.device_rows = False
+        prestates = None
+        if isinstance(chain_engine, _capi.DeviceChainEngine) and os.environ.get('FOKL_DCHAIN_ROWS', '1') != '0':
+            try:
+                prestates = chain_engine.prestate_ring()
+            except _capi.FoklNativeError:
+                prestates = None
         try:
-            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads())
+            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads(),
+                                       prestates=prestates)
+            if prestates is not None:
+                chain_engine.bind(self.pool.stream_handle())
+                self.device_rows = True
         except BaseException:
             self._restore_affinity()        # the caller may carry on in line: not pinned to one L3 domain
             raise
@@ -474,6 +489,9 @@ class HostPipeline:
         self._reap()                        # buffers of the jobs that have run now go back to the thread's spares
         self._live = []
         busy = self.pool.busy_seconds()
+        if self.device_rows:
+            self.dchain.bind(None)          # the stream goes with the pool
+            self.device_rows = False
         self.pool.close()
         self._restore_affinity()
         return busy
@@ -695,9 +713,7 @@ class NativeOutcome:
     @property
     def w(self):
         if self._w is None:
-            t0 = time.perf_counter()
-            self._w = self._ns.outcome_draws(self.h, self.lamb.shape[0])
-            self._owner.stats['t_chain'] += time.perf_counter() - t0
+            self._w = self._ns.outcome_draws(self.h, self.lamb.shape[0])     # (the wait is counted by the native side)
         return self._w
 
     @property

@@ -333,6 +333,13 @@ int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, doubl
  * bulk data does not move).  fokl_stream_state writes numpy's state tuple at the walker's position.
  * One thread at a time may walk / seek / tell / ask for the state; expand, hold-release and stats are thread-safe.
  */
+#define FOKL_SEGMENT_BLOCKS 256                      /* MT19937 blocks per segment of the stream */
+#define FOKL_SEGMENT_DOUBLES 79872                  /* = 256 * 624 / 2 doubles per segment */
+#define FOKL_ROW_LEAD (1ull << 63)                  /* fokl_tape_row.start: the row opens with the cached normal */
+#define FOKL_SOURCE_X1_HALF (1ull << 63)            /* a normal's source: the x1 half of the attempt (else x2) */
+#define FOKL_SOURCE_GIVEN ((1ull << 62) - 1)        /* source position: the cached normal of the state handed over */
+#define FOKL_GAMMA_FINAL_VALUE (~0ull)              /* fokl_tape_row.gamma[j]: the walker stored the variate itself */
+#define FOKL_PRESTATE_WORDS 640                     /* one entry of the pre-state ring (see fokl_stream_create) */
 typedef struct fokl_stream fokl_stream;
 typedef struct fokl_tape_row {
     uint64_t start;
@@ -344,8 +351,15 @@ typedef struct fokl_stream_cursor {
     uint64_t gauss_source;
     int32_t has_gauss;
 } fokl_stream_cursor;
+/* prestate_ring (may be NULL) [prestate_entries * FOKL_PRESTATE_WORDS]: for a second consumer that regenerates the stream
+ * itself (the device: fokl_dchain_*), the bulk threads leave there, per segment and in order, entry index %
+ * prestate_entries = the 624 raw words of the MT19937 block in front of the segment (segment 0: block 0 itself, word 626 =
+ * 1), the segment index (words 624, 625) and the word parity the doubles pair up from (word 627);
+ * fokl_stream_prestates_published counts them. */
 int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_t has_gauss, double gauss_cache, int bulk_threads,
-                       fokl_stream **out);
+                       uint32_t *prestate_ring, int prestate_entries, fokl_stream **out);
+int64_t fokl_stream_prestates_published(const fokl_stream *stream);
+double fokl_stream_given_gauss(const fokl_stream *stream);
 void fokl_stream_destroy(fokl_stream *stream);
 int fokl_stream_walk(fokl_stream *stream, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
                      double *gam_sig, double *gam_tau, int32_t *progress);
@@ -388,7 +402,9 @@ typedef struct fokl_host_job fokl_host_job;
  */
 int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads, int noise_cpu,
                      void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
-                     fokl_host_pool **out);
+                     uint32_t *prestate_ring, int prestate_entries, fokl_host_pool **out);
+/* the pool's stream (fokl_stream_expand of rows-only tapes; alive as long as the pool) */
+fokl_stream *fokl_pool_stream(fokl_host_pool *pool);
 void fokl_pool_destroy(fokl_host_pool *pool);
 /*
  * One model evaluation's tape on the noise thread: fokl_stream_walk into rows [draws] (progress must be given and start
@@ -396,7 +412,12 @@ void fokl_pool_destroy(fokl_host_pool *pool);
  * identical numbers) by the finish threads, block by block of `block` rows behind the walk: block_done [ceil(draws /
  * block)] (zero-initialised) receives 1 (release) per block, -1 if the tape is sent back.  finish != 0: the normals of
  * each block are also completed IN PLACE (the log / sqrt half of the polar method: tapes a host chain reads); the job
- * counts as run only when the finish threads have left the tape too.
+ * counts as run only when the finish threads have left the tape too.  finish == 2: ROWS ONLY -- nobody materialises
+ * the tape here (normals / pair_r2 / lead / block_done may be NULL): a consumer that has the stream itself expands the
+ * rows (the device: fokl_dchain_submit_rows; or fokl_stream_expand on fokl_pool_stream).
+ * span_out (may be NULL; required with finish == 2) receives [position the stream is held from for this tape, walker
+ * position behind the tape] before progress reaches `draws`; the hold is then the CALLER's: fokl_pool_release_hold
+ * when nobody will expand the rows any more.
  * tentative != 0: the tape is walked ahead of the decision that it is needed, and fokl_pool_resolve(job, commit) is
  * its verdict -- commit keeps the tape (identical to a plain submission at that point of the stream), otherwise the
  * walker is put back where the tape began and `progress` is set to -1.  Tentative tapes may be NESTED: up to 16 can be
@@ -409,7 +430,8 @@ void fokl_pool_destroy(fokl_host_pool *pool);
 int fokl_pool_submit_noise(fokl_host_pool *pool, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
                            double *normals, double *pair_r2, int32_t *lead, double *gam_sig, double *gam_tau,
                            int32_t *progress, int tentative, int32_t *block_done, int block, int finish,
-                           fokl_host_job **out);
+                           uint64_t *span_out, fokl_host_job **out);
+int fokl_pool_release_hold(fokl_host_pool *pool, uint64_t position);
 int fokl_pool_resolve(fokl_host_job *job, int commit);
 /*
  * The draws of one candidate from its tape (whose noise job must have been submitted with the same block_done): the
@@ -485,6 +507,8 @@ typedef struct fokl_search_params {
     int32_t device_chain_columns;               /* device chains for models of up to this many columns */
     int32_t finish_threads;                     /* of the pool (0: chains complete their normals themselves) */
     int32_t flip_guess;                         /* tests: the n-th guessed decision is taken wrong */
+    int32_t device_rows;                        /* the pool's stream leaves its pre-states with dchain: kill tests' tapes
+                                                   stay rows, the device expands them (fokl_dchain_submit_rows) */
 } fokl_search_params;
 int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_search_params *params, fokl_search **out);
 void fokl_search_destroy(fokl_search *search);
@@ -615,6 +639,24 @@ int fokl_dchain_submit(fokl_dchain *engine, int p1, int draws, const double *lam
                        const int32_t *lead, const double *gam_sig, const double *gam_tau, const int32_t *progress,
                        const int32_t *block_done, int block, int finished, int stat_first, int64_t *ticket,
                        const double **stats_area);
+/*
+ * The tape as ROWS (round 4): the engine keeps its own copy of the random stream -- fokl_dchain_prestate_ring hands out the
+ * page-locked ring a stream created with it (fokl_stream_create / fokl_pool_create) leaves its pre-states in, one
+ * workgroup per segment regenerates MT19937 -> tempering -> numpy's doubles -> x = 2 d - 1 from a pre-state into a ring in
+ * device memory (when a chain first needs the segment), fokl_dchain_bind_stream says whose pre-states the ring holds -- and
+ * fokl_dchain_submit_rows expands a tape's 32-byte rows there: accepted attempts re-decided from x1^2 + x2^2 (the host's
+ * roundings: same flags), normals finished, gamma variates formed.  What crosses the bus per chain is its rows; the
+ * arithmetic differs from the host's expansion only through log().
+ */
+int fokl_dchain_prestate_ring(fokl_dchain *engine, uint32_t **ring, int *entries);
+int fokl_dchain_bind_stream(fokl_dchain *engine, const fokl_stream *stream);
+int fokl_dchain_submit_rows(fokl_dchain *engine, int p1, int draws, const double *lamb, const double *qty, double b,
+                            double btau, double dtd, double sigsqd0, double tausqd0, double astar, double atau_star,
+                            const fokl_tape_row *rows, const double *gam_sig, const double *gam_tau,
+                            const int32_t *progress, const uint64_t *span, int stat_first, int64_t *ticket,
+                            const double **stats_area);
+/* segments regenerated on the device so far, chains submitted as rows */
+int fokl_dchain_stream_stats(fokl_dchain *engine, int64_t *segments_made, int64_t *rows_jobs);
 int fokl_dchain_poll(fokl_dchain *engine, int64_t ticket);
 int fokl_dchain_wait(fokl_dchain *engine, int64_t ticket, double *stats_out);
 int fokl_dchain_fetch_w(fokl_dchain *engine, int64_t ticket, double *w_out);

@@ -210,3 +210,52 @@ def test_tapes_in_ordinary_memory_are_staged(engine, monkeypatch):
     w_pinned, _, _ = _capi.gibbs_chain_device(engine, *args, pinned)
     assert engine.stats()['staged'] == before + 1
     assert np.array_equal(w_plain, w_pinned)
+
+
+@pytest.mark.parametrize('p1,pos', [(1, 0), (2, 1), (7, 623), (60, 2), (61, 311), (129, 624), (586, 5)])
+def test_rows_expanded_on_the_device_equal_the_tape_expanded_on_the_host(p1, pos, monkeypatch):
+    """Round 4: a tape as 32-byte rows (fokl_stream_walk).  The engine regenerates the stream's segments from the raw
+    pre-states the host's bulk threads leave in its ring (MT19937 recurrence, tempering, numpy's doubles: exact) and
+    expands the rows there -- accepted attempts re-decided from x1^2 + x2^2 with the host's roundings -- so the chain it
+    runs is the host chain on the host-expanded tape up to log()."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    eng = _capi.DeviceChainEngine(int(os.environ.get('FOKL_DEVICE', '0')), slots=8)
+    try:
+        np.random.seed(100 + p1)
+        st = np.random.get_state()
+        stream = _capi.LegacyStream(('MT19937', st[1], pos, 0, 0.0))
+        se = _capi.StreamEngine(stream, 2, prestates=eng.prestate_ring())
+        eng.bind(se._h)
+        rng = np.random.default_rng(p1)
+        draws = 300 if p1 > 200 else 2000
+        astar, atau_star = 5e5 + p1 / 2, 4 + (p1 - 1) / 2
+        args = (900.0, 2.0, 5e5, 0.3, 0.9)
+        jobs, wants, holds = [], [], []
+        for rep in range(3):                                  # three tapes back to back: later ones start mid-segment
+            lamb, qty = model(p1, rng)
+            tape = _capi.NoiseTape(p1, draws, raw=_capi.pinned_empty(_capi.NoiseTape.doubles_needed(p1, draws)))
+            first = se.tell().position
+            holds.append(se.walk(tape, astar, atau_star))
+            span = np.array([holds[-1], se.tell().position], dtype=np.uint64)
+            assert span[0] <= first
+            jobs.append(eng.submit_rows(lamb, qty, *args, astar, atau_star, tape, span, stat_first=draws // 2))
+            host = _capi.NoiseTape(p1, draws)
+            host.rows[:] = tape.rows
+            se.expand(host, astar, atau_star)
+            host.progress[0] = draws
+            wants.append(_capi.gibbs_chain_from_tape(lamb, qty, *args, host)[0])
+        for job, want in zip(jobs, wants):
+            mean_w, flag = job.wait()
+            w = job.fetch_w()
+            scale = np.max(np.abs(want), axis=0)
+            assert not flag[0]
+            assert np.max(np.abs(w - want) / scale) < 1e-13
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+            job.release()
+        assert eng.stream_stats()['rows_jobs'] == 3 and eng.stream_stats()['segments_made'] >= 1
+        for hold in holds:
+            se.release(hold)
+        eng.bind(None)
+        se.close()
+    finally:
+        eng.close()

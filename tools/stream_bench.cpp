@@ -15,7 +15,7 @@ int main(int argc, char **argv)
     std::mt19937 gen(5);
     for (auto &k : key) k = gen();
     fokl_stream *e;
-    fokl_stream_create(key, 624, 0, 0.0, nt, &e);
+    fokl_stream_create(key, 624, 0, 0.0, nt, nullptr, 0, &e);
     const int draws = 2000;
     std::vector<fokl_tape_row> rows(draws);
     std::vector<double> gs(draws), gt(draws);
