@@ -920,7 +920,8 @@ def main():
                     guess_waits=0, guesses_verified=0, searches_repeated=0, dchain_dispatch_s=0.0, dchain_kernel_s=0.0,
                     dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
-                    walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0)
+                    walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
+                    rows_chains=0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']

@@ -684,7 +684,7 @@ class _KillTestsResult(ctypes.Structure):
 SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain', 'chains_materialised', 'bic_from_gram',
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
-                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains')
+                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted')
 
 
 class NativeSearch:

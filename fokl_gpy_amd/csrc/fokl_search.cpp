@@ -206,7 +206,7 @@ enum Stat {
     S_GIBBS_CALLS, S_KILL_TESTS, S_TERMS_LOGICAL, S_T_EIGH, S_T_CHAIN, S_CHAINS_MATERIALISED, S_BIC_FROM_GRAM,
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
-    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_COUNT
+    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_COUNT
 };
 
 }  // namespace
@@ -988,6 +988,76 @@ int verify(fokl_search *s, bool block)
     return FOKL_OK;
 }
 
+// Where a sub-stage's kill tests will go, without an eigen-decomposition per step: removing column c from a least-squares
+// model raises the sum of squared residuals by exactly b_c^2 / [(X'X)^-1]_cc and leaves (X'X)^-1 and b one rank-one
+// downdate away.  The loop keeps this model next to the real one -- started from the sub-stage model's spectrum, advanced
+// with every accepted test -- and asks it which of the remaining proposals will be tested and which accepted, so that the
+// G2 jobs and the tapes of the whole path can be ordered far ahead (a spectral job is 0.4 ms: every wrong guess about the
+// next model used to stall the loop for that long).  It only ever PREDICTS: every decision is taken from the real BIC.
+struct PathModel {
+    int p = 0, ld = 0;
+    std::vector<int32_t> cols;              // active column of every model position
+    std::vector<double> inv;                // (X'X)^-1, [ld x ld], rows / columns of removed positions compacted away
+    std::vector<double> beta;
+    double ssr = 0, s1 = 0;
+
+    void init(const Spectrum *sp)
+    {
+        p = ld = sp->p1;
+        cols.assign(sp->idx.begin(), sp->idx.end());
+        beta.assign(sp->betahat(), sp->betahat() + p);
+        ssr = sp->moments()[1];
+        s1 = sp->moments()[0];
+        inv.assign((size_t)p * p, 0.0);
+        const double *Qt = sp->Qt(), *lamb = sp->lamb();
+        std::vector<double> row((size_t)p);
+        for (int e = 0; e < p; ++e) {                       // sum over eigenpairs of q q' / lamb
+            const double *q = Qt + (size_t)e * p;
+            const double w = 1.0 / lamb[e];
+            for (int i = 0; i < p; ++i) row[(size_t)i] = q[i] * w;
+            for (int i = 0; i < p; ++i) {
+                double *out = inv.data() + (size_t)i * p;
+                const double qi = row[(size_t)i];
+                for (int j = 0; j < p; ++j) out[j] += qi * q[j];
+            }
+        }
+    }
+
+    int position(int32_t col) const
+    {
+        for (int i = 0; i < p; ++i)
+            if (cols[(size_t)i] == col) return i;
+        return -1;
+    }
+
+    double ssr_without(int pos) const { return ssr + beta[(size_t)pos] * beta[(size_t)pos] / inv[(size_t)pos * ld + pos]; }
+
+    void remove(int pos)
+    {
+        const double pivot = inv[(size_t)pos * ld + pos], bc = beta[(size_t)pos];
+        ssr += bc * bc / pivot;
+        std::vector<double> column((size_t)p);
+        for (int i = 0; i < p; ++i) column[(size_t)i] = inv[(size_t)i * ld + pos];
+        // downdate, compacting row / column `pos` away as we go
+        int oi = 0;
+        for (int i = 0; i < p; ++i) {
+            if (i == pos) continue;
+            const double f = column[(size_t)i] / pivot;
+            double *dst = inv.data() + (size_t)oi * ld;
+            const double *src = inv.data() + (size_t)i * ld;
+            int oj = 0;
+            for (int j = 0; j < p; ++j) {
+                if (j == pos) continue;
+                dst[oj++] = src[j] - f * column[(size_t)j];
+            }
+            beta[(size_t)oi] = beta[(size_t)i] - f * bc;
+            cols[(size_t)oi] = cols[(size_t)i];
+            ++oi;
+        }
+        p -= 1;
+    }
+};
+
 std::vector<int32_t> columns_without(int A, const std::vector<int32_t> &removed /* sorted */)
 {
     std::vector<int32_t> idx;
@@ -1367,7 +1437,6 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         std::vector<int32_t> key;
         size_t r = 0;
         for (int c = 1; c < A; ++c) {
-            if (r < pred.size() && pred[r] < c) ++r;
             while (r < pred.size() && pred[r] < c) ++r;
             if (r < pred.size() && pred[r] == c) continue;
             key.push_back(a->slots[c]);
@@ -1380,16 +1449,48 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (f.key == key) return &f;
         return nullptr;
     };
+    // the predicted rest of the loop: for proposal[first_step + k] whether its test will run and be accepted
+    struct Step {
+        bool run, accept;
+    };
+    PathModel committed;                                    // the model accepted so far, as the predictor sees it
+    committed.init(best->spec);
+    std::vector<Step> path;
+    size_t path_from = 0;                                   // path[k] <-> proposal[path_from + k]
+    auto predict = [&](size_t pos) {
+        PathModel m = committed;
+        double ev_floor = evmin;
+        path.clear();
+        path_from = pos;
+        for (size_t q = pos; q < proposal.size(); ++q) {
+            const int j = proposal[q];
+            const double scale = std::fabs(m.beta[0]);      // the intercept of the model accepted so far (predicted)
+            Step st{clause1[(size_t)j] || a->mean_abs[j] < threshav * (q == pos ? scale_guess : scale), false};
+            if (st.run) {
+                const int at = m.position(a->columns[j]);
+                if (at > 0) {
+                    const double ev = ev_from_moments(s, m.s1, m.ssr_without(at), m.p - 1);
+                    st.accept = ev < ev_floor;
+                    if (st.accept) {
+                        ev_floor = ev;
+                        m.remove(at);
+                    }
+                }
+            }
+            path.push_back(st);
+        }
+    };
+    auto step_at = [&](size_t q) -> Step { return q >= path_from && q - path_from < path.size() ? path[q - path_from] : Step{false, false}; };
     auto forecast = [&](size_t pos) {
-        // the kill set at the end of the loop if every remaining test that looks likely runs and is accepted
+        // the kill set at the end of the loop if the rest goes as predicted
         if (!a->foresee) return;
         std::vector<int32_t> pred(killed);
         int rest = 0;
-        for (size_t q = pos; q < proposal.size(); ++q)
-            if (likely(proposal[q])) {
-                pred = with_column(pred, a->columns[proposal[q]]);
-                ++rest;
-            }
+        for (size_t q = pos; q < proposal.size(); ++q) {
+            const Step st = step_at(q);
+            if (st.run) ++rest;
+            if (st.run && st.accept) pred = with_column(pred, a->columns[proposal[q]]);
+        }
         if (rest <= s->prm.foresight) a->foresee(a->user, pred.data(), (int)pred.size());
     };
     auto order_tapes = [&](size_t pos) {
@@ -1402,10 +1503,10 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 through = false;
                 break;
             }
-            const int j = proposal[q];
-            if (likely(j)) {
+            const Step st = step_at(q);
+            if (st.run) {
                 sizes.push_back({A - (int)pred.size() - 1, false});
-                if (last_accepted) pred = with_column(pred, a->columns[j]);
+                if (st.accept) pred = with_column(pred, a->columns[proposal[q]]);
             }
         }
         if (through && a->vm_next >= 0) {
@@ -1427,7 +1528,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         // ... and the chain of the very next evaluation, if its G2 is there
         int nxt = -1;
         for (size_t q = pos; q < proposal.size(); ++q)
-            if (likely(proposal[q])) {
+            if (step_at(q).run) {
                 nxt = proposal[q];
                 break;
             }
@@ -1438,7 +1539,28 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (Forecast *f = find_forecast(killed)) chain_ahead(s, f->spec, A - (int)killed.size() + a->vm_next, f->dtd);
         }
     };
+    // G2 of the models on the predicted path, `lookahead` tests deep beyond the one at `pos` (which is submitted whatever
+    // the prediction says about it: it is about to be needed)
+    auto submit_ahead = [&](size_t pos) -> int {
+        std::vector<int32_t> cur(killed);
+        int deep = 0;
+        for (size_t q = pos; q < proposal.size() && deep <= s->prm.lookahead; ++q) {
+            const Step st = step_at(q);
+            if (q > pos && !st.run) continue;
+            ++deep;
+            auto key = with_column(cur, a->columns[proposal[q]]);
+            if (ahead.find(key) == ahead.end()) {
+                const auto idx = columns_without(A, key);
+                Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size());
+                if (!sp) return FOKL_ERR_STATE;
+                ahead.emplace(key, sp);
+            }
+            if (q == pos ? (st.run ? st.accept : true) : st.accept) cur = std::move(key);
+        }
+        return FOKL_OK;
+    };
 
+    predict(0);
     forecast(0);
     order_tapes(0);
     for (size_t pos = 0; pos < proposal.size() && rc == FOKL_OK; ++pos) {
@@ -1453,7 +1575,14 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 rc = quick + 2;
                 break;
             }
-            if (quick == 0) continue;
+            if (quick == 0) {
+                if (step_at(pos).run) {
+                    predict(pos + 1);
+                    s->stats[S_PATH_REPREDICTED] += 1;
+                    order_tapes(pos + 1);
+                }
+                continue;
+            }
             if (quick == 1) {
                 decided = true;
                 if (!std::isnan(best->intercept_scale)) scale_guess = best->intercept_scale;
@@ -1463,31 +1592,17 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             // second clause without G2 of a model that will probably not be needed: from the known scale, or -- the test
             // looks unlikely -- after waiting for the chain of `best`
             if ((rc = intercept_scale(s, best, &scale_guess)) != FOKL_OK) break;
-            if (!(a->mean_abs[i] < threshav * scale_guess)) continue;
+            if (!(a->mean_abs[i] < threshav * scale_guess)) {
+                if (step_at(pos).run) {
+                    predict(pos + 1);
+                    s->stats[S_PATH_REPREDICTED] += 1;
+                    order_tapes(pos + 1);
+                }
+                continue;
+            }
             decided = true;
         }
-        // G2 of the models on the predicted path, `lookahead` tests deep (a wrong guess costs latency only)
-        {
-            std::vector<int32_t> cur(killed);
-            int deep = 0;
-            for (size_t q = pos; q < proposal.size() && deep <= s->prm.lookahead; ++q) {
-                const int j = proposal[q];
-                if (q > pos && !likely(j)) continue;
-                ++deep;
-                auto key = with_column(cur, a->columns[j]);
-                if (ahead.find(key) == ahead.end()) {
-                    const auto idx = columns_without(A, key);
-                    Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size());
-                    if (!sp) {
-                        rc = FOKL_ERR_STATE;
-                        break;
-                    }
-                    ahead.emplace(key, sp);
-                }
-                if (last_accepted) cur = std::move(key);
-            }
-            if (rc != FOKL_OK) break;
-        }
+        if ((rc = submit_ahead(pos)) != FOKL_OK) break;
         const auto trial = with_column(killed, a->columns[i]);
         const int p1 = A - (int)trial.size();
         // the test runs for sure: its tape is committed (or, not on order after a wrong guess, requested) now, so that
@@ -1518,6 +1633,11 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
             if (!(a->mean_abs[i] < threshav * scale_guess)) {
                 unref(s, sp);
+                if (step_at(pos).run) {
+                    predict(pos + 1);
+                    s->stats[S_PATH_REPREDICTED] += 1;
+                    order_tapes(pos + 1);
+                }
                 continue;
             }
             tape = tape_for(s, p1, false);
@@ -1561,6 +1681,11 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         }
         record(s, p1, a->n_prev, ev, true);
         last_accepted = ev < evmin;
+        const Step foreseen = step_at(pos);
+        if (last_accepted) {
+            const int at = committed.position(a->columns[i]);
+            if (at > 0) committed.remove(at);
+        }
         if (last_accepted) {
             killed = trial;
             evmin = ev;
@@ -1573,6 +1698,12 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             best->refs += 1;                                // this loop's reference (the creation reference is the caller's)
         }
         unref(s, sp);
+        if (!foreseen.run || foreseen.accept != last_accepted) {
+            // the path parts from what was predicted: resynchronise the predictor with the real model and look again
+            if (last_accepted) committed.init(best->spec);
+            predict(pos + 1);
+            s->stats[S_PATH_REPREDICTED] += 1;
+        }
         forecast(pos + 1);
         order_tapes(pos + 1);
         if ((pos & 7) == 7) reap(s, false);

@@ -329,21 +329,27 @@ void generate_raw(fokl_stream *e, Segment *seg, int64_t index)
     } else {
         std::memcpy(buf, e->carry, MT_N * sizeof(uint32_t));
     }
-    if (e->pre_ring) {
-        uint32_t *entry = e->pre_ring + (size_t)(index % e->pre_entries) * FOKL_PRESTATE_WORDS;
-        std::memcpy(entry, index == 0 ? e->key0 : e->carry, MT_N * sizeof(uint32_t));
-        entry[MT_N] = (uint32_t)((uint64_t)index & 0xffffffffu);
-        entry[MT_N + 1] = (uint32_t)((uint64_t)index >> 32);
-        entry[MT_N + 2] = index == 0 ? 1u : 0u;
-        entry[MT_N + 3] = (uint32_t)e->o;
-        e->pre_published.store(index + 1, std::memory_order_release);
-    }
     const int to = MT_N + kSegWords + kSegTail;
     if (e->wide)
         recurrence_wide(buf, from, to);
     else
         recurrence_portable(buf, from, to);
     std::memcpy(e->carry, buf + kSegWords, MT_N * sizeof(uint32_t));    // the segment's last block, raw
+    if (e->pre_ring) {
+        // the raw block in front of every run of FOKL_PRESTATE_BLOCKS blocks (the buffer is still raw here)
+        constexpr int kRuns = kSegBlocks / FOKL_PRESTATE_BLOCKS;
+        for (int run = 0; run < kRuns; ++run) {
+            const int64_t entry_index = index * kRuns + run;
+            uint32_t *entry = e->pre_ring + (size_t)(entry_index % e->pre_entries) * FOKL_PRESTATE_WORDS;
+            const bool given = index == 0 && run == 0;
+            std::memcpy(entry, given ? e->key0 : buf + (size_t)MT_N * FOKL_PRESTATE_BLOCKS * run, MT_N * sizeof(uint32_t));
+            entry[MT_N] = (uint32_t)((uint64_t)entry_index & 0xffffffffu);
+            entry[MT_N + 1] = (uint32_t)((uint64_t)entry_index >> 32);
+            entry[MT_N + 2] = given ? 1u : 0u;
+            entry[MT_N + 3] = (uint32_t)e->o;
+        }
+        e->pre_published.store(index + 1, std::memory_order_release);
+    }
 }
 
 void bulk_worker(fokl_stream *e)
@@ -1022,7 +1028,7 @@ extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_
                                   int bulk_threads, uint32_t *prestate_ring, int prestate_entries, fokl_stream **out)
 {
     if (!out || !mt_key || mt_pos < 0 || mt_pos > MT_N || bulk_threads < 1 || bulk_threads > 16 ||
-        (prestate_ring && prestate_entries < 4 * kAhead)) {
+        (prestate_ring && prestate_entries < 4 * kAhead * (kSegBlocks / FOKL_PRESTATE_BLOCKS))) {
         fokl_set_global_error("fokl_stream_create: null pointer, invalid MT19937 position or thread count");
         return FOKL_ERR_ARG;
     }

@@ -340,6 +340,7 @@ int fokl_rng_gammas(uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, doubl
 #define FOKL_SOURCE_GIVEN ((1ull << 62) - 1)        /* source position: the cached normal of the state handed over */
 #define FOKL_GAMMA_FINAL_VALUE (~0ull)              /* fokl_tape_row.gamma[j]: the walker stored the variate itself */
 #define FOKL_PRESTATE_WORDS 640                     /* one entry of the pre-state ring (see fokl_stream_create) */
+#define FOKL_PRESTATE_BLOCKS 32                     /* a pre-state is left every 32 blocks: 8 per segment */
 typedef struct fokl_stream fokl_stream;
 typedef struct fokl_tape_row {
     uint64_t start;
@@ -352,10 +353,10 @@ typedef struct fokl_stream_cursor {
     int32_t has_gauss;
 } fokl_stream_cursor;
 /* prestate_ring (may be NULL) [prestate_entries * FOKL_PRESTATE_WORDS]: for a second consumer that regenerates the stream
- * itself (the device: fokl_dchain_*), the bulk threads leave there, per segment and in order, entry index %
- * prestate_entries = the 624 raw words of the MT19937 block in front of the segment (segment 0: block 0 itself, word 626 =
- * 1), the segment index (words 624, 625) and the word parity the doubles pair up from (word 627);
- * fokl_stream_prestates_published counts them. */
+ * itself (the device: fokl_dchain_*), the bulk threads leave there, for every run of FOKL_PRESTATE_BLOCKS blocks and in
+ * order, entry index % prestate_entries (index = segment * 8 + run) = the 624 raw words of the MT19937 block in front of
+ * the run (the very first: block 0 itself, word 626 = 1), the index (words 624, 625) and the word parity the doubles pair
+ * up from (word 627); fokl_stream_prestates_published counts the SEGMENTS whose eight entries are there. */
 int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_t has_gauss, double gauss_cache, int bulk_threads,
                        uint32_t *prestate_ring, int prestate_entries, fokl_stream **out);
 int64_t fokl_stream_prestates_published(const fokl_stream *stream);
