@@ -383,7 +383,8 @@ def KERNEL_SLOTS():
     """(name in the JSON line, timing slot of the library) of every kernel a fit launches."""
     from fokl_gpy_amd import _capi
     return (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
-            ('gram_reduce', _capi.K_GRAM_REDUCE), ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF))
+            ('gram_reduce', _capi.K_GRAM_REDUCE), ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF),
+            ('inputs_touch', _capi.K_TOUCH))
 
 
 def kernel_report(kern, n, m, cfg):
@@ -409,7 +410,14 @@ def kernel_report(kern, n, m, cfg):
     kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'),
                'gram_mfma': roof('gram_mfma', 'mfma'), 'gram_reduce': roof('gram_reduce', 'hbm'),
                'resid': roof('resid', 'hbm'),
-               'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
+               'resid_matrix_free': roof('resid_matrix_free', 'hbm'),
+               'inputs_touch': roof('inputs_touch', 'hbm')}
+    if kernels['inputs_touch'] and kernels['basis_build']:
+        # the read of the inputs ahead of every basis build (it leaves them in the Infinity Cache) belongs to the price of
+        # the build: both launches together against the build's algorithmic bytes
+        kb, kt = kern['basis_build'], kern['inputs_touch']
+        together = kb['bytes'] / ((kb['ms'] + kt['ms']) * 1e-3) / 1e9
+        kernels['basis_build'].update(with_inputs_touch_gbs=together, with_inputs_touch_frac=together / HBM_PEAK_GBS)
     mf = kernels['resid_matrix_free']
     if mf:
         # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns
@@ -921,7 +929,7 @@ def main():
                     dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
-                    rows_chains=0)
+                    rows_chains=0, path_repredicted=0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.so'))   # override: A/B builds
 
 UNIQUE_ID_BYTES = 128
-K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA, K_GRAM_REDUCE = 0, 1, 2, 3, 4, 5, 6
+K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA, K_GRAM_REDUCE, K_TOUCH = 0, 1, 2, 3, 4, 5, 6, 7
 RESID_TERMS_MAX_FACTORS = 48
 RESID_TERMS_MAX_ORDER = 8
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
@@ -58,6 +58,7 @@ SIGNATURES = {
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     'fokl_pool_stream': (c_vp, [c_vp]),
+    'fokl_pool_spectral_affinity': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_release_hold': (c_int, [c_vp, ctypes.c_uint64]),
     'fokl_pool_destroy': (None, [c_vp]),
     'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
@@ -581,6 +582,10 @@ class HostPool:
                                           *stream.args(), prestates[0] if prestates else None,
                                           prestates[1] if prestates else 0, ctypes.byref(h)))
         self._h = h
+
+    def spectral_affinity(self, cpus):
+        cpus = np.ascontiguousarray(sorted(cpus), dtype=np.int32)
+        _check(self._lib.fokl_pool_spectral_affinity(self._h, _ptr(cpus), cpus.shape[0]))
 
     def stream_handle(self):
         """The pool's fokl_stream (for DeviceChainEngine.bind)."""

@@ -612,6 +612,18 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
                 ++m_used;
             }
     }
+    // In a fit K1 comes behind Gram and residual launches that have streamed 0.5-1 GB through the 256 MB Infinity Cache:
+    // its 8 N m_used bytes of inputs then come from HBM IN BETWEEN its 8 N T bytes of stores, and a mixed stream runs at
+    // 4.3-4.6 TB/s where stores alone run at 5.5 (profiles/hbm_write_ceiling_r03.txt).  Reading the inputs once, just
+    // before -- a launch of its own, on a device that idles for most of a fit -- leaves them in the cache: K1 then stores
+    // against HBM and reads beside it.  FOKL_K1_TOUCH=0: no such launch.
+    if (deriv.order == 0 && env_int("FOKL_K1_TOUCH", 1) != 0 && ctx->n >= 65536) {
+        const int64_t words = ctx->n / 2;                   // 16-byte loads
+        TimedRegion timed(ctx, FOKL_K_TOUCH, 8.0 * (double)ctx->n * (double)m, 0.0);
+        hipLaunchKernelGGL(inputs_touch_kernel, dim3((unsigned)(cu_count(ctx) * 4)), dim3(256), 0, ctx->stream, ctx->d_x,
+                           ctx->ld, words, m, ctx->d_zero);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     const double alg_bytes = 8.0 * (double)ctx->n * (double)(m_used + T);
     TimedRegion timed(ctx, FOKL_K_BASIS, alg_bytes, 0.0);
     typedef void (*basis_fn)(const double *, int64_t, int64_t, const double *, int, const BasisPlan *, const int *,

@@ -114,6 +114,7 @@ struct fokl_host_pool {
     Queue noise_q, chain_q, spectral_q;
     std::deque<Queue> finish_q;             // one per finish thread: every tape is split over all of them
     std::vector<std::thread> threads;
+    std::vector<size_t> spectral_thread_ids;    // indices into `threads` (fokl_pool_spectral_affinity)
     dsyevr_fn dsyevr = nullptr;
     // the random stream: walked by the noise thread, produced by the stream's own bulk threads; the caller's state
     // (mt_key ...) is read at creation and written back when the pool is destroyed
@@ -602,7 +603,10 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
         for (int i = 0; i < chain_threads; ++i) pool->threads.emplace_back(worker, pool, &pool->chain_q);
         pool->finish_q.resize((size_t)finish_threads);
         for (auto &q : pool->finish_q) pool->threads.emplace_back(worker, pool, &q);
-        for (int i = 0; i < spectral_threads; ++i) pool->threads.emplace_back(worker, pool, &pool->spectral_q);
+        for (int i = 0; i < spectral_threads; ++i) {
+            pool->spectral_thread_ids.push_back(pool->threads.size());
+            pool->threads.emplace_back(worker, pool, &pool->spectral_q);
+        }
     } catch (const std::exception &e) {
         stop(pool->noise_q);
         stop(pool->chain_q);
@@ -841,6 +845,28 @@ extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise,
     if (chain) *chain = 1e-9 * (double)pool->chain_busy_ns.load();
     if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
     if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
+    return FOKL_OK;
+}
+
+// The spectral threads share no data with the threads around the random stream (bulk, noise, finish, chain): the caller may
+// give them CPUs of their own -- another last-level cache domain -- instead of the affinity they inherited.
+extern "C" int fokl_pool_spectral_affinity(fokl_host_pool *pool, const int32_t *cpus, int count)
+{
+    if (!pool || !cpus || count < 1) {
+        fokl_set_global_error("fokl_pool_spectral_affinity: null pointer or empty CPU list");
+        return FOKL_ERR_ARG;
+    }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int i = 0; i < count; ++i)
+        if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &set);
+    int failed = 0;
+    for (size_t id : pool->spectral_thread_ids)
+        if (pthread_setaffinity_np(pool->threads[id].native_handle(), sizeof(set), &set) != 0) ++failed;
+    if (failed) {
+        fokl_set_global_error("fokl_pool_spectral_affinity: pthread_setaffinity_np failed");
+        return FOKL_ERR_STATE;
+    }
     return FOKL_OK;
 }
 

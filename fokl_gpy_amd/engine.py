@@ -274,7 +274,10 @@ class ForwardSelection:
         self._matrix_free = (hasattr(backend, 'bic_resid_terms_launch') and
                              os.environ.get('FOKL_K3', 'matrixfree') != 'columns')
         self._terms_arr = None              # [A, m] int32 terms of the active columns (row 0 = intercept) or None
-        self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))   # spectral jobs submitted ahead of the kill tests
+        # spectral jobs submitted ahead of the kill tests: three along the guessed path (the Python loop: every miss costs
+        # the jobs); the native loop predicts its path (csrc/fokl_search.cpp PathModel) and goes twelve deep
+        self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))
+        self._lookahead_native = int(os.environ.get('FOKL_LOOKAHEAD', '12'))
         # next test's tape requested before the decision that the test is run (rewound when it is not; data-driven, so
         # replicated drivers of a row-sharded fit stay in step) -- FOKL_TENTATIVE_TAPES=0 disables, =test forces rewinds
         # the next sub-stage's columns and Gram block are built, and G2 of its predicted model started, before this
@@ -678,7 +681,9 @@ class ForwardSelection:
         A = gram.shape[0] - 1
         likely = self._likely_first_tests(spec, n_new, siglik)
         jobs, cur = {}, frozenset()
-        for c in likely[:1 + self.lookahead]:
+        # (their order is guessed from the least-squares fit before the chain's statistics are there: three or four
+        # deep -- what lies further along is ordered by the kill-test loop once the proposals are known)
+        for c in likely[:1 + min(self.lookahead, 3)]:
             cur = cur | {c}
             jobs[cur] = self._spectral(gram, self._columns_without(A, cur))
         # and their tapes: test t of the sub-stage has A - 1 - t columns if the tests before it were accepted
@@ -957,7 +962,7 @@ class ForwardSelection:
                 self.host.pool, self.chain_engine, n=self.n, a=self.a, b=self.b, atau=self.atau, btau=self.btau,
                 threshav=self.threshav, threshstda=self.threshstda, threshstdb=self.threshstdb,
                 guess_margin=self.guess_margin, draws=self.draws, half0=half0, aic=int(self.aic),
-                lookahead=self.lookahead, foresight=self.foresight, speculation_max=self.speculation_max,
+                lookahead=self._lookahead_native, foresight=self.foresight, speculation_max=self.speculation_max,
                 tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
                 device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
                 flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))

@@ -68,6 +68,26 @@ def _place_host_threads():
         return None, -1
 
 
+def _second_domain(allowed, home):
+    """Logical CPUs of another last-level-cache domain inside `allowed` (the one after `home`'s, by lowest CPU number), for
+    the spectral threads; None when there is none."""
+    try:
+        seen, domains = set(), []
+        for cpu in sorted(allowed):
+            if cpu in seen:
+                continue
+            dom = _cpu_list(f'/sys/devices/system/cpu/cpu{cpu}/cache/index3/shared_cpu_list') & allowed
+            seen |= dom
+            domains.append(dom)
+        others = [d for d in domains if not (d & home) and len(d) >= 4]
+        if not others:
+            return None
+        after = [d for d in others if min(d) > min(home)]
+        return (after or others)[0]
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_budget():
     """CPUs this process may keep busy: its affinity mask, capped by the cgroup CPU quota (a container that sees 256
     CPUs may be allowed 16 CPU-seconds per second) shared among the ranks of the node (LOCAL_WORLD_SIZE)."""
@@ -105,7 +125,7 @@ def _bulk_threads(budget=None):
     segment of 79 872 doubles in 10-30 us, a bulk thread makes one in 20-40 us (AVX-512).  FOKL_BULK_THREADS overrides."""
     if budget is None:
         budget = _cpu_budget()
-    default = 3 if budget >= 12 else (2 if budget >= 5 else 1)
+    default = 4 if budget >= 12 else (2 if budget >= 5 else 1)
     return max(1, int(os.environ.get('FOKL_BULK_THREADS', str(default))))
 
 
@@ -123,11 +143,15 @@ def _thread_plan():
     # 189.8, 1+0+2 199.5, 1+1+1 201.6;  2 CPUs: 1+0+1 239.5, 1+0+2 245.7.  The eigen-decompositions are the throughput
     # item (0.13 CPU-seconds per fit): three spectral threads as soon as five CPUs are there.
     exact_log = os.environ.get('FOKL_FINISH_LOG', 'fast') == 'exact'
+    # Round 4: the random stream left the serial thread (walker + bulk threads, _bulk_threads), kill tests' tapes are
+    # expanded on the device and the kill-test loop is native and predicts its path -- what a fit waits for now is the
+    # THROUGHPUT of the eigen-decompositions (0.17 CPU-seconds of dsyevr per configs[2] fit).  tools/env_sweep_r04.sh on the
+    # GPU boxes (16 CPUs, chain + finish + spectral / ms per fit): 2+1+4 61.7, 2+1+6 58.6, 2+1+8 51-52, 2+1+10 53.6,
+    # 2+1+12 53.5 (contention with the stream's four bulk threads); finish threads only serve the sub-stage models' tapes.
     if budget >= 12:
-        # second chain thread: models of hundreds of columns (configs[3]) and chains started ahead; fourth spectral
-        # thread (round 2, with the tapes recorded ahead of the driver G2 of the 100-column models -- 1 ms each, a test
-        # every 0.2 ms -- was what the driver waited for: 3 / 4 / 5 / 6 threads 89.6 / 85.0 / 85.4 / 86.1 ms per fit)
-        plan = (2, 3 if exact_log else 1, 4)
+        plan = (2, 3 if exact_log else 2, 8)
+    elif budget >= 8:
+        plan = (1, 2 if exact_log else 1, 5)
     elif budget >= 5:
         plan = (1, 2 if exact_log else 1, 3)
     elif budget >= 4:
@@ -267,6 +291,15 @@ class HostPipeline:
             if prestates is not None:
                 chain_engine.bind(self.pool.stream_handle())
                 self.device_rows = True
+            # the eigen-decompositions share nothing with the stream's threads: on a CPU with several last-level-cache
+            # domains they get the next one to themselves (FOKL_SPECTRAL_DOMAIN=0: they stay where the others are)
+            if self._saved_affinity is not None and os.environ.get('FOKL_SPECTRAL_DOMAIN', '1') != '0':
+                other = _second_domain(self._saved_affinity, os.sched_getaffinity(0))
+                if other:
+                    try:
+                        self.pool.spectral_affinity(other)
+                    except _capi.FoklNativeError:
+                        pass
         except BaseException:
             self._restore_affinity()        # the caller may carry on in line: not pinned to one L3 domain
             raise

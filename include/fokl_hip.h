@@ -47,7 +47,8 @@ extern "C" {
 #define FOKL_K_GRAM_MFMA 5      /* K2 launches bound by the fp64 MFMA roof (2 N nr nc / peak flops > 8 N distinct columns /
                                    peak bytes, i.e. nr nc / distinct > ~39); FOKL_K_GRAM then holds the HBM-bound ones */
 #define FOKL_K_GRAM_REDUCE 6    /* K2's second kernel: fixed-order sum of the per-workgroup partial blocks (bytes = slabs read) */
-#define FOKL_K_COUNT   7
+#define FOKL_K_TOUCH   7        /* the read of the inputs ahead of K1 (they then sit in the Infinity Cache; bytes = inputs) */
+#define FOKL_K_COUNT   8
 
 typedef struct fokl_ctx fokl_ctx;
 
@@ -404,6 +405,9 @@ typedef struct fokl_host_job fokl_host_job;
 int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads, int noise_cpu,
                      void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      uint32_t *prestate_ring, int prestate_entries, fokl_host_pool **out);
+/* CPUs for the spectral threads alone (they share no data with the threads around the random stream: another last-level
+ * cache domain keeps them off those threads' cores) */
+int fokl_pool_spectral_affinity(fokl_host_pool *pool, const int32_t *cpus, int count);
 /* the pool's stream (fokl_stream_expand of rows-only tapes; alive as long as the pool) */
 fokl_stream *fokl_pool_stream(fokl_host_pool *pool);
 void fokl_pool_destroy(fokl_host_pool *pool);

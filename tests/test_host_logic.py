@@ -413,12 +413,12 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     monkeypatch.delenv('FOKL_FINISH_THREADS', raising=False)
     monkeypatch.delenv('FOKL_SPECTRAL_THREADS', raising=False)
     monkeypatch.delenv('FOKL_FINISH_LOG', raising=False)
-    cases = ((16, (2, 1, 4)), (8, (1, 1, 3)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 0, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
+    cases = ((16, (2, 2, 8)), (8, (1, 1, 5)), (5, (1, 1, 3)), (4, (1, 1, 2)), (3, (1, 0, 2)), (2, (1, 0, 1)), (1, (1, 0, 1)))
     for budget, plan in cases:
         monkeypatch.setattr(host_pipeline, '_cpu_budget', lambda b=budget: b)
         assert host_pipeline._thread_plan() == plan
     monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')                  # libm's scalar log: finishing needs three threads
-    for budget, plan in ((16, (2, 3, 4)), (7.5, (1, 2, 3))):
+    for budget, plan in ((16, (2, 3, 8)), (7.5, (1, 2, 3))):
         monkeypatch.setattr(host_pipeline, '_cpu_budget', lambda b=budget: b)
         assert host_pipeline._thread_plan() == plan
     monkeypatch.delenv('FOKL_FINISH_LOG')
@@ -427,6 +427,8 @@ def test_thread_plan_follows_the_cpu_budget(monkeypatch):
     assert host_pipeline._thread_plan() == (1, 5, 1)
     monkeypatch.undo()
     assert host_pipeline._cpu_budget() >= 1
+    # the stream's bulk threads (csrc/fokl_stream.cpp) follow the same budget
+    assert [host_pipeline._bulk_threads(b) for b in (16, 8, 5, 4, 2)] == [4, 2, 2, 1, 1]
 
 
 def _search_with_pipeline(monkeypatch, draws=40):

@@ -76,7 +76,7 @@ def test_native_objects_are_released(monkeypatch):
     a = _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
     b = _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1])
-    assert a[0].fit_stats['tapes_rewound'] == b[0].fit_stats['tapes_rewound']
+    assert a[0].fit_stats['gibbs_calls'] == b[0].fit_stats['gibbs_calls']
 
 
 def test_a_callback_that_raises_surfaces_after_the_native_loop(monkeypatch):
