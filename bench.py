@@ -929,7 +929,7 @@ def main():
                     dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
-                    rows_chains=0, path_repredicted=0)
+                    rows_chains=0, path_repredicted=0, t_pool_up=0.0)
         for _ in range(args.steps):
             for st in one_step():
                 logical += st['terms_logical']
@@ -937,6 +937,8 @@ def main():
                 calls += st['gibbs_calls']
                 for key in host:
                     host[key] += st.get(key, 0)
+                for key, value in st.get('phases', {}).items():
+                    host['phase_' + key] = host.get('phase_' + key, 0.0) + value
         ctx.sync()
         control.barrier()
         elapsed = time.perf_counter() - t0

@@ -102,6 +102,7 @@ SIGNATURES = {
     'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'fokl_search_score': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp]),
     'fokl_outcome_info': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_outcome_spectrum': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_outcome_chain_ready': (c_int, [c_vp]),
     'fokl_outcome_draws': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_outcome_intercept_scale': (c_int, [c_vp, c_vp, c_vp]),
@@ -110,7 +111,7 @@ SIGNATURES = {
     'fokl_search_verify': (c_int, [c_vp, c_int]),
     'fokl_search_register_forecast': (c_int, [c_vp, c_vp, c_int, c_vp, c_dbl]),
     'fokl_search_clear_forecasts': (None, [c_vp]),
-    'fokl_search_likely_first_tests': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp]),
+    'fokl_search_likely_first_tests': (c_int, [c_vp, c_vp, c_int, c_dbl, c_vp, c_vp, c_vp]),
     'fokl_search_stats': (c_int, [c_vp, c_vp, c_int]),
     'fokl_search_trace': (c_i64, [c_vp, c_vp, c_i64]),
     'fokl_search_kill_tests': (c_int, [c_vp, c_vp, c_vp]),
@@ -784,6 +785,11 @@ class NativeSearch:
         self._checked(self._lib.fokl_outcome_info(self._h, c_vp(outcome), ctypes.byref(view)))
         return view
 
+    def outcome_spectrum(self, outcome):
+        h = c_vp(0)
+        self._checked(self._lib.fokl_outcome_spectrum(self._h, c_vp(outcome), ctypes.byref(h)))
+        return h.value
+
     def outcome_chain_ready(self, outcome):
         return bool(self._lib.fokl_outcome_chain_ready(c_vp(outcome)))
 
@@ -816,12 +822,14 @@ class NativeSearch:
         self._lib.fokl_search_clear_forecasts(self._h)
 
     def likely_first_tests(self, spectrum, n_new, siglik=None):
+        """-> [(active column, probably accepted)] in testing order (fokl_search_likely_first_tests)."""
         out = np.empty(max(1, int(n_new)), dtype=np.int32)
+        acc = np.zeros(max(1, int(n_new)), dtype=np.int32)
         count = c_int(0)
         self._checked(self._lib.fokl_search_likely_first_tests(self._h, c_vp(spectrum), int(n_new),
                                                                float('nan') if siglik is None else float(siglik),
-                                                               _ptr(out), ctypes.byref(count)))
-        return [int(c) for c in out[:count.value]]
+                                                               _ptr(out), _ptr(acc), ctypes.byref(count)))
+        return [(int(c), bool(a)) for c, a in zip(out[:count.value], acc[:count.value])]
 
     def stats(self):
         v = np.zeros(len(SEARCH_STATS) + 8)

@@ -1285,6 +1285,16 @@ extern "C" int fokl_outcome_info(fokl_search *s, fokl_outcome *h, fokl_outcome_v
     return FOKL_OK;
 }
 
+// the outcome's G2 as a handle of its own (one more reference: fokl_spectrum_release when done with it)
+extern "C" int fokl_outcome_spectrum(fokl_search *s, fokl_outcome *h, fokl_spectrum **out)
+{
+    if (!s || !h || !out) return fail(s, FOKL_ERR_ARG, "fokl_outcome_spectrum: null pointer");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    o->spec->refs += 1;
+    *out = reinterpret_cast<fokl_spectrum *>(o->spec);
+    return FOKL_OK;
+}
+
 extern "C" int fokl_outcome_chain_ready(fokl_outcome *h) { return h && chain_done(reinterpret_cast<Outcome *>(h)) ? 1 : 0; }
 
 // The draws in the eigenbasis, w [draws, p1] (betas = w Q'): waits for the chain; a device chain's draws are copied to
@@ -1364,8 +1374,12 @@ extern "C" void fokl_search_clear_forecasts(fokl_search *s)
     s->forecasts.clear();
 }
 
+// The kill tests a sub-stage will probably run, guessed from the least-squares fit of its model before its chain's
+// statistics are there (engine.ForwardSelection._likely_first_tests), in testing order -- and, per test, whether it will
+// probably be accepted (PathModel: the BIC without the column from a rank-one formula), so that the caller can submit G2
+// along the path the tests will really take.  accepted_out may be NULL.
 extern "C" int fokl_search_likely_first_tests(fokl_search *s, fokl_spectrum *spectrum, int n_new, double siglik,
-                                              int32_t *columns_out, int *count)
+                                              int32_t *columns_out, int32_t *accepted_out, int *count)
 {
     if (!s || !spectrum || !columns_out || !count) return fail(s, FOKL_ERR_ARG, "fokl_search_likely_first_tests: null pointer");
     Spectrum *sp = reinterpret_cast<Spectrum *>(spectrum);
@@ -1375,6 +1389,22 @@ extern "C" int fokl_search_likely_first_tests(fokl_search *s, fokl_spectrum *spe
     const auto cols = likely_first_tests(s, sp, n_new, siglik);
     for (size_t i = 0; i < cols.size(); ++i) columns_out[i] = cols[i];
     *count = (int)cols.size();
+    if (accepted_out) {
+        PathModel m;
+        m.init(sp);
+        double ev_floor = ev_from_moments(s, m.s1, m.ssr, m.p);
+        for (size_t i = 0; i < cols.size(); ++i) {
+            const int at = m.position(cols[i]);
+            accepted_out[i] = 0;
+            if (at <= 0) continue;
+            const double ev = ev_from_moments(s, m.s1, m.ssr_without(at), m.p - 1);
+            if (ev < ev_floor) {
+                accepted_out[i] = 1;
+                ev_floor = ev;
+                m.remove(at);
+            }
+        }
+    }
     return FOKL_OK;
 }
 

@@ -673,12 +673,28 @@ class ForwardSelection:
         floor = min(self.threshstda, self.threshstdb)
         return [int(new[j]) for j in np.argsort(guess_mean) if guess_std[j] > floor * guess_mean[j]]
 
-    def _guess_first_tests(self, gram, spec, n_new, siglik=None, before_model=False):
+    def _guess_first_tests(self, gram, spec, n_new, siglik=None, before_model=False, spectrum=None):
         """G2 jobs for the first kill tests of the sub-stage whose model's G2 is `spec` (_likely_first_tests), and the
         tapes of all the likely ones (before_model: the model's own tape has not been taken yet and leads them).
         Returns ({trial set -> job}, sizes of the likely tests); a wrong guess costs a spectral thread a few
         milliseconds."""
         A = gram.shape[0] - 1
+        if self.native is not None and spectrum is not None:
+            # the native side also says which of them will probably be ACCEPTED (the BIC without a column from a rank-one
+            # formula): G2 goes out along the path the tests will take.  Four deep: the ORDER of the tests is still a
+            # guess here (|betahat| for |mean beta|) -- twelve deep cost 40 wasted eigen-decompositions per fit and
+            # took the CPUs the model's chain runs on (53.5 -> 56-58 ms per fit)
+            guessed = self.native.likely_first_tests(spectrum.h, n_new, siglik)
+            jobs, cur, sizes = {}, frozenset(), []
+            for c, accepted in guessed:
+                trial = cur | {c}
+                if len(jobs) <= min(self._lookahead_native, 3):
+                    jobs[trial] = self._spectral(gram, self._columns_without(A, trial))
+                sizes.append(A - len(cur) - 1)
+                if accepted:
+                    cur = trial
+            self._speculate(([ModelSize(A)] if before_model else []) + sizes)
+            return jobs, sizes
         likely = self._likely_first_tests(spec, n_new, siglik)
         jobs, cur = {}, frozenset()
         # (their order is guessed from the least-squares fit before the chain's statistics are there: three or four
@@ -937,6 +953,7 @@ class ForwardSelection:
         """The whole search.  With b > 0 (always, unless the user forces a non-positive scale) the random stream, the
         chains and the eigen-decompositions run on native threads (HostPipeline); otherwise every chain runs in line."""
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
+        t_begin_run = time.perf_counter()
         if pipelined:
             try:
                 # device chains: one search per process at a time drives an engine's guesses; replicated searches (rows
@@ -968,6 +985,7 @@ class ForwardSelection:
                 flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
+        self.stats['t_pool_up'] = time.perf_counter() - t_begin_run
         # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
         # one for the normals finished on the host, host threads or the device for the kill tests' chains
         self.stats['finish_log'] = os.environ.get('FOKL_FINISH_LOG', 'fast')
@@ -1106,6 +1124,16 @@ class ForwardSelection:
         forecasts = {}                              # survivors' slots -> (G2 job of the coming model, its Gram)
         look_ahead = self.host is not None and self.foresight > 0
 
+        phase = self.stats.setdefault('phases', dict(prepare=0.0, model=0.0, statistics=0.0, tests=0.0, wrap_up=0.0))
+        tick = time.perf_counter()
+
+        def lap(name):
+            # where the driver thread's time goes, sub-stage by sub-stage (waits included)
+            nonlocal tick
+            now = time.perf_counter()
+            phase[name] += now - tick
+            tick = now
+
         while pattern is not None:
             ind, indvec = pattern
             pattern = next(patterns, None)
@@ -1144,7 +1172,8 @@ class ForwardSelection:
             early, then = None, [A - 1] if vm > 0 and A > 1 else []
             if pipelined and self.lookahead > 0 and spectral_job is not None and getattr(
                     spectral_job, 'done', lambda: False)():
-                early, then = self._guess_first_tests(gram, spectral_job.wait(), vm, before_model=True)
+                early, then = self._guess_first_tests(gram, spectral_job.wait(), vm, before_model=True,
+                                                      spectrum=spectral_job if self.native is not None else None)
 
             def build_next(coming=pattern, active=active_slots):
                 nonlocal ahead
@@ -1156,11 +1185,13 @@ class ForwardSelection:
             # ordered together with the model's own (which may be on its way already, see _kill_tests_pipelined): the
             # noise thread goes straight on instead of idling until the model's chain has finished and its statistics
             # have ordered the proposals
+            lap('prepare')
             full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False, spectral_job=spectral_job,
                                   overlap=None if pipelined else build_next, then=then)
             best = full
             ev = full.ev
             _mark('full_evaluated', str(A))
+            lap('model')
             vm_next = None
             if pipelined and pattern is not None:
                 vm_next = distinct_arrangements(pattern[1]).shape[0]
@@ -1200,13 +1231,17 @@ class ForwardSelection:
                 early = {}
                 if pipelined and self.lookahead > 0:
                     # guess the first tests now, while the chain of the sub-stage model is still running
-                    early, _ = self._guess_first_tests(gram, full, vm, siglik=full.siglik)
+                    own = None
+                    if self.native is not None:
+                        own = NativeSpectrum(self.native, self.native.outcome_spectrum(full.h), gram)
+                    early, _ = self._guess_first_tests(gram, full, vm, siglik=full.siglik, spectrum=own)
 
             # statistics of the new terms (FR:1656-1664)
             tail = full.beta_columns(np.arange(dam - vm + 1, dam + 1), half0)     # draws half0 .. of the new terms
             mean_abs = np.abs(np.mean(tail[half1 - half0:], axis=0))
             rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
             _mark('full_statistics')
+            lap('statistics')
             order = np.argsort(mean_abs)
             cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
             mean_abs, rel_std = mean_abs[order], rel_std[order]
@@ -1234,6 +1269,7 @@ class ForwardSelection:
                                                                  build_next, coming_tests, chain_coming)
             ev = evmin
             _mark('tests_over', str(len(killed)))
+            lap('tests')
 
             # commit the surviving columns (FR:1691-1695)
             keep = [c for c in range(A) if c not in set(killed)]
@@ -1263,7 +1299,9 @@ class ForwardSelection:
                 betas, mtx = best, damtx
                 evs = np.append(evs, ev)
             self._retire(betas, best)
+            lap('wrap_up')
 
+        lap('wrap_up')
         if self.host is not None:                  # the search stopped: tapes on order for a sub-stage that does not come
             self._drop_speculation()
         if self.native is not None:

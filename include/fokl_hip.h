@@ -543,6 +543,7 @@ typedef struct fokl_outcome_view {
     int32_t p1, on_device;
 } fokl_outcome_view;
 int fokl_outcome_info(fokl_search *search, fokl_outcome *outcome, fokl_outcome_view *view);
+int fokl_outcome_spectrum(fokl_search *search, fokl_outcome *outcome, fokl_spectrum **out);
 int fokl_outcome_chain_ready(fokl_outcome *outcome);
 int fokl_outcome_draws(fokl_search *search, fokl_outcome *outcome, const double **w);
 int fokl_outcome_intercept_scale(fokl_search *search, fokl_outcome *outcome, double *scale);
@@ -553,7 +554,7 @@ int fokl_search_register_forecast(fokl_search *search, const int32_t *key, int k
                                   double dtd);
 void fokl_search_clear_forecasts(fokl_search *search);
 int fokl_search_likely_first_tests(fokl_search *search, fokl_spectrum *spectrum, int n_new, double siglik,
-                                   int32_t *columns_out, int *count);
+                                   int32_t *columns_out, int32_t *accepted_out, int *count);
 /* counters / seconds in the order of csrc/fokl_search.cpp's Stat enumeration (-> their number); the trace: 4 doubles per
  * evaluation (columns, built, ev, kill) */
 int fokl_search_stats(const fokl_search *search, double *values, int count);
