@@ -994,6 +994,34 @@ int verify(fokl_search *s, bool block)
 // with every accepted test -- and asks it which of the remaining proposals will be tested and which accepted, so that the
 // G2 jobs and the tapes of the whole path can be ordered far ahead (a spectral job is 0.4 ms: every wrong guess about the
 // next model used to stall the loop for that long).  It only ever PREDICTS: every decision is taken from the real BIC.
+#define FOKL_SEARCH_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+
+// inv [p x p] = sum over eigenpairs of q q' / lamb (Qt row e = eigenvector e)
+FOKL_SEARCH_CLONES void inverse_from_spectrum(const double *__restrict__ Qt, const double *__restrict__ lamb, int p,
+                                              double *__restrict__ inv, double *__restrict__ scaled)
+{
+    std::memset(inv, 0, sizeof(double) * (size_t)p * p);
+    for (int e = 0; e < p; ++e) {
+        const double *__restrict__ q = Qt + (size_t)e * p;
+        const double w = 1.0 / lamb[e];
+        for (int i = 0; i < p; ++i) scaled[i] = q[i] * w;
+        for (int i = 0; i < p; ++i) {
+            double *__restrict__ out = inv + (size_t)i * p;
+            const double qi = scaled[i];
+            for (int j = 0; j < p; ++j) out[j] += qi * q[j];
+        }
+    }
+}
+
+// row `oi` of the downdated inverse from row `i` of the old one: dst[j'] = src[j] - f column[j], column `pos` skipped
+// (dst may be src: every element is read before the place it goes to is written)
+FOKL_SEARCH_CLONES void downdate_row(const double *src, const double *__restrict__ column, double f, int p, int pos,
+                                     double *dst)
+{
+    for (int j = 0; j < pos; ++j) dst[j] = src[j] - f * column[j];
+    for (int j = pos + 1; j < p; ++j) dst[j - 1] = src[j] - f * column[j];
+}
+
 struct PathModel {
     int p = 0, ld = 0;
     std::vector<int32_t> cols;              // active column of every model position
@@ -1008,19 +1036,9 @@ struct PathModel {
         beta.assign(sp->betahat(), sp->betahat() + p);
         ssr = sp->moments()[1];
         s1 = sp->moments()[0];
-        inv.assign((size_t)p * p, 0.0);
-        const double *Qt = sp->Qt(), *lamb = sp->lamb();
-        std::vector<double> row((size_t)p);
-        for (int e = 0; e < p; ++e) {                       // sum over eigenpairs of q q' / lamb
-            const double *q = Qt + (size_t)e * p;
-            const double w = 1.0 / lamb[e];
-            for (int i = 0; i < p; ++i) row[(size_t)i] = q[i] * w;
-            for (int i = 0; i < p; ++i) {
-                double *out = inv.data() + (size_t)i * p;
-                const double qi = row[(size_t)i];
-                for (int j = 0; j < p; ++j) out[j] += qi * q[j];
-            }
-        }
+        inv.resize((size_t)p * p);
+        std::vector<double> scaled((size_t)p);
+        inverse_from_spectrum(sp->Qt(), sp->lamb(), p, inv.data(), scaled.data());
     }
 
     int position(int32_t col) const
@@ -1038,18 +1056,12 @@ struct PathModel {
         ssr += bc * bc / pivot;
         std::vector<double> column((size_t)p);
         for (int i = 0; i < p; ++i) column[(size_t)i] = inv[(size_t)i * ld + pos];
-        // downdate, compacting row / column `pos` away as we go
+        // downdate, compacting row / column `pos` away as we go (row oi <= i is written after row i was read)
         int oi = 0;
         for (int i = 0; i < p; ++i) {
             if (i == pos) continue;
             const double f = column[(size_t)i] / pivot;
-            double *dst = inv.data() + (size_t)oi * ld;
-            const double *src = inv.data() + (size_t)i * ld;
-            int oj = 0;
-            for (int j = 0; j < p; ++j) {
-                if (j == pos) continue;
-                dst[oj++] = src[j] - f * column[(size_t)j];
-            }
+            downdate_row(inv.data() + (size_t)i * ld, column.data(), f, p, pos, inv.data() + (size_t)oi * ld);
             beta[(size_t)oi] = beta[(size_t)i] - f * bc;
             cols[(size_t)oi] = cols[(size_t)i];
             ++oi;
@@ -1487,16 +1499,23 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     committed.init(best->spec);
     std::vector<Step> path;
     size_t path_from = 0;                                   // path[k] <-> proposal[path_from + k]
+    // (as far as the loop orders things ahead: G2 jobs `lookahead` tests deep, tapes speculation_max deep -- a downdate
+    // is O(columns^2), the whole rest of a sub-stage of hundreds of columns would cost more than it saves)
+    const int horizon = std::max(s->prm.lookahead, s->prm.speculation_max) + 8;
+    bool path_complete = false;                             // the path reaches the end of the proposals
     auto predict = [&](size_t pos) {
         PathModel m = committed;
         double ev_floor = evmin;
         path.clear();
         path_from = pos;
-        for (size_t q = pos; q < proposal.size(); ++q) {
+        int running = 0;
+        size_t q = pos;
+        for (; q < proposal.size() && running < horizon; ++q) {
             const int j = proposal[q];
             const double scale = std::fabs(m.beta[0]);      // the intercept of the model accepted so far (predicted)
             Step st{clause1[(size_t)j] || a->mean_abs[j] < threshav * (q == pos ? scale_guess : scale), false};
             if (st.run) {
+                ++running;
                 const int at = m.position(a->columns[j]);
                 if (at > 0) {
                     const double ev = ev_from_moments(s, m.s1, m.ssr_without(at), m.p - 1);
@@ -1509,11 +1528,15 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
             path.push_back(st);
         }
+        path_complete = q == proposal.size();
     };
-    auto step_at = [&](size_t q) -> Step { return q >= path_from && q - path_from < path.size() ? path[q - path_from] : Step{false, false}; };
+    auto step_at = [&](size_t q) -> Step {
+        if (q >= path_from && q - path_from < path.size()) return path[q - path_from];
+        return Step{likely(proposal[q]), true};            // beyond the horizon: the round-3 guess
+    };
     auto forecast = [&](size_t pos) {
         // the kill set at the end of the loop if the rest goes as predicted
-        if (!a->foresee) return;
+        if (!a->foresee || !path_complete) return;
         std::vector<int32_t> pred(killed);
         int rest = 0;
         for (size_t q = pos; q < proposal.size(); ++q) {
@@ -1597,6 +1620,10 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         const int i = proposal[pos];
         bool decided = clause1[(size_t)i];
         if ((rc = verify(s, false)) != FOKL_OK) break;
+        if (!path_complete && pos + (size_t)(horizon / 2) >= path_from + path.size()) {
+            predict(pos);                                   // the window of predicted steps moves on
+            order_tapes(pos);
+        }
         if (!decided) {
             // the second clause without a wait: from the chain of `best` if it has run, from its least-squares intercept
             // (confirmed later) if that is a device chain and the proposal is not a borderline case

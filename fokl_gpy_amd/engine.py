@@ -965,8 +965,10 @@ class ForwardSelection:
                         self.device_chain_columns = min(self.device_chain_columns,
                                                         getattr(self.chain_engine, 'max_columns', 768))
                     self._dchain_stats0 = self.chain_engine.stats() if self.chain_engine is not None else {}
+                # (a sub-stage of 3-way terms over m inputs adds up to m (m - 1) (m - 2) columns: models of hundreds)
+                wide = self.m * (self.m - 1) * (self.m - 2 if self.way3 else 1) >= 1000
                 self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None,
-                                         chain_engine=self.chain_engine)
+                                         chain_engine=self.chain_engine, wide_models=wide)
             except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
                 # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
                 # line, only slower

@@ -120,18 +120,21 @@ def _cpu_budget():
     return budget
 
 
-def _bulk_threads(budget=None):
+def _bulk_threads(budget=None, wide_models=False):
     """Threads that produce the random stream ahead of the noise thread's walk (csrc/fokl_stream.cpp): the walk consumes a
     segment of 79 872 doubles in 10-30 us, a bulk thread makes one in 20-40 us (AVX-512).  FOKL_BULK_THREADS overrides."""
     if budget is None:
         budget = _cpu_budget()
-    default = 4 if budget >= 12 else (2 if budget >= 5 else 1)
+    default = (3 if wide_models else 4) if budget >= 12 else (2 if budget >= 5 else 1)
     return max(1, int(os.environ.get('FOKL_BULK_THREADS', str(default))))
 
 
-def _thread_plan():
+def _thread_plan(wide_models=False):
     """(chain, finish, spectral) thread counts of the host pipeline for the CPU budget of this process; the driver and
-    the noise thread come on top.  FOKL_CHAIN_THREADS / FOKL_FINISH_THREADS / FOKL_SPECTRAL_THREADS override."""
+    the noise thread come on top.  FOKL_CHAIN_THREADS / FOKL_FINISH_THREADS / FOKL_SPECTRAL_THREADS override.
+    wide_models: the search will evaluate models of hundreds of columns (configs[3]: 3-way terms over 16 inputs) -- an
+    eigen-decomposition then costs tens of milliseconds and the fit waits for little else: the spectral threads get what
+    the stream's bulk threads can spare."""
     budget = _cpu_budget()
     # Finishing threads follow the recorder block by block and spin while they wait for it, so each of them costs about
     # the recorder's own busy time in CPU whatever it computes.  With the vector log (default, fokl_vlog.cpp) one thread
@@ -148,7 +151,9 @@ def _thread_plan():
     # THROUGHPUT of the eigen-decompositions (0.17 CPU-seconds of dsyevr per configs[2] fit).  tools/env_sweep_r04.sh on the
     # GPU boxes (16 CPUs, chain + finish + spectral / ms per fit): 2+1+4 61.7, 2+1+6 58.6, 2+1+8 51-52, 2+1+10 53.6,
     # 2+1+12 53.5 (contention with the stream's four bulk threads); finish threads only serve the sub-stage models' tapes.
-    if budget >= 12:
+    if budget >= 12 and wide_models:
+        plan = (2, 3, 9)                                    # their tapes are expanded and finished on the host: 3 threads
+    elif budget >= 12:
         plan = (2, 3 if exact_log else 2, 8)
     elif budget >= 8:
         plan = (1, 2 if exact_log else 1, 5)
@@ -255,7 +260,7 @@ class HostPipeline:
     The driver thread keeps what needs Python or the device: the sequential decisions, the K1 / K2 / K3 launches.
     """
 
-    def __init__(self, stream, draws, comm=None, chain_engine=None):
+    def __init__(self, stream, draws, comm=None, chain_engine=None, wide_models=False):
         self.stream, self.draws = stream, int(draws)
         self.dchain = chain_engine          # G3 of kill-test candidates on the device (None: host chain threads)
         self._pinned = chain_engine is not None and getattr(chain_engine, 'wants_pinned_tapes', True)
@@ -273,7 +278,7 @@ class HostPipeline:
         self._saved_affinity, noise_cpu = None, -1
         if os.environ.get('FOKL_PIN_L3', '1') != '0':
             self._saved_affinity, noise_cpu = _place_host_threads()
-        chain, finish, spectral = _thread_plan()
+        chain, finish, spectral = _thread_plan(wide_models)
         # With a device chain engine the stream's bulk threads leave every segment's pre-state in the engine's page-locked
         # ring: the device regenerates the segments a tape covers and expands the tape from its 32-byte rows
         # (fokl_dchain_submit_rows) -- the native search then never materialises a kill test's tape on the host.
@@ -286,7 +291,7 @@ class HostPipeline:
             except _capi.FoklNativeError:
                 prestates = None
         try:
-            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads(),
+            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads(wide_models=wide_models),
                                        prestates=prestates)
             if prestates is not None:
                 chain_engine.bind(self.pool.stream_handle())
