@@ -259,3 +259,58 @@ def test_rows_expanded_on_the_device_equal_the_tape_expanded_on_the_host(p1, pos
         se.close()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('p1', [586, 768])
+def test_sixteen_wide_chains_at_once_at_the_full_chain_length(p1, monkeypatch):
+    """the size classes above four elements per lane (T = 12: up to 768 columns) and tapes in page-locked buffers
+    of exactly the size they need had no clean batched run on record (tools/chain_device_probe.py died at 586 columns).
+    Sixteen chains of 2000 iterations in flight together, from tapes recorded into exact-size page-locked buffers (the
+    one-thread recorder and its whole-vector stores included) and from rows expanded on the device: every one equals the
+    host chain on the same tape."""
+    monkeypatch.setenv('FOKL_FINISH_LOG', 'exact')
+    draws, chains = 2000, 16
+    eng = _capi.DeviceChainEngine(int(os.environ.get('FOKL_DEVICE', '0')), slots=2 * chains)
+    try:
+        rng = np.random.default_rng(p1)
+        args = (900.0, 2.0, 5e5, 0.3, 0.9)
+        astar, atau_star = 5e5 + p1 / 2, 4 + (p1 - 1) / 2
+        np.random.seed(p1)
+        old_stream = _capi.LegacyStream()
+        se = _capi.StreamEngine(_capi.LegacyStream(), 3, prestates=eng.prestate_ring())
+        eng.bind(se._h)
+        jobs, holds = [], []
+        for c in range(chains):
+            lamb, qty = model(p1, rng)
+            raw = _capi.pinned_empty(_capi.NoiseTape.doubles_needed(p1, draws))
+            tape = _capi.NoiseTape(p1, draws, raw=raw)
+            if c % 2 == 0:
+                # the round-3 path: the one-thread recorder into the page-locked buffer, gathered over the bus
+                _capi.record_noise_tape(tape, astar, atau_star, old_stream)
+                job = eng.submit(lamb, qty, *args, tape, stat_first=draws // 2, follow=False)
+                want = _capi.gibbs_chain_from_tape(lamb, qty, *args, tape)[0]
+            else:
+                # the round-4 path: rows, expanded on the device
+                holds.append(se.walk(tape, astar, atau_star))
+                span = np.array([holds[-1], se.tell().position], dtype=np.uint64)
+                job = eng.submit_rows(lamb, qty, *args, astar, atau_star, tape, span, stat_first=draws // 2)
+                host = _capi.NoiseTape(p1, draws)
+                host.rows[:] = tape.rows
+                se.expand(host, astar, atau_star)
+                host.progress[0] = draws
+                want = _capi.gibbs_chain_from_tape(lamb, qty, *args, host)[0]
+            jobs.append((job, want))
+        for job, want in jobs:
+            mean_w, flag = job.wait()
+            w = job.fetch_w()
+            scale = np.max(np.abs(want), axis=0)
+            assert not flag[0]
+            assert np.max(np.abs(w - want) / scale) < 1e-13
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+            job.release()
+        for hold in holds:
+            se.release(hold)
+        eng.bind(None)
+        se.close()
+    finally:
+        eng.close()
