@@ -30,6 +30,8 @@ SIGNATURES = {
     'fokl_last_error': (ctypes.c_char_p, [c_vp]),
     'fokl_sync': (c_int, [c_vp]),
     'fokl_upload': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int]),
+    'fokl_column_min_max': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int]),
+    'fokl_normalize_columns': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int]),
     'fokl_reserve_slots': (c_int, [c_vp, c_int]),
     'fokl_slot_capacity': (c_int, [c_vp]),
     'fokl_rows': (c_i64, [c_vp]),
@@ -260,6 +262,30 @@ class LegacyStream:
         out = np.empty(int(n), dtype=np.float64)
         _check(load().fokl_rng_gammas(*self.args(), c_dbl(shape), c_dbl(scale), c_i64(int(n)), _ptr(out)))
         return out
+
+
+def _host_threads():
+    try:
+        return max(1, min(8, len(os.sched_getaffinity(0))))
+    except (AttributeError, OSError):
+        return 1
+
+
+def column_min_max(x):
+    """(minima, maxima) of the columns of a C-contiguous float64 [n, m] array on several host threads (fokl_column_min_max:
+    np.min / np.max per column, exact)."""
+    n, m = x.shape
+    lows, highs = np.empty(m), np.empty(m)
+    _check(load().fokl_column_min_max(_ptr(x), n, m, _ptr(lows), _ptr(highs), _host_threads()))
+    return lows, highs
+
+
+def normalize_columns(x, lows, spans):
+    """x <- (x - lows) / spans in place, element by element as numpy does it (fokl_normalize_columns)."""
+    lows = np.ascontiguousarray(lows, dtype=np.float64)
+    spans = np.ascontiguousarray(spans, dtype=np.float64)
+    _check(load().fokl_normalize_columns(_ptr(x), x.shape[0], x.shape[1], _ptr(lows), _ptr(spans), _host_threads()))
+    return x
 
 
 def gibbs_chain(lamb, qty, astar, atau_star, b, btau, dtd, sigsqd0, tausqd0, draws, stream, want_sig_tau=False):

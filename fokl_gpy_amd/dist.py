@@ -6,9 +6,10 @@ The forward-selection path has exactly two exchange steps, both tiny:
     over ranks;
   * all-reduce(sum) of Gram blocks / residual moments when *rows* are sharded over ranks.
 
-``RcclComm`` drives them on the GPU; ``GlooComm`` offers the same interface over ``torch.distributed``'s gloo
-backend so that the N > 1 host logic is testable on CPU (tests/test_dist_gloo.py).  torch is used for that CPU
-test only: a GPU process never imports it (its bundled HIP / RCCL copies must not share a process with ours).
+``RcclComm`` drives them on the GPU; ``TcpComm`` is the control plane (barriers, a few timing figures) and the data path
+of launcher rehearsals.  No PyTorch anywhere in this package: the stand-in with the same interface over
+``torch.distributed``'s gloo backend, with which the N > 1 host logic is tested on CPU, is test scaffolding
+(tests/dist_worker.py).
 """
 import os
 
@@ -395,35 +396,6 @@ def bring_up(ctx, rank, world, need_rccl, timeout_s=180.0, log=None):
         tcp.close()
         raise RuntimeError(f"this mode exchanges data through RCCL, which did not come up: {why}")
     return tcp, f'TCP control plane only (RCCL did not come up: {why})'
-
-
-class GlooComm:
-    """Same interface over an initialised ``torch.distributed`` process group (CPU tests)."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self._dist = dist
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
-
-    def allgather(self, values):
-        import torch
-        v = torch.as_tensor(np.asarray(values, dtype=np.float64).reshape(-1))
-        out = [torch.empty_like(v) for _ in range(self.world)]
-        self._dist.all_gather(out, v)
-        return np.stack([o.numpy() for o in out], axis=0)
-
-    def allreduce_sum(self, values):
-        import torch
-        v = torch.as_tensor(np.array(values, dtype=np.float64, copy=True))
-        self._dist.all_reduce(v)
-        return v.numpy()
-
-    def barrier(self):
-        self._dist.barrier()
-
-    def close(self):
-        pass
 
 
 def shard_range(count, rank, world):

@@ -89,6 +89,14 @@ int fokl_reserve_slots(fokl_ctx *ctx, int n_slots);
 int fokl_slot_capacity(const fokl_ctx *ctx);
 int64_t fokl_rows(const fokl_ctx *ctx);
 
+/*
+ * FoKL.clean's two passes over a row-major dataset x [n, m] on `threads` host threads (FR:395, 436-437): the minimum and
+ * maximum of every column (exact; NaN-propagating like np.min / np.max), and x <- (x - lows) / spans in place -- one
+ * subtraction and one division per element, separately rounded: the reference's numbers bit for bit.
+ */
+int fokl_column_min_max(const double *x, int64_t n, int m, double *lows, double *highs, int threads);
+int fokl_normalize_columns(double *x, int64_t n, int m, const double *lows, const double *spans, int threads);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* K1: basis-matrix columns.  Replaces the X-build triple loop of gibbs(), FR:1446-1485, with              */
 /* evaluate_basis (FR:807-849, d = 0) and _inputs_to_phind (FR:570-589) fused in.                          */

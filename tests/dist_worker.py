@@ -1,6 +1,6 @@
 """Worker for tests/test_dist_gloo.py: launched with torch.distributed.run (2 ranks, gloo, CPU).
 
-Exercises the N > 1 host logic with the same communicator interface the GPU path uses (dist.RcclComm <-> dist.GlooComm):
+Exercises the N > 1 host logic with the same communicator interface the GPU path uses (dist.RcclComm <-> GlooComm below):
   1. the two collectives (all-gather, all-reduce-sum) and the shard partition;
   2. a ROW-SHARDED fit: each rank holds half of the rows, Gram blocks / residual moments are summed over ranks,
      the (N-independent) sampler is replicated -> every rank must select the same model as a single-process fit;
@@ -41,6 +41,38 @@ class ShardedOracleBackend(OracleBackend):
         return float(s[0]), float(s[1])
 
 
+
+# The product's communicators are RCCL over xGMI and a TCP control plane (fokl_gpy_amd/dist.py, no PyTorch); this stand-in
+# with the same interface over a torch.distributed gloo group is test scaffolding and lives here.
+class GlooComm:
+    """Same interface over an initialised ``torch.distributed`` process group (CPU tests)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+
+    def allgather(self, values):
+        import torch
+        v = torch.as_tensor(np.asarray(values, dtype=np.float64).reshape(-1))
+        out = [torch.empty_like(v) for _ in range(self.world)]
+        self._dist.all_gather(out, v)
+        return np.stack([o.numpy() for o in out], axis=0)
+
+    def allreduce_sum(self, values):
+        import torch
+        v = torch.as_tensor(np.array(values, dtype=np.float64, copy=True))
+        self._dist.all_reduce(v)
+        return v.numpy()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def close(self):
+        pass
+
+
 def synth(seed, n, m):
     rng = np.random.default_rng(seed)
     x = rng.random((n, m))
@@ -51,7 +83,7 @@ def synth(seed, n, m):
 def main():
     out_dir = sys.argv[1]
     tdist.init_process_group('gloo')
-    comm = dist.GlooComm()
+    comm = GlooComm()
     rank, world = comm.rank, comm.world
     res = {}
 
