@@ -57,7 +57,7 @@ constexpr int kSegSlots = kSegDoubles / 2;                  // 39 936 attempts p
 constexpr int kSegMaskWords = kSegSlots / 64;               // 624 mask words per alignment
 constexpr int kSegTail = 32;                                // words of the next segment kept behind this one's
 constexpr int kTable = 8192;                                // segments that can be alive at a time (524 M doubles)
-constexpr int kAhead = 6;                                   // segments produced ahead of the walker
+constexpr int kAhead = 24;                                  // segments produced ahead of the walker (a 585-column tape is 19)
 constexpr uint64_t kLeadBit = FOKL_ROW_LEAD;                // fokl_tape_row.start: the row opens with the cached normal
 constexpr uint64_t kCachedHalf = FOKL_SOURCE_X1_HALF;       // a normal's source: the x1 half of the attempt (else x2)
 constexpr uint64_t kGivenGauss = FOKL_SOURCE_GIVEN;         // source position: the cached value of the state handed over
@@ -270,6 +270,7 @@ struct fokl_stream {
     // token_m: the walker must never wait for a recurrence to finish
     std::mutex room_m;
     std::condition_variable room_cv;
+    std::atomic<int> sleepers{0};                           // producers inside (or about to enter) room_cv.wait
     uint32_t carry[MT_N];                                   // last raw block generated so far
     int64_t next_raw = 0;                                   // next segment to be generated
     int64_t oldest_alive = 0;                               // segments below were given back
@@ -366,13 +367,23 @@ void bulk_worker(fokl_stream *e)
                 if (e->next_raw < e->limit.load(std::memory_order_acquire) && e->next_raw - low < kTable - 2) break;
                 const int64_t next = e->next_raw;
                 lock.unlock();
-                {
+                auto room_now = [&] {
+                    return e->stop_flag.load(std::memory_order_seq_cst) ||
+                           (next < e->limit.load(std::memory_order_seq_cst) &&
+                            next - e->low_water.load(std::memory_order_seq_cst) < kTable - 2);
+                };
+                // a walker in the middle of a tape comes for the next segments within microseconds: look a few times
+                // before going to sleep (a sleep and a wake-up per segment cost more than the segment)
+                bool ready = false;
+                for (int spins = 0; spins < 400 && !ready; ++spins) {
+                    ready = room_now();
+                    if (!ready) _mm_pause();
+                }
+                if (!ready) {
                     std::unique_lock<std::mutex> room(e->room_m);
-                    e->room_cv.wait(room, [&] {
-                        return e->stop_flag.load(std::memory_order_acquire) ||
-                               (next < e->limit.load(std::memory_order_acquire) &&
-                                next - e->low_water.load(std::memory_order_acquire) < kTable - 2);
-                    });
+                    e->sleepers.fetch_add(1, std::memory_order_seq_cst);
+                    e->room_cv.wait(room, room_now);
+                    e->sleepers.fetch_sub(1, std::memory_order_seq_cst);
                 }
                 lock.lock();
             }
@@ -423,11 +434,11 @@ Segment *segment_of(fokl_stream *e, uint64_t D, bool walker)
     Segment *seg = e->table[index % kTable].load(std::memory_order_acquire);
     if (seg && seg->index == index) return seg;
     if (walker && index + kAhead > e->limit.load(std::memory_order_relaxed)) {
-        {
-            std::lock_guard<std::mutex> lock(e->room_m);
-            e->limit.store(index + kAhead, std::memory_order_release);
+        e->limit.store(index + kAhead, std::memory_order_seq_cst);
+        if (e->sleepers.load(std::memory_order_seq_cst) > 0) {
+            { std::lock_guard<std::mutex> lock(e->room_m); }
+            e->room_cv.notify_all();
         }
-        e->room_cv.notify_all();
     }
     const int64_t t0 = now_ns();
     for (int spins = 0;; ++spins) {
@@ -474,11 +485,11 @@ struct Reader {
             // keep the producers kAhead segments in front of this one
             const int64_t want = (int64_t)(D / kSegDoubles) + 1 + kAhead;
             if (want > e->limit.load(std::memory_order_relaxed)) {
-                {
-                    std::lock_guard<std::mutex> lock(e->room_m);
-                    e->limit.store(want, std::memory_order_release);
+                e->limit.store(want, std::memory_order_seq_cst);
+                if (e->sleepers.load(std::memory_order_seq_cst) > 0) {
+                    { std::lock_guard<std::mutex> lock(e->room_m); }
+                    e->room_cv.notify_all();
                 }
-                e->room_cv.notify_all();
             }
         }
         return true;

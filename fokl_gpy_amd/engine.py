@@ -323,7 +323,11 @@ class ForwardSelection:
         # ... for models of up to this many columns.  Beyond, the chain stays on the host threads: a 585-column tape is 14 MB
         # of page-locked memory and dozens of them are alive at a time (configs[3]: 1.74 s per fit with device chains,
         # 1.49 s with host chains -- and the eigen-decompositions, not the chains, are what that fit waits for)
-        self.device_chain_columns = int(os.environ.get('FOKL_DCHAIN_MAX_COLUMNS', '256'))
+        # (round 4: with tapes expanded on the device from rows nothing of a 585-column tape crosses the bus or is
+        # materialised on the host -- every kill test's chain goes to the device, up to the engine's 768 columns:
+        # configs[3] 1.76 -> 1.11 s per fit; FOKL_DCHAIN_ROWS=0 falls back to 256)
+        self.device_chain_columns = int(os.environ.get(
+            'FOKL_DCHAIN_MAX_COLUMNS', '768' if os.environ.get('FOKL_DCHAIN_ROWS', '1') != '0' else '256'))
         self.guess_margin = float(os.environ.get('FOKL_GUESS_MARGIN', '0.02'))
         self._flip_guess = int(os.environ.get('FOKL_GUESS_TEST_FLIP', '0'))   # tests: the n-th guess is taken wrong
         self._unverified = collections.deque()   # (device-chained outcome, half0) whose checks are open, oldest first

@@ -152,7 +152,7 @@ def _thread_plan(wide_models=False):
     # GPU boxes (16 CPUs, chain + finish + spectral / ms per fit): 2+1+4 61.7, 2+1+6 58.6, 2+1+8 51-52, 2+1+10 53.6,
     # 2+1+12 53.5 (contention with the stream's four bulk threads); finish threads only serve the sub-stage models' tapes.
     if budget >= 12 and wide_models:
-        plan = (2, 3, 9)                                    # their tapes are expanded and finished on the host: 3 threads
+        plan = (2, 3 if exact_log else 1, 11)               # (kill tests' tapes are expanded on the device; 6 CPU-s of dsyevr)
     elif budget >= 12:
         plan = (2, 3 if exact_log else 2, 8)
     elif budget >= 8:
