@@ -136,6 +136,9 @@ struct fokl_host_pool {
     // FOKL_POOL_TEST_DELAY_US (tests only): the noise thread sleeps this long between looking at the verdicts of its open
     // tapes and taking the next request -- the window in which a driver can send tapes back and queue a new one
     int test_delay_us = 0;
+    // FOKL_EIGH_SIGNS=lapack: eigenvectors keep the signs dsyevr returns (the untouched reference's draws on a host
+    // whose BLAS forms the same Gram); default: largest-magnitude component positive (what the goldens pin)
+    bool lapack_signs = false;
 };
 
 namespace {
@@ -194,7 +197,7 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
         return FOKL_ERR_NUMERIC;
     }
     // sign convention of engine.eigh_canonical: the largest-magnitude component (first one on ties) is positive
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < n && !pool->lapack_signs; ++j) {
         double *v = z + (size_t)j * n;
         int piv = 0;
         double best = std::fabs(v[0]);
@@ -590,6 +593,7 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
     pool->gauss_cache = gauss_cache;
     if (const char *path = std::getenv("FOKL_POOL_TRACE")) pool->trace_path = path;
     if (const char *us = std::getenv("FOKL_POOL_TEST_DELAY_US")) pool->test_delay_us = std::max(0, std::atoi(us));
+    if (const char *signs = std::getenv("FOKL_EIGH_SIGNS")) pool->lapack_signs = std::strcmp(signs, "lapack") == 0;
     try {
         pool->threads.emplace_back(noise_worker, pool);
         if (noise_cpu >= 0 && noise_cpu < CPU_SETSIZE) {

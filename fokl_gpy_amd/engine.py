@@ -109,6 +109,8 @@ def eigh_canonical(A):
     Q diag(d^1/2) vec (FR:1525-1528); the convention makes draws comparable across summation orders.
     """
     lam, Q = _eigh(A)
+    if os.environ.get('FOKL_EIGH_SIGNS', 'canonical') == 'lapack':
+        return lam, Q                   # LAPACK's own signs: the untouched reference's draws (see README, parity)
     piv = np.argmax(np.abs(Q), axis=0)
     sgn = np.sign(Q[piv, np.arange(Q.shape[1])])
     sgn[sgn == 0] = 1.0
