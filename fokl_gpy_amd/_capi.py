@@ -90,6 +90,8 @@ SIGNATURES = {
     'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
     'fokl_search_mispredicted': (c_int, [c_vp]),
@@ -139,6 +141,16 @@ SIGNATURES = {
     'fokl_dchain_fetch_w': (c_int, [c_vp, c_i64, c_vp]),
     'fokl_dchain_release': (c_int, [c_vp, c_i64]),
     'fokl_dchain_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_dspectral_create': (c_int, [c_int, c_vp]),
+    'fokl_dspectral_destroy': (None, [c_vp]),
+    'fokl_dspectral_max_columns': (c_int, []),
+    'fokl_dspectral_set_signs': (c_int, [c_vp, c_int]),
+    'fokl_dspectral_submit': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    'fokl_dspectral_flush': (c_int, [c_vp]),
+    'fokl_dspectral_poll': (c_int, [c_vp, c_i64]),
+    'fokl_dspectral_wait': (c_int, [c_vp, c_i64]),
+    'fokl_dspectral_release': (c_int, [c_vp, c_i64]),
+    'fokl_dspectral_stats': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_host_alloc': (c_int, [ctypes.c_size_t, c_vp]),
     'fokl_host_free': (c_int, [c_vp]),
     'fokl_comm_unique_id': (c_int, [c_vp]),
@@ -716,7 +728,7 @@ class _KillTestsResult(ctypes.Structure):
 SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain', 'chains_materialised', 'bic_from_gram',
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
-                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted')
+                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device')
 
 
 class NativeSearch:
@@ -761,6 +773,15 @@ class NativeSearch:
 
     def drop_speculation(self):
         self._checked(self._lib.fokl_search_drop_speculation(self._h))
+
+    def bind_spectral(self, engine, max_columns=None):
+        """G2 of models of up to max_columns columns on the device (a DeviceSpectralEngine; None: the pool's threads)."""
+        self._spectral_engine = engine                   # kept alive as long as the search
+        limit = (engine.max_columns if max_columns is None else int(max_columns)) if engine is not None else 0
+        self._checked(self._lib.fokl_search_bind_spectral(self._h, engine._h if engine is not None else None, limit))
+
+    def hold_spectral(self, hold):
+        self._checked(self._lib.fokl_search_hold_spectral(self._h, 1 if hold else 0))
 
     def spectral(self, gram, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
@@ -1131,6 +1152,81 @@ class DeviceChainEngine:
         _check(self._lib.fokl_dchain_stats(self._h, ctypes.byref(busy), ctypes.byref(issued), ctypes.byref(launches),
                                            ctypes.byref(staged)))
         return dict(dispatch_s=busy.value, issued=issued.value, launches=launches.value, staged=staged.value)
+
+
+class DeviceSpectralJob:
+    """One eigen-decomposition on the device; the arrays are views of the engine's page-locked result area (valid until
+    ``release``)."""
+
+    def __init__(self, engine, ticket, result, p1):
+        self.engine, self.ticket, self.p1 = engine, int(ticket), int(p1)
+        n = self.p1
+        area = (ctypes.c_double * (n * n + 3 * n + 7)).from_address(result)
+        self._area = np.frombuffer(area, dtype=np.float64)
+        self._released = False
+
+    def done(self):
+        rc = self.engine._lib.fokl_dspectral_poll(self.engine._h, self.ticket)
+        if rc < 0:
+            _check(-rc)
+        return rc == 1
+
+    def wait(self):
+        """-> (lamb, Qt, qty, betahat, moments) like HostPool's spectral job."""
+        _check(self.engine._lib.fokl_dspectral_wait(self.engine._h, self.ticket))
+        n, a = self.p1, self._area
+        return a[:n], a[3 * n:3 * n + n * n].reshape(n, n), a[n:2 * n], a[2 * n:3 * n], a[3 * n + n * n:3 * n + n * n + 2]
+
+    def info(self):
+        """-> dict(sweeps, rotations, seconds on the device) of a job that has run."""
+        a = self._area[3 * self.p1 + self.p1 * self.p1 + 2:]
+        return dict(sweeps=int(a[0]), rotations=int(a[1]), seconds=float(a[2]), not_converged=bool(a[3]))
+
+    def release(self):
+        if not self._released and self.engine._h:
+            self._released = True
+            _check(self.engine._lib.fokl_dspectral_release(self.engine._h, self.ticket))
+
+
+class DeviceSpectralEngine:
+    """include/fokl_hip.h: fokl_dspectral_* -- G2 (eigh of XtX sub-blocks, Q'Xty, betahat, residual moments) on the GPU."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = None
+        h = c_vp(0)
+        _check(self._lib.fokl_dspectral_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.max_columns = int(self._lib.fokl_dspectral_max_columns())
+
+    def close(self):
+        if self._h:
+            self._lib.fokl_dspectral_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_signs(self, canonical=True):
+        _check(self._lib.fokl_dspectral_set_signs(self._h, 1 if canonical else 0))
+
+    def submit(self, gram, idx, launch=True):
+        """Queue the decomposition of gram[idx][:, idx] (gram: [(A + 1), (A + 1)], ones column first, y last)."""
+        gram = np.ascontiguousarray(gram, dtype=np.float64)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        ticket, result = c_i64(0), c_vp(0)
+        _check(self._lib.fokl_dspectral_submit(self._h, _ptr(gram), int(gram.shape[0]), _ptr(idx), int(idx.size),
+                                               int(gram.shape[0]) - 1, 1 if launch else 0, ctypes.byref(ticket),
+                                               ctypes.byref(result)))
+        return DeviceSpectralJob(self, ticket.value, result.value, idx.size)
+
+    def flush(self):
+        _check(self._lib.fokl_dspectral_flush(self._h))
+
+    def stats(self):
+        submitted, launches = c_i64(0), c_i64(0)
+        _check(self._lib.fokl_dspectral_stats(self._h, ctypes.byref(submitted), ctypes.byref(launches)))
+        return dict(submitted=submitted.value, launches=launches.value)
 
 
 def gibbs_chain_device(engine, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, stat_first=0):

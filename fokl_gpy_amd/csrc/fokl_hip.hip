@@ -1727,6 +1727,7 @@ extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, i
 // the RCCL half lives in fokl_comm.hip; it needs the context layout
 #include "fokl_comm.inc"
 #include "fokl_chain_device.inc"
+#include "fokl_spectral_device.inc"
 #include "fokl_predict.inc"
 #include "fokl_probe.inc"
 

@@ -158,6 +158,10 @@ struct Spectrum {
     std::vector<int32_t> idx;
     double *buf = nullptr;                  // lamb | qty | betahat | Qt | moments
     fokl_host_job *job = nullptr;
+    // G2 on the device (fokl_dspectral_*): buf is the job's page-locked result area until the ticket is released
+    fokl_dspectral *dev = nullptr;
+    int64_t ticket = 0;
+    bool dev_waited = false;
     int status = FOKL_OK;
     int refs = 1;
     double *lamb() const { return buf; }
@@ -206,7 +210,7 @@ enum Stat {
     S_GIBBS_CALLS, S_KILL_TESTS, S_TERMS_LOGICAL, S_T_EIGH, S_T_CHAIN, S_CHAINS_MATERIALISED, S_BIC_FROM_GRAM,
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
-    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_COUNT
+    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_COUNT
 };
 
 }  // namespace
@@ -214,6 +218,9 @@ enum Stat {
 struct fokl_search {
     fokl_host_pool *pool = nullptr;
     fokl_dchain *dchain = nullptr;
+    fokl_dspectral *dspec = nullptr;        // G2 on the device for models of up to dspec_max columns (fokl_search_bind_spectral)
+    int dspec_max = 0;
+    bool dspec_staged = false, dspec_hold = false;
     fokl_search_params prm{};
     double sigsqd0 = 0, tausqd0 = 0;
     int speculation = 0;
@@ -421,6 +428,19 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     auto *sp = new Spectrum();
     sp->p1 = p1;
     sp->idx.assign(idx, idx + p1);
+    if (s->dspec && p1 <= s->dspec_max) {
+        // staged only: the entry point that ends this burst of requests launches them as one grid (flush_spectra)
+        if (fokl_dspectral_submit(s->dspec, gram, ld, sp->idx.data(), p1, ld - 1, 0, &sp->ticket, &sp->buf) != FOKL_OK) {
+            delete sp;
+            s->error = "fokl_search: the device refused a spectral job";
+            return nullptr;
+        }
+        sp->dev = s->dspec;
+        s->dspec_staged = true;
+        s->stats[S_SPECTRAL_SUBMITTED] += 1;
+        s->stats[S_SPECTRAL_DEVICE] += 1;
+        return sp;
+    }
     sp->buf = static_cast<double *>(std::malloc(((size_t)p1 * (p1 + 3) + 2) * sizeof(double)));
     if (!sp->buf ||
         fokl_pool_submit_spectral(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, sp->lamb(), sp->Qt(), sp->qty(),
@@ -434,10 +454,32 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     return sp;
 }
 
-bool spectrum_done(Spectrum *sp) { return !sp->job || fokl_pool_poll(sp->job) != 0; }
+// Launch the device jobs staged since the last call (one grid: they run side by side).
+void flush_spectra(fokl_search *s)
+{
+    if (s->dspec_staged) {
+        s->dspec_staged = false;
+        (void)fokl_dspectral_flush(s->dspec);               // a failed launch is reported by the jobs' waits
+    }
+}
+
+bool spectrum_done(Spectrum *sp)
+{
+    if (sp->dev) return sp->dev_waited || fokl_dspectral_poll(sp->dev, sp->ticket) != 0;   // (an error counts: wait reports it)
+    return !sp->job || fokl_pool_poll(sp->job) != 0;
+}
 
 int wait_spectrum(fokl_search *s, Spectrum *sp)
 {
+    if (sp->dev) {
+        if (!sp->dev_waited) {
+            const double t0 = now_s();
+            sp->status = fokl_dspectral_wait(sp->dev, sp->ticket);
+            sp->dev_waited = true;
+            s->stats[S_T_EIGH] += now_s() - t0;
+        }
+        return sp->status;
+    }
     if (sp->job) {
         const double t0 = now_s();
         sp->status = fokl_pool_wait(sp->job);
@@ -450,6 +492,11 @@ int wait_spectrum(fokl_search *s, Spectrum *sp)
 void unref(fokl_search *s, Spectrum *sp)
 {
     if (!sp || --sp->refs > 0) return;
+    if (sp->dev) {
+        (void)fokl_dspectral_release(sp->dev, sp->ticket);  // waits for a job still in flight
+        delete sp;
+        return;
+    }
     if (sp->job) (void)fokl_pool_wait(sp->job);             // its buffers are written until it has run
     std::free(sp->buf);
     delete sp;
@@ -1202,6 +1249,25 @@ extern "C" int fokl_search_spectral(fokl_search *s, const double *gram, int ld, 
     Spectrum *sp = submit_spectrum(s, gram, ld, idx, p1);
     if (!sp) return FOKL_ERR_STATE;
     *out = reinterpret_cast<fokl_spectrum *>(sp);
+    if (!s->dspec_hold) flush_spectra(s);
+    return FOKL_OK;
+}
+
+// G2 of models of up to max_columns columns goes to `engine` (NULL: back to the pool's LAPACK threads).
+extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine, int max_columns)
+{
+    if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_bind_spectral: null search");
+    s->dspec = engine;
+    s->dspec_max = engine ? std::min(max_columns, fokl_dspectral_max_columns()) : 0;
+    return FOKL_OK;
+}
+
+// Between hold(1) and hold(0) fokl_search_spectral only stages its jobs: hold(0) launches them as one grid.
+extern "C" int fokl_search_hold_spectral(fokl_search *s, int hold)
+{
+    if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_hold_spectral: null search");
+    s->dspec_hold = hold != 0;
+    if (!s->dspec_hold) flush_spectra(s);
     return FOKL_OK;
 }
 
@@ -1246,6 +1312,7 @@ extern "C" int fokl_search_model_begin(fokl_search *s, const double *gram, int l
         unref(s, t);
         return FOKL_ERR_STATE;
     }
+    flush_spectra(s);
     const int rc = wait_spectrum(s, sp);
     if (rc != FOKL_OK) {
         unref(s, sp);
@@ -1610,6 +1677,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
             if (q == pos ? (st.run ? st.accept : true) : st.accept) cur = std::move(key);
         }
+        flush_spectra(s);
         return FOKL_OK;
     };
 

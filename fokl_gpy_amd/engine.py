@@ -30,7 +30,7 @@ from . import _capi
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = _capi.SLOT_ONES, _capi.SLOT_Y, _capi.SLOT_FIRST_FREE
 from .host_pipeline import (  # noqa: F401  (re-exported: tests and tools reach them through this module)
     HostPipeline, ShardedSpectralJob, GibbsOutcome, EagerOutcome, NativeOutcome, NativeSpectrum, Misprediction, ModelSize,
-    chain_engine_for,
+    chain_engine_for, spectral_engine_for,
     close_chain_engines, drop_spare_buffers, _mark, _flush_marks, _cpu_budget, _thread_plan, _thread_spares,
     _place_host_threads, _SPARES)
 
@@ -322,6 +322,7 @@ class ForwardSelection:
         # Misprediction and the search is repeated without guessing -- results never depend on a guess.
         self.allow_device_chains = True
         self.chain_engine = None
+        self.spectral_engine = None         # G2 on the device (spectral_engine_for; decided in run())
         # ... for models of up to this many columns.  Beyond, the chain stays on the host threads: a 585-column tape is 14 MB
         # of page-locked memory and dozens of them are alive at a time (configs[3]: 1.74 s per fit with device chains,
         # 1.49 s with host chains -- and the eigen-decompositions, not the chains, are what that fit waits for)
@@ -692,13 +693,17 @@ class ForwardSelection:
             # took the CPUs the model's chain runs on (53.5 -> 56-58 ms per fit)
             guessed = self.native.likely_first_tests(spectrum.h, n_new, siglik)
             jobs, cur, sizes = {}, frozenset(), []
-            for c, accepted in guessed:
-                trial = cur | {c}
-                if len(jobs) <= min(self._lookahead_native, 3):
-                    jobs[trial] = self._spectral(gram, self._columns_without(A, trial))
-                sizes.append(A - len(cur) - 1)
-                if accepted:
-                    cur = trial
+            self.native.hold_spectral(True)             # device G2: the four jobs become one grid
+            try:
+                for c, accepted in guessed:
+                    trial = cur | {c}
+                    if len(jobs) <= min(self._lookahead_native, 3):
+                        jobs[trial] = self._spectral(gram, self._columns_without(A, trial))
+                    sizes.append(A - len(cur) - 1)
+                    if accepted:
+                        cur = trial
+            finally:
+                self.native.hold_spectral(False)
             self._speculate(([ModelSize(A)] if before_model else []) + sizes)
             return jobs, sizes
         likely = self._likely_first_tests(spec, n_new, siglik)
@@ -991,6 +996,13 @@ class ForwardSelection:
                 tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
                 device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
                 flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
+            # G2 of the kill tests' models on the device (Jacobi in LDS) where the search runs on one process and the
+            # model fits the kernel; wider models, replicated searches and FOKL_EIGH=host keep LAPACK on the pool's threads
+            self.spectral_engine = None
+            if not self.allreduce and not self.candidate_sharded:
+                self.spectral_engine = spectral_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
+            if self.spectral_engine is not None:
+                self.native.bind_spectral(self.spectral_engine)
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run
@@ -998,6 +1010,7 @@ class ForwardSelection:
         # one for the normals finished on the host, host threads or the device for the kill tests' chains
         self.stats['finish_log'] = os.environ.get('FOKL_FINISH_LOG', 'fast')
         self.stats['chain_mode'] = 'device' if self.chain_engine is not None else 'host'
+        self.stats['eigh_mode'] = 'device' if getattr(self, 'spectral_engine', None) is not None and self.native is not None else 'host'
         t_up = time.perf_counter()
         try:
             return self._run()

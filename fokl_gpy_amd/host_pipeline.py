@@ -213,10 +213,38 @@ def chain_engine_for(device):
     return engine
 
 
+# G2 on the device (csrc/fokl_spectral_device.inc): likewise one engine per process and device.  FOKL_EIGH = host (default)
+# | device.  The device solver (Jacobi in LDS) takes the eigen-decompositions off the host entirely -- 0.31 -> 0.16-0.20
+# CPU-seconds per headline fit -- but a decomposition takes 0.6 ms at 66 columns and 4 ms at 144 against LAPACK's 0.2-0.4 and
+# 1.2 ms on a host thread, and the search waits for the first decompositions of every sub-stage: 79-100 ms per fit against
+# 54 (profiles/eigh_device_r04.txt).  It is there for hosts with fewer CPUs than a fit's thread plan wants.
+# Under FOKL_EIGH_SIGNS=lapack always the host's LAPACK -- Jacobi rotations have no LAPACK signs to keep.
+_SPECTRAL_ENGINES = {}
+
+
+def spectral_engine_for(device):
+    mode = os.environ.get('FOKL_EIGH', 'host')
+    if mode not in ('device', 'host'):
+        raise ValueError("FOKL_EIGH must be device or host")
+    if mode == 'host' or os.environ.get('FOKL_EIGH_SIGNS', 'canonical') == 'lapack':
+        return None
+    if device is None:
+        raise RuntimeError("FOKL_EIGH=device: the backend has no HIP device")
+    engine = _SPECTRAL_ENGINES.get(device)
+    if engine is None:
+        engine = _SPECTRAL_ENGINES[device] = _capi.DeviceSpectralEngine(device)
+    return engine
+
+
 def close_chain_engines():
-    for engine in _CHAIN_ENGINES.values():
+    for engine in list(_CHAIN_ENGINES.values()) + list(_SPECTRAL_ENGINES.values()):
         engine.close()
     _CHAIN_ENGINES.clear()
+    _SPECTRAL_ENGINES.clear()
+
+
+import atexit                                               # noqa: E402  (engines own streams and page-locked memory)
+atexit.register(close_chain_engines)
 
 
 # Spare tape / draw buffers of the calling thread, by size class: they survive the fit that allocated them, so that the

@@ -524,6 +524,12 @@ typedef struct fokl_search_params {
                                                    stay rows, the device expands them (fokl_dchain_submit_rows) */
 } fokl_search_params;
 int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_search_params *params, fokl_search **out);
+/* G2 of models of up to max_columns columns goes to the device engine (fokl_dspectral_*, declared further down; NULL:
+ * back to the pool's LAPACK threads).  Between fokl_search_hold_spectral(s, 1) and (s, 0) fokl_search_spectral only
+ * stages its jobs; the closing call launches them as one grid. */
+typedef struct fokl_dspectral fokl_dspectral;
+int fokl_search_bind_spectral(fokl_search *search, fokl_dspectral *engine, int max_columns);
+int fokl_search_hold_spectral(fokl_search *search, int hold);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);
 /* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */
@@ -682,6 +688,36 @@ int fokl_dchain_try_release(fokl_dchain *engine, int64_t ticket);
  * queued, at once when somebody waits for a result); `staged` = chains whose tape was not in page-locked memory and
  * went through copy calls + a device staging buffer instead of being read in place */
 int fokl_dchain_stats(fokl_dchain *engine, double *busy_seconds, int64_t *issued, int64_t *launches, int64_t *staged);
+
+/* ---- G2 on the device: eigen-decompositions of candidate models' XtX sub-blocks -------------------------------------
+ * Replaces, for models of up to FOKL_DSPECTRAL_MAX_COLUMNS columns, the scipy.linalg.eigh call of FoKLRoutines.py:1499
+ * and the products of FR:1502-1504 that hang on it (on the host: fokl_pool_submit_spectral, LAPACK dsyevr on a thread).
+ * One workgroup per matrix runs a cyclic Jacobi iteration on the matrix in LDS, one wavefront per eigenvector column
+ * replays its rotations (csrc/fokl_spectral_device.inc).
+ *
+ * fokl_dspectral_submit copies the sub-block XtX[idx][idx], Xty = gram[idx][ycol], the ones row gram[0][idx] and
+ * gram[0][ycol], gram[ycol][ycol] (gram: [ld][ld] row-major, symmetric, column 0 the ones column) into page-locked memory
+ * of the engine -- the caller's array is not referenced after the call -- and stages the job; launch != 0 launches what is
+ * staged at once, 0 leaves it for fokl_dspectral_flush (several jobs become one grid) or for the first poll / wait of any
+ * of them.  *result is the job's page-locked result area, owned by the engine until fokl_dspectral_release:
+ *   lamb [p1] ascending | qty = Q'Xty [p1] | betahat [p1] | Qt [p1][p1] (row j = eigenvector j) | sum r, sum r^2 |
+ *   sweeps, rotations, seconds on the device, 1 if the sweeps did not converge | the job's ticket (as a double)
+ * the ticket stored last with system-wide release semantics: a caller may poll that word.  Eigenvector signs follow
+ * engine.eigh_canonical (largest-magnitude component positive, first on ties) unless fokl_dspectral_set_signs(e, 0).
+ * fokl_dspectral_poll: 1 = has run, 0 = not yet, < 0 = -error.  fokl_dspectral_wait: FOKL_OK, or FOKL_ERR_NUMERIC when
+ * the sweeps did not converge.  fokl_dspectral_release waits for a job still in flight; idempotent. */
+#define FOKL_DSPECTRAL_MAX_COLUMNS 192
+int fokl_dspectral_create(int device, fokl_dspectral **out);
+void fokl_dspectral_destroy(fokl_dspectral *engine);
+int fokl_dspectral_max_columns(void);
+int fokl_dspectral_set_signs(fokl_dspectral *engine, int canonical);
+int fokl_dspectral_submit(fokl_dspectral *engine, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
+                          int launch, int64_t *ticket, double **result);
+int fokl_dspectral_flush(fokl_dspectral *engine);
+int fokl_dspectral_poll(fokl_dspectral *engine, int64_t ticket);
+int fokl_dspectral_wait(fokl_dspectral *engine, int64_t ticket);
+int fokl_dspectral_release(fokl_dspectral *engine, int64_t ticket);
+int fokl_dspectral_stats(fokl_dspectral *engine, int64_t *submitted, int64_t *launches);
 /* Page-locked host memory for tapes: the device reads such a tape in place (no copy calls on the dispatcher). */
 int fokl_host_alloc(size_t bytes, void **out);
 int fokl_host_free(void *ptr);

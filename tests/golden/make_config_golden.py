@@ -113,6 +113,9 @@ CASES = {
     # on the 4.7 GB design matrices the restatement copies per evaluation; with the configuration's 1000 + 1000 draws
     # the O(P^3) products per Gibbs iteration would add days)
     'cfg3big': lambda: run_case('cfg3_n1e6_m16_way3', 3, rows=1_000_000, burnin=30, draws=30),
+    # ... and with chains long enough for the kill tests' Monte-Carlo statistics to mean something (round 4: 250 + 250 draws;
+    # the O(P^3) products of 450 000 Gibbs iterations add about 2e14 flop to the 3.5 h above)
+    'cfg3long': lambda: run_case('cfg3_n1e6_m16_way3_d250', 3, rows=1_000_000, burnin=250, draws=250),
 }
 
 if __name__ == '__main__':

@@ -105,3 +105,18 @@ def test_full_size_config_on_gpu_matches_the_golden(name):
     1000 + 1000 draws and the configs[3] family through the HIP path."""
     g = load_golden(name)
     assert_matches_golden(g, *fit_like_golden(g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cfg2_n1e6_m8', 'cfg1_n1e5_m4_splines', 'cfg4_unit0_n1e5_m8'])
+def test_full_size_config_with_the_eigen_decompositions_on_the_device(monkeypatch, name):
+    """FOKL_EIGH=device: G2 of every model of up to 192 columns by the Jacobi kernels (csrc/fokl_spectral_device.inc)
+    instead of LAPACK on host threads.  Its eigenvectors differ from dsyevr's within their conditioning (both from the
+    exact ones: tests/test_spectral_device.py), which reaches the draws at the 1e-10 level of the column scale -- the
+    selected model, every gibbs() call, every kill-test decision and numpy's stream are the golden's, the draws within
+    the same 1e-9."""
+    g = load_golden(name)
+    monkeypatch.setenv('FOKL_EIGH', 'device')
+    model, betas, mtx, evs, state = fit_like_golden(g)
+    assert model.fit_stats['eigh_mode'] == 'device' and model.fit_stats['spectral_device'] > 0
+    assert_matches_golden(g, model, betas, mtx, evs, state)

@@ -606,7 +606,8 @@ def test_device_probes_report_plausible_rates(device_ctx):
     """fokl_probe: what the device sustains for trivial streaming kernels and register-only fp64 MFMA (bench.py reports
     them beside the roofline fractions).  Loose physical bounds only."""
     read, write, mix, mfma = (device_ctx.probe(k) for k in range(4))
-    assert 2e12 < write < read < 8.5e12 and write < mix < read
+    # (the write probe streams in K1's shape with non-temporal stores: it can beat the read + write mix)
+    assert 2e12 < write < read < 8.5e12 and 2e12 < mix < read
     assert 2e13 < mfma < 8e13
     with pytest.raises(_capi.FoklNativeError):
         device_ctx.probe(9)

@@ -1,0 +1,211 @@
+"""
+G2 on the device (include/fokl_hip.h: fokl_dspectral_*): the Jacobi eigen-decomposition of a candidate's XtX sub-block and
+the products of FR:1502-1504 against LAPACK (scipy.linalg.eigh, the reference's own call, FR:1499) and against the host
+spectral job (fokl_pool_submit_spectral) on the same Gram matrices.
+
+Tolerances.  Eigenvalues, residual ||A Q - Q diag(lamb)|| and orthogonality are checked at 1e-13 of ||A|| (both solvers
+are backward stable; n eps ||A|| is ~1e-14 at n = 96).  Eigenvectors are only determined to eps ||A|| / gap: they are
+compared with LAPACK's through that bound, and exactly (up to 1e-12) on matrices whose gaps are large.  The residual
+moments (double-double on the device, 80-bit on the host) are compared at 1e-12 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+from fokl_gpy_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine():
+    eng = _capi.DeviceSpectralEngine(int(os.environ.get('FOKL_DEVICE', '0')))
+    yield eng
+    eng.close()
+
+
+def gram_like(cols, rng, rows=600, spread=3.0):
+    """[1 | X | y]'[1 | X | y] with columns of very different scales (condition numbers of 1e4 .. 1e8, as the basis
+    columns of a fit produce)."""
+    X = rng.standard_normal((rows, cols - 1)) * 10.0 ** rng.uniform(-spread / 2, spread / 2, cols - 1)
+    X[:, ::3] += 0.7 * X[:, :1]                                   # correlated columns
+    y = X @ rng.standard_normal(cols - 1) * 0.1 + rng.standard_normal(rows)
+    Z = np.column_stack([np.ones(rows), X, y])
+    return Z.T @ Z
+
+
+def canonical(Qt):
+    Qt = Qt.copy()
+    for j in range(Qt.shape[0]):
+        piv = int(np.argmax(np.abs(Qt[j])))
+        if Qt[j, piv] < 0:
+            Qt[j] = -Qt[j]
+    return Qt
+
+
+def check_job(job, gram, idx):
+    lamb, Qt, qty, betahat, moments = job.wait()
+    n = len(idx)
+    A = gram[np.ix_(idx, idx)]
+    ycol = gram.shape[0] - 1
+    xty = gram[idx, ycol]
+    norm = np.abs(A).max() * n
+    ref_l, ref_Q = sl.eigh(A)
+    assert np.all(np.diff(lamb) >= 0)
+    assert np.abs(lamb - ref_l).max() <= 1e-13 * norm
+    assert np.abs(A @ Qt.T - Qt.T * lamb).max() <= 1e-13 * norm
+    assert np.abs(Qt @ Qt.T - np.eye(n)).max() <= 1e-13
+    assert np.array_equal(Qt, canonical(Qt))
+    assert np.abs(qty - Qt @ xty).max() <= 1e-13 * (np.abs(xty).max() * n)
+    # eigenvectors against LAPACK's, through the bound eps ||A|| / gap of each
+    ref_Qt = canonical(ref_Q.T)
+    gaps = np.minimum(np.diff(ref_l, prepend=-np.inf), np.diff(ref_l, append=np.inf))
+    bound = 64 * np.finfo(float).eps * norm / gaps
+    for j in range(n):
+        if bound[j] < 1e-3:                                           # else the vector (and its sign) is not determined
+            assert np.abs(Qt[j] - ref_Qt[j]).max() <= bound[j] + 1e-14, (j, n)
+    # betahat solves the normal equations as well as the conditioning allows
+    bh = Qt.T @ (qty / lamb)
+    assert np.abs(betahat - bh).max() <= 1e-12 * max(np.abs(bh).max(), 1e-300)
+    # residual moments from the Gram alone, in extended precision
+    L = np.longdouble
+    b = betahat.astype(L)
+    quad = (b @ (A.astype(L) @ b))
+    cross = xty.astype(L) @ b
+    s1 = L(gram[0, ycol]) - gram[0, idx].astype(L) @ b
+    ssr = L(gram[ycol, ycol]) - 2 * cross + quad
+    assert abs(moments[0] - float(s1)) <= 1e-12 * (abs(float(s1)) + np.abs(gram[0, idx] * betahat).sum())
+    assert abs(moments[1] - float(ssr)) <= 1e-12 * abs(float(ssr)) + 1e-15 * abs(float(gram[ycol, ycol]))
+    return job.info()
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 8, 17, 31, 32, 33, 47, 48, 49, 64, 65, 66, 95, 96, 97, 127, 128, 129, 130, 144, 191, 192])
+def test_decomposition_against_lapack(engine, n):
+    rng = np.random.default_rng(100 + n)
+    gram = gram_like(n + 3, rng)
+    idx = np.sort(rng.choice(np.arange(n + 3), size=n, replace=False)).astype(np.int32)
+    idx[0] = 0                                                        # the ones column is always in the model
+    idx = np.unique(idx)
+    job = engine.submit(gram, idx)
+    try:
+        info = check_job(job, gram, idx)
+        assert not info['not_converged'] and (n < 2 or 1 <= info["sweeps"] <= 24)
+    finally:
+        job.release()
+
+
+def test_more_jobs_than_work_areas(engine):
+    """A job in flight holds one of 64 device work areas: the 65th launch waits for the oldest to finish."""
+    rng = np.random.default_rng(17)
+    gram = gram_like(40, rng)
+    jobs = []
+    for k in range(150):
+        idx = np.concatenate([[0], 1 + np.sort(rng.choice(38, size=int(rng.integers(3, 38)), replace=False))]).astype(np.int32)
+        jobs.append((engine.submit(gram, idx, launch=(k % 7 == 0)), idx))
+    engine.flush()
+    for job, idx in jobs[::5]:
+        check_job(job, gram, idx)
+    for job, idx in jobs:
+        job.release()
+
+
+def test_many_jobs_of_mixed_sizes_in_one_grid(engine):
+    rng = np.random.default_rng(7)
+    gram = gram_like(195, rng)
+    before = engine.stats()
+    jobs = []
+    for k in range(40):
+        n = int(rng.integers(2, 193))
+        idx = np.concatenate([[0], 1 + np.sort(rng.choice(193, size=n - 1, replace=False))]).astype(np.int32)
+        jobs.append((engine.submit(gram, idx, launch=False), idx))
+    engine.flush()
+    after = engine.stats()
+    assert after['submitted'] - before['submitted'] == 40 and after['launches'] - before['launches'] == 1
+    for job, idx in jobs:
+        check_job(job, gram, idx)
+        job.release()
+
+
+def test_a_staged_job_is_launched_by_its_first_wait(engine):
+    rng = np.random.default_rng(8)
+    gram = gram_like(12, rng)
+    idx = np.arange(11, dtype=np.int32)
+    job = engine.submit(gram, idx, launch=False)
+    check_job(job, gram, idx)                                         # wait() flushes
+    job.release()
+    job.release()                                                     # idempotent
+
+
+def test_degenerate_spectra(engine):
+    # identity: nothing to rotate, order by index; a diagonal matrix in descending order: only the sort acts;
+    # exactly repeated eigenvalues (identical 2 x 2 blocks): any orthonormal basis of each eigenspace is right
+    n = 10
+    for A in (np.eye(n), np.diag(np.arange(n, 0, -1.0)),
+              np.kron(np.eye(n // 2), np.array([[2.0, 1.0], [1.0, 2.0]]))):
+        gram = np.zeros((n + 1, n + 1))
+        gram[:n, :n] = A
+        gram[:n, n] = gram[n, :n] = np.arange(1.0, n + 1)
+        gram[n, n] = 1000.0
+        job = engine.submit(gram, np.arange(n, dtype=np.int32))
+        lamb, Qt, qty, betahat, moments = job.wait()
+        assert np.abs(lamb - np.sort(np.linalg.eigvalsh(A))).max() <= 1e-14 * n
+        assert np.abs(A @ Qt.T - Qt.T * lamb).max() <= 1e-14 * n
+        assert np.abs(Qt @ Qt.T - np.eye(n)).max() <= 1e-14
+        assert np.abs(betahat - np.linalg.solve(A, gram[:n, n])).max() <= 1e-13 * n
+        job.release()
+
+
+def test_lapack_sign_mode_leaves_the_rotations_signs(engine):
+    rng = np.random.default_rng(9)
+    gram = gram_like(9, rng)
+    idx = np.arange(8, dtype=np.int32)
+    engine.set_signs(False)
+    try:
+        job = engine.submit(gram, idx)
+        lamb, Qt, qty, betahat, moments = job.wait()
+        raw = Qt.copy()
+        job.release()
+    finally:
+        engine.set_signs(True)
+    job = engine.submit(gram, idx)
+    lamb2, Qt2, *_ = job.wait()
+    assert np.array_equal(canonical(raw), Qt2) and np.array_equal(lamb, lamb2)
+    job.release()
+
+
+def test_too_large_a_model_is_refused(engine):
+    gram = np.eye(engine.max_columns + 3)
+    with pytest.raises(_capi.FoklNativeError):
+        engine.submit(gram, np.arange(engine.max_columns + 1, dtype=np.int32))
+
+
+def test_against_the_host_spectral_job_on_a_fit_like_gram(engine):
+    """Same Gram, both solvers: what a chain would draw differs by no more than the eigenvector conditioning allows --
+    the bound bench.py gates the headline fit's draws with."""
+    import scipy.linalg.lapack  # noqa: F401  (the pool takes LAPACK's dsyevr from scipy)
+    rng = np.random.default_rng(11)
+    gram = gram_like(68, rng, rows=4000, spread=2.0)
+    idx = np.arange(67, dtype=np.int32)
+    np.random.seed(1)
+    stream = _capi.LegacyStream()
+    pool = _capi.HostPool(stream, chain_threads=1, spectral_threads=1)
+    try:
+        res = pool.submit_spectral(gram, idx, gram.shape[0] - 1).wait()
+        h_lamb, h_Qt, h_qty, h_bh, h_mom = [np.array(v) for v in (res.lamb, res.Qt, res.qty, res.betahat, res.moments)]
+    finally:
+        pool.close()
+    job = engine.submit(gram, idx)
+    lamb, Qt, qty, betahat, moments = job.wait()
+    scale = np.abs(gram[:67, :67]).max() * 67
+    assert np.abs(lamb - h_lamb).max() <= 1e-13 * scale
+    # the map a chain applies to its noise: Q diag((lamb + 1/tau2)^-1/2), and the posterior mean Q (qty / lamb)
+    M = Qt.T / np.sqrt(lamb + 1.0)
+    H = h_Qt.T / np.sqrt(h_lamb + 1.0)
+    gaps = np.minimum(np.diff(h_lamb, prepend=-np.inf), np.diff(h_lamb, append=np.inf))
+    bound = 64 * np.finfo(float).eps * scale / gaps.min()
+    assert np.abs(M - H).max() <= bound * np.abs(H).max()
+    assert np.abs(betahat - h_bh).max() <= max(bound, 1e-12) * np.abs(h_bh).max()
+    assert np.abs(moments - h_mom).max() <= 1e-11 * np.abs(h_mom).max()
+    job.release()
