@@ -198,7 +198,57 @@ _CLEAN_DEFAULTS = {'train': 1, 'AutoTranspose': True, 'SingleInstance': False, '
                    'normalize': True, 'minmax': None, 'pillow': None, 'pillow_type': 'percent'}
 
 
+class _DeviceInputs:
+    """The normalised inputs of a model whose fit(clean=True) normalised them on the device (fokl_stage_inputs /
+    fokl_upload_staged): they exist there only until somebody reads the model's ``inputs`` attribute, which fetches them
+    (fokl_download_inputs: the numbers FoKL.clean produces on the host, bit for bit) and keeps the array."""
+    ndim = 2
+    dtype = np.dtype(np.float64)
+
+    def __init__(self, backend, shape):
+        self.backend, self.shape = backend, tuple(shape)
+
+    def fetch(self):
+        return self.backend.download_inputs()
+
+
 class FoKL:
+    # ``inputs`` is stored under its own name in the instance (files written by ``save`` and by the reference carry it
+    # there); reading it turns a _DeviceInputs into the array it stands for.
+    def _get_inputs(self):
+        try:
+            value = self.__dict__['inputs']
+        except KeyError:
+            raise AttributeError("'FoKL' object has no attribute 'inputs'") from None
+        if isinstance(value, _DeviceInputs):
+            value = self.__dict__['inputs'] = value.fetch()
+        return value
+
+    def _set_inputs(self, value):
+        self.__dict__['inputs'] = value
+
+    def _del_inputs(self):
+        try:
+            del self.__dict__['inputs']
+        except KeyError:
+            raise AttributeError('inputs') from None
+
+    inputs = property(_get_inputs, _set_inputs, _del_inputs)
+
+    def _materialise_inputs(self):
+        if isinstance(self.__dict__.get('inputs'), _DeviceInputs):
+            self._get_inputs()
+
+    def __getstate__(self):
+        self._materialise_inputs()
+        return self.__dict__
+
+    def __copy__(self):
+        self._materialise_inputs()
+        twin = type(self).__new__(type(self))
+        twin.__dict__.update(self.__dict__)
+        return twin
+
     def __init__(self, **kwargs):
         """
         Hyper-parameters and defaults as in the reference (FR:168-216):
@@ -245,7 +295,7 @@ class FoKL:
     # dataset formatting (host side, not on the device path; behaviour of FR:248-542)
     # -----------------------------------------------------------------------------------------------------
 
-    def _format(self, inputs, data=None, AutoTranspose=True, SingleInstance=False, bit=64):
+    def _format(self, inputs, data=None, AutoTranspose=True, SingleInstance=False, bit=64, _copy_inputs=True):
         """inputs -> [n, m] ndarray, data -> [n, 1] ndarray of the requested float width (FR:248-316)."""
         import pandas as pd
         AutoTranspose = _str_to_bool(AutoTranspose)
@@ -268,7 +318,7 @@ class FoKL:
             warnings.warn("'data' was auto-converted to numpy. Convert manually for assured accuracy.",
                           category=UserWarning)
 
-        inputs = np.array(inputs)
+        inputs = np.array(inputs) if _copy_inputs else np.asarray(inputs)    # (no copy: the caller only reads them)
         if inputs.ndim > 2:
             inputs = np.squeeze(inputs)
         if inputs.dtype != dtype:
@@ -299,8 +349,10 @@ class FoKL:
                     warnings.warn("'data' was transposed to match FoKL formatting.", category=UserWarning)
         return inputs, data
 
-    def _normalize(self, inputs, minmax=None, pillow=None, pillow_type='percent'):
-        """Min-max normalisation of every input column to [0, 1]; updates ``self.minmax`` (FR:318-439)."""
+    def _normalize(self, inputs, minmax=None, pillow=None, pillow_type='percent', _bounds=None):
+        """Min-max normalisation of every input column to [0, 1]; updates ``self.minmax`` (FR:318-439).
+        _bounds = (column minima, column maxima) found elsewhere (the device): the bookkeeping only -- returns
+        (lows, spans) of the normalisation (x - lows) / spans instead of applying it."""
         mm = inputs.shape[1]
         allowed = ['percent', 'absolute']
         if isinstance(pillow_type, str):
@@ -339,7 +391,7 @@ class FoKL:
             else:
                 # one contiguous pass each instead of a strided pass per column and bound (minima / maxima are exact:
                 # the same values as the reference's np.min / np.max per column, FR:395)
-                lows, highs = _column_min_max(inputs)
+                lows, highs = _column_min_max(inputs) if _bounds is None else _bounds
                 minmax = list([lows[k], highs[k]] for k in range(mm))
         elif isinstance(minmax[0], (int, float)):
             flat = list(minmax)
@@ -380,6 +432,9 @@ class FoKL:
                               "bounds.", category=UserWarning)
         self.minmax = minmax
 
+        if _bounds is not None:
+            return (np.array([float(minmax[k][0]) for k in range(mm)], dtype=np.float64),
+                    np.array([float(minmax[k][1] - minmax[k][0]) for k in range(mm)], dtype=np.float64))
         if inputs.dtype == np.float64 and inputs.flags.c_contiguous and inputs.flags.writeable:
             # the reference's per-column statement (FR:436-437) over whole rows: the same subtraction and the same
             # division per element, two contiguous passes instead of 2 m strided ones (N = 1e6, M = 8: 0.14 -> 0.04 s)
@@ -400,12 +455,42 @@ class FoKL:
                 inputs[:, k] = (inputs[:, k] - minmax[k][0]) / (minmax[k][1] - minmax[k][0])
         return inputs
 
-    def clean(self, inputs, data=None, kwargs_from_other=None, _setattr=False, **kwargs):
-        """Format and normalise a dataset; defines ``inputs, data, trainlog`` on first use (FR:441-507)."""
+    def _clean_on_device(self, inputs, data, current, backend):
+        """fit(clean=True) of a large float64 dataset: the rows go to the device as they are, minima / maxima and the
+        normalisation happen there (fokl_stage_inputs, fokl_upload_staged: the host's numbers bit for bit), the host
+        keeps the bookkeeping (minmax, pillow) and, until somebody reads it, no normalised copy."""
+        inputs, data = self._format(inputs, data, current['AutoTranspose'], current['SingleInstance'], current['bit'],
+                                    _copy_inputs=False)
+        bounds = backend.stage_inputs(inputs, self)
+        lows, spans = self._normalize(inputs, current['minmax'], current['pillow'], current['pillow_type'], _bounds=bounds)
+        self._staged_upload = (backend, lows, spans, inputs.shape)
+        trainlog = self.generate_trainlog(current['train'], inputs.shape[0])
+        _set_attributes(self, {'inputs': _DeviceInputs(backend, inputs.shape), 'data': data, 'trainlog': trainlog})
+        return self.__dict__['inputs'], data
+
+    def _device_clean_wanted(self, inputs, data, current):
+        """The device route covers the plain case: float64 rows [n, m] in C order, n >= m, large enough to matter, all rows
+        used for training, 64-bit, the Bernoulli kernel (the spline kernel validates the normalised values on the host)."""
+        return (os.environ.get('FOKL_CLEAN', 'device') != 'host' and current['normalize'] is True and
+                isinstance(inputs, np.ndarray) and inputs.dtype == np.float64 and inputs.ndim == 2 and
+                inputs.flags.c_contiguous and inputs.shape[0] >= inputs.shape[1] and inputs.size >= 1 << 18 and
+                data is not None and current['bit'] == 64 and current['train'] == 1 and
+                _str_to_bool(current['SingleInstance']) is not True and
+                self._kernel_id() == getKernels.KERNEL_BERNOULLI)
+
+    def clean(self, inputs, data=None, kwargs_from_other=None, _setattr=False, _device=None, **kwargs):
+        """Format and normalise a dataset; defines ``inputs, data, trainlog`` on first use (FR:441-507).
+        _device (fit's own call only): a callable returning the backend the dataset is about to be uploaded to."""
         if kwargs_from_other is not None:
             kwargs = _merge_dicts(kwargs, kwargs_from_other)
         current = _process_kwargs(dict(_CLEAN_DEFAULTS), kwargs)
         current['normalize'] = _str_to_bool(current['normalize'])
+
+        self.__dict__.pop('_staged_upload', None)
+        if _device is not None and _setattr is True and self._device_clean_wanted(inputs, data, current):
+            backend = _device()
+            if hasattr(backend, 'stage_inputs'):
+                return self._clean_on_device(inputs, data, current, backend)
 
         inputs, data = self._format(inputs, data, current['AutoTranspose'], current['SingleInstance'], current['bit'])
         if current['normalize'] is True:
@@ -521,6 +606,11 @@ class FoKL:
 
     def _upload(self, backend, inputs, data):
         kid = self._kernel_id()
+        staged = self.__dict__.pop('_staged_upload', None)
+        if staged is not None and staged[0] is backend:
+            packed, nb, width = getKernels.pack_phis(self.phis, kid)
+            backend.upload_staged(np.asarray(data, dtype=np.float64), kid, packed, nb, width, staged[1], staged[2], self)
+            return
         inputs = np.asarray(inputs, dtype=np.float64)
         if kid == getKernels.KERNEL_SPLINES:
             self._inputs_to_phind(inputs)              # range validation with the reference's own expression
@@ -573,7 +663,7 @@ class FoKL:
                     _, data = self.trainset()
             except Exception:
                 clean_failed = True
-            self.clean(inputs, data, kwargs_from_other=kwargs_to_clean, _setattr=True)
+            self.clean(inputs, data, kwargs_from_other=kwargs_to_clean, _setattr=True, _device=self._backend)
         else:
             try:
                 if inputs is None:
@@ -591,15 +681,20 @@ class FoKL:
         if clean_failed:
             raise ValueError("'inputs' and/or 'data' were not provided so 'clean' could not be performed.")
 
-        try:
-            inputs, data = self.trainset()
-        except Exception:
-            warnings.warn("If not calling 'clean' prior to 'fit' or within the argument of 'fit', then this is the "
-                          "likely source of any subsequent errors. To troubleshoot, simply include 'clean=True' within "
-                          "the argument of 'fit'.", category=UserWarning)
+        staged = self.__dict__.get('_staged_upload')
+        if staged is not None:
+            # normalised on the device: all rows train (trainlog is None), the host holds no normalised copy to hand on
+            inputs, data = self.__dict__['inputs'], self.data
+        else:
+            try:
+                inputs, data = self.trainset()
+            except Exception:
+                warnings.warn("If not calling 'clean' prior to 'fit' or within the argument of 'fit', then this is the "
+                              "likely source of any subsequent errors. To troubleshoot, simply include 'clean=True' within "
+                              "the argument of 'fit'.", category=UserWarning)
 
-        self.inputs = inputs
-        self.data = data
+            self.inputs = inputs
+            self.data = data
 
 
         # data-driven defaults of the inverse-gamma scales (FR:1322-1348)
@@ -938,7 +1033,7 @@ class FoKL:
             filename = filename + '.fokl'
         path = os.path.join(directory, filename) if directory is not None else filename
         state = copy.copy(self)
-        for transient in ('_backend_override', '_comm', '_rng_state_after'):
+        for transient in ('_backend_override', '_comm', '_rng_state_after', '_staged_upload'):
             if hasattr(state, transient):
                 delattr(state, transient)
         with open(path, 'wb') as fh:

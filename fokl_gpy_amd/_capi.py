@@ -30,6 +30,9 @@ SIGNATURES = {
     'fokl_last_error': (ctypes.c_char_p, [c_vp]),
     'fokl_sync': (c_int, [c_vp]),
     'fokl_upload': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int]),
+    'fokl_stage_inputs': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    'fokl_upload_staged': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    'fokl_download_inputs': (c_int, [c_vp, c_vp]),
     'fokl_column_min_max': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int]),
     'fokl_normalize_columns': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_int]),
     'fokl_reserve_slots': (c_int, [c_vp, c_int]),
@@ -90,7 +93,7 @@ SIGNATURES = {
     'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
-    'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
     'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
@@ -774,11 +777,13 @@ class NativeSearch:
     def drop_speculation(self):
         self._checked(self._lib.fokl_search_drop_speculation(self._h))
 
-    def bind_spectral(self, engine, max_columns=None):
-        """G2 of models of up to max_columns columns on the device (a DeviceSpectralEngine; None: the pool's threads)."""
+    def bind_spectral(self, engine, max_columns=None, slack=-1.0, lookahead=-1):
+        """G2 of models of up to max_columns columns on the device (a DeviceSpectralEngine; None: the pool's threads) when
+        requested `slack` kernel durations ahead of need (0: always; < 0: the library's default)."""
         self._spectral_engine = engine                   # kept alive as long as the search
         limit = (engine.max_columns if max_columns is None else int(max_columns)) if engine is not None else 0
-        self._checked(self._lib.fokl_search_bind_spectral(self._h, engine._h if engine is not None else None, limit))
+        self._checked(self._lib.fokl_search_bind_spectral(self._h, engine._h if engine is not None else None, limit,
+                                                          float(slack), int(lookahead)))
 
     def hold_spectral(self, hold):
         self._checked(self._lib.fokl_search_hold_spectral(self._h, 1 if hold else 0))
@@ -1005,7 +1010,7 @@ class DeviceChainJob:
     Completion is read from the job's statistics area in page-locked host memory (the kernel stores the ticket there
     last): ``done()`` is a memory load, not a call into the runtime."""
     __slots__ = ('_engine', '_ticket', 'p1', 'draws', 'keep', 'recycle', '_stats', 'ignore_failure', '_area', '_flag',
-                 '_mark')
+                 '_mark', '_misses')
     unresolved = False                  # PoolJob's interface: only tentative noise jobs wait for a verdict
 
     def __init__(self, engine, ticket, p1, draws, keep, stats_address=None):
@@ -1015,6 +1020,7 @@ class DeviceChainJob:
         self.ignore_failure = False
         self._area = self._flag = None
         self._mark = float(ticket) if ticket is not None else 0.0
+        self._misses = 0
         if stats_address:
             self._area = np.ctypeslib.as_array((ctypes.c_double * (6 + p1)).from_address(stats_address))
             self._flag = ctypes.c_double.from_address(stats_address + 8 * (4 + p1))
@@ -1030,7 +1036,11 @@ class DeviceChainJob:
         if self._ticket is None or self._stats is not None or self._ran():
             return True
         if self._flag is not None:
-            return False                # a failed job never sets the flag: wait() / release() report it
+            # a failed job never sets the flag: the engine is asked now and then (it knows a failed job: poll reports it as
+            # finished, wait() / release() report the error), so that such a job does not hold its buffers for good
+            self._misses += 1
+            if self._misses % 64:
+                return False
         return bool(self._engine._lib.fokl_dchain_poll(self._engine._h, self._ticket))
 
     def wait(self):
@@ -1270,7 +1280,18 @@ class DeviceContext:
     def sync(self):
         self._ck(self._lib.fokl_sync(self._h))
 
+    # A model whose normalised inputs exist on this context only (upload_staged) is told to fetch them before the dataset
+    # is replaced (owner._materialise_inputs()).
+    _lazy_owner = None
+
+    def _settle_lazy_inputs(self, keep=None):
+        owner, self._lazy_owner = self._lazy_owner, None
+        model = owner() if owner is not None else None
+        if model is not None and model is not keep:
+            model._materialise_inputs()
+
     def upload(self, x, y, kernel_id, phis_packed, n_basis, width):
+        self._settle_lazy_inputs()
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(np.reshape(y, -1), dtype=np.float64)
         if x.ndim != 2 or x.shape[0] != y.shape[0]:
@@ -1279,6 +1300,37 @@ class DeviceContext:
         self._ck(self._lib.fokl_upload(self._h, _ptr(x), _ptr(y), x.shape[0], x.shape[1], int(kernel_id),
                                        _ptr(phis_packed), int(n_basis), int(width)))
         self.n, self.m = x.shape
+
+    def stage_inputs(self, x, owner=None):
+        """Raw inputs [n, m] (float64, C-contiguous) to the device; -> (column minima, column maxima)."""
+        if x.dtype != np.float64 or x.ndim != 2 or not x.flags.c_contiguous:
+            raise ValueError("stage_inputs: float64 C-contiguous [n, m] expected")
+        self._settle_lazy_inputs(keep=owner)
+        lows, highs = np.empty(x.shape[1]), np.empty(x.shape[1])
+        self._ck(self._lib.fokl_stage_inputs(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(lows), _ptr(highs)))
+        self._staged_shape = x.shape
+        return lows, highs
+
+    def upload_staged(self, y, kernel_id, phis_packed, n_basis, width, lows, spans, owner=None):
+        """fokl_upload from the staged raw inputs, normalised on the device as (x - lows) / spans.  owner: the model whose
+        ``inputs`` these are (asked to fetch them before the next dataset replaces them here)."""
+        n, m = self._staged_shape
+        y = np.ascontiguousarray(np.reshape(y, -1), dtype=np.float64)
+        if y.shape[0] != n:
+            raise ValueError("inputs must be [n, m] and data [n]")
+        phis_packed = np.ascontiguousarray(phis_packed, dtype=np.float64)
+        lows, spans = np.ascontiguousarray(lows, dtype=np.float64), np.ascontiguousarray(spans, dtype=np.float64)
+        self._ck(self._lib.fokl_upload_staged(self._h, _ptr(y), n, m, int(kernel_id), _ptr(phis_packed), int(n_basis),
+                                              int(width), _ptr(lows), _ptr(spans)))
+        self.n, self.m = n, m
+        if owner is not None:
+            import weakref
+            self._lazy_owner = weakref.ref(owner)
+
+    def download_inputs(self):
+        out = np.empty((self.n, self.m), dtype=np.float64)
+        self._ck(self._lib.fokl_download_inputs(self._h, _ptr(out)))
+        return out
 
     def reserve_slots(self, n_slots):
         self._ck(self._lib.fokl_reserve_slots(self._h, int(n_slots)))

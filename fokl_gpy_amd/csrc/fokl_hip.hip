@@ -57,6 +57,9 @@ struct fokl_ctx {
     int m = 0, kernel = 0, n_basis = 0, width = 0;
     double *d_x = nullptr;      // [m][ld]
     double *d_zero = nullptr;   // [ld] zeros: stands in for padding columns of Gram panels
+    double *d_staged = nullptr; // [staged_n][staged_m] raw inputs waiting for fokl_upload_staged (fokl_stage_inputs)
+    int64_t staged_n = 0;
+    int staged_m = 0;
     double *d_phis = nullptr;
     std::vector<double> h_phis;  // host copy of the coefficient table (launch planning of the matrix-free K3)
     size_t phis_doubles = 0;
@@ -361,6 +364,7 @@ extern "C" void fokl_ctx_destroy(fokl_ctx *ctx)
     if (ctx->d_x) (void)hipFree(ctx->d_x);
     if (ctx->d_phis) (void)hipFree(ctx->d_phis);
     if (ctx->d_zero) (void)hipFree(ctx->d_zero);
+    if (ctx->d_staged) (void)hipFree(ctx->d_staged);
     if (ctx->d_args) (void)hipFree(ctx->d_args);
     if (ctx->h_args) (void)hipHostFree(ctx->h_args);
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
@@ -429,17 +433,19 @@ extern "C" int fokl_reserve_slots(fokl_ctx *ctx, int n_slots)
 // dataset upload
 // ---------------------------------------------------------------------------------------------------------
 
-extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
-                           const double *phis, int n_basis, int width)
+// x: host rows (fokl_upload) or NULL: the copy fokl_stage_inputs left on the device, normalised on the way
+// (xT[k][i] = (x[i][k] - lows[k]) / spans[k], the reference's two separately rounded operations, FR:436-437).
+static int upload_dataset(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel, const double *phis,
+                          int n_basis, int width, const double *lows, const double *spans, const char *who)
 {
-    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_upload: null context");
-    if (!x || !y || !phis) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: null pointer");
-    if (n <= 0 || m <= 0 || m > 4096) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: need n > 0 and 0 < m <= 4096");
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, std::string(who) + ": null context");
+    if (!y || !phis) return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": null pointer");
+    if (n <= 0 || m <= 0 || m > 4096) return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": need n > 0 and 0 < m <= 4096");
     if (kernel != FOKL_KERNEL_SPLINES && kernel != FOKL_KERNEL_BERNOULLI)
-        return fail(ctx, FOKL_ERR_ARG, "fokl_upload: unknown kernel id");
-    if (n_basis <= 0 || width <= 0) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: empty coefficient table");
+        return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": unknown kernel id");
+    if (n_basis <= 0 || width <= 0) return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": empty coefficient table");
     if (kernel == FOKL_KERNEL_BERNOULLI && width < n_basis + 1)
-        return fail(ctx, FOKL_ERR_ARG, "fokl_upload: Bernoulli table needs width >= n_basis + 1");
+        return fail(ctx, FOKL_ERR_ARG, std::string(who) + ": Bernoulli table needs width >= n_basis + 1");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     drain_events(ctx);
@@ -474,18 +480,98 @@ extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int6
     if (rc) return rc;
 
     // raw row-major copy in a temporary, transposed on the device
-    double *d_raw = nullptr, *d_y = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&d_raw, (size_t)n * m * sizeof(double)));
+    double *d_raw = nullptr, *d_y = nullptr, *d_bounds = nullptr;
+    if (x) {
+        HIP_TRY(ctx, hipMalloc((void **)&d_raw, (size_t)n * m * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(d_raw, x, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        d_raw = ctx->d_staged;
+        ctx->d_staged = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&d_bounds, (size_t)2 * m * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(d_bounds, lows, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(d_bounds + m, spans, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIP_TRY(ctx, hipMalloc((void **)&d_y, (size_t)n * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(d_raw, x, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(d_y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     const int blocks = (int)std::min<int64_t>((ctx->ld + 255) / 256, 4096);
     hipLaunchKernelGGL(transpose_inputs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_raw, d_y, n, m, ctx->ld,
-                       ctx->d_x, ctx->slot_ptr[FOKL_SLOT_ONES], ctx->slot_ptr[FOKL_SLOT_Y]);
+                       ctx->d_x, ctx->slot_ptr[FOKL_SLOT_ONES], ctx->slot_ptr[FOKL_SLOT_Y], d_bounds);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(d_raw));
     HIP_TRY(ctx, hipFree(d_y));
+    if (d_bounds) HIP_TRY(ctx, hipFree(d_bounds));
+    return FOKL_OK;
+}
+
+extern "C" int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
+                           const double *phis, int n_basis, int width)
+{
+    if (ctx && !x) return fail(ctx, FOKL_ERR_ARG, "fokl_upload: null pointer");
+    return upload_dataset(ctx, x, y, n, m, kernel, phis, n_basis, width, nullptr, nullptr, "fokl_upload");
+}
+
+// FoKL.clean's normalisation on the device, in two calls around the host's few lines of bookkeeping (minmax / pillow):
+// fokl_stage_inputs copies the RAW rows and returns every column's minimum and maximum; fokl_upload_staged lays the
+// staged rows out as fokl_upload does, each value normalised on the way.
+extern "C" int fokl_stage_inputs(fokl_ctx *ctx, const double *x, int64_t n, int m, double *lows_out, double *highs_out)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_stage_inputs: null context");
+    if (!x || !lows_out || !highs_out) return fail(ctx, FOKL_ERR_ARG, "fokl_stage_inputs: null pointer");
+    if (n <= 0 || m <= 0 || m > 4096) return fail(ctx, FOKL_ERR_ARG, "fokl_stage_inputs: need n > 0 and 0 < m <= 4096");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_staged) HIP_TRY(ctx, hipFree(ctx->d_staged));
+    ctx->d_staged = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_staged, (size_t)n * m * sizeof(double)));
+    ctx->staged_n = n;
+    ctx->staged_m = m;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_staged, x, (size_t)n * m * sizeof(double), hipMemcpyHostToDevice));
+    // lane t of the grid owns column t mod m (the stride is a multiple of m); partial (min, max) per lane, then per column
+    const int64_t total = n * (int64_t)m;
+    int64_t lanes = std::min<int64_t>((int64_t)1024 * 256, (total + 7) / 8);
+    lanes = std::max<int64_t>(m, lanes / m * m);
+    const int blocks = (int)((lanes + 255) / 256);
+    double *d_part = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_part, (size_t)(2 * lanes + 2 * m) * sizeof(double)));
+    hipLaunchKernelGGL(column_bounds_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_staged, total, m, lanes, d_part);
+    hipLaunchKernelGGL(column_bounds_finish_kernel, dim3(m), dim3(256), 0, ctx->stream, d_part, lanes, m, d_part + 2 * lanes);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> h((size_t)2 * m);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_part + 2 * lanes, (size_t)2 * m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_part));
+    for (int k = 0; k < m; ++k) {
+        lows_out[k] = h[(size_t)k];
+        highs_out[k] = h[(size_t)m + k];
+    }
+    return FOKL_OK;
+}
+
+extern "C" int fokl_upload_staged(fokl_ctx *ctx, const double *y, int64_t n, int m, int kernel, const double *phis,
+                                  int n_basis, int width, const double *lows, const double *spans)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_upload_staged: null context");
+    if (!lows || !spans) return fail(ctx, FOKL_ERR_ARG, "fokl_upload_staged: null pointer");
+    if (!ctx->d_staged || ctx->staged_n != n || ctx->staged_m != m)
+        return fail(ctx, FOKL_ERR_STATE, "fokl_upload_staged: no staged inputs of this shape (fokl_stage_inputs first)");
+    return upload_dataset(ctx, nullptr, y, n, m, kernel, phis, n_basis, width, lows, spans, "fokl_upload_staged");
+}
+
+// The inputs as the kernels see them (normalised), back in rows: x_out [n, m].
+extern "C" int fokl_download_inputs(fokl_ctx *ctx, double *x_out)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_download_inputs: null context");
+    if (!x_out) return fail(ctx, FOKL_ERR_ARG, "fokl_download_inputs: null pointer");
+    if (!ctx->have_data) return fail(ctx, FOKL_ERR_STATE, "fokl_download_inputs: call fokl_upload first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *d_rows = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_rows, (size_t)ctx->n * ctx->m * sizeof(double)));
+    const int blocks = (int)std::min<int64_t>((ctx->n + 255) / 256, 4096);
+    hipLaunchKernelGGL(rows_from_columns_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_x, ctx->n, ctx->m, ctx->ld, d_rows);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(x_out, d_rows, (size_t)ctx->n * ctx->m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_rows));
     return FOKL_OK;
 }
 
@@ -1218,7 +1304,12 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
             const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, G4S_THREADS, lds));
-            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            // ... nor with the device the fit happens to run on (a partition with fewer CUs, another SKU) or with what the
+            // occupancy query says today: the cut is the one of 256 CUs hosting `by_registers` workgroups each, whatever
+            // hosts them -- the same rows meet in the same partial sums everywhere, so a golden measured on one device
+            // holds on another; resident or queued, every workgroup has the same work.
+            constexpr int kCutCus = 256;
+            const int target = std::max(1, (std::min(wgs_cap, by_registers) * kCutCus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;

@@ -393,16 +393,73 @@ __global__ __launch_bounds__(K1_THREADS) void basis_build_reg_kernel(
 // upload helpers
 // ---------------------------------------------------------------------------------------------------------
 
-// x [n, m] row-major -> xT [m][ld]; also fills the ones column and copies y.
+// x [n, m] row-major -> xT [m][ld]; also fills the ones column and copies y.  bounds (or NULL): lows [m] | spans [m] --
+// every value normalised on the way, (x - low) / span in two separately rounded operations (FoKL.clean, FR:436-437).
 __global__ void transpose_inputs_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t n, int m,
                                         int64_t ld, double *__restrict__ xT, double *__restrict__ ones,
-                                        double *__restrict__ ycol)
+                                        double *__restrict__ ycol, const double *__restrict__ bounds)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += (int64_t)gridDim.x * blockDim.x) {
         const bool in = i < n;
-        for (int k = 0; k < m; ++k) xT[(size_t)k * ld + i] = in ? x[(size_t)i * m + k] : 0.0;
+        for (int k = 0; k < m; ++k) {
+            double v = in ? x[(size_t)i * m + k] : 0.0;
+            if (bounds && in) v = (v - bounds[k]) / bounds[m + k];
+            xT[(size_t)k * ld + i] = v;
+        }
         ones[i] = in ? 1.0 : 0.0;
         ycol[i] = in ? y[i] : 0.0;
+    }
+}
+
+// xT [m][ld] -> rows [n, m]
+__global__ void rows_from_columns_kernel(const double *__restrict__ xT, int64_t n, int m, int64_t ld, double *__restrict__ rows)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int k = 0; k < m; ++k) rows[(size_t)i * m + k] = xT[(size_t)k * ld + i];
+}
+
+// Column minima / maxima of x [n, m] row-major (np.min / np.max per column: exact, NaN-propagating).  Lane t of `lanes`
+// (a multiple of m) sweeps the elements t, t + lanes, ... -- all of column t mod m, consecutive lanes on consecutive
+// addresses -- and leaves its (min, max) in part[t], part[lanes + t]; the finishing kernel folds the lanes of a column.
+__device__ __forceinline__ double nan_min(double a, double b) { return (b < a || b != b) ? b : a; }
+__device__ __forceinline__ double nan_max(double a, double b) { return (b > a || b != b) ? b : a; }
+
+__global__ void column_bounds_kernel(const double *__restrict__ x, int64_t total, int m, int64_t lanes, double *__restrict__ part)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    double lo = x[t < total ? t : t % m], hi = lo;        // (fewer elements than lanes: the column's first value stands in)
+    for (int64_t at = t + lanes; at < total; at += lanes) {
+        const double v = x[at];
+        lo = nan_min(lo, v);
+        hi = nan_max(hi, v);
+    }
+    part[t] = lo;
+    part[lanes + t] = hi;
+}
+
+__global__ void column_bounds_finish_kernel(const double *__restrict__ part, int64_t lanes, int m, double *__restrict__ out)
+{
+    __shared__ double lo_s[256], hi_s[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    double lo = part[k], hi = part[lanes + k];
+    for (int64_t t = k + (int64_t)tid * m; t < lanes; t += (int64_t)256 * m) {
+        lo = nan_min(lo, part[t]);
+        hi = nan_max(hi, part[lanes + t]);
+    }
+    lo_s[tid] = lo;
+    hi_s[tid] = hi;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) {
+            lo_s[tid] = nan_min(lo_s[tid], lo_s[tid + w]);
+            hi_s[tid] = nan_max(hi_s[tid], hi_s[tid + w]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[k] = lo_s[0];
+        out[m + k] = hi_s[0];
     }
 }
 

@@ -221,6 +221,12 @@ struct fokl_search {
     fokl_dspectral *dspec = nullptr;        // G2 on the device for models of up to dspec_max columns (fokl_search_bind_spectral)
     int dspec_max = 0;
     bool dspec_staged = false, dspec_hold = false;
+    // which jobs go there: those whose result is not wanted before the device can have it -- slack (microseconds until a
+    // kill test will ask for the model) >= dspec_slack * the kernels' duration at that size; dspec_slack = 0: all of them.
+    // The rest stay with LAPACK on the pool's threads (0.2-0.4 ms at 66 columns against the device's 0.6).
+    double dspec_slack = 1.5;
+    int dspec_lookahead = 32;               // how far ahead of the kill tests device jobs are requested
+    double test_us = 70.0;                  // running mean of the time one kill test takes this search
     fokl_search_params prm{};
     double sigsqd0 = 0, tausqd0 = 0;
     int speculation = 0;
@@ -423,12 +429,22 @@ void resolve(Tape *t, bool commit)
 
 // ---- spectra --------------------------------------------------------------------------------------------------
 
-Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1)
+// how long the device takes for one decomposition, microseconds (profiles/eigh_device_r04.txt)
+inline double device_spectral_us(int p1) { return p1 <= 72 ? 9.0 * p1 : (p1 <= 128 ? 14.0 * p1 : 28.0 * p1); }
+
+// slack_us: microseconds until the result will be asked for, as far as the caller can tell (< 0: now)
+inline bool spectrum_to_device(const fokl_search *s, int p1, double slack_us)
+{
+    if (!s->dspec || p1 > s->dspec_max) return false;
+    return s->dspec_slack <= 0.0 || slack_us >= s->dspec_slack * device_spectral_us(p1);
+}
+
+Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1, double slack_us = -1.0)
 {
     auto *sp = new Spectrum();
     sp->p1 = p1;
     sp->idx.assign(idx, idx + p1);
-    if (s->dspec && p1 <= s->dspec_max) {
+    if (spectrum_to_device(s, p1, slack_us)) {
         // staged only: the entry point that ends this burst of requests launches them as one grid (flush_spectra)
         if (fokl_dspectral_submit(s->dspec, gram, ld, sp->idx.data(), p1, ld - 1, 0, &sp->ticket, &sp->buf) != FOKL_OK) {
             delete sp;
@@ -1254,11 +1270,14 @@ extern "C" int fokl_search_spectral(fokl_search *s, const double *gram, int ld, 
 }
 
 // G2 of models of up to max_columns columns goes to `engine` (NULL: back to the pool's LAPACK threads).
-extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine, int max_columns)
+extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine, int max_columns, double slack,
+                                         int lookahead)
 {
     if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_bind_spectral: null search");
     s->dspec = engine;
     s->dspec_max = engine ? std::min(max_columns, fokl_dspectral_max_columns()) : 0;
+    if (slack >= 0.0) s->dspec_slack = slack;
+    if (lookahead >= 0) s->dspec_lookahead = lookahead;
     return FOKL_OK;
 }
 
@@ -1664,16 +1683,22 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     auto submit_ahead = [&](size_t pos) -> int {
         std::vector<int32_t> cur(killed);
         int deep = 0;
-        for (size_t q = pos; q < proposal.size() && deep <= s->prm.lookahead; ++q) {
+        // host threads: `lookahead` tests deep; the device, which costs no CPU but answers later: as far as dspec_lookahead,
+        // and only jobs it can finish before their test comes up
+        const int far = s->dspec ? std::max(s->prm.lookahead, s->dspec_lookahead) : s->prm.lookahead;
+        for (size_t q = pos; q < proposal.size() && deep <= far; ++q) {
             const Step st = step_at(q);
             if (q > pos && !st.run) continue;
             ++deep;
             auto key = with_column(cur, a->columns[proposal[q]]);
             if (ahead.find(key) == ahead.end()) {
                 const auto idx = columns_without(A, key);
-                Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size());
-                if (!sp) return FOKL_ERR_STATE;
-                ahead.emplace(key, sp);
+                const double slack = (deep - 1) * s->test_us;
+                if (deep <= s->prm.lookahead + 1 || spectrum_to_device(s, (int)idx.size(), slack)) {
+                    Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size(), slack);
+                    if (!sp) return FOKL_ERR_STATE;
+                    ahead.emplace(key, sp);
+                }
             }
             if (q == pos ? (st.run ? st.accept : true) : st.accept) cur = std::move(key);
         }
@@ -1684,9 +1709,15 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     predict(0);
     forecast(0);
     order_tapes(0);
+    double t_test = now_s();
     for (size_t pos = 0; pos < proposal.size() && rc == FOKL_OK; ++pos) {
         const int i = proposal[pos];
         bool decided = clause1[(size_t)i];
+        {
+            const double t = now_s(), us = 1e6 * (t - t_test);
+            t_test = t;
+            if (pos > 0) s->test_us = std::min(400.0, std::max(20.0, 0.9 * s->test_us + 0.1 * us));
+        }
         if ((rc = verify(s, false)) != FOKL_OK) break;
         if (!path_complete && pos + (size_t)(horizon / 2) >= path_from + path.size()) {
             predict(pos);                                   // the window of predicted steps moves on

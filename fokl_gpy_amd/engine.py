@@ -131,6 +131,19 @@ class HipBackend:
         self.ctx.upload(inputs, data, kernel_id, packed, n_basis, width)
         self.kernel_id = kernel_id
 
+    # FoKL.clean's normalisation on the device (fokl_stage_inputs / fokl_upload_staged): the model's `inputs` attribute
+    # then exists on the device only until somebody asks for it (FoKLRoutines._DeviceInputs) -- or until the next dataset
+    # arrives on this context, which makes the previous owner fetch its copy first (_capi.DeviceContext).
+    def stage_inputs(self, x, owner):
+        return self.ctx.stage_inputs(x, owner)
+
+    def upload_staged(self, data, kernel_id, packed, n_basis, width, lows, spans, owner):
+        self.ctx.upload_staged(data, kernel_id, packed, n_basis, width, lows, spans, owner)
+        self.kernel_id = kernel_id
+
+    def download_inputs(self):
+        return self.ctx.download_inputs()
+
     def reserve_slots(self, count):
         self.ctx.reserve_slots(count)
 
@@ -1002,7 +1015,12 @@ class ForwardSelection:
             if not self.allreduce and not self.candidate_sharded:
                 self.spectral_engine = spectral_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
             if self.spectral_engine is not None:
-                self.native.bind_spectral(self.spectral_engine)
+                # hybrid: only jobs the device finishes before their kill test comes up (FOKL_DSPECTRAL_SLACK kernel
+                # durations ahead, default 1.5; FOKL_DSPECTRAL_LOOKAHEAD tests ahead at most, default 32); device: all
+                everything = os.environ.get('FOKL_EIGH') == 'device'
+                self.native.bind_spectral(self.spectral_engine,
+                                          slack=0.0 if everything else float(os.environ.get('FOKL_DSPECTRAL_SLACK', '-1')),
+                                          lookahead=int(os.environ.get('FOKL_DSPECTRAL_LOOKAHEAD', '-1')))
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run
@@ -1010,7 +1028,8 @@ class ForwardSelection:
         # one for the normals finished on the host, host threads or the device for the kill tests' chains
         self.stats['finish_log'] = os.environ.get('FOKL_FINISH_LOG', 'fast')
         self.stats['chain_mode'] = 'device' if self.chain_engine is not None else 'host'
-        self.stats['eigh_mode'] = 'device' if getattr(self, 'spectral_engine', None) is not None and self.native is not None else 'host'
+        self.stats['eigh_mode'] = (os.environ.get('FOKL_EIGH', 'host') if getattr(self, 'spectral_engine', None) is not None
+                                   and self.native is not None else 'host')
         t_up = time.perf_counter()
         try:
             return self._run()

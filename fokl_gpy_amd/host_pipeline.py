@@ -224,8 +224,8 @@ _SPECTRAL_ENGINES = {}
 
 def spectral_engine_for(device):
     mode = os.environ.get('FOKL_EIGH', 'host')
-    if mode not in ('device', 'host'):
-        raise ValueError("FOKL_EIGH must be device or host")
+    if mode not in ('device', 'hybrid', 'host'):
+        raise ValueError("FOKL_EIGH must be host, hybrid or device")
     if mode == 'host' or os.environ.get('FOKL_EIGH_SIGNS', 'canonical') == 'lapack':
         return None
     if device is None:
@@ -368,14 +368,8 @@ class HostPipeline:
 
     def _reap(self):
         live = []
-        device_busy = False                 # device chains complete in submission order: one poll finds the frontier
-        for job in self._live:
-            if isinstance(job, _capi.DeviceChainJob):
-                if device_busy:
-                    live.append(job)
-                    continue
-                device_busy = not job.done()
-            if job.done():
+        for job in self._live:              # (a device chain's done() is a load from page-locked memory: no frontier needed,
+            if job.done():                  # and with several streams chains do not complete in submission order)
                 if job.recycle:
                     for entry in job.recycle:
                         self._retire_buffer(entry)

@@ -84,6 +84,20 @@ int fokl_sync(fokl_ctx *ctx);
 int fokl_upload(fokl_ctx *ctx, const double *x, const double *y, int64_t n, int m, int kernel,
                 const double *phis, int n_basis, int width);
 
+/*
+ * FoKL.clean's normalisation (FR:395, 436-437) on the device, for fits that start from the RAW dataset: fokl_stage_inputs
+ * copies x [n, m] (row-major, raw) to the device and returns every column's minimum and maximum (exact; NaN-propagating
+ * like np.min / np.max) -- the host derives `lows` and `spans` from them (minmax / pillow keywords, a few scalars) --
+ * and fokl_upload_staged does what fokl_upload does from that copy, every value normalised on the way:
+ * (x - lows[k]) / spans[k], one subtraction and one division, separately rounded: the numbers FoKL.clean produces on the
+ * host bit for bit.  fokl_download_inputs returns the inputs as the kernels see them, in rows [n, m] (the `inputs`
+ * attribute of the model is materialised from it when somebody asks for it).
+ */
+int fokl_stage_inputs(fokl_ctx *ctx, const double *x, int64_t n, int m, double *lows_out, double *highs_out);
+int fokl_upload_staged(fokl_ctx *ctx, const double *y, int64_t n, int m, int kernel, const double *phis, int n_basis,
+                       int width, const double *lows, const double *spans);
+int fokl_download_inputs(fokl_ctx *ctx, double *x_out);
+
 /* Make sure slots [0, n_slots) exist (grows in chunks; existing slot contents are preserved). */
 int fokl_reserve_slots(fokl_ctx *ctx, int n_slots);
 int fokl_slot_capacity(const fokl_ctx *ctx);
@@ -524,11 +538,14 @@ typedef struct fokl_search_params {
                                                    stay rows, the device expands them (fokl_dchain_submit_rows) */
 } fokl_search_params;
 int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_search_params *params, fokl_search **out);
-/* G2 of models of up to max_columns columns goes to the device engine (fokl_dspectral_*, declared further down; NULL:
- * back to the pool's LAPACK threads).  Between fokl_search_hold_spectral(s, 1) and (s, 0) fokl_search_spectral only
- * stages its jobs; the closing call launches them as one grid. */
+/* G2 on the device engine (fokl_dspectral_*, declared further down; NULL: everything back to the pool's LAPACK threads)
+ * for models of up to max_columns columns whose result is not wanted before the device can have it: a job requested
+ * `slack` times the kernels' duration (or more) ahead of its kill test goes to the device, the others to the pool;
+ * slack = 0: all of them, < 0: the default (1.5).  lookahead: how many tests ahead device jobs are requested (< 0: the
+ * default, 32; the pool's jobs stay at fokl_search_params.lookahead).  Between fokl_search_hold_spectral(s, 1) and (s, 0)
+ * fokl_search_spectral only stages its jobs; the closing call launches them as one grid. */
 typedef struct fokl_dspectral fokl_dspectral;
-int fokl_search_bind_spectral(fokl_search *search, fokl_dspectral *engine, int max_columns);
+int fokl_search_bind_spectral(fokl_search *search, fokl_dspectral *engine, int max_columns, double slack, int lookahead);
 int fokl_search_hold_spectral(fokl_search *search, int hold);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);

@@ -193,7 +193,7 @@ def test_oracle_restates_the_second_update_call_bit_for_bit(tag, variant):
     if strict:
         assert np.array_equal(b1, S[pre + 'betas1'])
     else:
-        loose_equal(S[pre + 'evs1'], S[pre + 'evs1'], b1, S[pre + 'betas1'])
+        loose_equal(e1, S[pre + 'evs1'], b1, S[pre + 'betas1'])
         b1 = S[pre + 'betas1']                      # the second call's prior is the REFERENCE's first-call draws
     assert built == bool(S[pre + 'built1'])
     assert np.array_equal(rng_fingerprint()[0], S[pre + 'rng_mid'])

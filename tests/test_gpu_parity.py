@@ -611,3 +611,58 @@ def test_device_probes_report_plausible_rates(device_ctx):
     assert 2e13 < mfma < 8e13
     with pytest.raises(_capi.FoklNativeError):
         device_ctx.probe(9)
+
+
+def test_column_bounds_on_the_device_are_numpys(device_ctx):
+    """fokl_stage_inputs: np.min / np.max of every column, exact and NaN-propagating, for ragged sizes."""
+    rng = np.random.default_rng(5)
+    for n, m in ((1, 1), (7, 3), (300_001, 5), (70_000, 33), (4096, 64)):
+        x = rng.standard_normal((n, m)) * 10.0 ** rng.uniform(-3, 3, m)
+        if n > 6:
+            x[3, 0] = np.inf
+            x[5, m - 1] = -np.inf
+            if m > 2:
+                x[n // 2, 1] = np.nan
+        lows, highs = device_ctx.stage_inputs(np.ascontiguousarray(x))
+        with np.errstate(invalid='ignore'):
+            assert np.array_equal(lows, np.min(x, axis=0), equal_nan=True), (n, m)
+            assert np.array_equal(highs, np.max(x, axis=0), equal_nan=True), (n, m)
+
+
+def test_fit_normalises_raw_inputs_on_the_device_bit_for_bit(monkeypatch, tmp_path):
+    """fit(clean=True) of a large float64 dataset: minima / maxima and (x - min) / (max - min) on the device
+    (fokl_stage_inputs, fokl_upload_staged) instead of two host passes -- the same minmax, the same normalised numbers bit
+    for bit (FR:395, 436-437), the same draws; ``inputs`` is fetched when somebody asks for it, before another dataset
+    replaces it on the device, and travels with ``save``."""
+    from fokl_gpy_amd.FoKLRoutines import _DeviceInputs
+    rng = np.random.default_rng(12)
+    n, m = 150_000, 4
+    x = rng.uniform(-3.0, 7.0, (n, m)) * np.array([1.0, 1e-3, 250.0, 1.0])
+    x[:, 3] += 1e6
+    y = np.sin(x[:, 0]) + 0.3 * (x[:, 2] / 250.0) ** 2 + 0.05 * rng.standard_normal(n)
+    kw = dict(kernel='Bernoulli Polynomials', UserWarnings=False, ConsoleOutput=False, burnin=30, draws=30)
+
+    def fit(mode):
+        monkeypatch.setenv('FOKL_CLEAN', mode)
+        model = FoKLRoutines.FoKL(**kw)
+        np.random.seed(3)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            out = model.fit(x, y, clean=True)
+        return model, out
+
+    host, (hb, hm, he) = fit('host')
+    assert isinstance(host.__dict__['inputs'], np.ndarray)
+    dev, (db, dm, de) = fit('device')
+    assert isinstance(dev.__dict__['inputs'], _DeviceInputs) and dev.__dict__['inputs'].shape == (n, m)
+    assert dev.minmax == host.minmax
+    assert np.array_equal(dm, hm) and np.array_equal(de, he) and np.array_equal(db, hb)
+    # another model's dataset arrives on the same device: the first model fetches its inputs before they are replaced
+    other, _ = fit('device')
+    assert isinstance(dev.__dict__['inputs'], np.ndarray) and isinstance(other.__dict__['inputs'], _DeviceInputs)
+    assert np.array_equal(dev.inputs, host.inputs) and dev.inputs.flags.c_contiguous
+    # a saved model carries the array
+    path = other.save('lazy.fokl', str(tmp_path))
+    loaded = FoKLRoutines.load(path)
+    assert np.array_equal(loaded.inputs, host.inputs) and np.array_equal(other.inputs, host.inputs)
+    assert np.array_equal(x[:, 3] > 0, np.ones(n, dtype=bool))                 # the caller's array is untouched
