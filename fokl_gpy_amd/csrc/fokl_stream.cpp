@@ -154,10 +154,10 @@ inline double to_double(uint32_t wa, uint32_t wb)
 
 // Tempering in place and the accept flags of a segment; `o` = parity of the word position the doubles pair up from
 // (double l of the segment <-> words o + 2 l, o + 2 l + 1).
-void finish_segment_portable(Segment *seg, int o)
+void finish_segment_portable(Segment *seg, int o, const uint32_t *raw)
 {
     uint32_t *w = seg->words();
-    for (int i = 0; i < kSegWords + kSegTail; ++i) w[i] = temper(w[i]);
+    for (int i = 0; i < kSegWords + kSegTail; ++i) w[i] = temper(raw[i]);
     std::vector<double> sq((size_t)kSegDoubles + 1);
     for (int l = 0; l <= kSegDoubles; ++l) {
         const double x = 2.0 * to_double(w[o + 2 * l], w[o + 2 * l + 1]) - 1.0;
@@ -184,12 +184,12 @@ FOKL_WIDE_TARGET inline __m512d polar_squares(const uint32_t *p)
     return _mm512_mul_pd(x, x);
 }
 
-FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o)
+FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *raw)
 {
     uint32_t *w = seg->words();
     const __m512i m7 = _mm512_set1_epi32((int)0x9d2c5680u), m15 = _mm512_set1_epi32((int)0xefc60000u);
     for (int i = 0; i < kSegWords + kSegTail; i += 16) {
-        __m512i y = _mm512_loadu_si512(w + i);
+        __m512i y = _mm512_loadu_si512(raw + i);
         y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
         y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), m7));
         y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), m15));
@@ -319,9 +319,13 @@ void update_low_water(fokl_stream *e)                       // hold_m held
 }
 
 // The token holder's part of segment `index`: its raw words (and the first words of the next segment behind them).
-void generate_raw(fokl_stream *e, Segment *seg, int64_t index)
+// The serial part of a segment, under the token: the recurrence from the block the previous segment ended with, into the
+// calling thread's own scratch buffer (the layout of Segment::buf).  The scratch stays in that core's L2 from segment to
+// segment: 6 us on Zen 5 -- run straight into a Segment that last saw use two dozen segments ago it cost 25 us of cache
+// misses, and that, not the walk, was what a fit's random stream was limited by (walker waiting for bulk threads 9 ms per
+// configs[2] fit).  Tempering reads the scratch and writes the Segment once, outside the token.
+void generate_raw(fokl_stream *e, uint32_t *buf, int64_t index)
 {
-    uint32_t *buf = seg->buf;
     int from = MT_N;
     if (index == 0) {
         std::memset(buf, 0, MT_N * sizeof(uint32_t));
@@ -355,6 +359,20 @@ void generate_raw(fokl_stream *e, Segment *seg, int64_t index)
 
 void bulk_worker(fokl_stream *e)
 {
+    void *scratch_mem = nullptr;
+    if (posix_memalign(&scratch_mem, 64, sizeof(uint32_t) * (size_t)(MT_N + kSegWords + kSegTail + 64)) != 0) {
+        std::lock_guard<std::mutex> lock(e->token_m);
+        e->error = "fokl_stream: out of memory";
+        e->stop = true;
+        e->stop_flag.store(true, std::memory_order_release);
+        e->room_cv.notify_all();
+        return;
+    }
+    struct Free {
+        void *p;
+        ~Free() { std::free(p); }
+    } scratch_owner{scratch_mem};
+    uint32_t *scratch = static_cast<uint32_t *>(scratch_mem);
     for (;;) {
         Segment *seg = nullptr;
         int64_t index = 0;
@@ -410,16 +428,17 @@ void bulk_worker(fokl_stream *e)
             seg->index = index;
             seg->ready.store(0, std::memory_order_relaxed);
             const int64_t t0 = now_ns();
-            generate_raw(e, seg, index);
+            generate_raw(e, scratch, index);
             e->bulk_busy_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
             ++e->next_raw;
         }
         for (Segment *s : retired) give_segment(s);
         const int64_t t0 = now_ns();
+        std::memcpy(seg->buf, scratch, MT_N * sizeof(uint32_t));       // the raw block in front (fokl_stream_state)
         if (e->wide)
-            finish_segment_wide(seg, e->o);
+            finish_segment_wide(seg, e->o, scratch + MT_N);
         else
-            finish_segment_portable(seg, e->o);
+            finish_segment_portable(seg, e->o, scratch + MT_N);
         seg->ready.store(1, std::memory_order_release);
         e->table[index % kTable].store(seg, std::memory_order_release);
         e->segments_made.fetch_add(1, std::memory_order_relaxed);

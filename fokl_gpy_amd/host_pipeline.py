@@ -88,6 +88,37 @@ def _second_domain(allowed, home):
         return None
 
 
+def _spectral_cpus(allowed, home, count):
+    """One logical CPU of each of `count` physical cores outside `home`'s last-level-cache domain(s), taken domain by
+    domain in CPU order after `home`: the eigen-decompositions are compute bound and share nothing -- two of them on the
+    hardware threads of one core run at half speed each (EPYC 9575F: an L3 domain is FOUR cores; the eight spectral
+    threads pinned to the eight logical CPUs of one domain took 0.42 ms per 66-column dsyevr against 0.21 alone).
+    None when the topology cannot be read or offers fewer than `count` such cores."""
+    try:
+        seen, domains = set(), []
+        for cpu in sorted(allowed):
+            if cpu in seen:
+                continue
+            dom = _cpu_list(f'/sys/devices/system/cpu/cpu{cpu}/cache/index3/shared_cpu_list') & allowed
+            seen |= dom
+            domains.append(dom)
+        others = [d for d in domains if not (d & home)]
+        after = [d for d in others if min(d) > min(home)] + [d for d in others if min(d) < min(home)]
+        picked, cores = [], set()
+        for dom in after:
+            for cpu in sorted(dom):
+                core = frozenset(_cpu_list(f'/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list'))
+                if core in cores:
+                    continue
+                cores.add(core)
+                picked.append(cpu)
+                if len(picked) == count:
+                    return set(picked)
+        return None
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_budget():
     """CPUs this process may keep busy: its affinity mask, capped by the cgroup CPU quota (a container that sees 256
     CPUs may be allowed 16 CPU-seconds per second) shared among the ranks of the node (LOCAL_WORLD_SIZE)."""
@@ -327,7 +358,11 @@ class HostPipeline:
             # the eigen-decompositions share nothing with the stream's threads: on a CPU with several last-level-cache
             # domains they get the next one to themselves (FOKL_SPECTRAL_DOMAIN=0: they stay where the others are)
             if self._saved_affinity is not None and os.environ.get('FOKL_SPECTRAL_DOMAIN', '1') != '0':
-                other = _second_domain(self._saved_affinity, os.sched_getaffinity(0))
+                other = None
+                if os.environ.get('FOKL_SPECTRAL_DOMAIN', '1') != 'domain' and spectral > 0:
+                    other = _spectral_cpus(self._saved_affinity, os.sched_getaffinity(0), spectral)
+                if other is None:
+                    other = _second_domain(self._saved_affinity, os.sched_getaffinity(0))
                 if other:
                     try:
                         self.pool.spectral_affinity(other)
