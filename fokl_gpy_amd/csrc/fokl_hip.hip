@@ -583,6 +583,7 @@ extern "C" int fokl_download_inputs(fokl_ctx *ctx, double *x_out)
 static int cu_count(fokl_ctx *ctx) { return ctx->cus > 0 ? ctx->cus : 256; }
 
 static int env_int(const char *name, int fallback);
+static int dev_int(const char *name, int fallback);
 
 // LDS available to one workgroup of the basis kernel; the factor table takes 4 KB per distinct factor.
 static constexpr size_t K1_LDS_BUDGET = 144 * 1024;
@@ -684,7 +685,7 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
     const int64_t tile_rows = (int64_t)threads * K1_ROWS_PER_THREAD;
     const int64_t n_tiles = (ctx->n + tile_rows - 1) / tile_rows;
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(reg_table ? 5 : 16, (160 * 1024) / std::max<size_t>(lds_bytes, 1)));
-    per_cu = std::min(per_cu, std::max(1, env_int("FOKL_K1_WGS", per_cu)));
+    per_cu = std::min(per_cu, std::max(1, dev_int("FOKL_K1_WGS", per_cu)));
     const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)cu_count(ctx) * per_cu);
     const BasisPlan *d_plan = reinterpret_cast<const BasisPlan *>(ctx->d_args);
     const int *d_arr = reinterpret_cast<const int *>(ctx->d_args + plan_bytes);
@@ -894,6 +895,18 @@ static int env_int(const char *name, int fallback)
     return v && *v ? std::atoi(v) : fallback;
 }
 
+// Knobs that select between measured variants of a kernel (A/B runs: docs/LAB_NOTEBOOK.md) exist in development builds
+// only (make DEV=1): the product library runs one configuration, the one the `-m gpu` suite covers.
+static int dev_int(const char *name, int fallback)
+{
+#ifdef FOKL_DEV_KERNELS
+    return env_int(name, fallback);
+#else
+    (void)name;
+    return fallback;
+#endif
+}
+
 // Internal column order, tile groups and kernel parameters for an nr x nc block (see gram_tiles_kernel).  Pure host
 // arithmetic: fokl_gram_plan exposes it to the CPU tests, which replay the lists with numpy.
 static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, GramPlan &pl,
@@ -975,10 +988,10 @@ static void plan_gram(const int32_t *row_slots, int nr, const int32_t *col_slots
     pl.nt = (most_tiles + teams - 1) / teams;
     pl.ct = most_staged;
     // rows per chunk: as many sub-chunks of 32 rows as the 16 staging passes and FOKL_GRAM_RB allow
-    const int rb_cap = std::max(1, std::min(16, env_int("FOKL_GRAM_RB", 1)));
+    const int rb_cap = std::max(1, std::min(16, dev_int("FOKL_GRAM_RB", 1)));
     pl.rb_shift = 0;
     while (kind == 0 && (pl.ct << (pl.rb_shift + 1)) <= GT_MAX_PASS && (2 << pl.rb_shift) <= rb_cap) ++pl.rb_shift;
-    pl.depth = kind == 0 && pl.nt <= 4 ? std::max(1, std::min(2, env_int("FOKL_GRAM_DEPTH", 1))) : 1;
+    pl.depth = kind == 0 && pl.nt <= 4 ? std::max(1, std::min(2, dev_int("FOKL_GRAM_DEPTH", 1))) : 1;
 
     // Half-tile slots (gram_tiles_dma_kernel<NT, NBUF, true>): when 1 .. 8 of the 16 columns of the last row tile are
     // row-side columns, a tile of that row tile costs the matrix pipe half a tile if it is formed as 8 x 16.  Entries 0
@@ -1161,9 +1174,9 @@ static gram_dma_fn tiles_dma_kernel(int nt8, int nbuf, bool half, int loaders = 
 static bool half_slots_wanted()
 {
 #ifdef FOKL_DEV_KERNELS
-    if (env_int("FOKL_GRAM_MFMA4", 0) == 2) return false;
+    if (dev_int("FOKL_GRAM_MFMA4", 0) == 2) return false;
 #endif
-    return env_int("FOKL_GRAM_DMA", 2) == 2 && env_int("FOKL_GRAM_HALF", 1) != 0;
+    return dev_int("FOKL_GRAM_DMA", 2) == 2 && dev_int("FOKL_GRAM_HALF", 1) != 0;
 }
 
 extern "C" int fokl_gram_plan(const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int kind, int32_t *info,
@@ -1214,7 +1227,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
 
     // path choice: the VALU kernel re-reads operands once per 4x4 register tile, fine while the block is small;
     // the MFMA kernels read every column of a group of tiles once per row chunk.
-    if (path == 0) path = (int64_t)nr * nc > 64 ? env_int("FOKL_GRAM_PATH", 2) : 1;
+    if (path == 0) path = (int64_t)nr * nc > 64 ? dev_int("FOKL_GRAM_PATH", 2) : 1;
     if (path < 1 || path > 3) path = 2;
     const double *grid_base = path == 2 ? slot_grid_base(ctx) : nullptr;
     if (path == 2 && !grid_base) path = 3;                   // slots off the 256-byte grid (never seen): panel kernel
@@ -1246,7 +1259,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         // tile lists over the internal column order; tiles below the diagonal of the row-side x row-side part skipped
         // FOKL_GRAM_MFMA4=2: the 4x4x4 form of the fp64 MFMA instruction (A/B runs; slower beyond the smallest blocks)
 #ifdef FOKL_DEV_KERNELS
-        const int kind = env_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
+        const int kind = dev_int("FOKL_GRAM_MFMA4", 0) == 2 ? 1 : 0;
 #else
         const int kind = 0;
 #endif
@@ -1293,7 +1306,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         const int nr_pad = 16 * pl.it, nc_pad = 16 * pl.jt;
         // workgroups per CU that share the rows of a group: more of them hide more latency but every one writes a
         // partial block the reduction has to read back (FOKL_GRAM_WGS caps it)
-        const int wgs_cap = std::max(1, env_int("FOKL_GRAM_WGS", 3));
+        const int wgs_cap = std::max(1, dev_int("FOKL_GRAM_WGS", 3));
         int S;
 #ifdef FOKL_DEV_KERNELS
         if (kind == 1) {
@@ -1319,15 +1332,15 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
                                ctx->d_zero, grid_base);
         } else
 #endif
-        if (pl.ks == 1 && (env_int("FOKL_GRAM_DMA", 2) == 2 ||
-                                  (env_int("FOKL_GRAM_DMA", 2) == 1 && gram_slot == FOKL_K_GRAM_MFMA))) {
+        if (pl.ks == 1 && (dev_int("FOKL_GRAM_DMA", 2) == 2 ||
+                                  (dev_int("FOKL_GRAM_DMA", 2) == 1 && gram_slot == FOKL_K_GRAM_MFMA))) {
             // LDS-DMA staging, 8 wavefronts per workgroup, two LDS buffers: every block of three tiles or more
             // (FOKL_GRAM_DMA=1: only the launches the matrix pipe bounds, 0: gram_tiles_kernel for everything)
             const int pieces = (pl.ct * 16 * 34 * 8 + 1023) / 1024;
             // three LDS buffers (a chunk's pieces in flight across the barrier) where they fit, FOKL_GRAM_BUFS to force
             int nbuf = 2;
 #ifdef FOKL_DEV_KERNELS
-            nbuf = env_int("FOKL_GRAM_BUFS", 2);
+            nbuf = dev_int("FOKL_GRAM_BUFS", 2);
             if (nbuf == 3 && 3 * (size_t)pieces * 1024 > 160 * 1024) nbuf = 2;
 #endif
             gram_dma_fn plain_fn = tiles_dma_kernel((pl.nt + 1) / 2, nbuf, pl.half);
@@ -1345,7 +1358,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             // wherever a CU can host as many of the larger workgroups as the row cut puts on it -- fewer resident
             // workgroups cost more than the loaders bring (56 x 98: 195 -> 216 us).  FOKL_GRAM_LOADERS=0: never.  Same tiles,
             // same order of summation: the block's bits do not depend on it.
-            int loaders = nbuf == 2 ? env_int("FOKL_GRAM_LOADERS", 4) : 0;
+            int loaders = nbuf == 2 ? dev_int("FOKL_GRAM_LOADERS", 4) : 0;
             if (loaders != 2 && loaders != 4) loaders = 0;
             gram_dma_fn fn = plain_fn;
             if (loaders) {

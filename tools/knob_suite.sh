@@ -1,0 +1,38 @@
+#!/bin/bash
+# tools/knob_suite.sh [out]: the fit-level GPU tests (goldens of every BASELINE config, reference fixtures, device chains,
+# native search) once per value of every environment knob the PRODUCT library and driver read (README's table; knobs
+# that only select kernel variants exist in DEV=1 builds and are not part of the product).  One pytest process per mode,
+# one after the other; stops at the first failing mode.
+out=${1:-gpurun_out/knob_suite.txt}
+mkdir -p "$(dirname "$out")"
+: > "$out"
+TESTS="tests/test_config_goldens.py tests/test_gpu_parity.py tests/test_chain_device.py tests/test_fitupdate.py tests/test_derivatives.py"
+KEYS="full_size_config_on_gpu or fit_matches_reference or reference_test_dataset or fitupdate or derivatives or against_oracle or kill_test_bic"
+modes=(
+  "FOKL_X=default"
+  "FOKL_SEARCH=python"
+  "FOKL_CHAIN=host"
+  "FOKL_DCHAIN_ROWS=0"
+  "FOKL_DCHAIN_RECURSION=exact"
+  "FOKL_EIGH=device"
+  "FOKL_EIGH=hybrid"
+  "FOKL_CLEAN=host"
+  "FOKL_K1_TOUCH=0"
+  "FOKL_K3=columns"
+  "FOKL_KILL_BIC=device"
+  "FOKL_KILL_BIC=check"
+  "FOKL_FINISH_LOG=exact"
+  "FOKL_NOISE_PIPELINE=0"
+  "FOKL_TENTATIVE_TAPES=0"
+  "FOKL_TENTATIVE_TAPES=test"
+  "FOKL_FORESIGHT=0"
+  "FOKL_PIN_L3=0"
+  "FOKL_SAMPLER_ISA=base"
+  "FOKL_SYNC=blocking"
+)
+for mode in "${modes[@]}"; do
+  echo "== $mode" | tee -a "$out"
+  env $mode timeout -k 10 900 python -m pytest $TESTS -m gpu -q -x -k "$KEYS" 2>&1 | tail -2 | tee -a "$out"
+  if [ "${PIPESTATUS[0]}" -ne 0 ]; then echo "FAILED under $mode" | tee -a "$out"; exit 1; fi
+done
+echo "all modes passed" | tee -a "$out"
