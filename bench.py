@@ -263,10 +263,11 @@ def l3_domain_of(cpu):
         return None
 
 
-def quietest_l3_domain(local, ranks, sample_s=0.25):
-    """The hosts of the pool are shared: other tenants' load on the cores a fit's threads sit on shows up one to one in
-    the (host-bound) fit time.  Sample /proc/stat for a moment and take the least busy L3 domain among those this rank
-    may claim (domains d with d % ranks == local, so that the ranks of a node never pick the same one)."""
+def l3_domains_by_load(cpus, sample_s=0.25, near=None, avoid=()):
+    """[(busy fraction, domain)] of the L3 domains that hold the logical CPUs `cpus`, in CPU order: /proc/stat sampled
+    twice, `sample_s` apart.  Domains that are not wholly inside `near` (the GPU's NUMA node) or touch `avoid` are left
+    out.  The hosts of the pool are shared: other tenants' load on the cores a fit's threads sit on shows up one to one
+    in the (host-bound) fit time."""
     def snap():
         out = {}
         with open('/proc/stat') as fh:
@@ -275,24 +276,30 @@ def quietest_l3_domain(local, ranks, sample_s=0.25):
                     p = line.split()
                     out[int(p[0][3:])] = (sum(map(int, p[1:9])), int(p[4]) + int(p[5]))
         return out
+    avoid = set(avoid or ())
+    a = snap()
+    time.sleep(sample_s)
+    b = snap()
+    domains, seen = [], set()
+    for cpu in sorted(cpus):
+        if cpu in seen:
+            continue
+        dom = l3_domain_of(cpu)
+        if not dom:
+            continue
+        seen.update(dom)
+        if avoid & set(dom) or (near is not None and not set(dom) <= near):
+            continue                                        # e.g. the other socket: far from the GPU's page-locked memory
+        busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
+        domains.append((sum(busy) / max(1, len(busy)), dom))
+    return domains
+
+
+def quietest_l3_domain(local, ranks, sample_s=0.25):
+    """The least busy L3 domain among those this rank may claim (domains d with d % ranks == local, so that the ranks of a
+    node never pick the same one)."""
     try:
-        allowed = set(os.sched_getaffinity(0))
-        near = gpu_numa_cpus(local)
-        a = snap()
-        time.sleep(sample_s)
-        b = snap()
-        domains, seen = [], set()
-        for cpu in sorted(allowed):
-            if cpu in seen:
-                continue
-            dom = l3_domain_of(cpu)
-            if not dom:
-                continue
-            seen.update(dom)
-            if near is not None and not set(dom) <= near:
-                continue                                    # the other socket: far from the GPU's page-locked memory
-            busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
-            domains.append((sum(busy) / max(1, len(busy)), dom))
+        domains = l3_domains_by_load(set(os.sched_getaffinity(0)), sample_s, near=gpu_numa_cpus(local))
         mine = [d for i, d in enumerate(domains) if i % max(1, ranks) == local % max(1, ranks)]
         if not mine:
             return None
@@ -337,31 +344,8 @@ def gpu_numa_cpus(local=0):
 def quiet_l3_domains(count, avoid=(), sample_s=0.25, near=None):
     """The `count` least busy L3 domains that share no CPU with `avoid` (worker processes of the throughput modes: one
     domain each, none on the domain this process has pinned itself to).  Fewer if the box has fewer."""
-    def snap():
-        out = {}
-        with open('/proc/stat') as fh:
-            for line in fh:
-                if line.startswith('cpu') and line[3].isdigit():
-                    p = line.split()
-                    out[int(p[0][3:])] = (sum(map(int, p[1:9])), int(p[4]) + int(p[5]))
-        return out
     try:
-        avoid = set(avoid or ())
-        a = snap()
-        time.sleep(sample_s)
-        b = snap()
-        domains, seen = [], set()
-        for cpu in range(os.cpu_count() or 1):
-            if cpu in seen:
-                continue
-            dom = l3_domain_of(cpu)
-            if not dom:
-                continue
-            seen.update(dom)
-            if avoid & set(dom) or (near is not None and not set(dom) <= near):
-                continue
-            busy = [1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in dom if c in a and c in b]
-            domains.append((sum(busy) / max(1, len(busy)), dom))
+        domains = l3_domains_by_load(range(os.cpu_count() or 1), sample_s, near=near, avoid=avoid)
         return [dom for _, dom in sorted(domains, key=lambda d: d[0])[:count]]
     except (OSError, ValueError, KeyError, IndexError):
         return []

@@ -68,6 +68,7 @@ SIGNATURES = {
     'fokl_pool_destroy': (None, [c_vp]),
     'fokl_pool_submit_noise': (c_int, [c_vp, c_int, c_int, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                        c_vp, c_int, c_int, c_vp, c_vp]),
+    'fokl_tape_ready': (c_int, [c_vp, c_int, c_vp, c_int]),
     'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -482,6 +483,13 @@ class StreamEngine:
         _check(self._lib.fokl_stream_stats(self._h, *[ctypes.byref(x) for x in (b, w, seg, ga, ge)]))
         return dict(bulk_s=b.value, walker_wait_s=w.value, segments=seg.value, gamma_attempts=ga.value,
                     gamma_attempts_exact=ge.value)
+
+
+def tape_ready(tape):
+    """fokl_tape_ready: 1 once the tape is recorded and -- a tape the pool's finish threads work on -- every block is there,
+    0 before, -1 if it never will be."""
+    return load().fokl_tape_ready(tape.progress_pointer(), tape.draws,
+                                  tape.block_done_pointer() if tape.materialised_by_pool else None, tape.BLOCK)
 
 
 def gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, want_sig_tau=False, follow=False):

@@ -798,6 +798,28 @@ extern "C" int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gra
     return FOKL_OK;
 }
 
+// Is a tape that the pool records (and, with finish threads, expands block by block) complete?  1 = every row is recorded
+// and every block is there, 0 = not yet, -1 = it never will be (the producer failed or the tape was sent back).  Acquire
+// loads of the words the noise and finish threads publish with release stores: what a consumer on any thread may poll
+// before it reads the tape's arrays.  progress / block_done may be NULL (not followed).
+extern "C" int fokl_tape_ready(const int32_t *progress, int draws, const int32_t *block_done, int block)
+{
+    if (progress) {
+        const int32_t p = __atomic_load_n(progress, __ATOMIC_ACQUIRE);
+        if (p < 0) return -1;
+        if (p < draws) return 0;
+    }
+    if (block_done && block > 0) {
+        const int nblocks = (draws + block - 1) / block;
+        for (int blk = nblocks - 1; blk >= 0; --blk) {
+            const int32_t f = __atomic_load_n(block_done + blk, __ATOMIC_ACQUIRE);
+            if (f < 0) return -1;
+            if (f == 0) return 0;
+        }
+    }
+    return 1;
+}
+
 // Verdict on a tentative noise job: commit != 0 keeps the tape (it is then exactly the tape a plain submission at that
 // point of the stream would have recorded), 0 discards it and rewinds the stream to where the tape began.
 extern "C" int fokl_pool_resolve(fokl_host_job *job, int commit)

@@ -641,6 +641,10 @@ struct Walk {
 
     Walk(fokl_stream *engine) : r(engine, true), e(engine), D(engine->D), has_gauss(engine->has_gauss),
                                 gauss_src(engine->gauss_src) {}
+    // for readers on other threads (fokl_stream_expand): the reader and value_of only -- the walker's cursor, which the
+    // walking thread writes at the end of every tape, is not looked at
+    struct ReaderOnly {};
+    Walk(fokl_stream *engine, ReaderOnly) : r(engine, false), e(engine), D(0), has_gauss(0), gauss_src(0) {}
 
     __attribute__((always_inline)) inline double next_double()
     {
@@ -1313,8 +1317,7 @@ extern "C" int fokl_stream_expand(fokl_stream *e, int p1, double astar, double a
         fokl_set_global_error("fokl_stream_expand: null pointer, empty model or bad row range");
         return FOKL_ERR_ARG;
     }
-    Walk w(e);                                              // only its reader and value_of are used
-    w.r.walker = false;
+    Walk w(e, Walk::ReaderOnly{});                          // only its reader and value_of are used
     Reader &r = w.r;
     const size_t half = (size_t)p1 / 2 + 1;
     const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);

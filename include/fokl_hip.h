@@ -433,6 +433,11 @@ int fokl_pool_spectral_affinity(fokl_host_pool *pool, const int32_t *cpus, int c
 /* the pool's stream (fokl_stream_expand of rows-only tapes; alive as long as the pool) */
 fokl_stream *fokl_pool_stream(fokl_host_pool *pool);
 void fokl_pool_destroy(fokl_host_pool *pool);
+/* 1 = every row of the tape is recorded (progress == draws) and every block of `block` rows is there (block_done[] != 0:
+ * expanded / finished by the pool's finish threads), 0 = not yet, -1 = it never will be.  Acquire loads: a consumer on any
+ * thread may poll this before it reads the tape's arrays.  Either pointer may be NULL (not looked at). */
+int fokl_tape_ready(const int32_t *progress, int draws, const int32_t *block_done, int block);
+
 /*
  * One model evaluation's tape on the noise thread: fokl_stream_walk into rows [draws] (progress must be given and start
  * at 0: rows walked so far), materialised into fokl_noise_tape's layout (normals / pair_r2 / lead / gam_sig / gam_tau:

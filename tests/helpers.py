@@ -240,7 +240,16 @@ class StandInChainEngine:
             if tape.finishing_requested:
                 w, flag = _capi.gibbs_chain_from_finished_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, follow=True)
             else:
-                w, flag = _capi.gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, follow=True)
+                # a raw tape of the pool is walked first and expanded block by block afterwards: wait for the blocks, not
+                # for the walk (what the real engine's dispatcher does)
+                while True:
+                    state = _capi.tape_ready(tape)
+                    if state < 0:
+                        raise _capi.FoklNativeError(-3, 'stand-in engine: the tape was sent back')
+                    if state:
+                        break
+                    time.sleep(0.0005)
+                w, flag = _capi.gibbs_chain_from_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape)
             return w, flag, int(stat_first)
 
         self.alive += 1
