@@ -1336,7 +1336,7 @@ class DeviceContext:
             self._lazy_owner = weakref.ref(owner)
 
     def download_inputs(self):
-        out = np.empty((self.n, self.m), dtype=np.float64)
+        out = np.empty((getattr(self, 'n', 0) or 1, getattr(self, 'm', 0) or 1), dtype=np.float64)   # (no dataset: the call says so)
         self._ck(self._lib.fokl_download_inputs(self._h, _ptr(out)))
         return out
 

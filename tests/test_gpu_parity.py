@@ -151,6 +151,20 @@ def test_argument_errors_are_reported(device_ctx):
     with pytest.raises(_capi.FoklNativeError) as e:
         fresh.build_terms([[1, 0]], [2])                            # before upload
     assert e.value.code == -3
+    # staged uploads (fit's normalisation on the device): nothing staged, or staged with another shape
+    packed, nb, width = getKernels.pack_phis(getKernels.bernoulli(), O.KERNEL_BERNOULLI)
+    with pytest.raises(_capi.FoklNativeError) as e:
+        fresh._staged_shape = (100, 2)
+        fresh.upload_staged(np.zeros(100), O.KERNEL_BERNOULLI, packed, nb, width, np.zeros(2), np.ones(2))
+    assert e.value.code == -3
+    fresh.stage_inputs(np.ascontiguousarray(np.random.default_rng(1).random((100, 2))))
+    with pytest.raises(_capi.FoklNativeError):
+        fresh._staged_shape = (50, 2)
+        fresh.upload_staged(np.zeros(50), O.KERNEL_BERNOULLI, packed, nb, width, np.zeros(2), np.ones(2))
+    with pytest.raises(ValueError):
+        fresh.stage_inputs(np.zeros((10, 3), dtype=np.float32))
+    with pytest.raises(_capi.FoklNativeError):
+        fresh.download_inputs()                                      # no dataset on this context yet
     fresh.close()
 
 

@@ -482,3 +482,24 @@ def test_chain_vector_statements_agree_bit_for_bit():
         assert out.returncode == 0, out.stderr
         digests[isa] = out.stdout.strip()
     assert len(set(digests.values())) == 1, digests
+
+
+def test_tape_ready_reports_walk_and_blocks():
+    """fokl_tape_ready: what a consumer on another thread polls before it reads a tape the pool records and expands."""
+    lib = _capi.load()
+    progress = np.zeros(1, dtype=np.int32)
+    blocks = np.zeros(3, dtype=np.int32)                               # 40 rows in blocks of 16
+    ready = lambda p=progress, b=blocks: lib.fokl_tape_ready(_capi._ptr(p) if p is not None else None, 40,
+                                                             _capi._ptr(b) if b is not None else None, 16)
+    assert ready() == 0
+    progress[0] = 40
+    assert ready() == 0 and ready(b=None) == 1
+    blocks[:] = 1
+    assert ready() == 1 and ready(p=None) == 1
+    blocks[1] = 0
+    assert ready() == 0
+    blocks[1] = -1
+    assert ready() == -1                                                # the tape was sent back while it was expanded
+    blocks[:] = 1
+    progress[0] = -1
+    assert ready() == -1                                                # the producer failed
