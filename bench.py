@@ -105,6 +105,11 @@ GOLDENS = {  # (config, unit, rows, fit overrides) -> fixture made by tests/gold
     (3, 0, 100_000): ('cfg3_n1e5_m16_way3', dict(burnin=30, draws=30)),
     (3, 0, 1_000_000): ('cfg3_n1e6_m16_way3', dict(burnin=30, draws=30)),
 }
+# configs[3] at its benchmarked N with chains long enough for the kill tests' Monte-Carlo statistics to settle (round 4:
+# 250 + 250 draws, five hours of oracle): preferred over the 30 + 30 twin when the fixture is there
+_LONG = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'cfg3_n1e6_m16_way3_d250.npz')
+if os.path.exists(_LONG):
+    GOLDENS[(3, 0, 1_000_000)] = ('cfg3_n1e6_m16_way3_d250', dict(burnin=250, draws=250))
 
 
 def kernel_and_phis(spec):

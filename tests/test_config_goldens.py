@@ -20,7 +20,7 @@ from helpers import GOLDEN, OracleBackend
 from fokl_gpy_amd import FoKLRoutines, getKernels
 
 CASES = ['cfg4_unit0_n1e5_m8', 'cfg4_unit5_n1e5_m8', 'cfg2_n1e6_m8', 'cfg1_n1e5_m4_splines', 'cfg3_n1e5_m16_way3',
-         'cfg3_n1e6_m16_way3']
+         'cfg3_n1e6_m16_way3', 'cfg3_n1e6_m16_way3_d250']
 
 
 def _sha(a):
