@@ -141,6 +141,7 @@ SIGNATURES = {
     'fokl_dchain_stream_stats': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_dchain_try_release': (c_int, [c_vp, c_i64]),
     'fokl_dchain_poll': (c_int, [c_vp, c_i64]),
+    'fokl_dchain_flush': (c_int, [c_vp]),
     'fokl_dchain_wait': (c_int, [c_vp, c_i64, c_vp]),
     'fokl_dchain_fetch_w': (c_int, [c_vp, c_i64, c_vp]),
     'fokl_dchain_release': (c_int, [c_vp, c_i64]),

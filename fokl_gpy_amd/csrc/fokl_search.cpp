@@ -1873,6 +1873,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     }
     for (auto &kv : ahead) unref(s, kv.second);
     reap(s, false);
+    if (s->dchain) (void)fokl_dchain_flush(s->dchain);      // the last tests' chains go out now, not when their batch has aged
     // the caller's handle on `best`: the outcome it passed in if no test was accepted, else a new one (whose creation
     // reference becomes the caller's)
     res->best = reinterpret_cast<fokl_outcome *>(best);

@@ -226,7 +226,9 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
 // process-wide spare segments: a fit uses a few dozen and the next fit wants them mapped and warm
 std::mutex g_spare_m;
 std::vector<Segment *> g_spares;
-constexpr size_t kSpareMax = 192;                           // 123 MB
+// (a configs[2] fit ends with ~330 segments alive -- tapes on the device hold theirs until their chains are confirmed; with
+// 192 spares the other 140 were unmapped at the end of every fit, 2-4 ms, and page-faulted in again by the next)
+constexpr size_t kSpareMax = 512;                           // 410 MB
 
 Segment *take_segment()
 {

@@ -700,6 +700,7 @@ int fokl_dchain_submit_rows(fokl_dchain *engine, int p1, int draws, const double
 /* segments regenerated on the device so far, chains submitted as rows */
 int fokl_dchain_stream_stats(fokl_dchain *engine, int64_t *segments_made, int64_t *rows_jobs);
 int fokl_dchain_poll(fokl_dchain *engine, int64_t ticket);
+int fokl_dchain_flush(fokl_dchain *engine);   /* issue what is queued now: nothing more is coming for a while */
 int fokl_dchain_wait(fokl_dchain *engine, int64_t ticket, double *stats_out);
 int fokl_dchain_fetch_w(fokl_dchain *engine, int64_t ticket, double *w_out);
 int fokl_dchain_release(fokl_dchain *engine, int64_t ticket);
