@@ -1166,6 +1166,10 @@ class DeviceChainEngine:
         _check(self._lib.fokl_dchain_stream_stats(self._h, ctypes.byref(seg), ctypes.byref(rows)))
         return dict(segments_made=seg.value, rows_jobs=rows.value)
 
+    def flush(self):
+        """Issue what is queued now (the caller knows that nothing more is coming for a while)."""
+        _check(self._lib.fokl_dchain_flush(self._h))
+
     def stats(self):
         busy, issued, launches, staged = c_dbl(0), c_i64(0), c_i64(0), c_i64(0)
         _check(self._lib.fokl_dchain_stats(self._h, ctypes.byref(busy), ctypes.byref(issued), ctypes.byref(launches),

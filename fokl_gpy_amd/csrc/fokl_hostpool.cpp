@@ -169,7 +169,12 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     const int32_t *idx = job->idx.data();
     const double *g = job->gram;
     const size_t ld = (size_t)job->ld;
-    std::vector<double> a((size_t)n * n), xty((size_t)n);
+    // scratch of the calling spectral thread, kept from job to job (a 140-column block is 157 KB: fresh from malloc that is
+    // an mmap, 40 page faults and a munmap per job)
+    static thread_local std::vector<double> a, xty, work;
+    static thread_local std::vector<int> iwork, isuppz;
+    if (a.size() < (size_t)n * n) a.resize((size_t)n * n);
+    if (xty.size() < (size_t)n) xty.resize((size_t)n);
     for (int i = 0; i < n; ++i) {
         const double *row = g + (size_t)idx[i] * ld;
         for (int j = 0; j < n; ++j) a[(size_t)j * n + i] = row[idx[j]];       // a(i, j) column-major = XtX[i][j]
@@ -178,7 +183,7 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     char jobz = 'V', range = 'A', uplo = 'L';
     int nn = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwork_query = 0;
     double vl = 0.0, vu = 1.0, abstol = 0.0, work_query = 0.0;
-    std::vector<int> isuppz((size_t)2 * std::max(1, n));
+    if (isuppz.size() < (size_t)2 * std::max(1, n)) isuppz.resize((size_t)2 * std::max(1, n));
     double *z = job->qt_out;                                // z(i, j) at z[j * n + i]: row j of Q' = eigenvector j
     pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
                  isuppz.data(), &work_query, &lwork, &iwork_query, &liwork, &info);
@@ -188,8 +193,8 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     }
     lwork = (int)work_query;
     liwork = iwork_query;
-    std::vector<double> work((size_t)std::max(1, lwork));
-    std::vector<int> iwork((size_t)std::max(1, liwork));
+    if (work.size() < (size_t)std::max(1, lwork)) work.resize((size_t)std::max(1, lwork));
+    if (iwork.size() < (size_t)std::max(1, liwork)) iwork.resize((size_t)std::max(1, liwork));
     pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
                  isuppz.data(), work.data(), &lwork, iwork.data(), &liwork, &info);
     if (info != 0 || m != n) {

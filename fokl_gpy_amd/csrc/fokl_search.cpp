@@ -429,6 +429,49 @@ void resolve(Tape *t, bool commit)
 
 // ---- spectra --------------------------------------------------------------------------------------------------
 
+// Result buffers of host G2 jobs (lamb | qty | betahat | Qt | moments: 160 KB at 140 columns) go round in size classes,
+// process-wide: fresh from malloc every one beyond 128 KB was its own mmap -- page-faulted in by the spectral thread that
+// filled it, unmapped by the search thread that dropped it, ~400 times per fit.
+constexpr int kSpectrumClass = 16;                          // columns per size class
+std::mutex g_spectrum_m;
+std::map<int, std::vector<double *>> g_spectrum_spares;     // class (columns rounded up) -> buffers
+size_t g_spectrum_spare_bytes = 0;
+constexpr size_t kSpectrumSpareMax = (size_t)256 << 20;
+
+inline int spectrum_class(int p1) { return (p1 + kSpectrumClass - 1) / kSpectrumClass * kSpectrumClass; }
+inline size_t spectrum_bytes(int cls) { return ((size_t)cls * (cls + 3) + 2) * sizeof(double); }
+
+double *take_spectrum_buffer(int p1)
+{
+    const int cls = spectrum_class(p1);
+    {
+        std::lock_guard<std::mutex> lock(g_spectrum_m);
+        auto it = g_spectrum_spares.find(cls);
+        if (it != g_spectrum_spares.end() && !it->second.empty()) {
+            double *buf = it->second.back();
+            it->second.pop_back();
+            g_spectrum_spare_bytes -= spectrum_bytes(cls);
+            return buf;
+        }
+    }
+    return static_cast<double *>(std::malloc(spectrum_bytes(cls)));
+}
+
+void give_spectrum_buffer(double *buf, int p1)
+{
+    if (!buf) return;
+    const int cls = spectrum_class(p1);
+    {
+        std::lock_guard<std::mutex> lock(g_spectrum_m);
+        if (g_spectrum_spare_bytes + spectrum_bytes(cls) <= kSpectrumSpareMax) {
+            g_spectrum_spares[cls].push_back(buf);
+            g_spectrum_spare_bytes += spectrum_bytes(cls);
+            return;
+        }
+    }
+    std::free(buf);
+}
+
 // how long the device takes for one decomposition, microseconds (profiles/eigh_device_r04.txt)
 inline double device_spectral_us(int p1) { return p1 <= 72 ? 9.0 * p1 : (p1 <= 128 ? 14.0 * p1 : 28.0 * p1); }
 
@@ -457,11 +500,11 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
         s->stats[S_SPECTRAL_DEVICE] += 1;
         return sp;
     }
-    sp->buf = static_cast<double *>(std::malloc(((size_t)p1 * (p1 + 3) + 2) * sizeof(double)));
+    sp->buf = take_spectrum_buffer(p1);
     if (!sp->buf ||
         fokl_pool_submit_spectral(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, sp->lamb(), sp->Qt(), sp->qty(),
                                   sp->betahat(), sp->moments(), &sp->job) != FOKL_OK) {
-        std::free(sp->buf);
+        give_spectrum_buffer(sp->buf, p1);
         delete sp;
         s->error = "fokl_search: the pool refused a spectral job";
         return nullptr;
@@ -514,7 +557,7 @@ void unref(fokl_search *s, Spectrum *sp)
         return;
     }
     if (sp->job) (void)fokl_pool_wait(sp->job);             // its buffers are written until it has run
-    std::free(sp->buf);
+    give_spectrum_buffer(sp->buf, sp->p1);
     delete sp;
 }
 
@@ -1873,7 +1916,6 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     }
     for (auto &kv : ahead) unref(s, kv.second);
     reap(s, false);
-    if (s->dchain) (void)fokl_dchain_flush(s->dchain);      // the last tests' chains go out now, not when their batch has aged
     // the caller's handle on `best`: the outcome it passed in if no test was accepted, else a new one (whose creation
     // reference becomes the caller's)
     res->best = reinterpret_cast<fokl_outcome *>(best);

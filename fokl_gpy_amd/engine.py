@@ -1342,6 +1342,8 @@ class ForwardSelection:
             lap('wrap_up')
 
         lap('wrap_up')
+        if self.chain_engine is not None and hasattr(self.chain_engine, 'flush'):
+            self.chain_engine.flush()              # the last kill tests' chains go out now, not when their batch has aged
         if self.host is not None:                  # the search stopped: tapes on order for a sub-stage that does not come
             self._drop_speculation()
         if self.native is not None:
