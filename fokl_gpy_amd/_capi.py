@@ -63,6 +63,7 @@ SIGNATURES = {
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     'fokl_pool_stream': (c_vp, [c_vp]),
+    'fokl_pool_use_dsyevd': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_spectral_affinity': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_release_hold': (c_int, [c_vp, ctypes.c_uint64]),
     'fokl_pool_destroy': (None, [c_vp]),
@@ -543,6 +544,24 @@ def gibbs_chain_from_finished_tape(lamb, qty, b, btau, dtd, sigsqd0, tausqd0, ta
 # host threads of one fit
 # ---------------------------------------------------------------------------------------------------------
 
+def _scipy_dsyevd_address():
+    """Address of scipy's dsyevd (Fortran ABI, 32-bit integers), or None."""
+    try:
+        from scipy.linalg import cython_lapack
+        capsule = cython_lapack.__pyx_capi__['dsyevd']
+        api = ctypes.pythonapi
+        api.PyCapsule_GetName.restype = ctypes.c_char_p
+        api.PyCapsule_GetName.argtypes = [ctypes.py_object]
+        api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+        api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+        name = api.PyCapsule_GetName(capsule)
+        if name is None or name.count(b'int *') != 6 or b'long' in name:
+            return None
+        return api.PyCapsule_GetPointer(capsule, name)
+    except (ImportError, KeyError):
+        return None
+
+
 def _scipy_dsyevr_address():
     """Address of the dsyevr that scipy.linalg.eigh itself calls (Fortran ABI, 32-bit integers)."""
     from scipy.linalg import cython_lapack
@@ -633,6 +652,15 @@ class HostPool:
                                           *stream.args(), prestates[0] if prestates else None,
                                           prestates[1] if prestates else 0, ctypes.byref(h)))
         self._h = h
+        # models of FOKL_EIGH_DC_FROM columns or more (default 80; 0: never): LAPACK's divide-and-conquer driver, which
+        # shares dsyevr's tridiagonal reduction and returns its eigenpairs to ~3e-12 in 2/3 of the time (half at 585 columns)
+        self.dsyevd_from = 0
+        dc_from = int(os.environ.get('FOKL_EIGH_DC_FROM', '80'))
+        if spectral_threads > 0 and dc_from > 0 and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
+            fd = _scipy_dsyevd_address()
+            if fd:
+                _check(self._lib.fokl_pool_use_dsyevd(self._h, c_vp(fd), dc_from))
+                self.dsyevd_from = dc_from
 
     def spectral_affinity(self, cpus):
         cpus = np.ascontiguousarray(sorted(cpus), dtype=np.int32)

@@ -56,6 +56,9 @@ using dsyevr_fn = void (*)(char *jobz, char *range, char *uplo, int *n, double *
                            int *il, int *iu, double *abstol, int *m, double *w, double *z, int *ldz, int *isuppz,
                            double *work, int *lwork, int *iwork, int *liwork, int *info);
 
+using dsyevd_fn = void (*)(char *jobz, char *uplo, int *n, double *a, int *lda, double *w, double *work, int *lwork,
+                          int *iwork, int *liwork, int *info);
+
 enum class Kind { noise, chain, finish, spectral };
 
 struct Queue {
@@ -116,6 +119,11 @@ struct fokl_host_pool {
     std::vector<std::thread> threads;
     std::vector<size_t> spectral_thread_ids;    // indices into `threads` (fokl_pool_spectral_affinity)
     dsyevr_fn dsyevr = nullptr;
+    // LAPACK's divide-and-conquer driver for the wider models (fokl_pool_use_dsyevd): same tridiagonal reduction as dsyevr,
+    // eigenpairs within ~3e-12 of dsyevr's in the chain's noise map (profiles/eigh_drivers_r04.txt), 1.3-1.5 x faster from
+    // 80 columns on
+    dsyevd_fn dsyevd = nullptr;
+    int dsyevd_from = 0;
     // the random stream: walked by the noise thread, produced by the stream's own bulk threads; the caller's state
     // (mt_key ...) is read at creation and written back when the pool is destroyed
     fokl_stream *stream = nullptr;
@@ -183,23 +191,42 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     char jobz = 'V', range = 'A', uplo = 'L';
     int nn = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwork_query = 0;
     double vl = 0.0, vu = 1.0, abstol = 0.0, work_query = 0.0;
-    if (isuppz.size() < (size_t)2 * std::max(1, n)) isuppz.resize((size_t)2 * std::max(1, n));
     double *z = job->qt_out;                                // z(i, j) at z[j * n + i]: row j of Q' = eigenvector j
-    pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
-                 isuppz.data(), &work_query, &lwork, &iwork_query, &liwork, &info);
-    if (info != 0) {
-        err = "dsyevr workspace query failed";
-        return FOKL_ERR_NUMERIC;
-    }
-    lwork = (int)work_query;
-    liwork = iwork_query;
-    if (work.size() < (size_t)std::max(1, lwork)) work.resize((size_t)std::max(1, lwork));
-    if (iwork.size() < (size_t)std::max(1, liwork)) iwork.resize((size_t)std::max(1, liwork));
-    pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
-                 isuppz.data(), work.data(), &lwork, iwork.data(), &liwork, &info);
-    if (info != 0 || m != n) {
-        err = "dsyevr did not converge (info = " + std::to_string(info) + ")";
-        return FOKL_ERR_NUMERIC;
+    if (pool->dsyevd && pool->dsyevd_from > 0 && n >= pool->dsyevd_from && !pool->lapack_signs) {
+        // divide and conquer: the eigenvectors overwrite the matrix, column j = eigenvector j -- the layout of Q' row-major
+        std::memcpy(z, a.data(), sizeof(double) * (size_t)n * n);
+        pool->dsyevd(&jobz, &uplo, &nn, z, &lda, job->lamb_out, &work_query, &lwork, &iwork_query, &liwork, &info);
+        if (info != 0) {
+            err = "dsyevd workspace query failed";
+            return FOKL_ERR_NUMERIC;
+        }
+        lwork = (int)work_query;
+        liwork = iwork_query;
+        if (work.size() < (size_t)std::max(1, lwork)) work.resize((size_t)std::max(1, lwork));
+        if (iwork.size() < (size_t)std::max(1, liwork)) iwork.resize((size_t)std::max(1, liwork));
+        pool->dsyevd(&jobz, &uplo, &nn, z, &lda, job->lamb_out, work.data(), &lwork, iwork.data(), &liwork, &info);
+        if (info != 0) {
+            err = "dsyevd did not converge (info = " + std::to_string(info) + ")";
+            return FOKL_ERR_NUMERIC;
+        }
+    } else {
+        if (isuppz.size() < (size_t)2 * std::max(1, n)) isuppz.resize((size_t)2 * std::max(1, n));
+        pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
+                     isuppz.data(), &work_query, &lwork, &iwork_query, &liwork, &info);
+        if (info != 0) {
+            err = "dsyevr workspace query failed";
+            return FOKL_ERR_NUMERIC;
+        }
+        lwork = (int)work_query;
+        liwork = iwork_query;
+        if (work.size() < (size_t)std::max(1, lwork)) work.resize((size_t)std::max(1, lwork));
+        if (iwork.size() < (size_t)std::max(1, liwork)) iwork.resize((size_t)std::max(1, liwork));
+        pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
+                     isuppz.data(), work.data(), &lwork, iwork.data(), &liwork, &info);
+        if (info != 0 || m != n) {
+            err = "dsyevr did not converge (info = " + std::to_string(info) + ")";
+            return FOKL_ERR_NUMERIC;
+        }
     }
     // sign convention of engine.eigh_canonical: the largest-magnitude component (first one on ties) is positive
     for (int j = 0; j < n && !pool->lapack_signs; ++j) {
@@ -876,6 +903,19 @@ extern "C" int fokl_pool_busy_seconds(const fokl_host_pool *pool, double *noise,
     if (chain) *chain = 1e-9 * (double)pool->chain_busy_ns.load();
     if (finish) *finish = 1e-9 * (double)pool->finish_busy_ns.load();
     if (spectral) *spectral = 1e-9 * (double)pool->spectral_busy_ns.load();
+    return FOKL_OK;
+}
+
+// Models of `from_columns` columns or more are diagonalised by LAPACK's dsyevd (`fn`: its address, Fortran ABI with 32-bit
+// integers -- scipy.linalg.cython_lapack's) instead of dsyevr; 0 / NULL: dsyevr for every size.  Before the first job.
+extern "C" int fokl_pool_use_dsyevd(fokl_host_pool *pool, void *fn, int from_columns)
+{
+    if (!pool) {
+        fokl_set_global_error("fokl_pool_use_dsyevd: null pool");
+        return FOKL_ERR_ARG;
+    }
+    pool->dsyevd = reinterpret_cast<dsyevd_fn>(fn);
+    pool->dsyevd_from = fn ? std::max(0, from_columns) : 0;
     return FOKL_OK;
 }
 

@@ -427,6 +427,12 @@ typedef struct fokl_host_job fokl_host_job;
 int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads, int bulk_threads, int noise_cpu,
                      void *dsyevr, uint32_t *mt_key, int32_t *mt_pos, int32_t *has_gauss, double *gauss_cache,
                      uint32_t *prestate_ring, int prestate_entries, fokl_host_pool **out);
+/* Models of from_columns columns or more are diagonalised by LAPACK's divide-and-conquer driver dsyevd (fn: its address,
+ * Fortran ABI with 32-bit integers, e.g. scipy.linalg.cython_lapack's) instead of dsyevr: the same tridiagonal reduction,
+ * eigenpairs within ~3e-12 of dsyevr's in the chain's noise map, 1.3-1.5 x faster from 80 columns on, 2 x at 585.  NULL or
+ * 0: dsyevr (what scipy.linalg.eigh calls, FR:1499) for every size.  Call before the first spectral job. */
+int fokl_pool_use_dsyevd(fokl_host_pool *pool, void *fn, int from_columns);
+
 /* CPUs for the spectral threads alone (they share no data with the threads around the random stream: another last-level
  * cache domain keeps them off those threads' cores) */
 int fokl_pool_spectral_affinity(fokl_host_pool *pool, const int32_t *cpus, int count);
