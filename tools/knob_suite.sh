@@ -16,6 +16,8 @@ modes=(
   "FOKL_DCHAIN_RECURSION=exact"
   "FOKL_EIGH=device"
   "FOKL_EIGH=hybrid"
+  "FOKL_EIGH_DC_FROM=0"
+  "FOKL_EIGH_DC_FROM=8"
   "FOKL_CLEAN=host"
   "FOKL_K1_TOUCH=0"
   "FOKL_K3=columns"
