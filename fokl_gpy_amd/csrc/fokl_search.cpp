@@ -204,6 +204,7 @@ struct Forecast {
     Spectrum *spec;
     int columns;
     double dtd;
+    int likely_tests = -1;                  // kill tests its least-squares fit makes likely (computed once G2 is there)
 };
 
 enum Stat {
@@ -1663,6 +1664,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         if (q >= path_from && q - path_from < path.size()) return path[q - path_from];
         return Step{likely(proposal[q]), true};            // beyond the horizon: the round-3 guess
     };
+    bool foreseen_any = false;
+    std::vector<int32_t> foreseen_last;
     auto forecast = [&](size_t pos) {
         // the kill set at the end of the loop if the rest goes as predicted
         if (!a->foresee || !path_complete) return;
@@ -1673,7 +1676,15 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (st.run) ++rest;
             if (st.run && st.accept) pred = with_column(pred, a->columns[proposal[q]]);
         }
-        if (rest <= s->prm.foresight) a->foresee(a->user, pred.data(), (int)pred.size());
+        // (the callback is Python: told once per predicted kill set, not once per test -- once the coming sub-stage has been
+        // built, idle_work, before which it can do nothing with the news)
+        if (rest <= s->prm.foresight && (idle_pending || !foreseen_any || pred != foreseen_last)) {
+            if (!idle_pending) {
+                foreseen_any = true;
+                foreseen_last = pred;
+            }
+            a->foresee(a->user, pred.data(), (int)pred.size());
+        }
     };
     auto order_tapes = [&](size_t pos) {
         // the tapes of what the stream serves next if the search goes on as predicted (see engine.py order_tapes)
@@ -1696,12 +1707,14 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             // proposal it removes) -- or, if G2 of that model is there already, all the tests its least-squares fit
             // makes likely
             int tests = std::min(a->vm_next, 1);
-            if (Forecast *f = find_forecast(pred))
-                if (spectrum_done(f->spec) && wait_spectrum(s, f->spec) == FOKL_OK) {
+            if (Forecast *f = find_forecast(pred)) {
+                if (f->likely_tests < 0 && spectrum_done(f->spec) && wait_spectrum(s, f->spec) == FOKL_OK) {
                     const double n = (double)s->prm.n;
                     const double *m = f->spec->moments();
-                    tests = (int)likely_first_tests(s, f->spec, a->vm_next, m[1] / n - (m[0] / n) * (m[0] / n)).size();
+                    f->likely_tests = (int)likely_first_tests(s, f->spec, a->vm_next, m[1] / n - (m[0] / n) * (m[0] / n)).size();
                 }
+                if (f->likely_tests >= 0) tests = f->likely_tests;
+            }
             const int coming = A - (int)pred.size() + a->vm_next;
             sizes.push_back({coming, true});
             for (int t = 1; t <= tests; ++t) sizes.push_back({coming - t, false});
