@@ -698,8 +698,8 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)      # (a fit is ~45 ms: the first two or three after start-up are 15 %
+    ap.add_argument('--warmup', type=int, default=3)      # slower -- fresh mappings, cold caches -- and are left to the warm-up)
     ap.add_argument('--config', type=int, choices=sorted(CONFIGS), default=2,
                     help='BASELINE.json configs[i]; the metric is quoted on configs[2] (default)')
     ap.add_argument('--rows', type=int, default=None, help='override the configuration\'s row count')
