@@ -503,3 +503,37 @@ def test_tape_ready_reports_walk_and_blocks():
     blocks[:] = 1
     progress[0] = -1
     assert ready() == -1                                                # the producer failed
+
+
+def test_divide_and_conquer_driver_returns_dsyevrs_eigenpairs(monkeypatch):
+    """fokl_pool_use_dsyevd: models from FOKL_EIGH_DC_FROM columns on are diagonalised by LAPACK's dsyevd instead of dsyevr (the
+    reference's driver, FR:1499).  Same tridiagonal reduction: eigenvalues to rounding, and the map a chain applies to its
+    noise, Q diag((lamb + 1)^-1/2), within 1e-10 of its scale (measured 1e-13 .. 3e-12) -- three orders inside what the draws
+    are held to.  Everything derived from the eigenpairs (Q'Xty, betahat, residual moments) follows."""
+    rng = np.random.default_rng(21)
+    n = 96
+    X = rng.standard_normal((3000, n - 1)) * 10.0 ** rng.uniform(-1, 1, n - 1)
+    X[:, ::3] += 0.7 * X[:, :1]
+    y = X @ rng.standard_normal(n - 1) * 0.1 + rng.standard_normal(3000)
+    Z = np.column_stack([np.ones(3000), X, y])
+    gram = Z.T @ Z
+    idx = np.arange(n, dtype=np.int32)
+    out = {}
+    for mode, dc_from in (('evr', '0'), ('evd', '8')):
+        monkeypatch.setenv('FOKL_EIGH_DC_FROM', dc_from)
+        np.random.seed(1)
+        pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
+        try:
+            assert pool.dsyevd_from == int(dc_from)
+            res = pool.submit_spectral(gram, idx, n).wait()
+            out[mode] = [np.array(v) for v in (res.lamb, res.Qt, res.qty, res.betahat, res.moments)]
+        finally:
+            pool.close()
+    (l0, Q0, q0, b0, m0), (l1, Q1, q1, b1, m1) = out['evr'], out['evd']
+    assert np.abs(l0 - l1).max() <= 1e-13 * np.abs(l0).max()
+    M0, M1 = Q0.T / np.sqrt(l0 + 1.0), Q1.T / np.sqrt(l1 + 1.0)
+    assert np.abs(M0 - M1).max() <= 1e-10 * np.abs(M0).max()
+    assert not np.array_equal(Q0, Q1)                                      # (another algorithm: not the same bits)
+    assert np.abs(b0 - b1).max() <= 1e-10 * np.abs(b0).max()
+    assert np.abs(m0 - m1).max() <= 1e-9 * np.abs(m0).max()
+    assert np.abs(Q1 @ Q1.T - np.eye(n)).max() <= 1e-13
