@@ -977,8 +977,9 @@ def main():
         elif cfg == 3 and not args.inputs and world == 1:
             # no oracle can run configs[3] with 2000 Gibbs iterations on 585-column models (O(P^3) products per
             # iteration): the golden is the benchmark's own dataset -- N = 1e6, stages capped at 3 -- with chains of
-            # burnin 30 + draws 30 (round 3; 3.5 h of oracle), or, should that file be missing, the N = 1e5 variant --
-            # fitted here, untimed
+            # burnin 250 + draws 250 (round 4; 3.4 h of oracle -- long enough for the kill tests' Monte-Carlo statistics to
+            # settle: it selects 68 terms where the 30 + 30 twin of round 3 selects 79), else that twin, or, should both
+            # files be missing, the N = 1e5 variant -- fitted here, untimed
             big = GOLDENS[(3, 0, 1_000_000)]
             rows_checked = n if (n == 1_000_000 and os.path.exists(
                 os.path.join(ROOT, 'tests', 'golden', big[0] + '.npz'))) else 100_000
@@ -993,9 +994,9 @@ def main():
                     np.random.seed(sp['seed_fit'])
                     sb, sm, se = side.fit(xs, ys, clean=True, **sp['fit'], **over)
                 parity = compare_with_golden(name, side, sb, sm, se, np.random.get_state())
-                parity['workload'] = f'configs[3] (stages capped at 3) at N={rows_checked}, burnin 30 + draws 30 (chains ' \
-                                     f'shortened: the oracle\'s O(P^3) products per Gibbs iteration), fitted after the ' \
-                                     f'timed region'
+                parity['workload'] = f'configs[3] (stages capped at 3) at N={rows_checked}, burnin {over["burnin"]} + draws ' \
+                                     f'{over["draws"]} (chains shortened: the oracle\'s O(P^3) products per Gibbs ' \
+                                     f'iteration), fitted after the timed region'
                 parity_checked = True
                 side._backend_override.ctx.close()
 
