@@ -4,11 +4,11 @@ The reference draws beta = mun + sigma Q diag(d^1/2) vec (FR:1525-1528): flippin
 of that direction's noise -- another, equally valid realisation of the same posterior.  The kill tests (FR:1656-1690)
 hinge on Monte-Carlo statistics of those draws, so the untouched reference (LAPACK's signs, which flip under 1-ulp changes
 of XtX) and its sign-canonical twin (largest-magnitude component positive, what this product and its goldens use) can
-select different models.  This script runs the ORACLE (oracle/fokl_oracle.py, test infrastructure) both ways on the same
+select different models.  This script (test infrastructure, like the golden generators next to it) runs the ORACLE (oracle/fokl_oracle.py) both ways on the same
 data and stream and reports where the two searches part.
 
-    python tools/sign_sensitivity.py [case ...]      cases: cfg1 cfg4u0 cfg4u5 cfg2short (default: all)
-    python tools/sign_sensitivity.py --last-bits [case ...]
+    python tests/golden/sign_sensitivity.py [case ...]      cases: cfg1 cfg4u0 cfg4u5 cfg2short (default: all)
+    python tests/golden/sign_sensitivity.py --last-bits [case ...]
 
 --last-bits asks the other half of the question: is either search reproducible when XtX changes in its last bits (another
 BLAS build, another summation order -- this product's Gram comes from an MFMA kernel, not from dgemm)?  Each mode is run
@@ -20,7 +20,7 @@ import sys
 import time
 import warnings
 
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT)
 import numpy as np
 

@@ -1,6 +1,6 @@
 """Where the draws of the benchmarked fit (configs[2]) sit relative to the oracle's golden, and why.
 
-    FOKL_FINISH_LOG=exact|fast python tools/draw_margin.py [golden name]
+    FOKL_FINISH_LOG=exact|fast python tests/stress/draw_margin.py [golden name]
 
 Prints, for the fit of tests/golden/<name>.npz's workload on the GPU: the largest |draw - golden| / column scale
 (the quantity bench.py and tests/test_config_goldens.py bound by 1e-9), where it sits, how the error is spread over the
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 

@@ -1,6 +1,6 @@
 """First-contact diagnostics on a real MI355X: every kernel against the oracle / numpy, plus rough timings.
 
-    python tools/gpu_probe.py [quick]
+    python tests/stress/gpu_probe.py [quick]
 
 Prints a verdict per check; exits non-zero if any check fails.  (Development aid; the judged parity tests are
 tests/test_gpu_*.py.)
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 

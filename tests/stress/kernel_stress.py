@@ -1,7 +1,7 @@
 """Random shapes through K1 / K2 / K3 / predict on the device against the oracle's C restatement and numpy (development
 aid / stress run; tolerances as in tests/test_gpu_parity.py)."""
 import os, sys
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from fokl_gpy_amd import _capi, getKernels

@@ -2,7 +2,7 @@
 the reference): selected model, BIC trace, draws and the final numpy stream must agree (development aid / stress run;
 problems whose model outgrows the data -- terms >= rows / 3 -- are reported but not compared beyond the model)."""
 import os, sys, warnings, hashlib
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from fokl_gpy_amd import FoKLRoutines, getKernels

@@ -2,7 +2,7 @@
 tests (same model object, same draws) -- development aid / stress run.  Tolerance 1e-8 of the output's scale: the device's
 Bernoulli columns differ from the libm-pow ones by an ulp of the largest monomial, which order-13 terms turn into 1e-9."""
 import os, sys, warnings, copy
-ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from fokl_gpy_amd import FoKLRoutines, getKernels

@@ -702,7 +702,7 @@ def test_lapack_signs_mode_follows_the_untouched_reference(monkeypatch, name):
     sequence of gibbs calls past the point where the sign-canonical search leaves it (bern_m3: 18 calls against 5,
     bern_m4_way3: 14 against 6) -- until the last bits of a kill test's XtX (here a sub-block of the sub-stage's Gram
     summed in another order, FR:1676-1683 recomputes it with dgemm) flip one of LAPACK's signs: from there on it is a
-    third, equally valid, realisation (bern_m6: call 25, one before the canonical search parts).  tools/
+    third, equally valid, realisation (bern_m6: call 25, one before the canonical search parts).  tests/golden/
     sign_sensitivity.py --last-bits shows the untouched reference parting from ITSELF under such last-bit noise, which
     is why parity is pinned on the canonical signs.  On any other host LAPACK's signs are not comparable at all and the
     test does not apply."""
