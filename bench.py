@@ -928,7 +928,7 @@ def main():
                     dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
-                    rows_chains=0, path_repredicted=0, t_pool_up=0.0)
+                    rows_chains=0, path_repredicted=0, t_pool_up=0.0, spectral_device=0, spectral_updated=0)
         drivers = set()
         for _ in range(args.steps):
             for st in one_step():

@@ -64,6 +64,7 @@ SIGNATURES = {
     'fokl_pool_create': (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     'fokl_pool_stream': (c_vp, [c_vp]),
     'fokl_pool_use_dsyevd': (c_int, [c_vp, c_vp, c_int]),
+    'fokl_pool_use_dgemm': (c_int, [c_vp, c_vp]),
     'fokl_pool_spectral_affinity': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_release_hold': (c_int, [c_vp, ctypes.c_uint64]),
     'fokl_pool_destroy': (None, [c_vp]),
@@ -75,6 +76,8 @@ SIGNATURES = {
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp]),
+    'fokl_pool_submit_spectral_update': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_poll': (c_int, [c_vp]),
     'fokl_pool_wait': (c_int, [c_vp]),
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -97,6 +100,7 @@ SIGNATURES = {
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
     'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
+    'fokl_search_set_update': (c_int, [c_vp, c_int, c_int]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
     'fokl_search_mispredicted': (c_int, [c_vp]),
@@ -562,6 +566,24 @@ def _scipy_dsyevd_address():
         return None
 
 
+def _scipy_dgemm_address():
+    """Address of scipy's dgemm (Fortran ABI, 32-bit integers), or None."""
+    try:
+        from scipy.linalg import cython_blas
+        capsule = cython_blas.__pyx_capi__['dgemm']
+        api = ctypes.pythonapi
+        api.PyCapsule_GetName.restype = ctypes.c_char_p
+        api.PyCapsule_GetName.argtypes = [ctypes.py_object]
+        api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+        api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+        name = api.PyCapsule_GetName(capsule)
+        if name is None or name.count(b'int *') != 6 or name.count(b'char *') != 2 or b'long' in name:
+            return None
+        return api.PyCapsule_GetPointer(capsule, name)
+    except (ImportError, KeyError):
+        return None
+
+
 def _scipy_dsyevr_address():
     """Address of the dsyevr that scipy.linalg.eigh itself calls (Fortran ABI, 32-bit integers)."""
     from scipy.linalg import cython_lapack
@@ -661,6 +683,13 @@ class HostPool:
             if fd:
                 _check(self._lib.fokl_pool_use_dsyevd(self._h, c_vp(fd), dc_from))
                 self.dsyevd_from = dc_from
+        # the product of the eigen-update (submit_spectral_update; the search core's FOKL_EIGH_UPDATE)
+        self.has_dgemm = False
+        if spectral_threads > 0:
+            fg = _scipy_dgemm_address()
+            if fg:
+                _check(self._lib.fokl_pool_use_dgemm(self._h, c_vp(fg)))
+                self.has_dgemm = True
 
     def spectral_affinity(self, cpus):
         cpus = np.ascontiguousarray(sorted(cpus), dtype=np.int32)
@@ -719,6 +748,19 @@ class HostPool:
                                                    *res.pointers(p1), ctypes.byref(h)))
         return PoolJob(h, (gram, idx, res), res)
 
+    def submit_spectral_update(self, gram, idx, ycol, parent, parent_pos):
+        """G2 of gram[idx][:, idx] from the finished SpectralResult ``parent`` of the model that has one more column, at
+        position ``parent_pos`` of its column list.  -> (job, updated): updated[0] is 1 when the eigenpairs were derived
+        from the parent's, 0 when the model was decomposed afresh after all (once the job has run)."""
+        p1 = idx.shape[0]
+        res = SpectralResult(p1)
+        updated = np.full(1, -1, dtype=np.int32)
+        h = c_vp(0)
+        _check(self._lib.fokl_pool_submit_spectral_update(self._h, _ptr(gram), gram.shape[1], _ptr(idx), p1, int(ycol),
+                                                          _ptr(parent.lamb), _ptr(parent.Qt), int(parent_pos), None,
+                                                          *res.pointers(p1), _ptr(updated), ctypes.byref(h)))
+        return PoolJob(h, (gram, idx, res, parent, updated), res), updated
+
     def busy_seconds(self):
         v = [c_dbl(0) for _ in range(4)]
         _check(self._lib.fokl_pool_busy_seconds(self._h, *[ctypes.byref(x) for x in v]))
@@ -768,7 +810,8 @@ class _KillTestsResult(ctypes.Structure):
 SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain', 'chains_materialised', 'bic_from_gram',
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
-                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device')
+                'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device',
+                'spectral_updated')
 
 
 class NativeSearch:
@@ -824,6 +867,11 @@ class NativeSearch:
 
     def hold_spectral(self, hold):
         self._checked(self._lib.fokl_search_hold_spectral(self._h, 1 if hold else 0))
+
+    def set_update(self, from_columns, depth):
+        """Kill tests' G2 from the tested-against model's eigenpairs for parents of from_columns columns or more (0: never), at
+        most `depth` steps from a fresh decomposition."""
+        self._checked(self._lib.fokl_search_set_update(self._h, int(from_columns), int(depth)))
 
     def spectral(self, gram, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

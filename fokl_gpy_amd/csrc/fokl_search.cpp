@@ -162,6 +162,11 @@ struct Spectrum {
     fokl_dspectral *dev = nullptr;
     int64_t ticket = 0;
     bool dev_waited = false;
+    // G2 from the eigenpairs of the model with one more column (fokl_pool_submit_spectral_update): `parent` is kept until
+    // this job has run; depth = how many such steps separate this model from a fresh decomposition
+    Spectrum *parent = nullptr;
+    int depth = 0;
+    int32_t updated = -1;
     int status = FOKL_OK;
     int refs = 1;
     double *lamb() const { return buf; }
@@ -211,7 +216,8 @@ enum Stat {
     S_GIBBS_CALLS, S_KILL_TESTS, S_TERMS_LOGICAL, S_T_EIGH, S_T_CHAIN, S_CHAINS_MATERIALISED, S_BIC_FROM_GRAM,
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
-    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_COUNT
+    S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_SPECTRAL_UPDATED,
+    S_COUNT
 };
 
 }  // namespace
@@ -228,6 +234,10 @@ struct fokl_search {
     double dspec_slack = 1.5;
     int dspec_lookahead = 32;               // how far ahead of the kill tests device jobs are requested
     double test_us = 70.0;                  // running mean of the time one kill test takes this search
+    // kill tests' G2 from their parent model's eigenpairs (fokl_search_set_update): parents of update_from columns or more,
+    // at most update_depth steps away from a fresh decomposition (each step waits for the one before it: the chain of
+    // accepted tests along the predicted path is cut into pieces that the spectral threads work on side by side)
+    int update_from = 0, update_depth = 3;
     fokl_search_params prm{};
     double sigsqd0 = 0, tausqd0 = 0;
     int speculation = 0;
@@ -483,7 +493,12 @@ inline bool spectrum_to_device(const fokl_search *s, int p1, double slack_us)
     return s->dspec_slack <= 0.0 || slack_us >= s->dspec_slack * device_spectral_us(p1);
 }
 
-Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1, double slack_us = -1.0)
+void unref(fokl_search *s, Spectrum *sp);
+
+// parent / parent_pos: the model this one is with its column number parent_pos deleted (a kill test's model and the model
+// it is tested against), when the caller has it -- G2 then follows from the parent's eigenpairs where that is allowed.
+Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1, double slack_us = -1.0,
+                          Spectrum *parent = nullptr, int parent_pos = -1)
 {
     auto *sp = new Spectrum();
     sp->p1 = p1;
@@ -502,9 +517,24 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
         return sp;
     }
     sp->buf = take_spectrum_buffer(p1);
-    if (!sp->buf ||
-        fokl_pool_submit_spectral(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, sp->lamb(), sp->Qt(), sp->qty(),
-                                  sp->betahat(), sp->moments(), &sp->job) != FOKL_OK) {
+    int rc = FOKL_ERR_STATE;
+    const bool from_parent = sp->buf && parent && s->update_from > 0 && parent_pos >= 0 && parent_pos <= p1 &&
+                             parent->p1 == p1 + 1 && parent->p1 >= s->update_from && !parent->dev && parent->buf &&
+                             parent->status == FOKL_OK && parent->depth < s->update_depth;
+    if (from_parent) {
+        rc = fokl_pool_submit_spectral_update(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, parent->lamb(), parent->Qt(),
+                                              parent_pos, parent->job, sp->lamb(), sp->Qt(), sp->qty(), sp->betahat(),
+                                              sp->moments(), &sp->updated, &sp->job);
+        if (rc == FOKL_OK) {
+            parent->refs += 1;                              // its arrays are read until this job has run
+            sp->parent = parent;
+            sp->depth = parent->depth + 1;
+        }
+    } else if (sp->buf) {
+        rc = fokl_pool_submit_spectral(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, sp->lamb(), sp->Qt(), sp->qty(),
+                                       sp->betahat(), sp->moments(), &sp->job);
+    }
+    if (rc != FOKL_OK) {
         give_spectrum_buffer(sp->buf, p1);
         delete sp;
         s->error = "fokl_search: the pool refused a spectral job";
@@ -512,6 +542,20 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     }
     s->stats[S_SPECTRAL_SUBMITTED] += 1;
     return sp;
+}
+
+// The job of `sp` has run: its parent's arrays are no longer read; a model decomposed afresh after all is depth 0.
+void job_has_run(fokl_search *s, Spectrum *sp)
+{
+    sp->job = nullptr;
+    if (Spectrum *parent = sp->parent) {
+        sp->parent = nullptr;
+        if (sp->updated == 1)
+            s->stats[S_SPECTRAL_UPDATED] += 1;
+        else
+            sp->depth = 0;
+        unref(s, parent);
+    }
 }
 
 // Launch the device jobs staged since the last call (one grid: they run side by side).
@@ -543,7 +587,7 @@ int wait_spectrum(fokl_search *s, Spectrum *sp)
     if (sp->job) {
         const double t0 = now_s();
         sp->status = fokl_pool_wait(sp->job);
-        sp->job = nullptr;
+        job_has_run(s, sp);
         s->stats[S_T_EIGH] += now_s() - t0;
     }
     return sp->status;
@@ -557,7 +601,10 @@ void unref(fokl_search *s, Spectrum *sp)
         delete sp;
         return;
     }
-    if (sp->job) (void)fokl_pool_wait(sp->job);             // its buffers are written until it has run
+    if (sp->job) {
+        (void)fokl_pool_wait(sp->job);                      // its buffers are written until it has run
+        job_has_run(s, sp);
+    }
     give_spectrum_buffer(sp->buf, sp->p1);
     delete sp;
 }
@@ -1325,6 +1372,16 @@ extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine,
     return FOKL_OK;
 }
 
+// G2 of the kill tests' models from their parent model's eigenpairs: parents of from_columns columns or more (0: never),
+// at most `depth` such steps away from a fresh decomposition.
+extern "C" int fokl_search_set_update(fokl_search *s, int from_columns, int depth)
+{
+    if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_set_update: null search");
+    s->update_from = std::max(0, from_columns);
+    s->update_depth = std::max(1, depth);
+    return FOKL_OK;
+}
+
 // Between hold(1) and hold(0) fokl_search_spectral only stages its jobs: hold(0) launches them as one grid.
 extern "C" int fokl_search_hold_spectral(fokl_search *s, int hold)
 {
@@ -1751,7 +1808,20 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 const auto idx = columns_without(A, key);
                 const double slack = (deep - 1) * s->test_us;
                 if (deep <= s->prm.lookahead + 1 || spectrum_to_device(s, (int)idx.size(), slack)) {
-                    Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size(), slack);
+                    // the model this test is held against: the current one, or the trial model of the accepted test before
+                    Spectrum *parent = nullptr;
+                    int parent_pos = -1;
+                    if (s->update_from > 0) {
+                        if (cur == killed)
+                            parent = best->spec;
+                        else if (auto it = ahead.find(cur); it != ahead.end())
+                            parent = it->second;
+                        if (parent) {
+                            const auto pidx = columns_without(A, cur);
+                            parent_pos = (int)(std::lower_bound(pidx.begin(), pidx.end(), a->columns[proposal[q]]) - pidx.begin());
+                        }
+                    }
+                    Spectrum *sp = submit_spectrum(s, gram, ld, idx.data(), (int)idx.size(), slack, parent, parent_pos);
                     if (!sp) return FOKL_ERR_STATE;
                     ahead.emplace(key, sp);
                 }

@@ -1021,6 +1021,16 @@ class ForwardSelection:
                 self.native.bind_spectral(self.spectral_engine,
                                           slack=0.0 if everything else float(os.environ.get('FOKL_DSPECTRAL_SLACK', '-1')),
                                           lookahead=int(os.environ.get('FOKL_DSPECTRAL_LOOKAHEAD', '-1')))
+            # Kill tests' G2 from the eigenpairs of the model each is tested against (secular equation + one product, a fifth
+            # of a decomposition's time): FOKL_EIGH_UPDATE = columns of the smallest such parent (default 8; 0: every model
+            # is decomposed afresh), at most FOKL_EIGH_UPDATE_DEPTH (default 6) such steps from a decomposition.  Not where
+            # several ranks repeat one search: which models are derived depends on what was requested ahead, and the ranks
+            # must agree to the last bit.
+            update_from = int(os.environ.get('FOKL_EIGH_UPDATE', '8'))
+            if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) and not self.allreduce \
+                    and not self.candidate_sharded and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
+                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')))
+                self.stats['eigh_update_from'] = update_from
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run

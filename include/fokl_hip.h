@@ -432,6 +432,9 @@ int fokl_pool_create(int chain_threads, int finish_threads, int spectral_threads
  * eigenpairs within ~3e-12 of dsyevr's in the chain's noise map, 1.3-1.5 x faster from 80 columns on, 2 x at 585.  NULL or
  * 0: dsyevr (what scipy.linalg.eigh calls, FR:1499) for every size.  Call before the first spectral job. */
 int fokl_pool_use_dsyevd(fokl_host_pool *pool, void *fn, int from_columns);
+/* BLAS dgemm (fn: its address, Fortran ABI with 32-bit integers, e.g. scipy.linalg.cython_blas's) for the product of
+ * fokl_pool_submit_spectral_update; NULL: those jobs decompose afresh.  Call before the first spectral job. */
+int fokl_pool_use_dgemm(fokl_host_pool *pool, void *fn);
 
 /* CPUs for the spectral threads alone (they share no data with the threads around the random stream: another last-level
  * cache domain keeps them off those threads' cores) */
@@ -493,6 +496,20 @@ int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const doubl
 int fokl_pool_submit_spectral(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
                               double *lamb_out, double *qt_out, double *qty_out, double *betahat_out,
                               double *moments_out, fokl_host_job **out);
+/* G2 of a kill test's model (FR:1666-1690 evaluate the current model minus one term) from the eigenpairs of the model with
+ * that ONE MORE column instead of from scratch: parent_lamb [p1 + 1] ascending, parent_qt [p1 + 1, p1 + 1] as qt_out above,
+ * parent_pos = which of the parent's columns this model lacks.  The eigenvalues are the roots of the secular equation
+ * sum_j z_j^2 / (lam_j - mu) = 0 (z = row parent_pos of Q), the eigenvectors one (p1 x (p1+1) x p1) dgemm; vectors from the
+ * z^ of Gu & Eisenstat, so orthogonal to working precision.  parent_job: NULL when the parent's arrays are complete, else
+ * the spectral job of this pool that writes them (not waited for yet): this job is queued, ahead of everything else, when
+ * that one has run.  updated (may be NULL): 1 = derived from the parent, 0 = decomposed afresh after all (the parent
+ * failed, nearly repeated eigenvalues or vanishing z_j -- no deflation here --, a failed check of diag(XtX) against the
+ * eigenpairs, no dgemm bound, FOKL_EIGH_SIGNS=lapack).  Same outputs, layout and sign convention as
+ * fokl_pool_submit_spectral; accuracy: tests/stress/eigen_deletion_study.py. */
+int fokl_pool_submit_spectral_update(fokl_host_pool *pool, const double *gram, int ld, const int32_t *idx, int p1, int ycol,
+                                     const double *parent_lamb, const double *parent_qt, int parent_pos,
+                                     fokl_host_job *parent_job, double *lamb_out, double *qt_out, double *qty_out,
+                                     double *betahat_out, double *moments_out, int32_t *updated, fokl_host_job **out);
 /* 1 if the job has run.  fokl_pool_wait blocks until then, frees the job and returns its status. */
 int fokl_pool_poll(const fokl_host_job *job);
 int fokl_pool_wait(fokl_host_job *job);
@@ -558,6 +575,12 @@ int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, const fokl_sea
 typedef struct fokl_dspectral fokl_dspectral;
 int fokl_search_bind_spectral(fokl_search *search, fokl_dspectral *engine, int max_columns, double slack, int lookahead);
 int fokl_search_hold_spectral(fokl_search *search, int hold);
+/* G2 of the kill tests' models from the eigenpairs of the model each is tested against (fokl_pool_submit_spectral_update:
+ * secular equation + one product, 4-5 x cheaper than a decomposition): for parents of from_columns columns or more (0, the
+ * default: never) and at most `depth` such steps away from a fresh decomposition -- a step runs when the one before it has,
+ * so `depth` cuts the chain of accepted tests along the predicted path into pieces the spectral threads work on side by side.
+ * Statistic 'spectral_updated' counts the models that were derived this way. */
+int fokl_search_set_update(fokl_search *search, int from_columns, int depth);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);
 /* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */

@@ -1,4 +1,5 @@
 """Host half of the sampler (C++ in libfokl_hip.so): numpy-legacy random stream and the eigenbasis Gibbs chain."""
+import ctypes
 import os
 import numpy as np
 import pytest
@@ -537,3 +538,154 @@ def test_divide_and_conquer_driver_returns_dsyevrs_eigenpairs(monkeypatch):
     assert np.abs(b0 - b1).max() <= 1e-10 * np.abs(b0).max()
     assert np.abs(m0 - m1).max() <= 1e-9 * np.abs(m0).max()
     assert np.abs(Q1 @ Q1.T - np.eye(n)).max() <= 1e-13
+
+
+def _gram_for_update(n, seed, rows=3000):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((rows, n - 1)) * 10.0 ** rng.uniform(-1, 1, n - 1)
+    X[:, ::3] += 0.7 * X[:, :1]
+    y = X @ rng.standard_normal(n - 1) * 0.1 + rng.standard_normal(rows)
+    Z = np.column_stack([np.ones(rows), X, y])
+    return Z.T @ Z
+
+
+def _noise_map(res):
+    return np.array(res.Qt).T / np.sqrt(np.array(res.lamb) + 1.0)
+
+
+@pytest.mark.parametrize('n', [9, 40, 96])
+def test_eigenpairs_from_the_parent_model_match_a_fresh_decomposition(n):
+    """fokl_pool_submit_spectral_update: a kill test's model (FR:1666-1690: the current model minus one term) gets its
+    eigenpairs from the current model's -- roots of the secular equation, one product -- instead of a decomposition.  Against
+    the fresh job of the same model, through a chain of ten deletions (each from the result before): eigenvalues to
+    rounding, the chain's noise map within 1e-9 of its scale (measured 1e-12 .. 4e-11: what dsyevr itself moves by when
+    XtX changes in its last bits), orthogonal vectors, and everything derived (Q'Xty, betahat, residual moments)."""
+    gram = _gram_for_update(n, 40 + n)
+    rng = np.random.default_rng(n)
+    np.random.seed(1)
+    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=2)
+    try:
+        assert pool.has_dgemm
+        alive = np.arange(n, dtype=np.int32)
+        parent = pool.submit_spectral(gram, alive, n).wait()
+        for step in range(min(10, n - 2)):
+            c = int(rng.integers(0, alive.shape[0]))                      # any column, the intercept included
+            child = np.ascontiguousarray(np.delete(alive, c))
+            job, updated = pool.submit_spectral_update(gram, child, n, parent, c)
+            res = job.wait()
+            fresh = pool.submit_spectral(gram, child, n).wait()
+            m = child.shape[0]
+            assert updated[0] == 1
+            assert np.all(np.diff(res.lamb) > 0)
+            assert np.abs(res.lamb - fresh.lamb).max() <= 1e-13 * np.abs(fresh.lamb).max()
+            assert np.abs(_noise_map(res) - _noise_map(fresh)).max() <= 1e-9 * np.abs(_noise_map(fresh)).max()
+            assert np.abs(res.Qt @ res.Qt.T - np.eye(m)).max() <= 1e-12
+            piv = np.abs(res.Qt).argmax(axis=1)
+            assert np.all(res.Qt[np.arange(m), piv] > 0)                   # the sign convention of the fresh job
+            assert np.abs(res.betahat - fresh.betahat).max() <= 1e-9 * np.abs(fresh.betahat).max()
+            assert np.abs(res.qty - fresh.qty).max() <= 1e-9 * np.abs(fresh.qty).max()
+            assert np.abs(res.moments - fresh.moments).max() <= 1e-9 * np.abs(fresh.moments).max()
+            parent, alive = res, child
+    finally:
+        pool.close()
+
+
+def test_eigen_update_queued_behind_its_parent_job():
+    """parent_job: the child may be submitted while the parent's decomposition is still queued or running -- it is put on
+    the queue when the parent has run.  Chains of three, many at once, two threads: every child equals the one derived from
+    the finished parent (the same arithmetic on the same numbers: bit for bit)."""
+    lib = _capi.load()
+    n = 48
+    gram = _gram_for_update(n, 7)
+    np.random.seed(1)
+    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=2)
+    try:
+        idx0 = np.arange(n, dtype=np.int32)
+        chains = []
+        for k in range(12):
+            cuts = [(5 + k) % n, (3 + 2 * k) % (n - 1), (11 + k) % (n - 2)]
+            results, handles, lists, flags = [_capi.SpectralResult(n)], [], [idx0], []
+            h = ctypes.c_void_p(0)
+            _capi._check(lib.fokl_pool_submit_spectral(pool._h, _capi._ptr(gram), n + 1, _capi._ptr(idx0), n, n,
+                                                       *results[0].pointers(n), ctypes.byref(h)))
+            handles.append(h)
+            for c in cuts:
+                child = np.ascontiguousarray(np.delete(lists[-1], c))
+                res, upd = _capi.SpectralResult(child.shape[0]), np.full(1, -1, dtype=np.int32)
+                hc = ctypes.c_void_p(0)
+                _capi._check(lib.fokl_pool_submit_spectral_update(
+                    pool._h, _capi._ptr(gram), n + 1, _capi._ptr(child), child.shape[0], n, _capi._ptr(results[-1].lamb),
+                    _capi._ptr(results[-1].Qt), c, handles[-1], *res.pointers(child.shape[0]), _capi._ptr(upd),
+                    ctypes.byref(hc)))
+                results.append(res), handles.append(hc), lists.append(child), flags.append(upd)
+            chains.append((cuts, results, handles, lists, flags))
+        for cuts, results, handles, lists, flags in chains:
+            for h in handles:
+                assert lib.fokl_pool_wait(h) == 0
+            assert [int(f[0]) for f in flags] == [1, 1, 1]
+            for c, parent, child_idx, got in zip(cuts, results[:-1], lists[1:], results[1:]):
+                job, upd = pool.submit_spectral_update(gram, child_idx, n, parent, c)
+                again = job.wait()
+                assert upd[0] == 1 and np.array_equal(again._buf, got._buf)
+    finally:
+        pool.close()
+
+
+def test_eigen_update_falls_back_to_a_decomposition(monkeypatch):
+    """What the update does not handle is decomposed afresh, with the fresh job's bits: a parent with a repeated eigenvalue
+    (no deflation), a deleted row of Q with a vanishing component (an eigenvector that stays), a parent that is not this
+    model's (caught by diag(XtX) against the eigenpairs), FOKL_EIGH_SIGNS=lapack.  Arguments that cannot be right fail."""
+    lib = _capi.load()
+    n = 12
+    rng = np.random.default_rng(3)
+    # block-diagonal XtX: the eigenvectors of one block vanish on the other's columns; and a repeated eigenvalue
+    B = rng.standard_normal((40, 5))
+    G = np.zeros((n + 1, n + 1))
+    G[:5, :5] = B.T @ B + np.eye(5)
+    G[5:n, 5:n] = np.diag([3.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0])
+    G[:n, n] = G[n, :n] = rng.standard_normal(n)
+    G[n, n] = 100.0
+    other = _gram_for_update(n, 5)
+    np.random.seed(1)
+    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
+    try:
+        idx = np.arange(n, dtype=np.int32)
+        parent = pool.submit_spectral(G, idx, n).wait()
+        child = np.ascontiguousarray(np.delete(idx, 2))
+        job, upd = pool.submit_spectral_update(G, child, n, parent, 2)
+        res = job.wait()
+        fresh = pool.submit_spectral(G, child, n).wait()
+        assert upd[0] == 0 and np.array_equal(res._buf, fresh._buf)
+        # the parent of another matrix: the diagonal identity fails, the answer is the model's own all the same
+        stranger = pool.submit_spectral(other, idx, n).wait()
+        job, upd = pool.submit_spectral_update(G, child, n, stranger, 2)
+        assert upd[0] == -1
+        res = job.wait()
+        assert upd[0] == 0 and np.array_equal(res._buf, fresh._buf)
+        # right parent, wrong position
+        good = pool.submit_spectral(other, idx, n).wait()
+        job, upd = pool.submit_spectral_update(other, child, n, good, 7)
+        res = job.wait()
+        fresh_other = pool.submit_spectral(other, child, n).wait()
+        assert upd[0] == 0 and np.array_equal(res._buf, fresh_other._buf)
+        job, upd = pool.submit_spectral_update(other, child, n, good, 2)
+        assert np.abs(job.wait().lamb - fresh_other.lamb).max() <= 1e-13 * fresh_other.lamb.max() and upd[0] == 1
+        with pytest.raises(_capi.FoklNativeError):
+            pool.submit_spectral_update(other, child, n, good, n)
+        h = ctypes.c_void_p(0)
+        r = _capi.SpectralResult(n - 1)
+        assert lib.fokl_pool_submit_spectral_update(pool._h, _capi._ptr(other), n + 1, _capi._ptr(child), n - 1, n, None,
+                                                    _capi._ptr(good.Qt), 2, None, *r.pointers(n - 1), None,
+                                                    ctypes.byref(h)) != 0
+    finally:
+        pool.close()
+    monkeypatch.setenv('FOKL_EIGH_SIGNS', 'lapack')
+    np.random.seed(1)
+    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
+    try:
+        good = pool.submit_spectral(other, idx, n).wait()
+        job, upd = pool.submit_spectral_update(other, child, n, good, 2)
+        res = job.wait()
+        assert upd[0] == 0 and np.array_equal(res._buf, pool.submit_spectral(other, child, n).wait()._buf)
+    finally:
+        pool.close()

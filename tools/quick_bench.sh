@@ -8,7 +8,7 @@ python - "$name" <<'PY'
 import json, sys
 d = json.loads(open(f"gpurun_out/qb_{sys.argv[1]}.json").read().strip().splitlines()[-1])
 h = d["host_main_thread_s_per_step"]
-keys = ('spectral_device', 't_eigh', 'pool_spectral_s', 'pool_noise_s', 'noise_verdict_wait_s', 'phase_tests', 'phase_model', 'phase_statistics', 't_kill_loop', 'spectral_submitted', 'tapes_rewound')
+keys = ('spectral_updated', 'spectral_device', 't_eigh', 'pool_spectral_s', 'pool_noise_s', 'noise_verdict_wait_s', 'phase_tests', 'phase_model', 'phase_statistics', 't_kill_loop', 'spectral_submitted', 'tapes_rewound')
 print(sys.argv[1], round(d["value"]), round(d["ms_per_step"], 2), round(d["cpu_seconds_per_step"], 3), d["parity"].get("ok"),
       d["parity"].get("max_draw_err_over_scale"), {k: round(h.get(k, 0), 4) for k in keys})
 PY

@@ -17,7 +17,7 @@ case $kind in
 esac
 out=profiles/sanitize_${kind}_r04.txt
 # (tests that start other processes are left out: a fork from a sanitized, multi-threaded interpreter does not come back)
-tests=${*:-"tests/test_sampler_host.py tests/test_stream_engine.py tests/test_native_search.py tests/test_host_logic.py -k '(native_search or pool or pipelined or device_chains or reap or tape or sampler or stream or chain or numpy or legacy or gibbs or fit) and not recorders_agree and not statements_agree and not rendezvous and not stale_file'"}
+tests=${*:-"tests/test_sampler_host.py tests/test_stream_engine.py tests/test_native_search.py tests/test_host_logic.py -k '(native_search or eigen or pool or pipelined or device_chains or reap or tape or sampler or stream or chain or numpy or legacy or gibbs or fit) and not recorders_agree and not statements_agree and not rendezvous and not stale_file'"}
 {
   echo "# $(date -u +%F) $kind: FOKL_HIP_LIBRARY=fokl_gpy_amd/libfokl_host_$kind.so FOKL_HOST_ONLY_LIBRARY=1, runtime preloaded"
   echo "# python -m pytest $tests"
