@@ -495,6 +495,11 @@ inline bool spectrum_to_device(const fokl_search *s, int p1, double slack_us)
 
 void unref(fokl_search *s, Spectrum *sp);
 
+// From this many columns on a decomposition takes milliseconds, the kill tests wait for G2 and nothing else, and the pool has
+// its largest number of threads: chains of derived models are kept short there so that more of them run side by side
+// (configs[3], 586-column models, 11 threads: depth 1 625 ms per fit, 2 637, 3 664, 6 688, unlimited 1127; none 694).
+constexpr int kWideModel = 192, kWideDepth = 2;
+
 // parent / parent_pos: the model this one is with its column number parent_pos deleted (a kill test's model and the model
 // it is tested against), when the caller has it -- G2 then follows from the parent's eigenpairs where that is allowed.
 Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1, double slack_us = -1.0,
@@ -520,7 +525,8 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     int rc = FOKL_ERR_STATE;
     const bool from_parent = sp->buf && parent && s->update_from > 0 && parent_pos >= 0 && parent_pos <= p1 &&
                              parent->p1 == p1 + 1 && parent->p1 >= s->update_from && !parent->dev && parent->buf &&
-                             parent->status == FOKL_OK && parent->depth < s->update_depth;
+                             parent->status == FOKL_OK &&
+                             parent->depth < (parent->p1 >= kWideModel ? std::min(s->update_depth, kWideDepth) : s->update_depth);
     if (from_parent) {
         rc = fokl_pool_submit_spectral_update(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, parent->lamb(), parent->Qt(),
                                               parent_pos, parent->job, sp->lamb(), sp->Qt(), sp->qty(), sp->betahat(),

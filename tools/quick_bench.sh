@@ -1,9 +1,10 @@
 #!/bin/bash
 # tools/quick_bench.sh NAME [ENV=VALUE ...]: a short timed run of the headline fit without side measurements; prints
-# value, ms per step, CPU-seconds and the host breakdown fields that matter (development aid, GPU box).
+# value, ms per step, CPU-seconds and the host breakdown fields that matter (development aid, GPU box).  QB_ARGS replaces
+# "--steps 8 --warmup 3" (e.g. QB_ARGS="--config 3 --steps 3 --warmup 1").
 name=$1; shift
 mkdir -p gpurun_out
-env "$@" python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-microbench --no-throughput > gpurun_out/qb_$name.json 2> gpurun_out/qb_$name.err || { tail -c 400 gpurun_out/qb_$name.err; exit 1; }
+env "$@" python bench.py ${QB_ARGS:---steps 8 --warmup 3} --no-cpu-baseline --no-microbench --no-throughput > gpurun_out/qb_$name.json 2> gpurun_out/qb_$name.err || { tail -c 400 gpurun_out/qb_$name.err; exit 1; }
 python - "$name" <<'PY'
 import json, sys
 d = json.loads(open(f"gpurun_out/qb_{sys.argv[1]}.json").read().strip().splitlines()[-1])
