@@ -108,6 +108,7 @@ SIGNATURES = {
     'fokl_search_speculate': (c_int, [c_vp, c_vp, c_vp, c_int]),
     'fokl_search_drop_speculation': (c_int, [c_vp]),
     'fokl_search_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
+    'fokl_search_spectral_from': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     'fokl_spectrum_done': (c_int, [c_vp]),
     'fokl_spectrum_wait': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_spectrum_release': (None, [c_vp, c_vp]),
@@ -873,11 +874,17 @@ class NativeSearch:
         most `depth` steps from a fresh decomposition."""
         self._checked(self._lib.fokl_search_set_update(self._h, int(from_columns), int(depth)))
 
-    def spectral(self, gram, idx):
+    def spectral(self, gram, idx, parent=None, parent_pos=-1):
+        """parent / parent_pos: a spectrum handle of this search for the model that has one more column, and which of its
+        columns this model lacks (G2 may then follow from the parent's eigenpairs, set_update)."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         h = c_vp(0)
-        self._checked(self._lib.fokl_search_spectral(self._h, _ptr(gram), gram.shape[1], _ptr(idx), idx.shape[0],
-                                                     ctypes.byref(h)))
+        if parent is None:
+            self._checked(self._lib.fokl_search_spectral(self._h, _ptr(gram), gram.shape[1], _ptr(idx), idx.shape[0],
+                                                         ctypes.byref(h)))
+        else:
+            self._checked(self._lib.fokl_search_spectral_from(self._h, _ptr(gram), gram.shape[1], _ptr(idx), idx.shape[0],
+                                                              c_vp(parent), int(parent_pos), ctypes.byref(h)))
         return h.value
 
     def spectrum_done(self, spectrum):

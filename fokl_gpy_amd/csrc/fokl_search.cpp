@@ -1366,6 +1366,20 @@ extern "C" int fokl_search_spectral(fokl_search *s, const double *gram, int ld, 
     return FOKL_OK;
 }
 
+// The same for a model that is `parent`'s (a spectrum of this search, finished or not) without its column number parent_pos:
+// G2 follows from the parent's eigenpairs where fokl_search_set_update allows it.
+extern "C" int fokl_search_spectral_from(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1,
+                                         fokl_spectrum *parent, int parent_pos, fokl_spectrum **out)
+{
+    if (!s || !gram || !idx || !out || p1 < 1 || ld < 2)
+        return fail(s, FOKL_ERR_ARG, "fokl_search_spectral_from: bad arguments");
+    Spectrum *sp = submit_spectrum(s, gram, ld, idx, p1, -1.0, reinterpret_cast<Spectrum *>(parent), parent_pos);
+    if (!sp) return FOKL_ERR_STATE;
+    *out = reinterpret_cast<fokl_spectrum *>(sp);
+    if (!s->dspec_hold) flush_spectra(s);
+    return FOKL_OK;
+}
+
 // G2 of models of up to max_columns columns goes to `engine` (NULL: back to the pool's LAPACK threads).
 extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine, int max_columns, double slack,
                                          int lookahead)
@@ -1732,13 +1746,16 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     auto forecast = [&](size_t pos) {
         // the kill set at the end of the loop if the rest goes as predicted
         if (!a->foresee || !path_complete) return;
-        std::vector<int32_t> pred(killed);
         int rest = 0;
+        for (size_t q = pos; q < proposal.size() && rest <= s->prm.foresight; ++q)
+            if (step_at(q).run) ++rest;
+        if (rest > s->prm.foresight) return;                // (most calls: nothing to tell yet)
+        std::vector<int32_t> pred(killed);
         for (size_t q = pos; q < proposal.size(); ++q) {
             const Step st = step_at(q);
-            if (st.run) ++rest;
-            if (st.run && st.accept) pred = with_column(pred, a->columns[proposal[q]]);
+            if (st.run && st.accept) pred.push_back(a->columns[proposal[q]]);
         }
+        std::sort(pred.begin(), pred.end());
         // (the callback is Python: told once per predicted kill set, not once per test -- once the coming sub-stage has been
         // built, idle_work, before which it can do nothing with the news)
         if (rest <= s->prm.foresight && (idle_pending || !foreseen_any || pred != foreseen_last)) {
@@ -1762,10 +1779,11 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             const Step st = step_at(q);
             if (st.run) {
                 sizes.push_back({A - (int)pred.size() - 1, false});
-                if (st.accept) pred = with_column(pred, a->columns[proposal[q]]);
+                if (st.accept) pred.push_back(a->columns[proposal[q]]);
             }
         }
         if (through && a->vm_next >= 0) {
+            std::sort(pred.begin(), pred.end());
             // across the boundary: the coming model, its first test (every first test is one column smaller whichever
             // proposal it removes) -- or, if G2 of that model is there already, all the tests its least-squares fit
             // makes likely

@@ -415,10 +415,12 @@ class ForwardSelection:
         else:
             self.backend.bic_resid_launch(cand_slots, betahat)
 
-    def _spectral(self, gram, idx):
-        """Queue G2 for the model made of columns idx of gram (pool job, or the native search's)."""
+    def _spectral(self, gram, idx, parent=None, parent_pos=-1):
+        """Queue G2 for the model made of columns idx of gram (pool job, or the native search's).  parent / parent_pos
+        (native search): the spectrum of the model with one more column and which of its columns this one lacks."""
         if self.native is not None:
-            return NativeSpectrum(self.native, self.native.spectral(gram, idx), gram)
+            return NativeSpectrum(self.native, self.native.spectral(gram, idx, getattr(parent, 'h', None), parent_pos),
+                                  gram)
         return self.host.spectral(gram, idx)
 
     def _set_active_terms(self, damtx):
@@ -706,15 +708,20 @@ class ForwardSelection:
             # took the CPUs the model's chain runs on (53.5 -> 56-58 ms per fit)
             guessed = self.native.likely_first_tests(spectrum.h, n_new, siglik)
             jobs, cur, sizes = {}, frozenset(), []
+            against = spectrum                          # the model the next test is held against, where its G2 is known
             self.native.hold_spectral(True)             # device G2: the four jobs become one grid
             try:
                 for c, accepted in guessed:
                     trial = cur | {c}
                     if len(jobs) <= min(self._lookahead_native, 3):
-                        jobs[trial] = self._spectral(gram, self._columns_without(A, trial))
+                        pos = -1
+                        if against is not None:
+                            pos = int(np.searchsorted(self._columns_without(A, cur), c))
+                        jobs[trial] = self._spectral(gram, self._columns_without(A, trial), against, pos)
                     sizes.append(A - len(cur) - 1)
                     if accepted:
                         cur = trial
+                        against = jobs.get(trial)
             finally:
                 self.native.hold_spectral(False)
             self._speculate(([ModelSize(A)] if before_model else []) + sizes)

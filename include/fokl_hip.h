@@ -592,6 +592,10 @@ int fokl_search_drop_speculation(fokl_search *search);
 /* G2 (fokl_pool_submit_spectral) with the result buffer owned by the search: lamb [p1] | qty [p1] | betahat [p1] |
  * Qt [p1, p1] | moments [2]; gram must stay alive until the job has run */
 int fokl_search_spectral(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1, fokl_spectrum **out);
+/* The same for the model that is `parent`'s (a spectrum of this search, waited for or not) without its column number
+ * parent_pos (NULL / -1: as fokl_search_spectral): derived from the parent's eigenpairs where fokl_search_set_update allows. */
+int fokl_search_spectral_from(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1,
+                              fokl_spectrum *parent, int parent_pos, fokl_spectrum **out);
 int fokl_spectrum_done(fokl_spectrum *spectrum);
 int fokl_spectrum_wait(fokl_search *search, fokl_spectrum *spectrum, const double **buffer, int *p1);
 void fokl_spectrum_release(fokl_search *search, fokl_spectrum *spectrum);
