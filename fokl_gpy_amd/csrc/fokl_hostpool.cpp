@@ -318,39 +318,90 @@ void spectral_tail(fokl_host_pool *pool, fokl_host_job *job, const double *xty)
 // a vanishing z_j, an iteration that does not settle, a result that fails the diagonal identity
 // XtX'_ii = sum_k mu_k q_ik^2 -- and the model is decomposed afresh.
 
+#define FOKL_POOL_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+
+// sum_j z2_j / d_j and sum_j z2_j / d_j^2 over [lo, hi) with d_j = (lam_j - pole) - t, stored to delta.  Eight partial sums
+// each, added up in a fixed order: the same arithmetic (IEEE division, no contraction) whatever the vector width of the clone.
+FOKL_POOL_CLONES void secular_sums(const double *lam, const double *z2, int lo, int hi, double pole, double t, double *delta,
+                                   double *sum, double *dsum)
+{
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = lo;
+    for (; j + 8 <= hi; j += 8)
+        for (int l = 0; l < 8; ++l) {
+            const double d = (lam[j + l] - pole) - t;
+            const double inv = 1.0 / d, term = z2[j + l] * inv;
+            delta[j + l] = d;
+            s[l] += term;
+            ds[l] += term * inv;
+        }
+    for (int l = 0; j < hi; ++j, ++l) {
+        const double d = (lam[j] - pole) - t;
+        const double inv = 1.0 / d, term = z2[j] * inv;
+        delta[j] = d;
+        s[l] += term;
+        ds[l] += term * inv;
+    }
+    *sum = ((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7]));
+    *dsum = ((ds[0] + ds[4]) + (ds[2] + ds[6])) + ((ds[1] + ds[5]) + (ds[3] + ds[7]));
+}
+
+// z^_j^2 as products of ratios in (0, inf) (interlacing): (mu_k - lam_j) / (lam_k - lam_j) for k < j, / (lam_k+1 - lam_j) for
+// k >= j; D[k * n + j] = lam_j - mu_k.
+FOKL_POOL_CLONES void secular_zhat(const double *lam, const double *D, int n, int m, double *zh)
+{
+    for (int j = 0; j < n; ++j) zh[j] = 1.0;
+    for (int k = 0; k < m; ++k) {
+        const double *d = D + (size_t)k * n;
+        const double above = lam[k + 1], below = lam[k];
+        for (int j = 0; j <= k; ++j) zh[j] *= -d[j] / (above - lam[j]);
+        for (int j = k + 1; j < n; ++j) zh[j] *= -d[j] / (below - lam[j]);
+    }
+}
+
+// x_k[j] = z^_j / (lam_j - mu_k) in place of the differences, each x_k normalised; false if one cannot be.
+FOKL_POOL_CLONES bool secular_vectors(const double *zh, double *D, int n, int m)
+{
+    for (int k = 0; k < m; ++k) {
+        double *d = D + (size_t)k * n;
+        double ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int j = 0;
+        for (; j + 8 <= n; j += 8)
+            for (int l = 0; l < 8; ++l) {
+                d[j + l] = zh[j + l] / d[j + l];
+                ss[l] += d[j + l] * d[j + l];
+            }
+        for (int l = 0; j < n; ++j, ++l) {
+            d[j] = zh[j] / d[j];
+            ss[l] += d[j] * d[j];
+        }
+        const double total = ((ss[0] + ss[4]) + (ss[2] + ss[6])) + ((ss[1] + ss[5]) + (ss[3] + ss[7]));
+        if (!(total > 0.0) || !std::isfinite(total)) return false;
+        const double r = 1.0 / std::sqrt(total);
+        for (int i = 0; i < n; ++i) d[i] *= r;
+    }
+    return true;
+}
+
 // One root: k-th interval.  delta[j] <- lam_j - mu_k.  Returns false when the iteration does not settle.
 bool secular_root(const double *lam, const double *z2, int n, int k, double *delta, double *mu)
 {
     const double eps = 2.220446049250313e-16;
     const double gap = lam[k + 1] - lam[k], half = 0.5 * gap;
     // which half of the interval: the sign of g at its middle (g rises from -inf to +inf across the interval)
-    double gmid = 0.0;
-    for (int j = 0; j < n; ++j) gmid += z2[j] / ((lam[j] - lam[k]) - half);
-    const int o = gmid > 0.0 ? k : k + 1;
+    double psi, dpsi, phi, dphi;
+    secular_sums(lam, z2, 0, k + 1, lam[k], half, delta, &psi, &dpsi);
+    secular_sums(lam, z2, k + 1, n, lam[k], half, delta, &phi, &dphi);
+    const int o = psi + phi > 0.0 ? k : k + 1;
     const double pole = lam[o];
     double lo = o == k ? 0.0 : -half, hi = o == k ? half : 0.0;
     double t = o == k ? half : -half;
     const double dk = lam[k] - pole, dk1 = lam[k + 1] - pole;
     bool settled = false;
     for (int it = 0; it < 80; ++it) {
-        double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, mag = 0.0;
-        for (int j = 0; j <= k; ++j) {
-            const double d = (lam[j] - pole) - t;
-            const double inv = 1.0 / d, term = z2[j] * inv;
-            delta[j] = d;
-            psi += term;
-            dpsi += term * inv;
-            mag -= term;                                    // d < 0 on this side
-        }
-        for (int j = k + 1; j < n; ++j) {
-            const double d = (lam[j] - pole) - t;
-            const double inv = 1.0 / d, term = z2[j] * inv;
-            delta[j] = d;
-            phi += term;
-            dphi += term * inv;
-            mag += term;
-        }
-        const double g = psi + phi;
+        secular_sums(lam, z2, 0, k + 1, pole, t, delta, &psi, &dpsi);       // every term negative
+        secular_sums(lam, z2, k + 1, n, pole, t, delta, &phi, &dphi);       // every term positive
+        const double g = psi + phi, mag = phi - psi;
         if (!(std::fabs(g) > (double)n * eps * mag)) {      // also leaves on NaN
             settled = g == g;
             break;
@@ -385,7 +436,6 @@ bool secular_root(const double *lam, const double *z2, int n, int k, double *del
         }
         if (next == t || !(hi - lo > 0.0)) {                // the bracket is down to neighbouring numbers
             settled = true;
-            for (int j = 0; j < n; ++j) delta[j] = (lam[j] - pole) - t;
             break;
         }
         t = next;
@@ -422,29 +472,12 @@ int spectral_from_parent(fokl_host_pool *pool, fokl_host_job *job, bool *used)
     double *mu = job->lamb_out;
     for (int k = 0; k < m; ++k)
         if (!secular_root(lam, z2.data(), n, k, D.data() + (size_t)k * n, mu + k)) return FOKL_OK;
-    // z^: ratios in (0, inf) by interlacing -- (mu_k - lam_j) / (lam_k - lam_j) for k < j, / (lam_k+1 - lam_j) for k >= j
-    for (int j = 0; j < n; ++j) zh[j] = 1.0;
-    for (int k = 0; k < m; ++k) {
-        const double *d = D.data() + (size_t)k * n;
-        for (int j = 0; j <= k; ++j) zh[j] *= -d[j] / (lam[k + 1] - lam[j]);
-        for (int j = k + 1; j < n; ++j) zh[j] *= -d[j] / (lam[k] - lam[j]);
-    }
+    secular_zhat(lam, D.data(), n, m, zh.data());
     for (int j = 0; j < n; ++j) {
         if (!(zh[j] > 0.0) || !(zh[j] < 4.0)) return FOKL_OK;      // (z^ is a row of an orthogonal matrix as z is)
         zh[j] = z[j] < 0.0 ? -std::sqrt(zh[j]) : std::sqrt(zh[j]);
     }
-    // x_k in place of the differences, normalised
-    for (int k = 0; k < m; ++k) {
-        double *d = D.data() + (size_t)k * n;
-        double ss = 0.0;
-        for (int j = 0; j < n; ++j) {
-            d[j] = zh[j] / d[j];
-            ss += d[j] * d[j];
-        }
-        if (!(ss > 0.0) || !std::isfinite(ss)) return FOKL_OK;
-        const double r = 1.0 / std::sqrt(ss);
-        for (int j = 0; j < n; ++j) d[j] *= r;
-    }
+    if (!secular_vectors(zh.data(), D.data(), n, m)) return FOKL_OK;
     // eigenvectors: (rows != c of Q) X.  In Fortran's column-major reading the parent's Qt IS Q (n x n), D is X (n x m) and
     // qt_out is the result (m x m, column k = eigenvector k): two calls, the rows above and below c
     char nn = 'N';

@@ -20,6 +20,7 @@ modes=(
   "FOKL_EIGH_DC_FROM=8"
   "FOKL_EIGH_UPDATE=0"
   "FOKL_EIGH_UPDATE_DEPTH=64"
+  "FOKL_BUILD_AHEAD=tests"
   "FOKL_CLEAN=host"
   "FOKL_K1_TOUCH=0"
   "FOKL_K3=columns"
