@@ -1257,7 +1257,8 @@ class ForwardSelection:
                 # G2 of the coming sub-stage's model if the kill tests end as predicted (at most two guesses)
                 if ahead is None or len(forecasts) >= 2:
                     return
-                keep_pred = [c for c in range(A) if c not in pred_killed]
+                gone = set(pred_killed)
+                keep_pred = [c for c in range(A) if c not in gone]
                 key = tuple(active[c] for c in keep_pred[1:])
                 if key not in forecasts:
                     g = self._extend_gram(gram, keep_pred, self._ahead_block(ahead), keep_pred, ahead['over'])
