@@ -568,9 +568,10 @@ int expand_tape_blocks(fokl_host_pool *pool, fokl_host_job *job)
     return FOKL_OK;
 }
 
-// The eigenpairs of `job` are there (or never will be): the jobs that derive theirs from them go to the FRONT of the queue
-// -- the thread that ran the parent takes the first one with the parent's vectors still in its cache.
-void release_dependents(fokl_host_pool *pool, fokl_host_job *job, int rc)
+// The eigenpairs of `job` are there (or never will be): the first of the jobs that derive theirs from them is returned -- the
+// calling thread runs it next, the parent's vectors still in its cache, no hand-over through the queue -- and the others go
+// to the FRONT of the queue.
+fokl_host_job *release_dependents(fokl_host_pool *pool, fokl_host_job *job, int rc)
 {
     std::vector<fokl_host_job *> deps;
     {
@@ -579,23 +580,26 @@ void release_dependents(fokl_host_pool *pool, fokl_host_job *job, int rc)
         job->run_status = rc;
         deps.swap(job->dependents);
     }
-    if (deps.empty()) return;
-    {
-        std::lock_guard<std::mutex> lk(pool->spectral_q.m);
-        for (auto it = deps.rbegin(); it != deps.rend(); ++it) {
-            (*it)->parent_failed = rc != FOKL_OK;
-            pool->spectral_q.q.push_front(*it);
+    if (deps.empty()) return nullptr;
+    for (fokl_host_job *d : deps) d->parent_failed = rc != FOKL_OK;
+    if (deps.size() > 1) {
+        {
+            std::lock_guard<std::mutex> lk(pool->spectral_q.m);
+            for (auto it = deps.rbegin(); it + 1 != deps.rend(); ++it) pool->spectral_q.q.push_front(*it);
         }
+        if (deps.size() > 2)
+            pool->spectral_q.cv.notify_all();
+        else
+            pool->spectral_q.cv.notify_one();
     }
-    if (deps.size() > 1)
-        pool->spectral_q.cv.notify_all();
-    else
-        pool->spectral_q.cv.notify_one();
+    return deps.front();
 }
 
-void run(fokl_host_pool *pool, fokl_host_job *job)
+// -> a job to run next on this thread (a spectral job's first dependent), or NULL
+fokl_host_job *run(fokl_host_pool *pool, fokl_host_job *job)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    fokl_host_job *next = nullptr;
     int rc = FOKL_OK;
     std::string err;
     std::atomic<int64_t> *busy = nullptr;
@@ -625,7 +629,7 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
         break;
     case Kind::spectral:
         rc = job->parent_lamb ? spectral_update(pool, job, err) : spectral(pool, job, err);
-        release_dependents(pool, job, rc);
+        next = release_dependents(pool, job, rc);
         busy = &pool->spectral_busy_ns;
         break;
     }
@@ -636,9 +640,10 @@ void run(fokl_host_pool *pool, fokl_host_job *job)
     if (job->self_owned) {
         if (job->parent) settle(job->parent);
         delete job;                                         // failures reach the chain job through block_done
-        return;
+        return next;
     }
     finish(job, rc, err.c_str());
+    return next;
 }
 
 void worker(fokl_host_pool *pool, Queue *queue)
@@ -653,7 +658,7 @@ void worker(fokl_host_pool *pool, Queue *queue)
             job = queue->q.front();
             queue->q.pop_front();
         }
-        run(pool, job);
+        while (job) job = run(pool, job);
     }
 }
 
