@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SIDE_FITS = 4                  # fits per process in the throughput side measurement
+SIDE_FITS = int(os.environ.get('FOKL_BENCH_SIDE_FITS', '4'))   # fits per process in the throughput side measurement
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
 
