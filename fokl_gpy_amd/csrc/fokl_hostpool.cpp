@@ -161,6 +161,13 @@ struct fokl_host_pool {
     // FOKL_EIGH_SIGNS=lapack: eigenvectors keep the signs dsyevr returns (the untouched reference's draws on a host
     // whose BLAS forms the same Gram); default: largest-magnitude component positive (what the goldens pin)
     bool lapack_signs = false;
+    // A (nearly) singular XtX (smallest eigenvalue <= singular * largest; FOKL_EIGH_SINGULAR, default 1e-9) has no
+    // eigenvectors to speak of in its (near) null space: what a fit then selects is whatever the reference's own driver
+    // returns there (random problems with a third as many terms as rows: tests/stress/random_parity.py 353, 465, 494, 584
+    // select other models with dsyevd or derived eigenpairs, the reference's with dsyevr).  Such models are decomposed by
+    // dsyevr, as scipy.linalg.eigh does (FR:1499) -- neither dsyevd nor the update; the BASELINE configurations' models
+    // (condition numbers 1e5 .. 1e8) are not among them.
+    double singular = 1e-9;
 };
 
 namespace {
@@ -208,6 +215,7 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
     int nn = n, lda = n, ldz = n, il = 1, iu = n, m = 0, info = 0, lwork = -1, liwork = -1, iwork_query = 0;
     double vl = 0.0, vu = 1.0, abstol = 0.0, work_query = 0.0;
     double *z = job->qt_out;                                // z(i, j) at z[j * n + i]: row j of Q' = eigenvector j
+    bool by_dsyevd = false;
     if (pool->dsyevd && pool->dsyevd_from > 0 && n >= pool->dsyevd_from && !pool->lapack_signs) {
         // divide and conquer: the eigenvectors overwrite the matrix, column j = eigenvector j -- the layout of Q' row-major
         std::memcpy(z, a.data(), sizeof(double) * (size_t)n * n);
@@ -225,7 +233,13 @@ int spectral(fokl_host_pool *pool, fokl_host_job *job, std::string &err)
             err = "dsyevd did not converge (info = " + std::to_string(info) + ")";
             return FOKL_ERR_NUMERIC;
         }
-    } else {
+        by_dsyevd = true;
+    }
+    if (by_dsyevd && !(job->lamb_out[0] > pool->singular * job->lamb_out[n - 1])) {
+        by_dsyevd = false;                                  // numerically singular: the reference's driver decides
+        lwork = liwork = -1;
+    }
+    if (!by_dsyevd) {
         if (isuppz.size() < (size_t)2 * std::max(1, n)) isuppz.resize((size_t)2 * std::max(1, n));
         pool->dsyevr(&jobz, &range, &uplo, &nn, a.data(), &lda, &vl, &vu, &il, &iu, &abstol, &m, job->lamb_out, z, &ldz,
                      isuppz.data(), &work_query, &lwork, &iwork_query, &liwork, &info);
@@ -466,6 +480,7 @@ int spectral_from_parent(fokl_host_pool *pool, fokl_host_job *job, bool *used)
         if (!(std::fabs(z[j]) > 1e-12)) return FOKL_OK;            // lam_j (nearly) stays an eigenvalue: deflation, not done here
     }
     if (!(std::fabs(norm - 1.0) < 1e-10)) return FOKL_OK;
+    if (!(lam[0] > pool->singular * lam[n - 1])) return FOKL_OK;             // numerically singular: dsyevr decides (see `singular`)
     for (int j = 0; j + 1 < n; ++j)
         if (!(lam[j + 1] - lam[j] > 1024.0 * eps * scale)) return FOKL_OK;   // (nearly) repeated eigenvalue
     // roots; D[k * n + j] = lam_j - mu_k
@@ -909,6 +924,7 @@ extern "C" int fokl_pool_create(int chain_threads, int finish_threads, int spect
     if (const char *path = std::getenv("FOKL_POOL_TRACE")) pool->trace_path = path;
     if (const char *us = std::getenv("FOKL_POOL_TEST_DELAY_US")) pool->test_delay_us = std::max(0, std::atoi(us));
     if (const char *signs = std::getenv("FOKL_EIGH_SIGNS")) pool->lapack_signs = std::strcmp(signs, "lapack") == 0;
+    if (const char *sing = std::getenv("FOKL_EIGH_SINGULAR")) pool->singular = std::max(0.0, std::atof(sing));
     try {
         pool->threads.emplace_back(noise_worker, pool);
         if (noise_cpu >= 0 && noise_cpu < CPU_SETSIZE) {

@@ -659,7 +659,6 @@ def test_eigen_update_falls_back_to_a_decomposition(monkeypatch):
         # the parent of another matrix: the diagonal identity fails, the answer is the model's own all the same
         stranger = pool.submit_spectral(other, idx, n).wait()
         job, upd = pool.submit_spectral_update(G, child, n, stranger, 2)
-        assert upd[0] == -1
         res = job.wait()
         assert upd[0] == 0 and np.array_equal(res._buf, fresh._buf)
         # right parent, wrong position
@@ -689,3 +688,40 @@ def test_eigen_update_falls_back_to_a_decomposition(monkeypatch):
         assert upd[0] == 0 and np.array_equal(res._buf, pool.submit_spectral(other, child, n).wait()._buf)
     finally:
         pool.close()
+
+
+def test_nearly_singular_models_get_the_references_driver(monkeypatch):
+    """A model whose XtX is singular to working precision (a repeated column) has no eigenvectors to speak of in its null
+    space: whatever a fit then selects hinges on what the reference's own LAPACK driver returns there.  Such models are
+    decomposed by dsyevr (FR:1499: scipy.linalg.eigh's default) bit for bit -- not by dsyevd, not derived from a parent."""
+    n = 90
+    gram_ok = _gram_for_update(n, 11)
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((400, n - 1))
+    X[:, 40] = X[:, 7] + 1e-13 * rng.standard_normal(400)              # two columns that agree to rounding
+    Z = np.column_stack([np.ones(400), X, rng.standard_normal(400)])
+    gram_sing = Z.T @ Z
+    idx = np.arange(n, dtype=np.int32)
+    child = np.ascontiguousarray(np.delete(idx, 3))
+
+    def run(gram):
+        np.random.seed(1)
+        pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
+        try:
+            parent = pool.submit_spectral(gram, idx, n).wait()
+            job, upd = pool.submit_spectral_update(gram, child, n, parent, 3)
+            kid = job.wait()
+            return np.array(parent._buf), np.array(kid._buf), int(upd[0]), pool.dsyevd_from
+        finally:
+            pool.close()
+
+    monkeypatch.setenv('FOKL_EIGH_DC_FROM', '0')
+    ref_parent, ref_kid, _, dc = run(gram_sing)
+    assert dc == 0
+    ref_ok_parent, _, _, _ = run(gram_ok)
+    monkeypatch.setenv('FOKL_EIGH_DC_FROM', '80')
+    parent, kid, updated, dc = run(gram_sing)
+    assert dc == 80 and updated == 0
+    assert np.array_equal(parent, ref_parent) and np.array_equal(kid, ref_kid)
+    ok_parent, _, ok_updated, _ = run(gram_ok)                          # a well-conditioned model: dsyevd and the update
+    assert ok_updated == 1 and not np.array_equal(ok_parent, ref_ok_parent)
