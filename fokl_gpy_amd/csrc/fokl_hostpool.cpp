@@ -402,10 +402,11 @@ bool secular_root(const double *lam, const double *z2, int n, int k, double *del
 {
     const double eps = 2.220446049250313e-16;
     const double gap = lam[k + 1] - lam[k], half = 0.5 * gap;
-    // which half of the interval: the sign of g at its middle (g rises from -inf to +inf across the interval)
+    // which half of the interval: the sign of g at its middle (g rises from -inf to +inf across the interval) -- which also
+    // is the first iterate
     double psi, dpsi, phi, dphi;
-    secular_sums(lam, z2, 0, k + 1, lam[k], half, delta, &psi, &dpsi);
-    secular_sums(lam, z2, k + 1, n, lam[k], half, delta, &phi, &dphi);
+    secular_sums(lam, z2, 0, k + 1, lam[k], half, delta, &psi, &dpsi);       // every term negative
+    secular_sums(lam, z2, k + 1, n, lam[k], half, delta, &phi, &dphi);       // every term positive
     const int o = psi + phi > 0.0 ? k : k + 1;
     const double pole = lam[o];
     double lo = o == k ? 0.0 : -half, hi = o == k ? half : 0.0;
@@ -413,8 +414,6 @@ bool secular_root(const double *lam, const double *z2, int n, int k, double *del
     const double dk = lam[k] - pole, dk1 = lam[k + 1] - pole;
     bool settled = false;
     for (int it = 0; it < 80; ++it) {
-        secular_sums(lam, z2, 0, k + 1, pole, t, delta, &psi, &dpsi);       // every term negative
-        secular_sums(lam, z2, k + 1, n, pole, t, delta, &phi, &dphi);       // every term positive
         const double g = psi + phi, mag = phi - psi;
         if (!(std::fabs(g) > (double)n * eps * mag)) {      // also leaves on NaN
             settled = g == g;
@@ -448,11 +447,15 @@ bool secular_root(const double *lam, const double *z2, int n, int k, double *del
                     next = r2;
             }
         }
-        if (next == t || !(hi - lo > 0.0)) {                // the bracket is down to neighbouring numbers
+        const bool stuck = next == t || !(hi - lo > 0.0);    // the bracket is down to neighbouring numbers
+        if (!stuck) t = next;
+        // the differences from the pole that was chosen (the first pass measured them from lam_k)
+        secular_sums(lam, z2, 0, k + 1, pole, t, delta, &psi, &dpsi);
+        secular_sums(lam, z2, k + 1, n, pole, t, delta, &phi, &dphi);
+        if (stuck) {
             settled = true;
             break;
         }
-        t = next;
     }
     if (!settled) return false;
     if (delta[k] >= 0.0 || delta[k + 1] <= 0.0) return false;   // mu_k must lie strictly inside its interval

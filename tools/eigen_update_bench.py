@@ -1,7 +1,8 @@
 """tools/eigen_update_bench.py: one spectral thread, one model per size -- G2 by fokl_pool_submit_spectral_update (from the
 eigenpairs of the model with one more column: secular equation + one dgemm) against a fresh decomposition (dsyevr below
 FOKL_EIGH_DC_FROM columns, dsyevd from there on) of the same model; best of 25 round trips each, so the ~30 us of the
-Python call and the thread's wake-up are in both.  Also the deviation between the two in the chain's noise map."""
+Python call and the thread's wake-up are in both; BLAS on one thread, as inside a fit (FoKLRoutines caps it).  Also the
+deviation between the two in the chain's noise map."""
 import os
 import sys
 import time
@@ -25,6 +26,12 @@ def best(f, reps=25):
 
 
 def main():
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1, user_api='blas'):
+        measure()
+
+
+def measure():
     rng = np.random.default_rng(5)
     np.random.seed(1)
     pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
