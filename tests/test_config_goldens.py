@@ -120,3 +120,23 @@ def test_full_size_config_with_the_eigen_decompositions_on_the_device(monkeypatc
     model, betas, mtx, evs, state = fit_like_golden(g)
     assert model.fit_stats['eigh_mode'] == 'device' and model.fit_stats['spectral_device'] > 0
     assert_matches_golden(g, model, betas, mtx, evs, state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cfg2_n1e6_m8', 'cfg4_unit5_n1e5_m8'])
+def test_kill_tests_eigenpairs_derived_from_the_tested_against_model(monkeypatch, name):
+    """The default: G2 of a kill test's model follows from the eigenpairs of the model it is tested against (secular equation
+    + one product, fokl_pool_submit_spectral_update) -- most of a fit's G2 jobs -- and the fit is the golden's: model, every
+    gibbs() call, numpy's stream exactly, draws within the same 1e-9.  FOKL_EIGH_UPDATE=0 (every model decomposed afresh)
+    gives the same fit; the two differ in the draws' last digits only."""
+    g = load_golden(name)
+    model, betas, mtx, evs, state = fit_like_golden(g)
+    st = model.fit_stats
+    assert st['eigh_update_from'] == 8 and st['spectral_updated'] > 0.5 * st['spectral_submitted']
+    assert_matches_golden(g, model, betas, mtx, evs, state)
+    monkeypatch.setenv('FOKL_EIGH_UPDATE', '0')
+    model0, betas0, mtx0, evs0, state0 = fit_like_golden(g)
+    assert 'eigh_update_from' not in model0.fit_stats and model0.fit_stats['spectral_updated'] == 0
+    assert_matches_golden(g, model0, betas0, mtx0, evs0, state0)
+    assert np.array_equal(mtx, mtx0) and betas.shape == betas0.shape
+    assert np.abs(betas - betas0).max() <= 1e-9 * np.abs(betas0).max()
