@@ -100,7 +100,7 @@ SIGNATURES = {
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
     'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
-    'fokl_search_set_update': (c_int, [c_vp, c_int, c_int]),
+    'fokl_search_set_update': (c_int, [c_vp, c_int, c_int, c_int]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
     'fokl_search_mispredicted': (c_int, [c_vp]),
@@ -869,10 +869,11 @@ class NativeSearch:
     def hold_spectral(self, hold):
         self._checked(self._lib.fokl_search_hold_spectral(self._h, 1 if hold else 0))
 
-    def set_update(self, from_columns, depth):
+    def set_update(self, from_columns, depth, lookahead=0):
         """Kill tests' G2 from the tested-against model's eigenpairs for parents of from_columns columns or more (0: never), at
-        most `depth` steps from a fresh decomposition."""
-        self._checked(self._lib.fokl_search_set_update(self._h, int(from_columns), int(depth)))
+        most `depth` steps from a fresh decomposition; `lookahead` (0: the search's own): G2 look-ahead while that is on, in
+        sub-stages whose model has fewer than 192 columns."""
+        self._checked(self._lib.fokl_search_set_update(self._h, int(from_columns), int(depth), int(lookahead)))
 
     def spectral(self, gram, idx, parent=None, parent_pos=-1):
         """parent / parent_pos: a spectrum handle of this search for the model that has one more column, and which of its

@@ -238,6 +238,12 @@ struct fokl_search {
     // at most update_depth steps away from a fresh decomposition (each step waits for the one before it: the chain of
     // accepted tests along the predicted path is cut into pieces that the spectral threads work on side by side)
     int update_from = 0, update_depth = 3;
+    // With derived models the look-ahead of the kill tests' G2 is this deep below kWideModel columns (0: prm.lookahead): a
+    // chain of derivations advances one link per 0.05-0.2 ms, slower than the loop tests (40 us), and only the pieces that
+    // the look-ahead window holds run side by side.  Not for the wide models: there a decomposition takes milliseconds and
+    // a deeper window orders tapes further ahead than the stream keeps pre-states for (configs[3]: 24 deep 1.06 s against
+    // 0.69, 48 deep fails).
+    int lookahead_derived = 0;
     fokl_search_params prm{};
     double sigsqd0 = 0, tausqd0 = 0;
     int speculation = 0;
@@ -1393,12 +1399,14 @@ extern "C" int fokl_search_bind_spectral(fokl_search *s, fokl_dspectral *engine,
 }
 
 // G2 of the kill tests' models from their parent model's eigenpairs: parents of from_columns columns or more (0: never),
-// at most `depth` such steps away from a fresh decomposition.
-extern "C" int fokl_search_set_update(fokl_search *s, int from_columns, int depth)
+// at most `depth` such steps away from a fresh decomposition; `lookahead` (0: the search's own): how many tests ahead G2 is
+// requested then, in sub-stages whose model has fewer than 192 columns.
+extern "C" int fokl_search_set_update(fokl_search *s, int from_columns, int depth, int lookahead)
 {
     if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_set_update: null search");
     s->update_from = std::max(0, from_columns);
     s->update_depth = std::max(1, depth);
+    s->lookahead_derived = std::max(0, lookahead);
     return FOKL_OK;
 }
 
@@ -1708,7 +1716,10 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
     size_t path_from = 0;                                   // path[k] <-> proposal[path_from + k]
     // (as far as the loop orders things ahead: G2 jobs `lookahead` tests deep, tapes speculation_max deep -- a downdate
     // is O(columns^2), the whole rest of a sub-stage of hundreds of columns would cost more than it saves)
-    const int horizon = std::max(s->prm.lookahead, s->prm.speculation_max) + 8;
+    // G2 look-ahead of this sub-stage (see lookahead_derived)
+    const int lookahead = s->update_from > 0 && s->lookahead_derived > 0 && A < kWideModel
+                              ? std::max(s->prm.lookahead, s->lookahead_derived) : s->prm.lookahead;
+    const int horizon = std::max(lookahead, s->prm.speculation_max) + 8;
     bool path_complete = false;                             // the path reaches the end of the proposals
     auto predict = [&](size_t pos) {
         PathModel m = committed;
@@ -1822,7 +1833,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         int deep = 0;
         // host threads: `lookahead` tests deep; the device, which costs no CPU but answers later: as far as dspec_lookahead,
         // and only jobs it can finish before their test comes up
-        const int far = s->dspec ? std::max(s->prm.lookahead, s->dspec_lookahead) : s->prm.lookahead;
+        const int far = s->dspec ? std::max(lookahead, s->dspec_lookahead) : lookahead;
         for (size_t q = pos; q < proposal.size() && deep <= far; ++q) {
             const Step st = step_at(q);
             if (q > pos && !st.run) continue;
@@ -1831,7 +1842,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (ahead.find(key) == ahead.end()) {
                 const auto idx = columns_without(A, key);
                 const double slack = (deep - 1) * s->test_us;
-                if (deep <= s->prm.lookahead + 1 || spectrum_to_device(s, (int)idx.size(), slack)) {
+                if (deep <= lookahead + 1 || spectrum_to_device(s, (int)idx.size(), slack)) {
                     // the model this test is held against: the current one, or the trial model of the accepted test before
                     Spectrum *parent = nullptr;
                     int parent_pos = -1;

@@ -1036,7 +1036,13 @@ class ForwardSelection:
             update_from = int(os.environ.get('FOKL_EIGH_UPDATE', '8'))
             if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) and not self.allreduce \
                     and not self.candidate_sharded and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
-                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')))
+                # FOKL_LOOKAHEAD_DERIVED (default 0: the ordinary look-ahead): a deeper G2 window while derivation is on, in
+                # sub-stages of fewer than 192 columns.  A chain of derivations advances slower than the loop tests, and 24
+                # deep keeps more of its pieces running side by side: configs[2] 40.0-40.1 ms per fit against 40.3-43.0,
+                # waiting for G2 8.0 -> 6.9 ms -- but configs[3] 0.69-1.07 s against 0.62-0.63 (its narrow sub-stages;
+                # not understood), so it stays a knob
+                derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else int(os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
+                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')), derived_ahead)
                 self.stats['eigh_update_from'] = update_from
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')

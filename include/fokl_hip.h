@@ -579,8 +579,10 @@ int fokl_search_hold_spectral(fokl_search *search, int hold);
  * secular equation + one product, 4-5 x cheaper than a decomposition): for parents of from_columns columns or more (0, the
  * default: never) and at most `depth` such steps away from a fresh decomposition -- a step runs when the one before it has,
  * so `depth` cuts the chain of accepted tests along the predicted path into pieces the spectral threads work on side by side.
- * Statistic 'spectral_updated' counts the models that were derived this way. */
-int fokl_search_set_update(fokl_search *search, int from_columns, int depth);
+ * A chain of derivations advances slower than the loop tests and only the pieces inside the look-ahead window run side by
+ * side: `lookahead` (0: fokl_search_params.lookahead) is the window's depth while derivation is on, in sub-stages whose model
+ * has fewer than 192 columns.  Statistic 'spectral_updated' counts the models that were derived this way. */
+int fokl_search_set_update(fokl_search *search, int from_columns, int depth, int lookahead);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);
 /* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */

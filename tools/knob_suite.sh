@@ -21,6 +21,7 @@ modes=(
   "FOKL_EIGH_UPDATE=0"
   "FOKL_EIGH_UPDATE_DEPTH=64"
   "FOKL_BUILD_AHEAD=tests"
+  "FOKL_LOOKAHEAD_DERIVED=24"
   "FOKL_CLEAN=host"
   "FOKL_K1_TOUCH=0"
   "FOKL_K3=columns"
