@@ -231,6 +231,23 @@ class SlotPool:
 # ---------------------------------------------------------------------------------------------------------
 
 
+# Deepest look-ahead of the native kill-test loop that every BASELINE configuration has been run with (0 .. 24: parity green;
+# 24 already costs configs[3] time).  48 on configs[3] orders work so far ahead that a kill test's tape is submitted to the
+# device after the stream has overwritten the pre-states of its segments (512 segments are kept) and the fit stops with
+# "the pre-state of a segment is not (or no longer) in the ring" -- a loud error, but not one a documented knob should reach.
+LOOKAHEAD_MAX = 24
+
+
+def _bounded_lookahead(name, value):
+    depth = max(0, int(value))
+    if depth > LOOKAHEAD_MAX:
+        import warnings
+        warnings.warn(f"{name}={depth} is deeper than the native search has been verified with; using {LOOKAHEAD_MAX}",
+                      RuntimeWarning)
+        depth = LOOKAHEAD_MAX
+    return depth
+
+
 class ForwardSelection:
     """
     One ``fit`` worth of forward selection on an uploaded dataset.
@@ -292,7 +309,7 @@ class ForwardSelection:
         # spectral jobs submitted ahead of the kill tests: three along the guessed path (the Python loop: every miss costs
         # the jobs); the native loop predicts its path (csrc/fokl_search.cpp PathModel) and goes twelve deep
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))
-        self._lookahead_native = int(os.environ.get('FOKL_LOOKAHEAD', '12'))
+        self._lookahead_native = _bounded_lookahead('FOKL_LOOKAHEAD', os.environ.get('FOKL_LOOKAHEAD', '12'))
         # next test's tape requested before the decision that the test is run (rewound when it is not; data-driven, so
         # replicated drivers of a row-sharded fit stay in step) -- FOKL_TENTATIVE_TAPES=0 disables, =test forces rewinds
         # the next sub-stage's columns and Gram block are built, and G2 of its predicted model started, before this
@@ -1041,7 +1058,8 @@ class ForwardSelection:
                 # deep keeps more of its pieces running side by side: configs[2] 40.0-40.1 ms per fit against 40.3-43.0,
                 # waiting for G2 8.0 -> 6.9 ms -- but configs[3] 0.69-1.07 s against 0.62-0.63 (its narrow sub-stages;
                 # not understood), so it stays a knob
-                derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else int(os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
+                derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else _bounded_lookahead(
+                    'FOKL_LOOKAHEAD_DERIVED', os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
                 self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')), derived_ahead)
                 self.stats['eigh_update_from'] = update_from
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'

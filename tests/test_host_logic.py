@@ -739,3 +739,19 @@ def test_lapack_signs_mode_follows_the_untouched_reference(monkeypatch, name):
            abs(g['canon_evs'][canon_shared] - g['ref_evs'][canon_shared]) <= 1e-9 * abs(g['ref_evs'][canon_shared])):
         canon_shared += 1
     assert shared >= canon_shared
+
+
+def test_lookahead_knobs_are_bounded_to_what_was_verified():
+    """FOKL_LOOKAHEAD / FOKL_LOOKAHEAD_DERIVED deeper than engine.LOOKAHEAD_MAX (the deepest window every BASELINE
+    configuration has been run with) are brought back to it with a warning: 48 on configs[3] used to stop the fit with
+    "the pre-state of a segment is not (or no longer) in the ring"."""
+    import warnings as _warnings
+    from fokl_gpy_amd import engine as _engine
+    with _warnings.catch_warnings(record=True) as seen:
+        _warnings.simplefilter('always')
+        assert _engine._bounded_lookahead('FOKL_LOOKAHEAD', '48') == _engine.LOOKAHEAD_MAX == 24
+    assert len(seen) == 1 and issubclass(seen[0].category, RuntimeWarning) and 'FOKL_LOOKAHEAD=48' in str(seen[0].message)
+    with _warnings.catch_warnings(record=True) as seen:
+        _warnings.simplefilter('always')
+        assert [_engine._bounded_lookahead('FOKL_LOOKAHEAD', v) for v in ('0', '12', '24', '-5')] == [0, 12, 24, 0]
+    assert not seen
