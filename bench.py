@@ -139,16 +139,14 @@ def compare_with_golden(name, model, betas, mtx, evs, state):
         out['max_draw_err_over_scale'] = float(np.max(np.abs(betas - g['betas']) / scale))
         out['numpy_stream_equal'] = bool(np.array_equal(state[1], g['rng_key']) and state[2] == int(g['rng_pos']) and
                                          state[3] == int(g['rng_has_gauss']) and state[4] == float(g['rng_cached']))
-        # The draws are betas = w Q': an eigenvector of XtX turns by about ||dXtX|| / gap when XtX changes by dXtX, and the
-        # GPU's Gram differs from the golden's BLAS Gram in its last bits (relative 2^-53 times a small multiple that
-        # grows with the depth of the summation trees).  eps ||XtX|| / (smallest gap) of the RETURNED model is in the fit's
-        # statistics; 1/64 of it is what those last bits can move a draw by, relative to its column's scale.  The gate is
-        # the stated 1e-9 or that bound where the returned model's conditioning puts it above: a host with
-        # another LAPACK build then fails the gate only if something other than conditioning is wrong; the margin against
-        # the fixed 1e-9 is still printed.
+        # The gate is the stated one: BIC 1e-9 relative, draws 1e-9 of the column scale -- the tolerances of
+        # tests/test_config_goldens.py, fixed.  `draw_bound` is information only: betas = w Q', an eigenvector of XtX turns
+        # by about ||dXtX|| / gap when XtX changes by dXtX, and the GPU's Gram differs from the golden's BLAS Gram in its
+        # last bits; 1/64 of eps ||XtX|| / (smallest gap) of the RETURNED model (a statistic of the fit under test, hence
+        # never part of the gate) is what those bits can move a draw by, relative to its column's scale.
         sens = model.fit_stats.get('final_eps_norm_over_gap')
         out['draw_bound'] = float(sens) / 64.0 if sens else None
-        out['draw_gate'] = max(1e-9, out['draw_bound'] or 0.0)
+        out['draw_gate'] = 1e-9
         out['ok'] = bool(out['max_rel_bic'] < 1e-9 and out['max_draw_err_over_scale'] < out['draw_gate'] and
                          out['numpy_stream_equal'] and len(evs) == len(g['evs']))
         # how far inside the stated tolerances (BIC 1e-9 relative, draws 1e-9 of the column scale) the fit

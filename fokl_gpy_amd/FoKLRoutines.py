@@ -753,6 +753,7 @@ class FoKL:
                 comm=comm if comm is not None else getattr(self, '_comm', None),
                 row_sharded=row_sharded, n_global=n_global, candidate_sharded=candidate_sharded)
             search.allow_device_chains = device_chains
+            search.allow_direct_decisions = device_chains        # (a repeated search decides every kill test from its own G2)
             return search
 
         search = new_search(stream)

@@ -101,6 +101,7 @@ SIGNATURES = {
     'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
     'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
     'fokl_search_set_update': (c_int, [c_vp, c_int, c_int, c_int]),
+    'fokl_search_set_decide': (c_int, [c_vp, c_int, c_dbl]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
     'fokl_search_mispredicted': (c_int, [c_vp]),
@@ -812,7 +813,7 @@ SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
                 'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device',
-                'spectral_updated')
+                'spectral_updated', 'direct_tests', 'direct_max_rel', 'chains_cancelled', 't_settle')
 
 
 class NativeSearch:
@@ -874,6 +875,11 @@ class NativeSearch:
         most `depth` steps from a fresh decomposition; `lookahead` (0: the search's own): G2 look-ahead while that is on, in
         sub-stages whose model has fewer than 192 columns."""
         self._checked(self._lib.fokl_search_set_update(self._h, int(from_columns), int(depth), int(lookahead)))
+
+    def set_decide(self, mode, tolerance=0.0):
+        """Kill tests' BIC decisions: 0 from G2 of every trial model, 1 from the downdated least-squares model of the
+        sub-stage, confirmed by the accepted models' eigenpairs to `tolerance` (relative; 0: 1e-9)."""
+        self._checked(self._lib.fokl_search_set_decide(self._h, int(mode), float(tolerance)))
 
     def spectral(self, gram, idx, parent=None, parent_pos=-1):
         """parent / parent_pos: a spectrum handle of this search for the model that has one more column, and which of its

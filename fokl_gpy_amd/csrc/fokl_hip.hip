@@ -1307,6 +1307,15 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
         // workgroups per CU that share the rows of a group: more of them hide more latency but every one writes a
         // partial block the reduction has to read back (FOKL_GRAM_WGS caps it)
         const int wgs_cap = std::max(1, dev_int("FOKL_GRAM_WGS", 3));
+        // The row cut S decides which rows meet in which partial sum, i.e. the last bits of the block.  It must move neither
+        // with a compiler or an edit that changes a kernel's register count, nor with the device the fit happens to run on (a
+        // partition with fewer CUs, another SKU), nor with what the occupancy query says today: it is the cut of kCutCus CUs
+        // hosting a PINNED number of workgroups each -- what these kernels could host when the goldens' margins were
+        // measured, under the 160 KB of LDS counted by arithmetic -- so the same rows meet in the same partial sums
+        // everywhere and a golden measured on one device holds on another.  Resident or queued, every
+        // workgroup has the same work.
+        constexpr int kCutCus = 256;
+        auto lds_fit = [](size_t lds) { return (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)); };
         int S;
 #ifdef FOKL_DEV_KERNELS
         if (kind == 1) {
@@ -1317,12 +1326,7 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + 31) / 32;
             const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, G4S_THREADS, lds));
-            // ... nor with the device the fit happens to run on (a partition with fewer CUs, another SKU) or with what the
-            // occupancy query says today: the cut is the one of 256 CUs hosting `by_registers` workgroups each, whatever
-            // hosts them -- the same rows meet in the same partial sums everywhere, so a golden measured on one device
-            // holds on another; resident or queued, every workgroup has the same work.
-            constexpr int kCutCus = 256;
-            const int target = std::max(1, (std::min(wgs_cap, by_registers) * kCutCus) / (int)pl.groups.size());
+            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());      // (A/B kernel: no pinned row cut)
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
@@ -1370,7 +1374,8 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
                 else
                     loaders = 0;
             }
-            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            const int cut_per_cu = std::min({wgs_cap, by_registers, lds_fit(lds)});
+            const int target = std::max(1, (cut_per_cu * kCutCus) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * nr_pad * nc_pad);
             if (rc) return rc;
@@ -1385,8 +1390,13 @@ static int gram_enqueue(fokl_ctx *ctx, const int32_t *row_slots, int nr, const i
             rc = raise_lds_limit(reinterpret_cast<const void *>(fn), lds);
             if (rc) return rc;
             const int64_t n_chunks = (ctx->n + R - 1) / R;
-            const int per_cu = std::min(wgs_cap, blocks_per_cu(fn, GT_THREADS, lds));
-            const int target = std::max(1, (per_cu * cus) / (int)pl.groups.size());
+            // the product's launches here are the k-split teams of the smallest blocks (ks = 2, 4: one tile per wavefront):
+            // three workgroups per CU by registers except with 16 staging passes and two chunks in flight (187 VGPRs: two);
+            // ks = 1 only runs here under FOKL_GRAM_DMA != 2 (A/B runs): the occupancy query, as before
+            const int passes = pl.ct << pl.rb_shift;
+            const int by_registers = pl.ks > 1 ? (passes > 8 && pl.depth == 2 ? 2 : 3) : blocks_per_cu(fn, GT_THREADS, lds);
+            const int cut_per_cu = std::min({wgs_cap, by_registers, lds_fit(lds)});
+            const int target = std::max(1, (cut_per_cu * (pl.ks > 1 ? kCutCus : cus)) / (int)pl.groups.size());
             S = (int)std::max<int64_t>(1, std::min<int64_t>(n_chunks, target));
             rc = ensure_slab(ctx, (size_t)S * pl.ks * nr_pad * nc_pad);
             if (rc) return rc;

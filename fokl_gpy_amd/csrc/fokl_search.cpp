@@ -201,6 +201,12 @@ struct Outcome {
     double intercept_scale = NAN;
     std::vector<Check> checks;
     bool release_wanted = false, released = false;
+    // A kill test decided from the downdated least-squares model (fokl_search_set_decide, mode 1): the outcome exists from
+    // the moment of the decision, its G2 may still be running and its chain has not been started -- `lazy` until
+    // settle_pending has started the chain (or found that nobody will ever look at it: `cancelled`)
+    bool lazy = false, cancelled = false;
+    double s1 = NAN, s2 = NAN;              // residual moments the BIC was formed from
+    double ls_intercept = NAN;              // least-squares intercept known at decision time (lazy outcomes)
     int refs = 1;                           // Python handle + the search's own lists
 };
 
@@ -217,6 +223,7 @@ enum Stat {
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
     S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_SPECTRAL_UPDATED,
+    S_DIRECT_TESTS, S_DIRECT_MAX_REL, S_CHAINS_CANCELLED, S_T_SETTLE,
     S_COUNT
 };
 
@@ -263,6 +270,16 @@ struct fokl_search {
     std::map<std::vector<int64_t>, double> ev_cache;
     std::vector<int64_t> active_ids;        // term id of every active column of the sub-stage (column 0: the intercept)
     std::deque<Outcome *> unverified;
+    // Kill tests' BIC decisions (fokl_search_set_decide).  0: from G2 of the trial model (round 4: the loop waits for the
+    // eigenpairs of every model it tests).  1: from the least-squares model of the sub-stage downdated column by column
+    // (PathModel: SSR without column c = SSR + b_c^2 / [(X'X)^-1]_cc, exact in exact arithmetic) -- the decision takes
+    // microseconds, G2 is requested for ACCEPTED models only and feeds nothing but their chains, which start when it
+    // arrives (`pending`, in decision order); the BIC G2 brings along (Gram identity in 80-bit) is held against the
+    // decision's, and a difference beyond direct_tolerance (relative) ends the search as a misprediction does.
+    int decide = 0;
+    double direct_tolerance = 1e-9;
+    size_t pending_max = 40;                // accepted models waiting for G2 at most: the loop then waits for the oldest
+    std::deque<Outcome *> pending;
     std::deque<Outcome *> zombies;          // device chains nobody will look at: slots go back once they have run
     std::vector<Outcome *> device_outcomes;  // every device-chained outcome alive (all released when the search ends)
     std::vector<Forecast> forecasts;
@@ -743,8 +760,12 @@ void speculate(fokl_search *s, const std::vector<std::pair<int, bool>> &sizes)
     }
 }
 
+int ensure_started(fokl_search *s, Outcome *o);
+int settle_pending(fokl_search *s, bool block, Outcome *upto);
+
 bool chain_done(Outcome *o)
 {
+    if (o->lazy) return false;                              // its chain has not even been started (settle_pending)
     if (o->on_device) {
         if (o->device_released) return true;
         double seen;
@@ -774,6 +795,10 @@ int wait_host_chain(fokl_search *s, Outcome *o)
 // mean over the rows from `first_row` on of the intercept draws (betas[:, 0] = w Q[0, :]')
 int mean_intercept_draw(fokl_search *s, Outcome *o, int first_row, double *out)
 {
+    if (o->lazy || o->cancelled) {
+        const int rc = ensure_started(s, o);
+        if (rc != FOKL_OK) return rc;
+    }
     const int p1 = o->spec->p1;
     const double *q0 = o->spec->Qt();                       // Qt[j][0] at j * p1
     if (o->on_device) {
@@ -865,6 +890,15 @@ void unref(fokl_search *s, Outcome *o)
 void release_outcome(fokl_search *s, Outcome *o)
 {
     if (o->released) return;
+    if (o->lazy) {
+        // no chain yet: with guessed decisions to confirm it will run and be released by verify(); without, settle_pending
+        // finds it released and never starts it
+        if (!o->checks.empty())
+            o->release_wanted = true;
+        else
+            o->released = true;
+        return;
+    }
     if (o->on_device) {
         if (!o->checks.empty()) {                           // its statistics still have to confirm guessed decisions
             o->release_wanted = true;
@@ -959,22 +993,18 @@ void record(fokl_search *s, int p1, int n_prev, double ev, bool kill)
     s->trace.insert(s->trace.end(), {(double)p1, (double)(p1 - n_prev), ev, kill ? 1.0 : 0.0});
 }
 
-// engine.ForwardSelection._commit: the chain of the evaluation (spectrum, tape) -- device engine for a kill test's
-// candidate if there is one, else a host chain thread (the one started ahead if it is this one)
-Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
+// engine.ForwardSelection._commit: the chain of the evaluation (o->spec, which has run; o->tape) -- device engine for a
+// kill test's candidate if there is one, else a host chain thread (the one started ahead if it is this one)
+int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
 {
-    auto *o = new Outcome();
-    o->spec = sp;
-    sp->refs += 1;
-    o->tape = t;                                            // takes over the caller's reference
+    Spectrum *sp = o->spec;
+    Tape *t = o->tape;
     const int p1 = sp->p1;
     if (test && t->rows_only && t->rows[0].lead_source == FOKL_SOURCE_GIVEN && (t->rows[0].start & FOKL_ROW_LEAD) &&
         __atomic_load_n(t->progress, __ATOMIC_ACQUIRE) > 0) {
         // (the very first tape of a stream handed over with a cached normal: that value exists on the host only)
-        if (materialise(s, t) != FOKL_OK) {
-            destroy_outcome(s, o);
-            return nullptr;
-        }
+        const int rc = materialise(s, t);
+        if (rc != FOKL_OK) return rc;
     }
     if (test && t->rows_only) {
         const int rc = fokl_dchain_submit_rows(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
@@ -986,12 +1016,11 @@ Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
             s->device_outcomes.push_back(o);
             s->stats[S_DEVICE_CHAINS] += 1;
             s->stats[S_ROWS_CHAINS] += 1;
-            return o;
+            return FOKL_OK;
         }
-        if (rc != FOKL_ERR_STATE || materialise(s, t) != FOKL_OK) {     // FOKL_ERR_STATE: every slot is alive -> host chain
-            destroy_outcome(s, o);
-            return nullptr;
-        }
+        if (rc != FOKL_ERR_STATE) return rc;                // FOKL_ERR_STATE: every slot is alive -> host chain
+        const int rcm = materialise(s, t);
+        if (rcm != FOKL_OK) return rcm;
     }
     if (test && s->dchain && !t->rows_mem && p1 <= s->prm.device_chain_columns && s->prechain.tape != t) {
         const int rc = fokl_dchain_submit(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
@@ -1003,12 +1032,9 @@ Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
             o->refs += 1;
             s->device_outcomes.push_back(o);
             s->stats[S_DEVICE_CHAINS] += 1;
-            return o;
+            return FOKL_OK;
         }
-        if (rc != FOKL_ERR_STATE) {                         // FOKL_ERR_STATE: every slot is alive -> the host chain
-            destroy_outcome(s, o);
-            return nullptr;
-        }
+        if (rc != FOKL_ERR_STATE) return rc;                // FOKL_ERR_STATE: every slot is alive -> the host chain
     }
     auto &pc = s->prechain;
     if (pc.tape) {
@@ -1021,24 +1047,99 @@ Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
             unref(s, pc.spec);
             unref(s, pc.tape);                              // the chain's reference: the outcome holds the tape now
             pc = {};
-            return o;
+            return FOKL_OK;
         }
         drop_prechain(s);
     }
     o->w = take_w(s, p1, &o->w_classes, &o->w_pinned);
     o->flag = new int32_t(0);
-    if (!o->w) {
-        destroy_outcome(s, o);
-        fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a chain's draws");
-        return nullptr;
-    }
+    if (!o->w) return fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a chain's draws");
     o->chain = submit_host_chain(s, sp, t, dtd, o->w, o->flag);
     if (!o->chain) {
         o->chain_waited = true;
+        return FOKL_ERR_STATE;
+    }
+    return FOKL_OK;
+}
+
+Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
+{
+    auto *o = new Outcome();
+    o->spec = sp;
+    sp->refs += 1;
+    o->tape = t;                                            // takes over the caller's reference
+    if (start_chain(s, o, dtd, test) != FOKL_OK) {
         destroy_outcome(s, o);
         return nullptr;
     }
     return o;
+}
+
+// ---- kill tests decided from the downdated least-squares model: outcomes whose chains wait for G2 --------------------
+
+// BIC of the moments, nothing else (ev_from_moments also notes siglik for the caller)
+double ev_only(const fokl_search *s, double s1, double s2, int p1)
+{
+    const double n = (double)s->prm.n;
+    const double siglik = s2 / n - (s1 / n) * (s1 / n);
+    const double lik = siglik > 0 ? -(n / 2) * std::log(siglik) - (n - 1) / 2 : NAN;
+    double ev = p1 * std::log(n) - 2 * lik;
+    if (s->prm.aic) ev = ev + (2 - std::log(n)) * p1;
+    return ev;
+}
+
+// The oldest pending outcomes whose G2 has run (block: all of them, waiting): the BIC of the eigenpairs is held against the
+// one the decision was taken from; the chain starts -- unless the model has been replaced since and no guessed decision
+// hangs on its intercept: nobody will ever look at those draws (FR:1686-1690 keeps the accepted model's only).
+// upto: stop once this outcome has been dealt with (NULL: no such limit).
+int settle_pending(fokl_search *s, bool block, Outcome *upto)
+{
+    while (!s->pending.empty()) {
+        Outcome *o = s->pending.front();
+        if (!block && !spectrum_done(o->spec)) break;
+        const double t0 = now_s();
+        const int rc = wait_spectrum(s, o->spec);
+        s->stats[S_T_SETTLE] += now_s() - t0;
+        s->pending.pop_front();
+        int out = rc;
+        if (rc == FOKL_OK) {
+            const double *m = o->spec->moments();
+            const double other = ev_only(s, m[0], m[1], o->spec->p1);
+            const double rel = std::fabs(other - o->ev) / std::fabs(o->ev);
+            if (rel > s->stats[S_DIRECT_MAX_REL]) s->stats[S_DIRECT_MAX_REL] = rel;
+            if (!(rel <= s->direct_tolerance) && m[1] > 1e-6 * o->dtd) {
+                s->mispredicted = true;
+                out = fail(s, FOKL_ERR_STATE, "kill test decided from a downdated least-squares fit whose BIC the eigenpairs "
+                                              "of the model do not confirm");
+            }
+        }
+        if (out == FOKL_OK && o->released && o->checks.empty() && !o->release_wanted) {
+            o->cancelled = true;                            // replaced before anybody needed its draws
+            s->stats[S_CHAINS_CANCELLED] += 1;
+        } else if (out == FOKL_OK) {
+            out = start_chain(s, o, o->dtd, true);
+        }
+        o->lazy = false;
+        if (out != FOKL_OK || o->cancelled) {
+            if (s->prechain.tape == o->tape) drop_prechain(s);
+            unref(s, o->tape);                              // walked all the same: the stream advances as the reference's
+            o->tape = nullptr;
+            if (out != FOKL_OK) o->chain_status = out, o->chain_waited = true;
+        }
+        const bool last = o == upto;
+        unref(s, o);                                        // the list's reference
+        if (out != FOKL_OK) return out;
+        if (last) break;
+    }
+    return FOKL_OK;
+}
+
+// The chain of a lazy outcome is needed now (its statistics, its draws): everything up to it is settled, waiting for G2.
+int ensure_started(fokl_search *s, Outcome *o)
+{
+    if (!o->lazy) return o->cancelled ? fail(s, FOKL_ERR_STATE, "fokl_search: the draws of a replaced model were never formed")
+                                      : FOKL_OK;
+    return settle_pending(s, true, o);
 }
 
 // engine.ForwardSelection._second_clause_now: `value < threshav * |mean intercept draw of o|` if it can be had without
@@ -1051,14 +1152,21 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
         if (rc != FOKL_OK) return -2 + rc;
         return value < s->prm.threshav * scale ? 1 : 0;
     }
-    if (!o->on_device) return -1;
-    const double threshold = s->prm.threshav * std::fabs(o->spec->betahat()[0]);
+    // a lazy outcome's chain will run on the device if there is an engine for it (start_chain)
+    const bool device_chain = o->on_device || (o->lazy && s->dchain && o->tape &&
+                                               (o->tape->rows_only || o->spec->p1 <= s->prm.device_chain_columns));
+    if (!device_chain) return -1;
+    const double threshold = s->prm.threshav * std::fabs(o->lazy ? o->ls_intercept : o->spec->betahat()[0]);
     if (!(threshold > 0.0) || !std::isfinite(threshold) ||
         std::fabs(value - threshold) <= s->prm.guess_margin * threshold) {
         // too close to call from the guess, and the device's answer is milliseconds away: the chain once more, in line on
         // this thread (same tape, same arithmetic up to the last bit of log()).  The tape is still there: the device job
         // is its reader until it has run.
         if (std::isnan(o->dtd) || !o->tape) return -1;
+        if (o->lazy) {                                      // the eigenpairs the chain runs on may still be on their way
+            const int rcw = wait_spectrum(s, o->spec);
+            if (rcw != FOKL_OK) return -2 + rcw;
+        }
         s->stats[S_GUESS_WAITS] += 1;
         const double t0 = now_s();
         Tape *t = o->tape;
@@ -1112,6 +1220,10 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
 // statistics -- those that have arrived, or (block) all of them.  FOKL_ERR_STATE + s->mispredicted if one does not hold.
 int verify(fokl_search *s, bool block)
 {
+    if (!s->pending.empty()) {
+        const int rc = settle_pending(s, block, nullptr);
+        if (rc != FOKL_OK) return rc;
+    }
     while (!s->zombies.empty()) {
         Outcome *z = s->zombies.front();
         if (!z->device_released) {
@@ -1311,6 +1423,16 @@ extern "C" void fokl_search_destroy(fokl_search *s)
     if (!s) return;
     drop_speculation(s, 0);
     if (s->prechain.tape) drop_prechain(s);
+    while (!s->pending.empty()) {                           // chains that were never started: their tapes were walked, that is all
+        Outcome *o = s->pending.front();
+        s->pending.pop_front();
+        o->lazy = false;
+        o->cancelled = true;
+        o->checks.clear();
+        unref(s, o->tape);
+        o->tape = nullptr;
+        unref(s, o);
+    }
     for (auto &f : s->forecasts) unref(s, f.spec);
     s->forecasts.clear();
     while (!s->unverified.empty()) {
@@ -1410,6 +1532,17 @@ extern "C" int fokl_search_set_update(fokl_search *s, int from_columns, int dept
     return FOKL_OK;
 }
 
+// How the kill tests' BICs are decided (see fokl_search::decide): 0 from G2 of every trial model, 1 from the sub-stage's
+// least-squares model downdated column by column, confirmed by the accepted models' eigenpairs to `tolerance` (relative;
+// <= 0: the default 1e-9).
+extern "C" int fokl_search_set_decide(fokl_search *s, int mode, double tolerance)
+{
+    if (!s || mode < 0 || mode > 1) return fail(s, FOKL_ERR_ARG, "fokl_search_set_decide: bad arguments");
+    s->decide = mode;
+    if (tolerance > 0.0) s->direct_tolerance = tolerance;
+    return FOKL_OK;
+}
+
 // Between hold(1) and hold(0) fokl_search_spectral only stages its jobs: hold(0) launches them as one grid.
 extern "C" int fokl_search_hold_spectral(fokl_search *s, int hold)
 {
@@ -1493,6 +1626,8 @@ extern "C" int fokl_search_score(fokl_search *s, fokl_outcome *h, double s1, dou
     const int p1 = o->spec->p1;
     o->ev = same_model_same_ev(s, o->spec->idx.data(), p1, ev_from_moments(s, s1, s2, p1));
     o->siglik = s->last_siglik;
+    o->s1 = s1;
+    o->s2 = s2;
     record(s, p1, n_prev, o->ev, kill != 0);
     *ev = o->ev;
     return FOKL_OK;
@@ -1531,6 +1666,10 @@ extern "C" int fokl_outcome_draws(fokl_search *s, fokl_outcome *h, const double 
     if (!s || !h || !w) return fail(s, FOKL_ERR_ARG, "fokl_outcome_draws: null pointer");
     Outcome *o = reinterpret_cast<Outcome *>(h);
     if (o->released) return fail(s, FOKL_ERR_STATE, "fokl_outcome_draws: the outcome's draws were released");
+    if (o->lazy || o->cancelled) {
+        const int rc = ensure_started(s, o);
+        if (rc != FOKL_OK) return rc;
+    }
     if (o->on_device) {
         if (!o->w) {
             o->w = take_w(s, o->spec->p1, &o->w_classes, &o->w_pinned);
@@ -1867,6 +2006,140 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         return FOKL_OK;
     };
 
+    // ---- mode 1: decisions from the downdated least-squares model (fokl_search::decide) -------------------------------
+    // Only where the sub-stage model's BIC came with its residual moments (fokl_search_score) and its Gram is not
+    // numerically singular (there the eigen-solver's own choices decide, see fokl_host_pool::singular).
+    const bool direct = s->decide == 1 && std::isfinite(best->s2) && best->spec->p1 == A &&
+                        best->spec->lamb()[0] > 1e-9 * best->spec->lamb()[A - 1];
+    auto run_direct = [&]() -> int {
+        PathModel &m = committed;
+        m.ssr = best->s2;                                   // the device's residual pass, not the Gram identity
+        m.s1 = best->s1;
+        for (size_t pos = 0; pos < proposal.size(); ++pos) {
+            const int i = proposal[pos];
+            bool decided = clause1[(size_t)i];
+            int rc2 = verify(s, false);                     // (also starts the chains whose G2 has arrived)
+            if (rc2 != FOKL_OK) return rc2;
+            if (!decided) {
+                const int quick = second_clause_now(s, best, a->mean_abs[i]);
+                if (quick < -1) return quick + 2;
+                if (quick == 0) continue;
+                if (quick == 1) {
+                    decided = true;
+                    if (!std::isnan(best->intercept_scale)) scale_guess = best->intercept_scale;
+                }
+            }
+            if (!decided) {
+                // no guess to be had (host chains; a borderline case whose tape is gone): the chain of `best` decides
+                if ((rc2 = intercept_scale(s, best, &scale_guess)) != FOKL_OK) return rc2;
+                if (!(a->mean_abs[i] < threshav * scale_guess)) continue;
+            }
+            const int32_t col = a->columns[i];
+            const int at = m.position(col);
+            if (at <= 0) return fail(s, FOKL_ERR_STATE, "fokl_search_kill_tests: a proposal is not a column of the model");
+            const auto trial = with_column(killed, col);
+            const int p1 = A - (int)trial.size();
+            Tape *tape = tape_for(s, p1, false);            // the stream moves on at once
+            if (!tape) return FOKL_ERR_STATE;
+            if (idle_pending) {
+                idle_pending = false;
+                if ((rc2 = a->idle_work(a->user)) != FOKL_OK) {
+                    unref(s, tape);
+                    return rc2;
+                }
+            }
+            const auto idx = columns_without(A, trial);
+            auto take_spectrum = [&]() -> Spectrum * {
+                Spectrum *sp = nullptr;
+                auto it = ahead.find(trial);
+                if (it != ahead.end()) {
+                    sp = it->second;                        // (the map's reference becomes the caller's)
+                    ahead.erase(it);
+                } else {
+                    sp = submit_spectrum(s, gram, ld, idx.data(), p1, -1.0, s->update_from > 0 ? best->spec : nullptr, at);
+                    flush_spectra(s);
+                }
+                return sp;
+            };
+            double s1 = m.s1, s2 = m.ssr_without(at);
+            Spectrum *sp = nullptr;
+            if (!(s2 > 1e-6 * dtd)) {
+                // a candidate that (nearly) interpolates the data: the device's residual pass on the eigenpairs' betahat,
+                // as in mode 0
+                if (!(sp = take_spectrum())) {
+                    unref(s, tape);
+                    return FOKL_ERR_STATE;
+                }
+                rc2 = wait_spectrum(s, sp);
+                const double t0 = now_s();
+                if (rc2 == FOKL_OK && !a->residual)
+                    rc2 = fail(s, FOKL_ERR_STATE, "fokl_search_kill_tests: a residual pass is needed and no callback was given");
+                if (rc2 == FOKL_OK) rc2 = a->residual(a->user, sp->idx.data(), p1, sp->betahat(), &s1, &s2);
+                if (rc2 != FOKL_OK) {
+                    unref(s, sp);
+                    unref(s, tape);
+                    return rc2;
+                }
+                s->stats[S_T_RESID] += now_s() - t0;
+            } else {
+                s->stats[S_BIC_FROM_GRAM] += 1;
+            }
+            const double ev = same_model_same_ev(s, idx.data(), p1, ev_from_moments(s, s1, s2, p1));
+            const double siglik = s->last_siglik;
+            s->stats[S_DIRECT_TESTS] += 1;
+            if (ev < evmin) {
+                if (!sp && !(sp = take_spectrum())) {
+                    unref(s, tape);
+                    return FOKL_ERR_STATE;
+                }
+                auto *cand = new Outcome();
+                cand->spec = sp;                            // takes over this block's reference
+                cand->tape = tape;
+                cand->lazy = true;
+                cand->dtd = dtd;
+                cand->ev = ev;
+                cand->siglik = siglik;
+                cand->s1 = s1;
+                cand->s2 = s2;
+                m.remove(at);
+                m.ssr = s2;                                 // (the residual pass's, where that decided)
+                cand->ls_intercept = m.beta[0];
+                cand->refs += 1;
+                s->pending.push_back(cand);
+                killed = trial;
+                evmin = ev;
+                release_outcome(s, best);                   // the model it replaces: its draws are history
+                const bool own = best != reinterpret_cast<Outcome *>(a->best);
+                unref(s, best);
+                if (own) unref(s, best);                    // (nobody else holds an intermediate model's creation reference)
+                best = cand;
+                best->refs += 1;                            // this loop's reference (the creation reference becomes the caller's)
+            } else {
+                if (s->prechain.tape == tape) drop_prechain(s);
+                unref(s, tape);                             // walked all the same: the stream advances as the reference's
+                if (sp) unref(s, sp);
+                s->stats[S_CHAINS_SKIPPED] += 1;
+            }
+            record(s, p1, a->n_prev, ev, true);
+            // bounded: accepted models waiting for G2 (their tapes hold the stream), tapes waiting for the walker
+            while (s->pending.size() > s->pending_max)
+                if ((rc2 = settle_pending(s, true, s->pending.front())) != FOKL_OK) return rc2;
+            if ((pos & 7) == 7) reap(s, false);
+            while (s->tape_limbo.size() > 2 * s->pending_max) {
+                (void)fokl_pool_wait(s->tape_limbo.front()->noise);
+                reap(s, false);
+            }
+        }
+        // the kill set is final: G2 of the coming sub-stage's model can start
+        if (a->foresee && !idle_pending) {
+            std::vector<int32_t> pred(killed);
+            a->foresee(a->user, pred.data(), (int)pred.size());
+        }
+        return FOKL_OK;
+    };
+    if (direct) {
+        rc = run_direct();
+    } else {
     predict(0);
     forecast(0);
     order_tapes(0);
@@ -2007,7 +2280,10 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             killed = trial;
             evmin = ev;
             release_outcome(s, best);                       // the model it replaces: its draws are history
+            // (an accepted test's outcome that is replaced in its turn: nobody holds its creation reference either)
+            const bool own = best != reinterpret_cast<Outcome *>(a->best);
             unref(s, best);
+            if (own) unref(s, best);
             best = cand;
             best->ev = ev;
             best->siglik = siglik;
@@ -2025,11 +2301,17 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
         order_tapes(pos + 1);
         if ((pos & 7) == 7) reap(s, false);
     }
+    }
     if (rc == FOKL_OK) {
         order_tapes(proposal.size());                       // the kill set is final
         if (idle_pending) {
             rc = a->idle_work(a->user);
-            if (rc == FOKL_OK) forecast(proposal.size());
+            if (rc == FOKL_OK && direct && a->foresee) {
+                std::vector<int32_t> pred(killed);
+                a->foresee(a->user, pred.data(), (int)pred.size());
+            } else if (rc == FOKL_OK) {
+                forecast(proposal.size());
+            }
         }
     }
     for (auto &kv : ahead) unref(s, kv.second);

@@ -1062,6 +1062,17 @@ class ForwardSelection:
                     'FOKL_LOOKAHEAD_DERIVED', os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
                 self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')), derived_ahead)
                 self.stats['eigh_update_from'] = update_from
+            # Kill tests' BICs from the sub-stage's least-squares model downdated column by column (microseconds on the
+            # search thread; G2 then only feeds the accepted models' chains and confirms the BIC) instead of from G2 of every
+            # trial model, which the loop had to wait for: FOKL_KILL_DECIDE = direct (default) | g2.  A fit repeated after a
+            # misprediction runs with g2.
+            decide = os.environ.get('FOKL_KILL_DECIDE', 'direct')
+            if decide not in ('direct', 'g2'):
+                raise ValueError("FOKL_KILL_DECIDE must be direct or g2")
+            if not getattr(self, 'allow_direct_decisions', True):
+                decide = 'g2'
+            self.native.set_decide(1 if decide == 'direct' else 0, float(os.environ.get('FOKL_KILL_DECIDE_TOL', '0')))
+            self.stats['kill_decide'] = decide
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         _mark('pool_up')
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run

@@ -758,8 +758,7 @@ class NativeOutcome:
     """One model evaluation of a NativeSearch (csrc/fokl_search.cpp): GibbsOutcome's interface over a native handle.  The
     spectrum, the draws and their buffers belong to the search; the arrays here are views that live as long as this
     object is not released / dropped."""
-    __slots__ = ('_ns', 'h', 'lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'siglik', 'on_device', '_w', '_betas',
-                 '_scale', '_owner')
+    __slots__ = ('_ns', 'h', 'lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'siglik', '_w', '_betas', '_scale', '_owner')
 
     def __init__(self, owner, ns, handle):
         self._owner, self._ns, self.h = owner, ns, handle
@@ -770,8 +769,13 @@ class NativeOutcome:
         spec = _capi.SpectralResult(p1, buf)
         self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
         self.idx = np.array(np.ctypeslib.as_array((ctypes.c_int32 * p1).from_address(view.idx)))
-        self.ev, self.siglik, self.on_device = view.ev, view.siglik, bool(view.on_device)
+        self.ev, self.siglik = view.ev, view.siglik
         self._w = self._betas = self._scale = None
+
+    @property
+    def on_device(self):
+        # (a kill test decided before its G2 had run has no chain yet: asked when somebody wants to know)
+        return bool(self._ns.outcome_info(self.h).on_device)
 
     @property
     def intercept_scale(self):

@@ -583,6 +583,17 @@ int fokl_search_hold_spectral(fokl_search *search, int hold);
  * side: `lookahead` (0: fokl_search_params.lookahead) is the window's depth while derivation is on, in sub-stages whose model
  * has fewer than 192 columns.  Statistic 'spectral_updated' counts the models that were derived this way. */
 int fokl_search_set_update(fokl_search *search, int from_columns, int depth, int lookahead);
+/* How a kill test's BIC (FR:1686: `evtest < evmin`) is decided.  mode 0: from G2 of the trial model -- the loop waits for the
+ * eigenpairs of every model it tests (round 4).  mode 1: from the sub-stage model's least-squares fit with the tested columns
+ * removed one by one (sum of squared residuals without column c = SSR + b_c^2 / [(X'X)^-1]_cc, (X'X)^-1 and b one rank-one
+ * downdate per accepted test): microseconds per test on the search thread; G2 is then requested for ACCEPTED models only,
+ * feeds nothing but their chains (started when it arrives) and brings a second BIC (Gram identity on the eigenpairs'
+ * betahat) that must agree with the decision's to `tolerance` (relative; <= 0: 1e-9) -- else the search ends as after a
+ * mispredicted guess (fokl_search_mispredicted) and the driver repeats it in mode 0.  Sub-stages whose model is
+ * numerically singular (smallest eigenvalue <= 1e-9 of the largest) run in mode 0 whatever is set here.  Statistics
+ * 'direct_tests', 'direct_max_rel' (largest relative difference seen), 'chains_cancelled' (accepted models replaced
+ * before anything looked at their draws: their chains never run). */
+int fokl_search_set_decide(fokl_search *search, int mode, double tolerance);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);
 /* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */

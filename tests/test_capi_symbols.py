@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from helpers import ROOT
 from fokl_gpy_amd import _capi
 
@@ -49,3 +51,18 @@ def test_no_device_is_reported_not_hidden():
 
 def test_version():
     assert _capi.load().fokl_version() >= 100
+
+
+def test_development_build_of_the_hip_translation_unit_still_parses():
+    """`make DEV=1` (the retired Gram kernels kept for A/B runs, -DFOKL_DEV_KERNELS) shares fokl_hip.hip with the product
+    build: a host-side syntax pass over it catches an edit that only compiles without the flag."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    src = os.path.join(os.path.dirname(os.path.abspath(_capi.__file__)), 'csrc', 'fokl_hip.hip')
+    res = subprocess.run([hipcc, '-std=c++17', '-ffp-contract=off', '--offload-arch=gfx950', '-DFOKL_DEV_KERNELS',
+                          '--cuda-host-only', '-fsyntax-only', '-Wno-unused-command-line-argument', src],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
