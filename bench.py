@@ -926,7 +926,9 @@ def main():
                     dchain_timed=0, t_final_verify=0.0,
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
-                    rows_chains=0, path_repredicted=0, t_pool_up=0.0, spectral_device=0, spectral_updated=0)
+                    rows_chains=0, path_repredicted=0, t_pool_up=0.0, spectral_device=0, spectral_updated=0,
+                    direct_tests=0, chains_cancelled=0, t_settle=0.0)
+        direct_max_rel = 0.0                                  # (a maximum, not a sum: kept out of `host`)
         drivers = set()
         for _ in range(args.steps):
             for st in one_step():
@@ -936,6 +938,7 @@ def main():
                 calls += st['gibbs_calls']
                 for key in host:
                     host[key] += st.get(key, 0)
+                direct_max_rel = max(direct_max_rel, st.get('direct_max_rel', 0.0))
                 for key, value in st.get('phases', {}).items():
                     host['phase_' + key] = host.get('phase_' + key, 0.0) + value
         ctx.sync()
@@ -1238,6 +1241,15 @@ def main():
         'chain_mode': os.environ.get('FOKL_CHAIN', 'auto'),
         # who ran the kill tests (csrc/fokl_search.cpp or engine.py's loop) and how the random stream reached the chains
         'search_driver': '+'.join(sorted(drivers)),
+        # how the kill tests' BICs were decided (fokl_search_set_decide): tests decided from the downdated least-squares model
+        # per step, the largest relative difference between such a BIC and the one the accepted model's eigenpairs gave
+        # afterwards (every accepted test is checked; the search ends if one exceeds 1e-9), accepted models whose chain
+        # never had to run
+        'kill_decisions': {'mode': os.environ.get('FOKL_KILL_DECIDE', 'direct'),
+                           'direct_tests_per_step': host['direct_tests'] / max(args.steps, 1),
+                           'max_rel_difference_to_eigen_bic': direct_max_rel,
+                           'chains_never_started_per_step': host['chains_cancelled'] / max(args.steps, 1),
+                           'waiting_for_eigenpairs_s_per_step': host['t_settle'] / max(args.steps, 1)},
         'random_stream': {
             'walker_busy_s_per_step': host['pool_noise_s'] / max(args.steps, 1),
             'walker_waiting_for_bulk_s_per_step': host['walker_wait_s'] / max(args.steps, 1),

@@ -113,6 +113,7 @@ SIGNATURES = {
     'fokl_spectrum_done': (c_int, [c_vp]),
     'fokl_spectrum_wait': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_spectrum_release': (None, [c_vp, c_vp]),
+    'fokl_spectrum_retain': (c_int, [c_vp, c_vp]),
     'fokl_search_model_begin': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'fokl_search_score': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp]),
@@ -904,6 +905,11 @@ class NativeSearch:
         n = p1.value
         arr = np.ctypeslib.as_array((ctypes.c_double * SpectralResult.doubles(n)).from_address(buf.value))
         return SpectralResult(n, arr)
+
+    def spectrum_retain(self, spectrum):
+        """-> the same handle, holding one more reference (spectrum_release when done with it)."""
+        self._checked(self._lib.fokl_spectrum_retain(self._h, c_vp(spectrum)))
+        return spectrum
 
     def spectrum_release(self, spectrum):
         if self._h:

@@ -691,7 +691,7 @@ struct Speculation {
     fokl_stream_cursor at_start;            // a rewind moves the walker; the stream's bulk data stays where it is
 };
 
-constexpr size_t kMaxSpeculation = 16;
+constexpr size_t kMaxSpeculation = 64;
 
 void trace_noise(fokl_host_pool *pool, fokl_host_job *job, int64_t verdict_seen)
 {

@@ -24,10 +24,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -145,7 +147,8 @@ struct Tape {
     bool rows_only = false;
     double *rows_mem = nullptr;
     size_t rows_classes = 0;
-    uint64_t span[2] = {0, 0};              // [position the stream is held from, position behind the tape]
+    // [position the stream is held from, position behind the tape]; ~0: the walker never got to it (sent back before)
+    uint64_t span[2] = {~(uint64_t)0, ~(uint64_t)0};
     bool holds_stream = false;
     double astar = 0, atau_star = 0;
     fokl_host_job *noise = nullptr;         // freed (fokl_pool_wait) when the tape goes
@@ -166,6 +169,9 @@ struct Spectrum {
     // this job has run; depth = how many such steps separate this model from a fresh decomposition
     Spectrum *parent = nullptr;
     int depth = 0;
+    // the Gram the job reads, when the search owns it (kill tests decided at once: their G2 jobs outlive the call -- and
+    // the caller's array -- that submitted them); jobs submitted through fokl_search_spectral* read the caller's
+    std::shared_ptr<const std::vector<double>> gram_keep;
     int32_t updated = -1;
     int status = FOKL_OK;
     int refs = 1;
@@ -278,8 +284,25 @@ struct fokl_search {
     // decision's, and a difference beyond direct_tolerance (relative) ends the search as a misprediction does.
     int decide = 0;
     double direct_tolerance = 1e-9;
-    size_t pending_max = 40;                // accepted models waiting for G2 at most: the loop then waits for the oldest
+    // accepted models waiting for G2 at most (the loop then waits for the oldest).  The device expands a tape from the
+    // stream's pre-states, which the bulk threads keep for the last 1024 segments of 79 872 doubles (fokl_dchain_prestate_ring;
+    // the device's own ring of regenerated segments is as long): a chain must be issued before the walker is that far past
+    // its tape, so the bound follows the tape length -- 448 segments' worth of accepted models' tapes, 192 of tapes on order
+    // (speculate), together well inside the 1024
+    size_t pending_limit(int p1) const
+    {
+        const double per_tape = (double)prm.draws * (1.3 * p1 + 4.0) / 79872.0 + 1.0;    // segments (polar method: 1.27 doubles per normal)
+        return (size_t)std::min(256.0, std::max(6.0, 448.0 / per_tape));
+    }
+    size_t order_limit(int p1) const
+    {
+        const double per_tape = (double)prm.draws * (1.3 * p1 + 4.0) / 79872.0 + 1.0;
+        return (size_t)std::min(64.0, std::max(4.0, 192.0 / per_tape));
+    }
     std::deque<Outcome *> pending;
+    // FOKL_SEARCH_PROFILE=1: where the kill-test loop's own time goes (seconds per section, printed when the search ends)
+    bool profile = std::getenv("FOKL_SEARCH_PROFILE") != nullptr;
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::deque<Outcome *> zombies;          // device chains nobody will look at: slots go back once they have run
     std::vector<Outcome *> device_outcomes;  // every device-chained outcome alive (all released when the search ends)
     std::vector<Forecast> forecasts;
@@ -714,7 +737,9 @@ void drop_speculation(fokl_search *s, size_t keep)
         s->stats[S_TAPES_REWOUND] += 1;
         if (begun) {
             s->stats[S_TAPES_WASTED] += 1;
-            s->speculation = std::max(1, s->speculation - 2);
+            // (a wrong order used to stall the loop behind the walker; with kill tests decided at once -- mode 1 -- the walker
+            // only ever walks a wrong tape in time it would have idled: the book stays as deep as it is allowed to be)
+            if (s->decide != 1) s->speculation = std::max(1, s->speculation - 2);
         }
     }
 }
@@ -743,7 +768,10 @@ void speculate(fokl_search *s, const std::vector<std::pair<int, bool>> &sizes)
     size_t k = 0;
     while (k < s->spec.size() && k < sizes.size() && s->spec[k]->p1 == sizes[k].first) ++k;
     if (k < s->spec.size()) drop_speculation(s, k);
-    const size_t upto = std::max(k, (size_t)s->speculation);
+    // (tapes on order hold the stream from where they begin, like the accepted models' tapes that wait for G2: the book is
+    // as deep as the search allows or as half of pending_limit's segments are long, whichever is less)
+    const size_t by_length = sizes.empty() ? 4 : s->order_limit(sizes.front().first);
+    const size_t upto = std::max(k, std::min((size_t)s->speculation, by_length));
     for (size_t i = k; i < sizes.size() && i < upto; ++i) {
         if (s->prm.test_rewinds) {                          // tests: a recorded tape that is then discarded
             Tape *bogus = request_tape(s, sizes[i].first + 1, true, true);
@@ -927,6 +955,18 @@ void release_outcome(fokl_search *s, Outcome *o)
     }
 }
 
+// A tape nobody refers to any more: waits until its noise job (walk + materialisation) has run -- which frees the job --,
+// then its memory goes back.
+void bury(fokl_search *s, Tape *t)
+{
+    (void)fokl_pool_wait(t->noise);
+    if (t->holds_stream && t->span[0] != ~(uint64_t)0)
+        (void)fokl_pool_release_hold(s->pool, t->span[0]);  // nobody expands its rows any more
+    give_buffer(t->mem, t->classes, t->pinned);
+    give_buffer(t->rows_mem, t->rows_classes, true);
+    delete t;
+}
+
 // What has been waiting for pool threads: tapes whose noise job (walk + materialisation) has run and that no chain reads
 // any more, chains nobody looks at.
 void reap(fokl_search *s, bool block)
@@ -950,11 +990,7 @@ void reap(fokl_search *s, bool block)
     for (size_t i = 0; i < s->tape_limbo.size();) {
         Tape *t = s->tape_limbo[i];
         if (block || fokl_pool_poll(t->noise)) {
-            (void)fokl_pool_wait(t->noise);
-            if (t->holds_stream) (void)fokl_pool_release_hold(s->pool, t->span[0]);   // nobody expands its rows any more
-            give_buffer(t->mem, t->classes, t->pinned);
-            give_buffer(t->rows_mem, t->rows_classes, true);
-            delete t;
+            bury(s, t);
             s->tape_limbo[i] = s->tape_limbo.back();
             s->tape_limbo.pop_back();
         } else {
@@ -1094,6 +1130,11 @@ double ev_only(const fokl_search *s, double s1, double s2, int p1)
 // upto: stop once this outcome has been dealt with (NULL: no such limit).
 int settle_pending(fokl_search *s, bool block, Outcome *upto)
 {
+    bool started = false;
+    // (a caller that waits wants the chains it has just started to run now, not when their batch has filled or aged)
+    auto flush = [&] {
+        if (block && started && s->dchain) (void)fokl_dchain_flush(s->dchain);
+    };
     while (!s->pending.empty()) {
         Outcome *o = s->pending.front();
         if (!block && !spectrum_done(o->spec)) break;
@@ -1118,6 +1159,7 @@ int settle_pending(fokl_search *s, bool block, Outcome *upto)
             s->stats[S_CHAINS_CANCELLED] += 1;
         } else if (out == FOKL_OK) {
             out = start_chain(s, o, o->dtd, true);
+            started = started || (out == FOKL_OK && o->on_device);
         }
         o->lazy = false;
         if (out != FOKL_OK || o->cancelled) {
@@ -1128,9 +1170,13 @@ int settle_pending(fokl_search *s, bool block, Outcome *upto)
         }
         const bool last = o == upto;
         unref(s, o);                                        // the list's reference
-        if (out != FOKL_OK) return out;
+        if (out != FOKL_OK) {
+            flush();
+            return out;
+        }
         if (last) break;
     }
+    flush();
     return FOKL_OK;
 }
 
@@ -1452,6 +1498,10 @@ extern "C" void fokl_search_destroy(fokl_search *s)
     s->device_outcomes.clear();
     reap(s, true);
     reap(s, true);                                          // tapes released by the chains of the first pass
+    if (s->profile)
+        std::fprintf(stderr, "fokl_search profile (ms): verify %.3f clause %.3f tape %.3f bic %.3f accept %.3f (spectrum %.3f) "
+                             "bounds %.3f tail %.3f\n", 1e3 * s->prof[0], 1e3 * s->prof[1], 1e3 * s->prof[2], 1e3 * s->prof[3],
+                     1e3 * s->prof[4], 1e3 * s->prof[5], 1e3 * s->prof[6], 1e3 * s->prof[7]);
     delete s;
 }
 
@@ -1563,6 +1613,14 @@ extern "C" int fokl_spectrum_wait(fokl_search *s, fokl_spectrum *h, const double
     if (buffer) *buffer = sp->buf;
     if (p1) *p1 = sp->p1;
     return rc;
+}
+
+// one more reference on a spectrum of this search (fokl_spectrum_release when done with it)
+extern "C" int fokl_spectrum_retain(fokl_search *s, fokl_spectrum *h)
+{
+    if (!s || !h) return fail(s, FOKL_ERR_ARG, "fokl_spectrum_retain: null pointer");
+    reinterpret_cast<Spectrum *>(h)->refs += 1;
+    return FOKL_OK;
 }
 
 extern "C" void fokl_spectrum_release(fokl_search *s, fokl_spectrum *h)
@@ -1916,6 +1974,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             a->foresee(a->user, pred.data(), (int)pred.size());
         }
     };
+    const bool direct_mode = s->decide == 1;
     auto order_tapes = [&](size_t pos) {
         // the tapes of what the stream serves next if the search goes on as predicted (see engine.py order_tapes)
         std::vector<std::pair<int, bool>> sizes;
@@ -1937,7 +1996,9 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             // across the boundary: the coming model, its first test (every first test is one column smaller whichever
             // proposal it removes) -- or, if G2 of that model is there already, all the tests its least-squares fit
             // makes likely
-            int tests = std::min(a->vm_next, 1);
+            // (kill tests that are decided at once, mode 1: as if every new term were tested and accepted until G2 of the
+            // coming model says better -- a tape of the wrong size is rewound, an idle walker is lost time)
+            int tests = direct_mode ? a->vm_next : std::min(a->vm_next, 1);
             if (Forecast *f = find_forecast(pred)) {
                 if (f->likely_tests < 0 && spectrum_done(f->spec) && wait_spectrum(s, f->spec) == FOKL_OK) {
                     const double n = (double)s->prm.n;
@@ -2013,12 +2074,26 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                         best->spec->lamb()[0] > 1e-9 * best->spec->lamb()[A - 1];
     auto run_direct = [&]() -> int {
         PathModel &m = committed;
+        // G2 of the accepted models is not waited for in here: the jobs read the search's own copy of the Gram
+        const auto own_gram = std::make_shared<const std::vector<double>>(gram, gram + (size_t)ld * ld);
+        std::vector<Spectrum *> callers;                    // spectra taken over from the caller (they read ITS array)
+        auto tests = [&]() -> int {
         m.ssr = best->s2;                                   // the device's residual pass, not the Gram identity
         m.s1 = best->s1;
+        double tp = s->profile ? now_s() : 0.0;
+        auto lap = [&](int k) {
+            if (s->profile) {
+                const double t = now_s();
+                s->prof[k] += t - tp;
+                tp = t;
+            }
+        };
         for (size_t pos = 0; pos < proposal.size(); ++pos) {
             const int i = proposal[pos];
             bool decided = clause1[(size_t)i];
+            lap(6);
             int rc2 = verify(s, false);                     // (also starts the chains whose G2 has arrived)
+            lap(0);
             if (rc2 != FOKL_OK) return rc2;
             if (!decided) {
                 const int quick = second_clause_now(s, best, a->mean_abs[i]);
@@ -2034,6 +2109,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 if ((rc2 = intercept_scale(s, best, &scale_guess)) != FOKL_OK) return rc2;
                 if (!(a->mean_abs[i] < threshav * scale_guess)) continue;
             }
+            lap(1);
             const int32_t col = a->columns[i];
             const int at = m.position(col);
             if (at <= 0) return fail(s, FOKL_ERR_STATE, "fokl_search_kill_tests: a proposal is not a column of the model");
@@ -2048,17 +2124,26 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                     return rc2;
                 }
             }
+            lap(2);
             const auto idx = columns_without(A, trial);
             auto take_spectrum = [&]() -> Spectrum * {
+                const double t_sp = s->profile ? now_s() : 0.0;
                 Spectrum *sp = nullptr;
                 auto it = ahead.find(trial);
                 if (it != ahead.end()) {
                     sp = it->second;                        // (the map's reference becomes the caller's)
                     ahead.erase(it);
+                    if (!sp->gram_keep) {
+                        sp->refs += 1;
+                        callers.push_back(sp);
+                    }
                 } else {
-                    sp = submit_spectrum(s, gram, ld, idx.data(), p1, -1.0, s->update_from > 0 ? best->spec : nullptr, at);
+                    sp = submit_spectrum(s, own_gram->data(), ld, idx.data(), p1, -1.0,
+                                         s->update_from > 0 ? best->spec : nullptr, at);
+                    if (sp) sp->gram_keep = own_gram;
                     flush_spectra(s);
                 }
+                if (s->profile) s->prof[5] += now_s() - t_sp;
                 return sp;
             };
             double s1 = m.s1, s2 = m.ssr_without(at);
@@ -2087,6 +2172,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             const double ev = same_model_same_ev(s, idx.data(), p1, ev_from_moments(s, s1, s2, p1));
             const double siglik = s->last_siglik;
             s->stats[S_DIRECT_TESTS] += 1;
+            lap(3);
             if (ev < evmin) {
                 if (!sp && !(sp = take_spectrum())) {
                     unref(s, tape);
@@ -2121,21 +2207,35 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 s->stats[S_CHAINS_SKIPPED] += 1;
             }
             record(s, p1, a->n_prev, ev, true);
+            lap(4);
             // bounded: accepted models waiting for G2 (their tapes hold the stream), tapes waiting for the walker
-            while (s->pending.size() > s->pending_max)
+            const size_t bound = s->pending_limit(A);
+            while (s->pending.size() > bound)
                 if ((rc2 = settle_pending(s, true, s->pending.front())) != FOKL_OK) return rc2;
             if ((pos & 7) == 7) reap(s, false);
-            while (s->tape_limbo.size() > 2 * s->pending_max) {
-                (void)fokl_pool_wait(s->tape_limbo.front()->noise);
+            while (s->tape_limbo.size() > 2 * bound) {
                 reap(s, false);
+                if (s->tape_limbo.size() <= 2 * bound) break;
+                bury(s, s->tape_limbo.front());             // (the walker works through its queue in order: the oldest first)
+                s->tape_limbo.erase(s->tape_limbo.begin());
             }
         }
         // the kill set is final: G2 of the coming sub-stage's model can start
+        lap(6);
         if (a->foresee && !idle_pending) {
             std::vector<int32_t> pred(killed);
             a->foresee(a->user, pred.data(), (int)pred.size());
         }
+        lap(7);
         return FOKL_OK;
+        };
+        const int rc_tests = tests();
+        // jobs that read the caller's Gram have run before this call returns
+        for (Spectrum *sp : callers) {
+            (void)wait_spectrum(s, sp);
+            unref(s, sp);
+        }
+        return rc_tests;
     };
     if (direct) {
         rc = run_direct();

@@ -323,7 +323,13 @@ class ForwardSelection:
         self.tentative_tapes = mode != '0'
         self._test_rewinds = mode == 'test'
         # how many tapes may be on order ahead of the decisions that they are needed (_speculate, _drop_speculation)
+        # (the native search's tapes on order are rows the device expands, 96 KB each, and its kill tests are decided within
+        # microseconds: its book is deep enough for a whole sub-stage's likely tests, so that the walker does not idle between
+        # a model's tape and the moment the model's statistics have ordered the proposals)
         self.speculation_max = max(1, min(16, int(os.environ.get('FOKL_SPECULATION', '12'))))
+        self._speculation_native = max(1, min(64, int(os.environ.get('FOKL_SPECULATION', '48'))))
+        # FOKL_SPECULATE_ACROSS=0: tapes are not ordered beyond the sub-stage whose tests are being guessed
+        self._speculate_across = os.environ.get('FOKL_SPECULATE_ACROSS', '1') != '0'
         self._speculation = self.speculation_max
         self._spec = collections.deque()    # (model size, tentative noise job): on order, in stream order, no verdict yet
         self._prechain = None               # (noise job, spec, chain job, buffer of w): chain started ahead (_chain_ahead)
@@ -595,7 +601,7 @@ class ForwardSelection:
             self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
         return self._same_model_same_ev(idx, ev)
 
-    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None, then=()):
+    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None, then=(), after_begin=None):
         """
         gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
         slots : device slot of each active column
@@ -603,6 +609,7 @@ class ForwardSelection:
         spectral_job : G2 of exactly this model submitted earlier (pipelined search), if any
         overlap : called once G2 is under way -- work for the driver thread in its shadow (pipelined search)
         then  : sizes of the models that will probably be evaluated after this one (tapes ordered ahead, _speculate)
+        after_begin : (native search) called with the model's spectrum handle once G2 has run and K3 is launched
         """
         idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
@@ -618,6 +625,8 @@ class ForwardSelection:
                 cand_slots = [slots[i] for i in idx]
                 if self._async_resid:
                     self._launch_resid(cand_slots, idx, betahat)
+                if after_begin is not None:
+                    after_begin(spectrum)       # G2 is there, the device is busy with K3: what can be ordered ahead now
                 ycol = gram.shape[0] - 1
                 handle = ns.model_commit(spectrum, tape, gram[ycol, ycol])
             except BaseException:
@@ -712,7 +721,7 @@ class ForwardSelection:
         floor = min(self.threshstda, self.threshstdb)
         return [int(new[j]) for j in np.argsort(guess_mean) if guess_std[j] > floor * guess_mean[j]]
 
-    def _guess_first_tests(self, gram, spec, n_new, siglik=None, before_model=False, spectrum=None):
+    def _guess_first_tests(self, gram, spec, n_new, siglik=None, before_model=False, spectrum=None, vm_next=None):
         """G2 jobs for the first kill tests of the sub-stage whose model's G2 is `spec` (_likely_first_tests), and the
         tapes of all the likely ones (before_model: the model's own tape has not been taken yet and leads them).
         Returns ({trial set -> job}, sizes of the likely tests); a wrong guess costs a spectral thread a few
@@ -741,7 +750,13 @@ class ForwardSelection:
                         against = jobs.get(trial)
             finally:
                 self.native.hold_spectral(False)
-            self._speculate(([ModelSize(A)] if before_model else []) + sizes)
+            beyond = []
+            if vm_next is not None and self._speculate_across:
+                # ... and across the boundary: the coming sub-stage's model if these tests end as predicted, and its tests as
+                # if every new term were tested and accepted (their G2 will say better; a tape of the wrong size is rewound)
+                coming = A - len(cur) + vm_next
+                beyond = [ModelSize(coming)] + [coming - t for t in range(1, vm_next + 1)]
+            self._speculate(([ModelSize(A)] if before_model else []) + sizes + beyond)
             return jobs, sizes
         likely = self._likely_first_tests(spec, n_new, siglik)
         jobs, cur = {}, frozenset()
@@ -1029,7 +1044,7 @@ class ForwardSelection:
                 self.host.pool, self.chain_engine, n=self.n, a=self.a, b=self.b, atau=self.atau, btau=self.btau,
                 threshav=self.threshav, threshstda=self.threshstda, threshstdb=self.threshstdb,
                 guess_margin=self.guess_margin, draws=self.draws, half0=half0, aic=int(self.aic),
-                lookahead=self._lookahead_native, foresight=self.foresight, speculation_max=self.speculation_max,
+                lookahead=self._lookahead_native, foresight=self.foresight, speculation_max=self._speculation_native,
                 tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
                 device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
                 flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
@@ -1262,10 +1277,14 @@ class ForwardSelection:
             # G2 of this model may be there already (started while the sub-stage before was being decided): the first
             # kill tests are guessed from it -- their G2 jobs and tapes -- before anything else happens
             early, then = None, [A - 1] if vm > 0 and A > 1 else []
+            vm_next = None
+            if pipelined and pattern is not None:
+                vm_next = distinct_arrangements(pattern[1]).shape[0]
             if pipelined and self.lookahead > 0 and spectral_job is not None and getattr(
                     spectral_job, 'done', lambda: False)():
                 early, then = self._guess_first_tests(gram, spectral_job.wait(), vm, before_model=True,
-                                                      spectrum=spectral_job if self.native is not None else None)
+                                                      spectrum=spectral_job if self.native is not None else None,
+                                                      vm_next=vm_next)
 
             def build_next(coming=pattern, active=active_slots):
                 nonlocal ahead
@@ -1278,15 +1297,21 @@ class ForwardSelection:
             # noise thread goes straight on instead of idling until the model's chain has finished and its statistics
             # have ordered the proposals
             lap('prepare')
+            def first_tests_now(spectrum, gram=gram, vm=vm):
+                # G2 of the model has just arrived (the native search's model_begin waited for it): the likely first tests'
+                # G2 jobs and tapes go out now, under the device's residual pass, not after it
+                nonlocal early
+                if early is None and self.lookahead > 0 and vm > 0:
+                    own = NativeSpectrum(self.native, self.native.spectrum_retain(spectrum), gram)
+                    early, _ = self._guess_first_tests(gram, None, vm, spectrum=own, vm_next=vm_next)
+
             full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False, spectral_job=spectral_job,
-                                  overlap=None if pipelined else build_next, then=then)
+                                  overlap=None if pipelined else build_next, then=then,
+                                  after_begin=first_tests_now if pipelined and self.native is not None else None)
             best = full
             ev = full.ev
             _mark('full_evaluated', str(A))
             lap('model')
-            vm_next = None
-            if pipelined and pattern is not None:
-                vm_next = distinct_arrangements(pattern[1]).shape[0]
 
             def foresee(pred_killed, gram=gram, active=active_slots, A=A):
                 # G2 of the coming sub-stage's model if the kill tests end as predicted (at most two guesses)
@@ -1327,7 +1352,7 @@ class ForwardSelection:
                     own = None
                     if self.native is not None:
                         own = NativeSpectrum(self.native, self.native.outcome_spectrum(full.h), gram)
-                    early, _ = self._guess_first_tests(gram, full, vm, siglik=full.siglik, spectrum=own)
+                    early, _ = self._guess_first_tests(gram, full, vm, siglik=full.siglik, spectrum=own, vm_next=vm_next)
             # K1 + K2 of the coming sub-stage now, while this thread would only wait for the model's chain (its BIC pass
             # has left the device): inside the kill tests -- where it used to hide behind the first test's decomposition --
             # a derived G2 answers in a fifth of the time this takes.  FOKL_BUILD_AHEAD=tests: there, as before

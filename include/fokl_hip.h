@@ -611,6 +611,7 @@ int fokl_search_spectral_from(fokl_search *search, const double *gram, int ld, c
                               fokl_spectrum *parent, int parent_pos, fokl_spectrum **out);
 int fokl_spectrum_done(fokl_spectrum *spectrum);
 int fokl_spectrum_wait(fokl_search *search, fokl_spectrum *spectrum, const double **buffer, int *p1);
+int fokl_spectrum_retain(fokl_search *search, fokl_spectrum *spectrum);     /* one more reference (released as below) */
 void fokl_spectrum_release(fokl_search *search, fokl_spectrum *spectrum);
 int fokl_search_model_begin(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1,
                             fokl_spectrum *given, const int32_t *then_sizes, const int32_t *then_model, int then_count,
