@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SIDE_FITS = int(os.environ.get('FOKL_BENCH_SIDE_FITS', '4'))   # fits per process in the throughput side measurement
+SIDE_FITS = int(os.environ.get('FOKL_BENCH_SIDE_FITS', '12'))   # fits per process in the throughput side measurement
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
 
@@ -162,6 +162,27 @@ def compare_with_golden(name, model, betas, mtx, evs, state):
                              finish_log=os.environ.get('FOKL_FINISH_LOG', 'fast'))
     else:
         out['ok'] = False
+    return out
+
+
+def cgroup_cpu():
+    """What the container's CPU controller says (cgroup v2): quota in CPUs (None: unlimited / unknown) and the counters of
+    cpu.stat -- usage_usec, nr_periods, nr_throttled, throttled_usec.  Fits side by side on one GPU are bounded by this quota
+    long before the device is busy: the throughput line reports how much of it they used and how often they were throttled."""
+    out = dict(quota_cpus=None)
+    try:
+        q, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            out['quota_cpus'] = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        for line in open('/sys/fs/cgroup/cpu.stat'):
+            k, v = line.split()
+            if k in ('usage_usec', 'nr_periods', 'nr_throttled', 'throttled_usec'):
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
     return out
 
 
@@ -916,6 +937,8 @@ def main():
         control.barrier()
         ctx.sync()
         cpu0 = time.process_time()                            # all threads of this process (pool, dispatcher, driver)
+        from fokl_gpy_amd import _capi as _capi_cpu
+        kinds0, driver0 = _capi_cpu.thread_cpu_seconds(), time.thread_time()
         t0 = time.perf_counter()
         logical = physical = calls = 0
         host = dict(t_eigh=0.0, t_resid=0.0, t_chain=0.0, chains_materialised=0, pool_noise_s=0.0, pool_chain_s=0.0,
@@ -945,6 +968,12 @@ def main():
         control.barrier()
         elapsed = time.perf_counter() - t0
         cpu_s = time.process_time() - cpu0
+        # ... and by kind of thread (fokl_thread_cpu_seconds: a pool's threads are counted when their fit's pool ends; the
+        # driver is this Python thread; `other` = the rest of the process: HIP runtime threads, fits on other threads)
+        kinds1, driver1 = _capi_cpu.thread_cpu_seconds(), time.thread_time()
+        cpu_by_thread = {k: (kinds1[k] - kinds0[k]) / max(args.steps, 1) for k in kinds1}
+        cpu_by_thread['driver'] = (driver1 - driver0) / max(args.steps, 1)
+        cpu_by_thread['other'] = cpu_s / max(args.steps, 1) - sum(cpu_by_thread.values())
         end_state = np.random.get_state()
         for _, backend, *_ in fits:
             backend.ctx.timing_enable(False)
@@ -1059,6 +1088,7 @@ def main():
         try:
             gate.set()
             start_b.wait(timeout=300)                       # all of them have uploaded and warmed up
+            cg0 = cgroup_cpu()
             t_side = time.perf_counter()
             own_terms = 0
             with warnings.catch_warnings():
@@ -1067,6 +1097,7 @@ def main():
                     own_terms += sum(st['terms_logical'] for st in one_step())
             side_res = [done_q.get(timeout=300) for _ in side_workers]
             t_side = time.perf_counter() - t_side
+            cg1 = cgroup_cpu()
             side_terms = own_terms + sum(r['stats']['terms_logical'] for r in side_res)
             side_fits = (side_procs + 1) * SIDE_FITS
             throughput_mode = dict(
@@ -1078,7 +1109,15 @@ def main():
                 worker_s_per_fit={key: sum(r['stats'].get(key, 0.0) for r in side_res) / max(1, side_procs * SIDE_FITS)
                                   for key in ('t_eigh', 't_chain', 'pool_noise_s', 'pool_spectral_s', 'noise_verdict_wait_s',
                                               'noise_queue_wait_s', 'seconds', 'cpu_s')},
-                worker_elapsed_s=[r['elapsed'] for r in side_res])
+                worker_elapsed_s=[r['elapsed'] for r in side_res],
+                # the CPU controller over the measurement: CPUs' worth of time the container used against its quota, and how
+                # many scheduler periods ended with its threads throttled (every thread of every fit stands still then)
+                host_cpu=dict(quota_cpus=cg0.get('quota_cpus'),
+                              cpus_used=(cg1.get('usage_usec', 0) - cg0.get('usage_usec', 0)) / 1e6 / t_side
+                              if 'usage_usec' in cg1 else None,
+                              periods=cg1.get('nr_periods', 0) - cg0.get('nr_periods', 0),
+                              periods_throttled=cg1.get('nr_throttled', 0) - cg0.get('nr_throttled', 0),
+                              throttled_s=(cg1.get('throttled_usec', 0) - cg0.get('throttled_usec', 0)) / 1e6))
         except Exception as exc:
             print(f"bench.py: throughput side measurement failed: {type(exc).__name__} {exc}", file=sys.stderr)
         finally:
@@ -1238,6 +1277,7 @@ def main():
         'fit_call_ms': fit_call['fit_call_ms'] if fit_call else None,
         'host_main_thread_s_per_step': {k: v / max(args.steps, 1) for k, v in host.items()},
         'cpu_seconds_per_step': cpu_s / max(args.steps, 1),   # process CPU time (every thread) over the timed region
+        'cpu_seconds_per_step_by_thread': cpu_by_thread,
         'chain_mode': os.environ.get('FOKL_CHAIN', 'auto'),
         # who ran the kill tests (csrc/fokl_search.cpp or engine.py's loop) and how the random stream reached the chains
         'search_driver': '+'.join(sorted(drivers)),

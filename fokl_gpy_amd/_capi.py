@@ -82,6 +82,7 @@ SIGNATURES = {
     'fokl_pool_wait': (c_int, [c_vp]),
     'fokl_pool_busy_seconds': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_noise_waits': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_thread_cpu_seconds': (c_int, [c_vp, c_int]),
     'fokl_pool_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_create': (c_int, [c_vp, c_i32, c_i32, c_dbl, c_int, c_vp, c_int, c_vp]),
     'fokl_stream_prestates_published': (c_i64, [c_vp]),
@@ -287,6 +288,18 @@ class LegacyStream:
         out = np.empty(int(n), dtype=np.float64)
         _check(load().fokl_rng_gammas(*self.args(), c_dbl(shape), c_dbl(scale), c_i64(int(n)), _ptr(out)))
         return out
+
+
+THREAD_KINDS = ('walker', 'chain', 'finish', 'spectral', 'bulk', 'device_chain_dispatcher')
+
+
+def thread_cpu_seconds():
+    """CPU-seconds used so far by the library's own threads, by kind (fokl_thread_cpu_seconds)."""
+    v = np.zeros(8)
+    n = load().fokl_thread_cpu_seconds(_ptr(v), v.shape[0])
+    if n < 0:
+        _check(n)
+    return dict(zip(THREAD_KINDS, v[:n].tolist()))
 
 
 def _host_threads():

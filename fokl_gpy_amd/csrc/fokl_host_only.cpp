@@ -3,6 +3,7 @@
 // (`make host-tsan host-asan`, tools/sanitize_host.sh) -- GPU sanitizers are not available on this pool, and the
 // hand-rolled lock-free pipeline of fokl_hostpool.cpp is exactly the part that wants a race detector.  Device entry
 // points are absent from those libraries: _capi.load() skips them when FOKL_HOST_ONLY_LIBRARY=1.
+#include <cstdint>
 #include <mutex>
 #include <string>
 
@@ -18,6 +19,8 @@ void fokl_set_global_error(const std::string &msg)
 }
 
 extern "C" int fokl_version(void) { return 100; }
+
+extern "C" __attribute__((visibility("hidden"))) int64_t fokl_dchain_dispatcher_cpu_ns() { return 0; }   // (no engine here)
 
 extern "C" const char *fokl_last_error(const fokl_ctx *)
 {

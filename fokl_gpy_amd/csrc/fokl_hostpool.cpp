@@ -50,7 +50,37 @@ extern "C" __attribute__((visibility("hidden"))) int fokl_gibbs_chain_from_raw_b
     int draws, const double *normals, const double *pair_r2, const int32_t *lead, const double *gam_sig,
     const double *gam_tau, const int32_t *block_done, int block, double *w_out, int32_t *bstar_negative);
 
+// CPU time of the library's own threads by kind, process-wide, added when a thread ends (a fit's pool lives as long as the
+// fit): what a fit costs in CPU-seconds and where -- the figure that bounds fits side by side on a host with a CPU quota.
+// kinds: 0 walker, 1 chain, 2 finish, 3 spectral, 4 bulk (fokl_stream.cpp), 5 device-chain dispatcher (read live)
+static std::atomic<int64_t> g_thread_cpu_ns[8];
+
+extern "C" __attribute__((visibility("hidden"))) void fokl_note_thread_cpu(int kind)
+{
+    timespec ts;
+    if (kind >= 0 && kind < 8 && clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+        g_thread_cpu_ns[kind].fetch_add((int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec, std::memory_order_relaxed);
+}
+
+extern "C" __attribute__((visibility("hidden"))) int64_t fokl_dchain_dispatcher_cpu_ns();   // fokl_chain_device.inc / host-only stub
+
+extern "C" int fokl_thread_cpu_seconds(double *seconds, int count)
+{
+    if (!seconds || count < 6) {
+        fokl_set_global_error("fokl_thread_cpu_seconds: room for six values is needed");
+        return FOKL_ERR_ARG;
+    }
+    for (int k = 0; k < 5; ++k) seconds[k] = 1e-9 * (double)g_thread_cpu_ns[k].load(std::memory_order_relaxed);
+    seconds[5] = 1e-9 * (double)fokl_dchain_dispatcher_cpu_ns();
+    return 6;
+}
+
 namespace {
+
+struct ThreadCpuNote {                                      // at the end of a thread's function
+    int kind;
+    ~ThreadCpuNote() { fokl_note_thread_cpu(kind); }
+};
 
 using dsyevr_fn = void (*)(char *jobz, char *range, char *uplo, int *n, double *a, int *lda, double *vl, double *vu,
                            int *il, int *iu, double *abstol, int *m, double *w, double *z, int *ldz, int *isuppz,
@@ -86,6 +116,10 @@ struct fokl_host_job {
     int64_t t_submit = 0, t_start = 0, t_recorded = 0;      // FOKL_POOL_TRACE
     // a noise job is done when the stream is through with it AND the finish jobs submitted with it have left the tape
     std::atomic<int> pending{1};
+    // noise: the walker has begun the tape (or sent it back unwalked); the finish jobs submitted with it sleep until then
+    // (fokl_host_pool::start_cv) -- a model's tape is queued behind a sub-stage's worth of kill-test tapes, milliseconds
+    // during which two threads per tape used to poll its progress word every 10 us
+    std::atomic<int> started{0};
     fokl_host_job *parent = nullptr;        // finish job submitted with a noise job: that job
     // noise / chain
     int p1 = 0, draws = 0;
@@ -151,6 +185,8 @@ struct fokl_host_pool {
     // eight ranks may share a CPU quota far below eight times the thread count)
     std::mutex done_m;
     std::condition_variable done_cv;
+    std::mutex start_m;                         // fokl_host_job::started of every noise job
+    std::condition_variable start_cv;
     // FOKL_POOL_TRACE=<file>: one line per noise job (steady-clock ns: submitted, started, recorded, verdict seen; p1;
     // tentative; verdict), appended when the pool is destroyed -- tools/pool_trace.py lines it up with the driver's log
     std::string trace_path;
@@ -557,6 +593,13 @@ int expand_tape_blocks(fokl_host_pool *pool, fokl_host_job *job)
 {
     const int nblocks = (job->draws + job->block - 1) / job->block;
     int32_t ready = 0;
+    if (fokl_host_job *tape = job->parent) {                // asleep until the walker gets to the tape
+        for (int spins = 0; spins < 200 && !tape->started.load(std::memory_order_acquire); ++spins) _mm_pause();
+        if (!tape->started.load(std::memory_order_acquire)) {
+            std::unique_lock<std::mutex> lock(pool->start_m);
+            pool->start_cv.wait(lock, [&] { return tape->started.load(std::memory_order_acquire) != 0; });
+        }
+    }
     for (int blk = job->part; blk < nblocks; blk += job->parts) {
         const int k0 = blk * job->block, k1 = std::min(job->draws, k0 + job->block);
         int rc = FOKL_OK;
@@ -666,6 +709,7 @@ fokl_host_job *run(fokl_host_pool *pool, fokl_host_job *job)
 
 void worker(fokl_host_pool *pool, Queue *queue)
 {
+    ThreadCpuNote note{queue == &pool->chain_q ? 1 : queue == &pool->spectral_q ? 3 : 2};
     prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);               // the short sleeps of the tape followers mean what they say
     for (;;) {
         fokl_host_job *job;
@@ -715,8 +759,22 @@ void settle(fokl_host_job *job)                            // status / error wer
     pool->done_cv.notify_all();
 }
 
+void mark_started(fokl_host_pool *pool, fokl_host_job *job)
+{
+    if (job->pending.load(std::memory_order_relaxed) > 1) {             // finish jobs were submitted with it
+        {
+            std::lock_guard<std::mutex> lock(pool->start_m);
+            job->started.store(1, std::memory_order_release);
+        }
+        pool->start_cv.notify_all();
+    } else {
+        job->started.store(1, std::memory_order_release);
+    }
+}
+
 void record_tape(fokl_host_pool *pool, fokl_host_job *job)
 {
+    mark_started(pool, job);
     const auto t0 = std::chrono::steady_clock::now();
     job->t_start = std::chrono::duration_cast<std::chrono::nanoseconds>(t0.time_since_epoch()).count();
     int rc = fokl_stream_hold(pool->stream, &job->hold);
@@ -774,11 +832,13 @@ void record_tape(fokl_host_pool *pool, fokl_host_job *job)
 
 void noise_worker(fokl_host_pool *pool)
 {
+    ThreadCpuNote note{0};
     prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
     Queue *queue = &pool->noise_q;
     std::deque<Speculation> open;                           // recorded, no verdict yet; oldest first
     auto aborted = [&](fokl_host_job *job) {
         __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);          // nobody may follow this tape
+        mark_started(pool, job);                                        // (finish threads asleep on it see the -1)
         trace_noise(pool, job, now_ns());
         settle(job);
     };
@@ -854,8 +914,13 @@ void noise_worker(fokl_host_pool *pool)
                     _mm_pause();
                     if ((spins & 63) == 63 && more()) break;
                 } else {
-                    std::this_thread::sleep_for(std::chrono::microseconds(10));
-                    if (more()) break;
+                    // asleep until a verdict (fokl_pool_resolve) or a request (submit) wakes the queue's condition; the
+                    // timeout only covers a verdict stored between the test above and the wait
+                    std::unique_lock<std::mutex> lock(queue->m);
+                    if (settled()) break;
+                    if (open.size() < kMaxSpeculation && !queue->q.empty() && queue->q.front()->tentative) break;
+                    queue->cv.wait_for(lock, std::chrono::microseconds(200));
+                    if (open.size() < kMaxSpeculation && !queue->q.empty() && queue->q.front()->tentative) break;
                 }
             }
             pool->noise_verdict_wait_ns.fetch_add(
@@ -1226,6 +1291,7 @@ extern "C" int fokl_pool_resolve(fokl_host_job *job, int commit)
         fokl_set_global_error("fokl_pool_resolve: the job has been resolved already");
         return FOKL_ERR_STATE;
     }
+    job->pool->noise_q.cv.notify_one();                    // (a walker asleep on the verdicts of its open tapes)
     return FOKL_OK;
 }
 

@@ -45,6 +45,7 @@
 #include "../../include/fokl_hip.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
+extern "C" __attribute__((visibility("hidden"))) void fokl_note_thread_cpu(int kind);   // fokl_hostpool.cpp
 
 namespace {
 
@@ -361,6 +362,9 @@ void generate_raw(fokl_stream *e, uint32_t *buf, int64_t index)
 
 void bulk_worker(fokl_stream *e)
 {
+    struct Note {
+        ~Note() { fokl_note_thread_cpu(4); }
+    } note;
     void *scratch_mem = nullptr;
     if (posix_memalign(&scratch_mem, 64, sizeof(uint32_t) * (size_t)(MT_N + kSegWords + kSegTail + 64)) != 0) {
         std::lock_guard<std::mutex> lock(e->token_m);

@@ -1075,7 +1075,13 @@ class ForwardSelection:
                 # not understood), so it stays a knob
                 derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else _bounded_lookahead(
                     'FOKL_LOOKAHEAD_DERIVED', os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
-                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', '6')), derived_ahead)
+                # (depth: with the kill tests decided at once nobody waits for a link of the chain of derived models any more --
+                # their G2 only feeds chains whose statistics are confirmed later -- so the chain may be long: 24 steps cost 27 ms
+                # of spectral CPU per configs[2] fit against 41 at 6, same fit time, same bits of the returned draws; while
+                # the loop waits for G2, FOKL_KILL_DECIDE=g2, a step every 0.1-0.2 ms is what it waits for: 6)
+                depth_default = '24' if os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
+                    getattr(self, 'allow_direct_decisions', True) else '6'
+                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', depth_default)), derived_ahead)
                 self.stats['eigh_update_from'] = update_from
             # Kill tests' BICs from the sub-stage's least-squares model downdated column by column (microseconds on the
             # search thread; G2 then only feeds the accepted models' chains and confirms the BIC) instead of from G2 of every

@@ -521,6 +521,11 @@ int fokl_pool_stream_stats(const fokl_host_pool *pool, double *bulk_busy_s, doub
                            int64_t *gamma_attempts, int64_t *gamma_attempts_exact);
 /* Seconds the noise thread spent waiting: with an empty queue, and for the verdict on tentative tapes. */
 int fokl_pool_noise_waits(const fokl_host_pool *pool, double *queue_wait, double *verdict_wait);
+/* CPU-seconds the library's own threads have used since it was loaded, by kind, process-wide (a pool's threads are added
+ * when they end, i.e. when their fit's pool is destroyed): seconds[0..5] = the stream's walker, chain threads, finish
+ * threads, spectral threads, the stream's bulk threads, the device-chain dispatchers (live).  -> 6, or an error.  What a fit
+ * costs in CPU and where: the figure that bounds fits running side by side on a host with a CPU quota. */
+int fokl_thread_cpu_seconds(double *seconds, int count);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* The search's per-evaluation work off the driver thread: tapes on order, G2 ahead, chains, kill tests     */
