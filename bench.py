@@ -433,9 +433,13 @@ def kernel_report(kern, n, m, cfg):
     if kernels['inputs_touch'] and kernels['basis_build']:
         # the read of the inputs ahead of every basis build (it leaves them in the Infinity Cache) belongs to the price of
         # the build: both launches together against the build's algorithmic bytes
+        # (FOKL_K1_TOUCH=1 runs only: `frac` / `achieved` ARE the pair then, the build launch alone goes under kernel_only_*)
         kb, kt = kern['basis_build'], kern['inputs_touch']
         together = kb['bytes'] / ((kb['ms'] + kt['ms']) * 1e-3) / 1e9
-        kernels['basis_build'].update(with_inputs_touch_gbs=together, with_inputs_touch_frac=together / HBM_PEAK_GBS)
+        alone = kernels['basis_build']
+        alone.update(kernel_only_gbs=alone['achieved'], kernel_only_frac=alone['frac'], achieved=together,
+                     frac=together / HBM_PEAK_GBS, with_inputs_touch_gbs=together,
+                     with_inputs_touch_frac=together / HBM_PEAK_GBS)
     mf = kernels['resid_matrix_free']
     if mf:
         # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns

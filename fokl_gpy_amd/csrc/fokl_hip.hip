@@ -699,12 +699,13 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
                 ++m_used;
             }
     }
-    // In a fit K1 comes behind Gram and residual launches that have streamed 0.5-1 GB through the 256 MB Infinity Cache:
-    // its 8 N m_used bytes of inputs then come from HBM IN BETWEEN its 8 N T bytes of stores, and a mixed stream runs at
-    // 4.3-4.6 TB/s where stores alone run at 5.5 (profiles/hbm_write_ceiling_r03.txt).  Reading the inputs once, just
-    // before -- a launch of its own, on a device that idles for most of a fit -- leaves them in the cache: K1 then stores
-    // against HBM and reads beside it.  FOKL_K1_TOUCH=0: no such launch.
-    if (deriv.order == 0 && env_int("FOKL_K1_TOUCH", 1) != 0 && ctx->n >= 65536) {
+    // In a fit K1 comes behind Gram and residual launches that stream 0.5-1 GB of columns.  While those went through the 256 MB
+    // Infinity Cache with the default policy they evicted the inputs, whose 8 N m_used bytes then came from HBM IN BETWEEN
+    // K1's 8 N T bytes of stores (a mixed stream runs at 4.3-4.6 TB/s where stores alone run at 5.5,
+    // profiles/hbm_write_ceiling_r03.txt).  Round 4 read the inputs once just before, in a launch of its own (0.53 -> 0.65 for
+    // K1 alone, 0.49-0.51 with that launch charged to it); round 5 marks the column streams non-temporal instead
+    // (FOKL_STREAM_NT, fokl_kernels.hip.h): 0.65 with no extra launch.  FOKL_K1_TOUCH=1 brings the launch back (A/B runs).
+    if (deriv.order == 0 && env_int("FOKL_K1_TOUCH", 0) != 0 && ctx->n >= 65536) {
         const int64_t words = ctx->n / 2;                   // 16-byte loads
         TimedRegion timed(ctx, FOKL_K_TOUCH, 8.0 * (double)ctx->n * (double)m, 0.0);
         hipLaunchKernelGGL(inputs_touch_kernel, dim3((unsigned)(cu_count(ctx) * 4)), dim3(256), 0, ctx->stream, ctx->d_x,

@@ -37,6 +37,24 @@ typedef __attribute__((address_space(1))) double *global_d_ptr;
 typedef __attribute__((address_space(1))) const double *global_cd_ptr;
 
 __device__ __forceinline__ d2 load_d2(const double *p) { return *(global_cd2_ptr)(p); }
+// Stored basis columns are read ONCE per launch (K2's LDS-DMA pieces and staged loads, K3's column loads): 0.5-1.2 GB that
+// used to pass through the 256 MB Infinity Cache and push the 64 MB of inputs out of it right before K1 read them again --
+// K1's input reads then came from HBM in between its stores (a 1 : 7 read / write mix sustains less than stores alone).
+// Marked non-temporal (global_load_lds aux = 2, nt on the register loads) they leave the inputs where they are: K1 in situ
+// 0.587 -> 0.650 of the HBM roof with no extra launch, K2 / K3 unchanged within their spread (profiles/nt_column_stream_r05.txt).
+// FOKL_STREAM_NT=0 (A/B builds, tools/k2_variants.sh): default-policy loads, as up to round 4.
+#ifndef FOKL_STREAM_NT
+#define FOKL_STREAM_NT 1
+#endif
+__device__ __forceinline__ d2 load_d2_stream(const double *p)
+{
+#if FOKL_STREAM_NT
+    return __builtin_nontemporal_load((global_cd2_ptr)(p));
+#else
+    return *(global_cd2_ptr)(p);
+#endif
+}
+#define FOKL_GD_AUX (FOKL_STREAM_NT ? 2 : 0)               /* aux of global_load_lds: 2 = nt */
 // Basis columns are written once and are far larger than L2 before anybody reads them: non-temporal stores
 // (measured on K1, N = 1e6: T = 56 Bernoulli 4.5 -> 5.2 TB/s, splines 3.5 -> 5.1 TB/s).
 __device__ __forceinline__ void store_d2(double *p, d2 v) { __builtin_nontemporal_store(v, (global_d2_ptr)(p)); }
@@ -509,12 +527,12 @@ __global__ __launch_bounds__(GV_THREADS) void gram_valu_kernel(double *const *__
         const bool two = r + 1 < n;
 #pragma unroll
         for (int i = 0; i < GV_TI; ++i) {
-            av[i] = load_d2(a[i] + r);
+            av[i] = load_d2_stream(a[i] + r);
             if (!two) av[i].y = 0.0;
         }
 #pragma unroll
         for (int j = 0; j < GV_TJ; ++j) {
-            bv[j] = load_d2(b[j] + r);
+            bv[j] = load_d2_stream(b[j] + r);
             if (!two) bv[j].y = 0.0;
         }
 #pragma unroll
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gram_tiles_kernel(double *const
                 const int64_t rc = ((padding >> q) & 1u) || r >= n ? 0 : r;      // rows past the end are masked at commit
                 uint32_t units = cb[q];
                 asm volatile("" : "+v"(units));            // keeps the 64-bit address from being formed once and kept
-                st[q] = load_d2(base + ((size_t)units << 5) + rc);
+                st[q] = load_d2_stream(base + ((size_t)units << 5) + rc);
             }
     };
     auto commit = [&](const d2(&st)[P], int64_t chunk) {
@@ -1017,7 +1035,7 @@ void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, i
             for (int i = 0; i < MAXP; ++i)
                 if (i < mine) {                                 // wave-uniform
                     __builtin_amdgcn_global_load_lds((global_cvoid_ptr)from[i],
-                                                     (lds_void_ptr)(gd_tile + buf * buf_doubles + 128 * (lw + LWD * i)), 16, 0, 0);
+                                                     (lds_void_ptr)(gd_tile + buf * buf_doubles + 128 * (lw + LWD * i)), 16, 0, FOKL_GD_AUX);
                     from[i] += step;
                 }
         };
@@ -1057,7 +1075,7 @@ void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, i
     do {                                                                                                   \
         if (LW == 0 && wave + 8 * (i) < pieces) {              /* wave-uniform; LW: the loaders' job */    \
             __builtin_amdgcn_global_load_lds((global_cvoid_ptr)src[i],                                     \
-                                             (lds_void_ptr)(gd_tile + (buf) * buf_doubles + 128 * (wave + 8 * (i))), 16, 0, 0); \
+                                             (lds_void_ptr)(gd_tile + (buf) * buf_doubles + 128 * (wave + 8 * (i))), 16, 0, FOKL_GD_AUX); \
             src[i] += src_step;                                                                            \
         }                                                                                                  \
     } while (0)
@@ -1554,7 +1572,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
 #pragma unroll 8
                 for (int j = 0; j < cnt; ++j) {
                     const ResidCol c = cols[j];
-                    const d2 xv = load_d2(c.ptr + r);
+                    const d2 xv = load_d2_stream(c.ptr + r);
                     fit.x = __builtin_fma(c.beta, xv.x, fit.x);
                     fit.y = __builtin_fma(c.beta, xv.y, fit.y);
                 }

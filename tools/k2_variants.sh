@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
     ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function $flags -c -o $VAR/$name.o fokl_hip.hip &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $VAR/$name.so $VAR/$name.o fokl_sampler.o fokl_sampler_wide.o fokl_vlog.o fokl_hostpool.o fokl_integrate.o -ldl -lpthread -lmvec -lm &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $VAR/$name.so $VAR/$name.o fokl_sampler.o fokl_sampler_wide.o fokl_vlog.o fokl_hostpool.o fokl_integrate.o fokl_stream.o fokl_search.o fokl_clean.o -ldl -lpthread -lmvec -lm &&
       rm -f $VAR/$name.o && echo "built $name ($flags)" ) &
   done
   wait
