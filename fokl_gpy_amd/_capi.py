@@ -103,6 +103,7 @@ SIGNATURES = {
     'fokl_search_hold_spectral': (c_int, [c_vp, c_int]),
     'fokl_search_set_update': (c_int, [c_vp, c_int, c_int, c_int]),
     'fokl_search_set_decide': (c_int, [c_vp, c_int, c_dbl]),
+    'fokl_search_set_deterministic': (c_int, [c_vp, c_int]),
     'fokl_search_destroy': (None, [c_vp]),
     'fokl_search_error': (ctypes.c_char_p, [c_vp]),
     'fokl_search_mispredicted': (c_int, [c_vp]),
@@ -894,6 +895,10 @@ class NativeSearch:
         """Kill tests' BIC decisions: 0 from G2 of every trial model, 1 from the downdated least-squares model of the
         sub-stage, confirmed by the accepted models' eigenpairs to `tolerance` (relative; 0: 1e-9)."""
         self._checked(self._lib.fokl_search_set_decide(self._h, int(mode), float(tolerance)))
+
+    def set_deterministic(self, on=True):
+        """Ranks repeating one search side by side: no decision may depend on when a chain's statistics arrive."""
+        self._checked(self._lib.fokl_search_set_deterministic(self._h, int(bool(on))))
 
     def spectral(self, gram, idx, parent=None, parent_pos=-1):
         """parent / parent_pos: a spectrum handle of this search for the model that has one more column, and which of its

@@ -838,6 +838,16 @@ void noise_worker(fokl_host_pool *pool)
     std::deque<Speculation> open;                           // recorded, no verdict yet; oldest first
     auto aborted = [&](fokl_host_job *job) {
         __atomic_store_n(job->progress, -1, __ATOMIC_RELEASE);          // nobody may follow this tape
+        // a chain started ahead follows the tape's block flags: with finish jobs on the tape they pass the -1 on (woken
+        // below); without, this thread materialises the blocks itself and has to say so itself -- a tape sent back before
+        // it was begun used to leave such a chain waiting for ever
+        if (job->block_done && job->pending.load(std::memory_order_acquire) <= 1) {
+            const int block = job->block > 0 ? job->block : FOKL_TAPE_BLOCK;
+            for (int blk = 0; blk < (job->draws + block - 1) / block; ++blk) {
+                int32_t open = 0;
+                __atomic_compare_exchange_n(job->block_done + blk, &open, -1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+            }
+        }
         mark_started(pool, job);                                        // (finish threads asleep on it see the -1)
         trace_noise(pool, job, now_ns());
         settle(job);

@@ -205,6 +205,7 @@ struct Outcome {
     const double *stats_area = nullptr;     // page-locked: [flag, sig, tau, rows, mean w [p1], ticket, seconds]
     bool device_released = false;
     double intercept_scale = NAN;
+    bool scale_inline = false;              // ... formed in line by the search thread (a borderline guess), not by verify()
     std::vector<Check> checks;
     bool release_wanted = false, released = false;
     // A kill test decided from the downdated least-squares model (fokl_search_set_decide, mode 1): the outcome exists from
@@ -284,6 +285,12 @@ struct fokl_search {
     // decision's, and a difference beyond direct_tolerance (relative) ends the search as a misprediction does.
     int decide = 0;
     double direct_tolerance = 1e-9;
+    // Several ranks repeat this search side by side and must take every decision alike (fokl_search_set_deterministic):
+    // nothing may then hinge on WHEN a chain's statistics arrive.  A second clause that can be guessed is guessed even if
+    // the chain has run already (the guess is a function of the Gram alone), and a guess that its chain does not confirm
+    // ends the search only where every rank finds out at the same point: in the blocking verification at the end.
+    bool deterministic = false;
+    bool misprediction_noted = false;
     // accepted models waiting for G2 at most (the loop then waits for the oldest).  The device expands a tape from the
     // stream's pre-states, which the bulk threads keep for the last 1024 segments of 79 872 doubles (fokl_dchain_prestate_ring;
     // the device's own ring of regenerated segments is as long): a chain must be issued before the walker is that far past
@@ -1192,15 +1199,18 @@ int ensure_started(fokl_search *s, Outcome *o)
 // waiting for a chain.  -> 1 / 0, -1: the caller has to wait for the chain, < -1: error (-2 + FOKL_ERR_*)
 int second_clause_now(fokl_search *s, Outcome *o, double value)
 {
-    if (!std::isnan(o->intercept_scale) || chain_done(o)) {
+    // a lazy outcome's chain will run on the device if there is an engine for it (start_chain)
+    const bool device_chain = o->on_device || (o->lazy && s->dchain && o->tape &&
+                                               (o->tape->rows_only || o->spec->p1 <= s->prm.device_chain_columns));
+    // (side by side with other ranks: only what every rank knows at this point of ITS search -- a scale formed in line
+    // below; not one that verify() happened to have fetched already, nor a chain that happens to have run)
+    const bool timing_free = !s->deterministic || !device_chain;
+    if ((!std::isnan(o->intercept_scale) && (timing_free || o->scale_inline)) || (timing_free && chain_done(o))) {
         double scale;
         const int rc = intercept_scale(s, o, &scale);
         if (rc != FOKL_OK) return -2 + rc;
         return value < s->prm.threshav * scale ? 1 : 0;
     }
-    // a lazy outcome's chain will run on the device if there is an engine for it (start_chain)
-    const bool device_chain = o->on_device || (o->lazy && s->dchain && o->tape &&
-                                               (o->tape->rows_only || o->spec->p1 <= s->prm.device_chain_columns));
     if (!device_chain) return -1;
     const double threshold = s->prm.threshav * std::fabs(o->lazy ? o->ls_intercept : o->spec->betahat()[0]);
     if (!(threshold > 0.0) || !std::isfinite(threshold) ||
@@ -1245,6 +1255,7 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
                 total += acc;
             }
             o->intercept_scale = std::fabs(total / (double)(t->draws - s->prm.half0));
+            o->scale_inline = true;
         }
         give_buffer(w, classes, pinned);
         s->stats[S_T_CHAIN] += now_s() - t0;
@@ -1298,6 +1309,10 @@ int verify(fokl_search *s, bool block)
         }
         for (const Check &c : o->checks) {
             if ((c.value < s->prm.threshav * scale) != c.decision) {
+                if (s->deterministic && !block) {           // every rank will see it in its blocking verification
+                    s->misprediction_noted = true;
+                    continue;
+                }
                 s->mispredicted = true;
                 unref(s, o);
                 return fail(s, FOKL_ERR_STATE,
@@ -1308,6 +1323,10 @@ int verify(fokl_search *s, bool block)
         o->checks.clear();
         if (o->release_wanted) release_outcome(s, o);
         unref(s, o);
+    }
+    if (block && s->misprediction_noted) {
+        s->mispredicted = true;
+        return fail(s, FOKL_ERR_STATE, "kill test decided from a guessed intercept scale that its chain does not confirm");
     }
     return FOKL_OK;
 }
@@ -1590,6 +1609,14 @@ extern "C" int fokl_search_set_decide(fokl_search *s, int mode, double tolerance
     if (!s || mode < 0 || mode > 1) return fail(s, FOKL_ERR_ARG, "fokl_search_set_decide: bad arguments");
     s->decide = mode;
     if (tolerance > 0.0) s->direct_tolerance = tolerance;
+    return FOKL_OK;
+}
+
+// Ranks that repeat one search side by side (see fokl_search::deterministic).
+extern "C" int fokl_search_set_deterministic(fokl_search *s, int on)
+{
+    if (!s) return fail(nullptr, FOKL_ERR_ARG, "fokl_search_set_deterministic: null search");
+    s->deterministic = on != 0;
     return FOKL_OK;
 }
 

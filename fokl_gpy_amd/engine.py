@@ -285,6 +285,7 @@ class ForwardSelection:
         # candidates -- is computed by one rank each and all-gathered (HostPipeline._exchange)
         self.candidate_sharded = bool(candidate_sharded) and comm is not None and (
             comm.world > 1 or os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1')
+        self._replicated_native = False     # a search replicated over ranks on the native driver (decided in run())
         # Both at once is the hybrid split: every rank holds N / G rows (K1, K2, K3 on its rows, the small Gram blocks and
         # residual moments all-reduced on the device -- the DEVICE work is divided by G) and the replicated search deals its
         # eigen-decompositions over the ranks as well (the HOST work that bounds configs[3] is divided by G too).  The Gram
@@ -1019,10 +1020,14 @@ class ForwardSelection:
         t_begin_run = time.perf_counter()
         if pipelined:
             try:
-                # device chains: one search per process at a time drives an engine's guesses; replicated searches (rows
-                # or candidates sharded over ranks) keep the host chains -- a rank whose chain had arrived decides from
-                # it, one that guesses would stop on a misprediction alone and leave the others in a collective
-                if self.allow_device_chains and not self.allreduce and not self.candidate_sharded:
+                # device chains: one search per process at a time drives an engine's guesses.  Searches replicated over ranks
+                # (rows or candidates sharded) have them under the native driver, which then keeps the arrival time of a
+                # chain out of every decision (fokl_search_set_deterministic); the Python loop keeps host chains there -- a
+                # rank whose chain had arrived would decide from it, one that guesses would stop on a misprediction alone
+                # and leave the others in a collective
+                replicated = self.allreduce or self.candidate_sharded
+                self._replicated_native = replicated and self._native_planned()
+                if self.allow_device_chains and (not replicated or self._replicated_native):
                     self.chain_engine = chain_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
                     if self.chain_engine is not None:
                         self.device_chain_columns = min(self.device_chain_columns,
@@ -1030,7 +1035,10 @@ class ForwardSelection:
                     self._dchain_stats0 = self.chain_engine.stats() if self.chain_engine is not None else {}
                 # (a sub-stage of 3-way terms over m inputs adds up to m (m - 1) (m - 2) columns: models of hundreds)
                 wide = self.m * (self.m - 1) * (self.m - 2 if self.way3 else 1) >= 1000
-                self.host = HostPipeline(self.stream, self.draws, self.comm if self.candidate_sharded else None,
+                # (the Python loop's candidate sharding deals the G2 jobs over the ranks, HostPipeline._exchange; the native
+                # driver's splits the Gram launches instead, _gram_of_new_columns, and keeps every G2 job at home)
+                self.host = HostPipeline(self.stream, self.draws,
+                                         self.comm if self.candidate_sharded and not self._replicated_native else None,
                                          chain_engine=self.chain_engine, wide_models=wide)
             except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
                 # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
@@ -1051,7 +1059,7 @@ class ForwardSelection:
             # G2 of the kill tests' models on the device (Jacobi in LDS) where the search runs on one process and the
             # model fits the kernel; wider models, replicated searches and FOKL_EIGH=host keep LAPACK on the pool's threads
             self.spectral_engine = None
-            if not self.allreduce and not self.candidate_sharded:
+            if not self.allreduce and not self.candidate_sharded:       # (G2 on the device: single-process searches)
                 self.spectral_engine = spectral_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
             if self.spectral_engine is not None:
                 # hybrid: only jobs the device finishes before their kill test comes up (FOKL_DSPECTRAL_SLACK kernel
@@ -1066,8 +1074,14 @@ class ForwardSelection:
             # several ranks repeat one search: which models are derived depends on what was requested ahead, and the ranks
             # must agree to the last bit.
             update_from = int(os.environ.get('FOKL_EIGH_UPDATE', '8'))
-            if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) and not self.allreduce \
-                    and not self.candidate_sharded and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
+            # (replicated searches: under direct decisions G2 is requested for accepted models only, at the moment of the
+            # decision -- which models are derived is then a function of the decisions, the same on every rank; while the
+            # loop orders G2 ahead along a path it predicts, FOKL_KILL_DECIDE=g2, it depends on timing: not there)
+            direct_wanted = os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
+                getattr(self, 'allow_direct_decisions', True)
+            if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) \
+                    and (direct_wanted or not (self.allreduce or self.candidate_sharded)) \
+                    and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
                 # FOKL_LOOKAHEAD_DERIVED (default 0: the ordinary look-ahead): a deeper G2 window while derivation is on, in
                 # sub-stages of fewer than 192 columns.  A chain of derivations advances slower than the loop tests, and 24
                 # deep keeps more of its pieces running side by side: configs[2] 40.0-40.1 ms per fit against 40.3-43.0,
@@ -1094,7 +1108,14 @@ class ForwardSelection:
                 decide = 'g2'
             self.native.set_decide(1 if decide == 'direct' else 0, float(os.environ.get('FOKL_KILL_DECIDE_TOL', '0')))
             self.stats['kill_decide'] = decide
+            if self.allreduce or self.candidate_sharded:
+                self.native.set_deterministic(True)
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
+        if self.native is None and self.host is not None and os.environ.get('FOKL_SEARCH', 'native') != 'python':
+            import warnings
+            warnings.warn("the native search driver is not available for this search (FOKL_KILL_BIC / FOKL_SEARCH_DIST / a "
+                          "stand-in chain engine): it runs on the Python statement of the loop, several times slower -- "
+                          "fit_stats['search_driver'] says which", RuntimeWarning)
         _mark('pool_up')
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run
         # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
@@ -1149,12 +1170,21 @@ class ForwardSelection:
         """The native search core drives single-process searches whose kill-test BICs come from the Gram; replicated
         searches (rows or candidates over ranks), FOKL_KILL_BIC=device|check and stand-in chain engines (tests) keep the
         Python statement of the loop.  FOKL_SEARCH=python forces that one."""
+        if not self._native_planned():
+            return False
+        if self.chain_engine is not None and not isinstance(self.chain_engine, _capi.DeviceChainEngine):
+            return False
+        return True
+
+    def _native_planned(self):
+        """What can be said before the host pipeline is up.  Searches replicated over ranks run the native driver too
+        (round 5; FOKL_SEARCH_DIST=python keeps the Python loop for them, with its G2 jobs dealt over the ranks)."""
         from . import host_pipeline
         if os.environ.get('FOKL_SEARCH', 'native') == 'python':
             return False
-        if self.allreduce or self.candidate_sharded or self.kill_bic not in ('auto', 'gram'):
+        if (self.allreduce or self.candidate_sharded) and os.environ.get('FOKL_SEARCH_DIST', 'native') == 'python':
             return False
-        if self.chain_engine is not None and not isinstance(self.chain_engine, _capi.DeviceChainEngine):
+        if self.kill_bic not in ('auto', 'gram'):
             return False
         return host_pipeline._chain_engine_factory is None
 
@@ -1173,6 +1203,40 @@ class ForwardSelection:
             if ind > self.n_phis:                  # FR:1747
                 return
 
+    # -- candidates sharded over ranks, native driver (round 5) ---------------------------------------------
+    # Every rank holds all rows and repeats the same search.  With the kill tests decided from the sub-stage's Gram nothing
+    # of a kill test depends on N any more; what does is the forward step itself: the T candidate terms' columns (K1) and
+    # their Gram rows against [model | candidates | y] (K2, 2 N T (P + T + 1) flops -- the launch the matrix pipe bounds).
+    # Each rank takes the Gram rows of its share of the candidates -- every rank builds all T columns, 8 N T bytes of
+    # stores, since a candidate's row needs every other candidate's column -- and ONE all-gather per forward step brings the
+    # per-candidate rows (from which each candidate's BIC follows on the host) to every rank: north_star's split.
+    def _candidate_split(self):
+        return self._replicated_native and self.candidate_sharded and not self.allreduce
+
+    def _share_of(self, slots):
+        """This rank's share of a forward step's candidate columns, padded to the common length by repeating its last
+        column (padding rows are dropped after the gather).  -> (slots of the share, common length)"""
+        world, rank = self.comm.world, self.comm.rank
+        share = -(-len(slots) // world)
+        mine = list(slots[rank * share:(rank + 1) * share])
+        mine += [slots[-1]] * (share - len(mine))
+        return mine, share
+
+    def _gather_rows(self, local, total, share):
+        """The candidates' Gram rows of all ranks in candidate order: one all-gather of share x columns doubles."""
+        t0 = time.perf_counter()
+        parts = self.comm.allgather(np.ascontiguousarray(local).reshape(-1)).reshape(self.comm.world, share, -1)
+        self.stats['candidate_gathers'] = self.stats.get('candidate_gathers', 0) + 1
+        self.stats['t_candidate_gather'] = self.stats.get('t_candidate_gather', 0.0) + time.perf_counter() - t0
+        return np.concatenate([parts[r, :max(0, min(share, total - r * share))] for r in range(self.comm.world)], axis=0)
+
+    def _gram_of_new_columns(self, new_slots, col_slots):
+        """Gram rows of a forward step's candidate columns (blocking form)."""
+        if not self._candidate_split():
+            return self.backend.gram(new_slots, col_slots, self.allreduce)
+        mine, share = self._share_of(new_slots)
+        return self._gather_rows(self.backend.gram(mine, col_slots, False), len(new_slots), share)
+
     def _build_ahead(self, indvec, active_slots):
         """K1 + K2 of a coming sub-stage while the current one is still being decided: its columns, and their Gram
         block against every column that can still be in the model then (all of the current sub-stage's) and y."""
@@ -1183,14 +1247,22 @@ class ForwardSelection:
         ahead = dict(indvec=indvec, vecs=vecs, slots=slots, over=len(active_slots))
         if hasattr(self.backend, 'gram_launch'):
             # the driver does not wait: the block is fetched when somebody looks at it (_ahead_block)
-            ahead['pending'] = self.backend.gram_launch(slots, active_slots + slots + [SLOT_Y], self.allreduce)
+            if self._candidate_split():
+                mine, share = self._share_of(slots)
+                ahead['share'] = share
+                ahead['pending'] = self.backend.gram_launch(mine, active_slots + slots + [SLOT_Y], False)
+            else:
+                ahead['pending'] = self.backend.gram_launch(slots, active_slots + slots + [SLOT_Y], self.allreduce)
         else:
-            ahead['block'] = self.backend.gram(slots, active_slots + slots + [SLOT_Y], self.allreduce)
+            ahead['block'] = self._gram_of_new_columns(slots, active_slots + slots + [SLOT_Y])
         return ahead
 
     def _ahead_block(self, ahead):
         if 'block' not in ahead:
-            ahead['block'] = self.backend.gram_fetch(ahead.pop('pending'))
+            block = self.backend.gram_fetch(ahead.pop('pending'))
+            if 'share' in ahead:                    # this rank's share of the candidates: the others' rows are gathered
+                block = self._gather_rows(block, len(ahead['slots']), ahead.pop('share'))
+            ahead['block'] = block
         return ahead['block']
 
     @staticmethod
@@ -1270,7 +1342,7 @@ class ForwardSelection:
                 new_slots = self.pool.take(vecs.shape[0])
                 self.backend.build_terms(vecs.astype(np.int32), new_slots)
                 self.stats['terms_physical'] += vecs.shape[0]
-                block = self.backend.gram(new_slots, [SLOT_ONES] + model_slots + new_slots + [SLOT_Y], self.allreduce)
+                block = self._gram_of_new_columns(new_slots, [SLOT_ONES] + model_slots + new_slots + [SLOT_Y])
                 gram = self._extend_gram(gram, keep, block, list(range(n_prev)), n_prev)
             _mark('substage', f"{ind} hit={int(spectral_job is not None)}")
             vm = vecs.shape[0]

@@ -599,6 +599,11 @@ int fokl_search_set_update(fokl_search *search, int from_columns, int depth, int
  * 'direct_tests', 'direct_max_rel' (largest relative difference seen), 'chains_cancelled' (accepted models replaced
  * before anything looked at their draws: their chains never run). */
 int fokl_search_set_decide(fokl_search *search, int mode, double tolerance);
+/* Several ranks repeat this search side by side (rows or candidates sharded over GPUs) and must take every decision alike:
+ * on != 0 keeps the arrival time of a chain's statistics out of every decision -- a second clause of FR:1670 that can be
+ * guessed from the least-squares intercept IS guessed (a function of the all-reduced / all-gathered Gram alone), and a guess
+ * that its chain does not confirm ends the search in the blocking fokl_search_verify at its end, where every rank finds it. */
+int fokl_search_set_deterministic(fokl_search *search, int on);
 void fokl_search_destroy(fokl_search *search);
 const char *fokl_search_error(const fokl_search *search);
 /* 1 after a guessed decision was not confirmed by its chain (the driver repeats the search without device chains) */

@@ -116,6 +116,10 @@ def main():
     res['rowshard_mtx_equal'] = bool(rm.shape == sm.shape and np.array_equal(rm, sm))
     res['rowshard_evs_err'] = float(np.max(np.abs(re - se) / np.abs(se))) if len(re) == len(se) else 1.0
     res['rowshard_betas_err'] = float(np.max(np.abs(rb - sb) / np.max(np.abs(sb), axis=0))) if rb.shape == sb.shape else 1.0
+    res['rowshard_driver'] = sharded.fit_stats['search_driver']
+    res['rowshard_calls_equal'] = [t['cols'] for t in sharded.fit_trace] == [t['cols'] for t in single.fit_trace]
+    digest = comm.allgather([float(np.sum(rb)), float(np.sum(re)), float(rm.sum())])
+    res['rowshard_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
 
     # 3. throughput mode: independent fits, one all-gather
     with warnings.catch_warnings():
@@ -157,12 +161,37 @@ def main():
     res['cand_betas_err'] = float(np.max(np.abs(cb - sb) / np.max(np.abs(sb), axis=0))) if cb.shape == sb.shape else 1.0
     res['cand_calls_equal'] = [t['cols'] for t in shard.fit_trace] == [t['cols'] for t in single.fit_trace]
     res['cand_stream_equal'] = bool(np.array_equal(single_state[1], shard_state[1]) and single_state[2:] == shard_state[2:])
-    res['cand_remote'] = int(shard.fit_stats['spectral_remote'])
-    res['cand_exchanges'] = int(shard.fit_stats['exchanges'])
+    res['cand_driver'] = shard.fit_stats['search_driver']
+    res['cand_gathers'] = int(shard.fit_stats.get('candidate_gathers', 0))
+    res['cand_substages'] = int(shard.fit_stats['substages'])
     res['cand_gibbs_calls'] = int(shard.fit_stats['gibbs_calls'])
     # bitwise agreement between the ranks: what every rank ends up with
     digest = comm.allgather([float(np.sum(cb)), float(np.sum(ce)), float(cm.sum())])
     res['cand_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
+
+    # 4b. the same split on the Python statement of the loop (FOKL_SEARCH_DIST=python): G2 + BIC of the candidate models are
+    #     dealt over the ranks and all-gathered window by window
+    os.environ['FOKL_SEARCH_DIST'] = 'python'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        shard = FoKLRoutines.FoKL(**hy3)
+        backend = OracleBackend()
+        shard._backend_override = backend
+        shard._prepare_fit(x, y, dict(clean=True))
+        np.random.seed(9)
+        pb, pm, pe = shard._search(backend, n, m, comm=comm, candidate_sharded=True)
+        py_state = np.random.get_state()
+    del os.environ['FOKL_SEARCH_DIST']
+    res['pycand_driver'] = shard.fit_stats['search_driver']
+    res['pycand_mtx_equal'] = bool(pm.shape == sm.shape and np.array_equal(pm, sm))
+    res['pycand_evs_err'] = float(np.max(np.abs(pe - se) / np.abs(se))) if len(pe) == len(se) else 1.0
+    res['pycand_betas_err'] = float(np.max(np.abs(pb - sb) / np.max(np.abs(sb), axis=0))) if pb.shape == sb.shape else 1.0
+    res['pycand_stream_equal'] = bool(np.array_equal(single_state[1], py_state[1]) and single_state[2:] == py_state[2:])
+    res['pycand_remote'] = int(shard.fit_stats['spectral_remote'])
+    res['pycand_exchanges'] = int(shard.fit_stats['exchanges'])
+    res['pycand_gibbs_calls'] = int(shard.fit_stats['gibbs_calls'])
+    digest = comm.allgather([float(np.sum(pb)), float(np.sum(pe)), float(pm.sum())])
+    res['pycand_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
 
     # 5. hybrid: rows AND candidates sharded (each rank holds half of the rows of section 4's dataset: its device work is
     #    halved; the eigen-decompositions of the replicated search are dealt over the ranks on top)
@@ -181,7 +210,7 @@ def main():
     res['hybrid_betas_err'] = float(np.max(np.abs(hb - sb) / np.max(np.abs(sb), axis=0))) if hb.shape == sb.shape else 1.0
     res['hybrid_calls_equal'] = [t['cols'] for t in hyb.fit_trace] == [t['cols'] for t in single.fit_trace]
     res['hybrid_stream_equal'] = bool(np.array_equal(single_state[1], hyb_state[1]) and single_state[2:] == hyb_state[2:])
-    res['hybrid_remote'] = int(hyb.fit_stats['spectral_remote'])
+    res['hybrid_driver'] = hyb.fit_stats['search_driver']
     digest = comm.allgather([float(np.sum(hb)), float(np.sum(he)), float(hm.sum())])
     res['hybrid_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
 

@@ -25,20 +25,31 @@ def test_two_rank_collectives_rowshard_and_replicas(tmp_path):
     results = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(2)]
     for res in results:
         assert res['allgather_ok'] and res['allreduce_ok'] and res['shard_ok']
-        # row-sharded fit: same model on every rank as the single-process fit (sums differ only in association)
-        assert res['rowshard_mtx_equal']
+        # row-sharded fit, native driver: same model and call sequence on every rank as the single-process fit (sums differ
+        # only in association), the ranks agree to the last bit
+        assert res['rowshard_driver'] == 'native'
+        assert res['rowshard_mtx_equal'] and res['rowshard_calls_equal'] and res['rowshard_ranks_bitwise_equal']
         assert res['rowshard_evs_err'] < 1e-10 and res['rowshard_betas_err'] < 1e-8
-        # candidate-sharded fit: the same model, call sequence, stream and (to rounding: the kill tests' BIC comes
-        # from the Gram identity in this mode) numbers as the single-process fit; about half of the spectral results
-        # arrived from the other rank
+        # candidate-sharded fit, native driver (round 5): every rank repeats the search, the Gram rows of a forward step's
+        # candidate columns are computed one share per rank and all-gathered -- one gather per sub-stage; same model, call
+        # sequence, stream and (to rounding) numbers as the single-process fit, ranks bitwise alike
+        assert res['cand_driver'] == 'native'
         assert res['cand_mtx_equal'] and res['cand_calls_equal'] and res['cand_stream_equal']
         assert res['cand_evs_err'] < 1e-10 and res['cand_betas_err'] < 1e-8
         assert res['cand_ranks_bitwise_equal']
-        assert res['cand_exchanges'] > 0 and res['cand_remote'] >= res['cand_gibbs_calls'] // 2 - 2
-        # hybrid (rows + candidates): same model, calls and stream; sums differ in association only
+        assert res['cand_gathers'] >= res['cand_substages']
+        # the Python loop's form of the split (FOKL_SEARCH_DIST=python): G2 + BIC of the candidate models dealt over the
+        # ranks; about half of the spectral results arrived from the other rank
+        assert res['pycand_driver'] == 'python'
+        assert res['pycand_mtx_equal'] and res['pycand_stream_equal'] and res['pycand_ranks_bitwise_equal']
+        assert res['pycand_evs_err'] < 1e-10 and res['pycand_betas_err'] < 1e-8
+        assert res['pycand_exchanges'] > 0 and res['pycand_remote'] >= res['pycand_gibbs_calls'] // 2 - 2
+        # hybrid (rows + candidates): under the native driver the rows are sharded (the Gram rows of a share of the
+        # candidates over a share of the rows would be partial sums nobody can use); same model, calls and stream
+        assert res['hybrid_driver'] == 'native'
         assert res['hybrid_mtx_equal'] and res['hybrid_calls_equal'] and res['hybrid_stream_equal']
         assert res['hybrid_evs_err'] < 1e-10 and res['hybrid_betas_err'] < 1e-8
-        assert res['hybrid_ranks_bitwise_equal'] and res['hybrid_remote'] > 0
+        assert res['hybrid_ranks_bitwise_equal']
     # throughput mode: every rank sees all ranks' counters after the single all-gather
     assert results[0]['replica_terms'] == results[1]['replica_terms']
     assert results[0]['replica_terms'][0] == results[0]['replica_own_terms']
