@@ -1175,7 +1175,11 @@ def main():
                     comm.barrier()
                     box['seconds'] = time.perf_counter() - t0
                 box.update(terms=terms, spectral_remote=int(joint.fit_stats.get('spectral_remote', 0)),
-                           exchanges=int(joint.fit_stats.get('exchanges', 0)))
+                           exchanges=int(joint.fit_stats.get('exchanges', 0)),
+                           search_driver=joint.fit_stats.get('search_driver'),
+                           gathers=int(joint.fit_stats.get('candidate_gathers', 0)),
+                           gather_s=float(joint.fit_stats.get('t_candidate_gather', 0.0)),
+                           substages=int(joint.fit_stats.get('substages', 0)))
                 # the joint fit against the same golden as the timed fit (every rank checks its own copy of the result)
                 key = (cfg, 0, sp['rows'])
                 if key in GOLDENS and not GOLDENS[key][1] and not args.inputs and \
@@ -1208,14 +1212,20 @@ def main():
             t_joint = float(np.max(report[:, 2]))
             sharded_line = dict(mode='candidates', value=box['terms'] / t_joint, unit='candidate-terms/s',
                                 ms_per_step=1e3 * t_joint / max(1, args.steps), scaling='strong',
+                                search_driver=box.get('search_driver'),
+                                # native driver: one all-gather of the candidates' Gram rows per forward step (sub-stage);
+                                # Python loop (FOKL_SEARCH_DIST=python): G2 jobs dealt over the ranks, gathered by windows
+                                all_gathers_per_fit=box.get('gathers'), all_gather_s_per_fit=box.get('gather_s'),
+                                substages_per_fit=box.get('substages'),
                                 spectral_remote=box['spectral_remote'], exchanges=box['exchanges'],
                                 parity=box.get('parity'),
                                 parity_ok_on_every_rank=None if float(np.max(report[:, 3])) < 0.0
                                 else bool(float(np.min(report[:, 3])) == 1.0),
                                 transport='RCCL' if comm_kind == 'RCCL' else 'TCP control plane (launcher rehearsal)',
-                                note='ONE fit of the unit-0 dataset by all ranks together: candidate models dealt over the '
-                                     'ranks, one all-gather per window of candidates (north_star\'s split); after the '
-                                     'timed region of the independent fits')
+                                note='ONE fit of the unit-0 dataset by all ranks together, every rank repeating the search: '
+                                     'the Gram rows of each forward step\'s candidate terms are computed one share per rank '
+                                     'and all-gathered, one gather per forward step (north_star\'s split); after the timed '
+                                     'region of the independent fits')
         if finished:
             np.random.set_state(state_before)
 

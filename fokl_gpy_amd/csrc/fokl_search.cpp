@@ -172,6 +172,12 @@ struct Spectrum {
     // the Gram the job reads, when the search owns it (kill tests decided at once: their G2 jobs outlive the call -- and
     // the caller's array -- that submitted them); jobs submitted through fokl_search_spectral* read the caller's
     std::shared_ptr<const std::vector<double>> gram_keep;
+    // G2 not requested yet (launch_deferred): an accepted kill test's model in a sub-stage of wide models, where a
+    // decomposition costs tens of milliseconds -- it is requested when something turns out to need it (a guessed decision
+    // to confirm, the sub-stage's surviving model), and never for a model that is replaced before anything looked at it
+    bool deferred = false;
+    const double *deferred_gram = nullptr;
+    int deferred_ld = 0;
     int32_t updated = -1;
     int status = FOKL_OK;
     int refs = 1;
@@ -291,6 +297,7 @@ struct fokl_search {
     // ends the search only where every rank finds out at the same point: in the blocking verification at the end.
     bool deterministic = false;
     bool misprediction_noted = false;
+    int defer_from = std::getenv("FOKL_G2_DEFER_FROM") ? std::atoi(std::getenv("FOKL_G2_DEFER_FROM")) : 192;   // (kWideModel)
     // accepted models waiting for G2 at most (the loop then waits for the oldest).  The device expands a tape from the
     // stream's pre-states, which the bulk threads keep for the last 1024 segments of 79 872 doubles (fokl_dchain_prestate_ring;
     // the device's own ring of regenerated segments is as long): a chain must be issued before the walker is that far past
@@ -556,11 +563,17 @@ constexpr int kWideModel = 192, kWideDepth = 2;
 // parent / parent_pos: the model this one is with its column number parent_pos deleted (a kill test's model and the model
 // it is tested against), when the caller has it -- G2 then follows from the parent's eigenpairs where that is allowed.
 Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int32_t *idx, int p1, double slack_us = -1.0,
-                          Spectrum *parent = nullptr, int parent_pos = -1)
+                          Spectrum *parent = nullptr, int parent_pos = -1, bool defer = false)
 {
     auto *sp = new Spectrum();
     sp->p1 = p1;
     sp->idx.assign(idx, idx + p1);
+    if (defer) {
+        sp->deferred = true;
+        sp->deferred_gram = gram;
+        sp->deferred_ld = ld;
+        return sp;
+    }
     if (spectrum_to_device(s, p1, slack_us)) {
         // staged only: the entry point that ends this burst of requests launches them as one grid (flush_spectra)
         if (fokl_dspectral_submit(s->dspec, gram, ld, sp->idx.data(), p1, ld - 1, 0, &sp->ticket, &sp->buf) != FOKL_OK) {
@@ -576,7 +589,7 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     }
     sp->buf = take_spectrum_buffer(p1);
     int rc = FOKL_ERR_STATE;
-    const bool from_parent = sp->buf && parent && s->update_from > 0 && parent_pos >= 0 && parent_pos <= p1 &&
+    const bool from_parent = sp->buf && parent && !parent->deferred && s->update_from > 0 && parent_pos >= 0 && parent_pos <= p1 &&
                              parent->p1 == p1 + 1 && parent->p1 >= s->update_from && !parent->dev && parent->buf &&
                              parent->status == FOKL_OK &&
                              parent->depth < (parent->p1 >= kWideModel ? std::min(s->update_depth, kWideDepth) : s->update_depth);
@@ -601,6 +614,27 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     }
     s->stats[S_SPECTRAL_SUBMITTED] += 1;
     return sp;
+}
+
+// G2 of a deferred spectrum is wanted after all: a decomposition of its own (whatever it could have been derived from may
+// never have been decomposed itself).
+int launch_deferred(fokl_search *s, Spectrum *sp)
+{
+    if (!sp->deferred) return FOKL_OK;
+    sp->buf = take_spectrum_buffer(sp->p1);
+    int rc = FOKL_ERR_STATE;
+    if (sp->buf)
+        rc = fokl_pool_submit_spectral(s->pool, sp->deferred_gram, sp->deferred_ld, sp->idx.data(), sp->p1, sp->deferred_ld - 1,
+                                       sp->lamb(), sp->Qt(), sp->qty(), sp->betahat(), sp->moments(), &sp->job);
+    if (rc != FOKL_OK) {
+        give_spectrum_buffer(sp->buf, sp->p1);
+        sp->buf = nullptr;
+        sp->status = fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a spectral job");
+        return sp->status;
+    }
+    sp->deferred = false;
+    s->stats[S_SPECTRAL_SUBMITTED] += 1;
+    return FOKL_OK;
 }
 
 // The job of `sp` has run: its parent's arrays are no longer read; a model decomposed afresh after all is depth 0.
@@ -628,12 +662,17 @@ void flush_spectra(fokl_search *s)
 
 bool spectrum_done(Spectrum *sp)
 {
+    if (sp->deferred) return false;
     if (sp->dev) return sp->dev_waited || fokl_dspectral_poll(sp->dev, sp->ticket) != 0;   // (an error counts: wait reports it)
     return !sp->job || fokl_pool_poll(sp->job) != 0;
 }
 
 int wait_spectrum(fokl_search *s, Spectrum *sp)
 {
+    if (sp->deferred) {
+        const int rc = launch_deferred(s, sp);
+        if (rc != FOKL_OK) return rc;
+    }
     if (sp->dev) {
         if (!sp->dev_waited) {
             const double t0 = now_s();
@@ -1144,6 +1183,20 @@ int settle_pending(fokl_search *s, bool block, Outcome *upto)
     };
     while (!s->pending.empty()) {
         Outcome *o = s->pending.front();
+        if (o->spec->deferred && o->released && o->checks.empty() && !o->release_wanted) {
+            // replaced before anything needed its eigenpairs: neither G2 nor a chain
+            s->pending.pop_front();
+            o->lazy = false;
+            o->cancelled = true;
+            s->stats[S_CHAINS_CANCELLED] += 1;
+            if (s->prechain.tape == o->tape) drop_prechain(s);
+            unref(s, o->tape);
+            o->tape = nullptr;
+            const bool last = o == upto;
+            unref(s, o);
+            if (last) break;
+            continue;
+        }
         if (!block && !spectrum_done(o->spec)) break;
         const double t0 = now_s();
         const int rc = wait_spectrum(s, o->spec);
@@ -1268,6 +1321,7 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
     if (o->checks.empty()) {
         o->refs += 1;
         s->unverified.push_back(o);
+        if (o->spec->deferred && launch_deferred(s, o->spec) != FOKL_OK) return -2 + FOKL_ERR_STATE;    // its chain will be needed
     }
     o->checks.push_back({value, decision});
     return decision ? 1 : 0;
@@ -2101,12 +2155,16 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                         best->spec->lamb()[0] > 1e-9 * best->spec->lamb()[A - 1];
     auto run_direct = [&]() -> int {
         PathModel &m = committed;
+        // Wide models (a decomposition takes tens of milliseconds, derivations are cut after two steps): G2 of an accepted
+        // model is requested when something needs it, not when the model is accepted (Spectrum::deferred)
+        const bool defer_g2 = A >= s->defer_from;
         // G2 of the accepted models is not waited for in here: the jobs read the search's own copy of the Gram
         const auto own_gram = std::make_shared<const std::vector<double>>(gram, gram + (size_t)ld * ld);
         std::vector<Spectrum *> callers;                    // spectra taken over from the caller (they read ITS array)
         auto tests = [&]() -> int {
         m.ssr = best->s2;                                   // the device's residual pass, not the Gram identity
         m.s1 = best->s1;
+        int rc2_end = FOKL_OK;
         double tp = s->profile ? now_s() : 0.0;
         auto lap = [&](int k) {
             if (s->profile) {
@@ -2153,7 +2211,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
             lap(2);
             const auto idx = columns_without(A, trial);
-            auto take_spectrum = [&]() -> Spectrum * {
+            auto take_spectrum = [&](bool want_now = false) -> Spectrum * {
                 const double t_sp = s->profile ? now_s() : 0.0;
                 Spectrum *sp = nullptr;
                 auto it = ahead.find(trial);
@@ -2166,7 +2224,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                     }
                 } else {
                     sp = submit_spectrum(s, own_gram->data(), ld, idx.data(), p1, -1.0,
-                                         s->update_from > 0 ? best->spec : nullptr, at);
+                                         s->update_from > 0 && !best->spec->deferred ? best->spec : nullptr, at,
+                                         defer_g2 && !want_now);
                     if (sp) sp->gram_keep = own_gram;
                     flush_spectra(s);
                 }
@@ -2178,7 +2237,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (!(s2 > 1e-6 * dtd)) {
                 // a candidate that (nearly) interpolates the data: the device's residual pass on the eigenpairs' betahat,
                 // as in mode 0
-                if (!(sp = take_spectrum())) {
+                if (!(sp = take_spectrum(true))) {
                     unref(s, tape);
                     return FOKL_ERR_STATE;
                 }
@@ -2247,6 +2306,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 s->tape_limbo.erase(s->tape_limbo.begin());
             }
         }
+        // the model that survives the sub-stage is the caller's: its eigenpairs will be looked at
+        if (best->lazy && best->spec->deferred && (rc2_end = launch_deferred(s, best->spec)) != FOKL_OK) return rc2_end;
         // the kill set is final: G2 of the coming sub-stage's model can start
         lap(6);
         if (a->foresee && !idle_pending) {

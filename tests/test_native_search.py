@@ -59,10 +59,14 @@ def _random_problem(seed, n=600, m=5):
 
 @pytest.mark.parametrize('seed', [3, 10, 29, 53])
 @pytest.mark.parametrize('env', [(), (('FOKL_TENTATIVE_TAPES', 'test'),), (('FOKL_LOOKAHEAD', '0'), ('FOKL_FORESIGHT', '0')),
-                                 (('FOKL_SPECULATION', '2'),), (('FOKL_FINISH_THREADS', '0'),)])
+                                 (('FOKL_SPECULATION', '2'),), (('FOKL_FINISH_THREADS', '0'),),
+                                 (('FOKL_KILL_DECIDE', 'g2'),), (('FOKL_G2_DEFER_FROM', '4'),),
+                                 (('FOKL_SPECULATE_ACROSS', '0'),)])
 def test_native_search_equals_the_python_search_whatever_is_ordered_ahead(monkeypatch, seed, env):
-    """Forced rewinds before every order, no look-ahead at all, a short order book, no finish threads: what is prepared
-    ahead differs, what is evaluated does not."""
+    """Forced rewinds before every order, no look-ahead at all, a short order book, no finish threads, kill tests decided
+    from G2 of every trial model (round 4) instead of from the downdated least-squares model, G2 of accepted models
+    requested only when something needs it, no tapes ordered across the sub-stage boundary: what is prepared ahead
+    differs, what is evaluated does not."""
     problem = _random_problem(seed)
     hy = dict(draws=60, burnin=60)
     _same(_fit(monkeypatch, 'native', problem=problem, env=env, **hy),
