@@ -611,6 +611,8 @@ class FoKL:
             packed, nb, width = getKernels.pack_phis(self.phis, kid)
             backend.upload_staged(np.asarray(data, dtype=np.float64), kid, packed, nb, width, staged[1], staged[2], self)
             return
+        if isinstance(inputs, _DeviceInputs):
+            raise RuntimeError("the dataset was staged on another device backend than the one the fit uploads to")
         inputs = np.asarray(inputs, dtype=np.float64)
         if kid == getKernels.KERNEL_SPLINES:
             self._inputs_to_phind(inputs)              # range validation with the reference's own expression
@@ -636,6 +638,18 @@ class FoKL:
 
     def _prepare_fit(self, inputs, data, kwargs):
         """Everything ``fit`` does before the search: keyword triage, cleaning, data-driven defaults, upload."""
+        try:
+            return self._prepare_fit_steps(inputs, data, kwargs)
+        except BaseException:
+            # a dataset staged for normalisation on the device whose upload never completed (relats_in rejected, a shape
+            # error): the placeholder would describe what is NOT on the device -- a later read of ``inputs`` would fetch
+            # another dataset's numbers -- so it goes; the model is left without inputs, as before the call
+            self.__dict__.pop('_staged_upload', None)
+            if isinstance(self.__dict__.get('inputs'), _DeviceInputs):
+                del self.__dict__['inputs']
+            raise
+
+    def _prepare_fit_steps(self, inputs, data, kwargs):
         t_begin = time.perf_counter()
         fit_opts = {'ConsoleOutput': _str_to_bool(kwargs.get('ConsoleOutput', self.ConsoleOutput)),
                     'clean': _str_to_bool(kwargs.get('clean', False))}

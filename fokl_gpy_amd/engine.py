@@ -1047,69 +1047,79 @@ class ForwardSelection:
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
         if self.host is not None and self._native_wanted():
-            half0 = int(math.ceil(self.draws / 2))
-            self.native = _capi.NativeSearch(
-                self.host.pool, self.chain_engine, n=self.n, a=self.a, b=self.b, atau=self.atau, btau=self.btau,
-                threshav=self.threshav, threshstda=self.threshstda, threshstdb=self.threshstdb,
-                guess_margin=self.guess_margin, draws=self.draws, half0=half0, aic=int(self.aic),
-                lookahead=self._lookahead_native, foresight=self.foresight, speculation_max=self._speculation_native,
-                tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
-                device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
-                flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
-            # G2 of the kill tests' models on the device (Jacobi in LDS) where the search runs on one process and the
-            # model fits the kernel; wider models, replicated searches and FOKL_EIGH=host keep LAPACK on the pool's threads
-            self.spectral_engine = None
-            if not self.allreduce and not self.candidate_sharded:       # (G2 on the device: single-process searches)
-                self.spectral_engine = spectral_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
-            if self.spectral_engine is not None:
-                # hybrid: only jobs the device finishes before their kill test comes up (FOKL_DSPECTRAL_SLACK kernel
-                # durations ahead, default 1.5; FOKL_DSPECTRAL_LOOKAHEAD tests ahead at most, default 32); device: all
-                everything = os.environ.get('FOKL_EIGH') == 'device'
-                self.native.bind_spectral(self.spectral_engine,
-                                          slack=0.0 if everything else float(os.environ.get('FOKL_DSPECTRAL_SLACK', '-1')),
-                                          lookahead=int(os.environ.get('FOKL_DSPECTRAL_LOOKAHEAD', '-1')))
-            # Kill tests' G2 from the eigenpairs of the model each is tested against (secular equation + one product, a fifth
-            # of a decomposition's time): FOKL_EIGH_UPDATE = columns of the smallest such parent (default 8; 0: every model
-            # is decomposed afresh), at most FOKL_EIGH_UPDATE_DEPTH (default 6) such steps from a decomposition.  Not where
-            # several ranks repeat one search: which models are derived depends on what was requested ahead, and the ranks
-            # must agree to the last bit.
-            update_from = int(os.environ.get('FOKL_EIGH_UPDATE', '8'))
-            # (replicated searches: under direct decisions G2 is requested for accepted models only, at the moment of the
-            # decision -- which models are derived is then a function of the decisions, the same on every rank; while the
-            # loop orders G2 ahead along a path it predicts, FOKL_KILL_DECIDE=g2, it depends on timing: not there)
-            direct_wanted = os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
-                getattr(self, 'allow_direct_decisions', True)
-            if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) \
-                    and (direct_wanted or not (self.allreduce or self.candidate_sharded)) \
-                    and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
-                # FOKL_LOOKAHEAD_DERIVED (default 0: the ordinary look-ahead): a deeper G2 window while derivation is on, in
-                # sub-stages of fewer than 192 columns.  A chain of derivations advances slower than the loop tests, and 24
-                # deep keeps more of its pieces running side by side: configs[2] 40.0-40.1 ms per fit against 40.3-43.0,
-                # waiting for G2 8.0 -> 6.9 ms -- but configs[3] 0.69-1.07 s against 0.62-0.63 (its narrow sub-stages;
-                # not understood), so it stays a knob
-                derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else _bounded_lookahead(
-                    'FOKL_LOOKAHEAD_DERIVED', os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
-                # (depth: with the kill tests decided at once nobody waits for a link of the chain of derived models any more --
-                # their G2 only feeds chains whose statistics are confirmed later -- so the chain may be long: 24 steps cost 27 ms
-                # of spectral CPU per configs[2] fit against 41 at 6, same fit time, same bits of the returned draws; while
-                # the loop waits for G2, FOKL_KILL_DECIDE=g2, a step every 0.1-0.2 ms is what it waits for: 6)
-                depth_default = '24' if os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
-                    getattr(self, 'allow_direct_decisions', True) else '6'
-                self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', depth_default)), derived_ahead)
-                self.stats['eigh_update_from'] = update_from
-            # Kill tests' BICs from the sub-stage's least-squares model downdated column by column (microseconds on the
-            # search thread; G2 then only feeds the accepted models' chains and confirms the BIC) instead of from G2 of every
-            # trial model, which the loop had to wait for: FOKL_KILL_DECIDE = direct (default) | g2.  A fit repeated after a
-            # misprediction runs with g2.
-            decide = os.environ.get('FOKL_KILL_DECIDE', 'direct')
-            if decide not in ('direct', 'g2'):
-                raise ValueError("FOKL_KILL_DECIDE must be direct or g2")
-            if not getattr(self, 'allow_direct_decisions', True):
-                decide = 'g2'
-            self.native.set_decide(1 if decide == 'direct' else 0, float(os.environ.get('FOKL_KILL_DECIDE_TOL', '0')))
-            self.stats['kill_decide'] = decide
-            if self.allreduce or self.candidate_sharded:
-                self.native.set_deterministic(True)
+            try:
+                half0 = int(math.ceil(self.draws / 2))
+                self.native = _capi.NativeSearch(
+                    self.host.pool, self.chain_engine, n=self.n, a=self.a, b=self.b, atau=self.atau, btau=self.btau,
+                    threshav=self.threshav, threshstda=self.threshstda, threshstdb=self.threshstdb,
+                    guess_margin=self.guess_margin, draws=self.draws, half0=half0, aic=int(self.aic),
+                    lookahead=self._lookahead_native, foresight=self.foresight, speculation_max=self._speculation_native,
+                    tentative_tapes=int(self.tentative_tapes), test_rewinds=int(self._test_rewinds),
+                    device_chain_columns=self.device_chain_columns, finish_threads=self.host.pool.finish_threads,
+                    flip_guess=self._flip_guess, device_rows=int(self.host.device_rows))
+                # G2 of the kill tests' models on the device (Jacobi in LDS) where the search runs on one process and the
+                # model fits the kernel; wider models, replicated searches and FOKL_EIGH=host keep LAPACK on the pool's threads
+                self.spectral_engine = None
+                if not self.allreduce and not self.candidate_sharded:       # (G2 on the device: single-process searches)
+                    self.spectral_engine = spectral_engine_for(getattr(getattr(self.backend, 'ctx', None), 'device', None))
+                if self.spectral_engine is not None:
+                    # hybrid: only jobs the device finishes before their kill test comes up (FOKL_DSPECTRAL_SLACK kernel
+                    # durations ahead, default 1.5; FOKL_DSPECTRAL_LOOKAHEAD tests ahead at most, default 32); device: all
+                    everything = os.environ.get('FOKL_EIGH') == 'device'
+                    self.native.bind_spectral(self.spectral_engine,
+                                              slack=0.0 if everything else float(os.environ.get('FOKL_DSPECTRAL_SLACK', '-1')),
+                                              lookahead=int(os.environ.get('FOKL_DSPECTRAL_LOOKAHEAD', '-1')))
+                # Kill tests' G2 from the eigenpairs of the model each is tested against (secular equation + one product, a fifth
+                # of a decomposition's time): FOKL_EIGH_UPDATE = columns of the smallest such parent (default 8; 0: every model
+                # is decomposed afresh), at most FOKL_EIGH_UPDATE_DEPTH (default 6) such steps from a decomposition.  Not where
+                # several ranks repeat one search: which models are derived depends on what was requested ahead, and the ranks
+                # must agree to the last bit.
+                update_from = int(os.environ.get('FOKL_EIGH_UPDATE', '8'))
+                # (replicated searches: under direct decisions G2 is requested for accepted models only, at the moment of the
+                # decision -- which models are derived is then a function of the decisions, the same on every rank; while the
+                # loop orders G2 ahead along a path it predicts, FOKL_KILL_DECIDE=g2, it depends on timing: not there)
+                direct_wanted = os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
+                    getattr(self, 'allow_direct_decisions', True)
+                if update_from > 0 and getattr(self.host.pool, 'has_dgemm', False) \
+                        and (direct_wanted or not (self.allreduce or self.candidate_sharded)) \
+                        and os.environ.get('FOKL_EIGH_SIGNS', 'canonical') != 'lapack':
+                    # FOKL_LOOKAHEAD_DERIVED (default 0: the ordinary look-ahead): a deeper G2 window while derivation is on, in
+                    # sub-stages of fewer than 192 columns.  A chain of derivations advances slower than the loop tests, and 24
+                    # deep keeps more of its pieces running side by side: configs[2] 40.0-40.1 ms per fit against 40.3-43.0,
+                    # waiting for G2 8.0 -> 6.9 ms -- but configs[3] 0.69-1.07 s against 0.62-0.63 (its narrow sub-stages;
+                    # not understood), so it stays a knob
+                    derived_ahead = 0 if 'FOKL_LOOKAHEAD' in os.environ else _bounded_lookahead(
+                        'FOKL_LOOKAHEAD_DERIVED', os.environ.get('FOKL_LOOKAHEAD_DERIVED', '0'))
+                    # (depth: with the kill tests decided at once nobody waits for a link of the chain of derived models any more --
+                    # their G2 only feeds chains whose statistics are confirmed later -- so the chain may be long: 24 steps cost 27 ms
+                    # of spectral CPU per configs[2] fit against 41 at 6, same fit time, same bits of the returned draws; while
+                    # the loop waits for G2, FOKL_KILL_DECIDE=g2, a step every 0.1-0.2 ms is what it waits for: 6)
+                    depth_default = '24' if os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
+                        getattr(self, 'allow_direct_decisions', True) else '6'
+                    self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', depth_default)), derived_ahead)
+                    self.stats['eigh_update_from'] = update_from
+                # Kill tests' BICs from the sub-stage's least-squares model downdated column by column (microseconds on the
+                # search thread; G2 then only feeds the accepted models' chains and confirms the BIC) instead of from G2 of every
+                # trial model, which the loop had to wait for: FOKL_KILL_DECIDE = direct (default) | g2.  A fit repeated after a
+                # misprediction runs with g2.
+                decide = os.environ.get('FOKL_KILL_DECIDE', 'direct')
+                if decide not in ('direct', 'g2'):
+                    raise ValueError("FOKL_KILL_DECIDE must be direct or g2")
+                if not getattr(self, 'allow_direct_decisions', True):
+                    decide = 'g2'
+                self.native.set_decide(1 if decide == 'direct' else 0, float(os.environ.get('FOKL_KILL_DECIDE_TOL', '0')))
+                self.stats['kill_decide'] = decide
+                if self.allreduce or self.candidate_sharded:
+                    self.native.set_deterministic(True)
+            except BaseException:
+                # (a bad FOKL_EIGH / FOKL_KILL_DECIDE value, a device that went away: the pool's threads -- the walker still
+                # attached to the stream --, the L3 pinning and the chain engine's binding do not outlive this search)
+                if self.native is not None:
+                    self.native.close()
+                    self.native = None
+                self.host.close()
+                self.host = None
+                raise
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         if self.native is None and self.host is not None and os.environ.get('FOKL_SEARCH', 'native') != 'python':
             import warnings
