@@ -955,7 +955,7 @@ def main():
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
                     rows_chains=0, path_repredicted=0, t_pool_up=0.0, spectral_device=0, spectral_updated=0,
                     direct_tests=0, chains_cancelled=0, t_settle=0.0)
-        direct_max_rel = 0.0                                  # (a maximum, not a sum: kept out of `host`)
+        direct_max_rel = guess_max_dev = 0.0                  # (maxima, not sums: kept out of `host`)
         drivers = set()
         for _ in range(args.steps):
             for st in one_step():
@@ -966,6 +966,7 @@ def main():
                 for key in host:
                     host[key] += st.get(key, 0)
                 direct_max_rel = max(direct_max_rel, st.get('direct_max_rel', 0.0))
+                guess_max_dev = max(guess_max_dev, st.get('guess_max_dev', 0.0))
                 for key, value in st.get('phases', {}).items():
                     host['phase_' + key] = host.get('phase_' + key, 0.0) + value
         ctx.sync()
@@ -1302,6 +1303,9 @@ def main():
         'kill_decisions': {'mode': os.environ.get('FOKL_KILL_DECIDE', 'direct'),
                            'direct_tests_per_step': host['direct_tests'] / max(args.steps, 1),
                            'max_rel_difference_to_eigen_bic': direct_max_rel,
+                           # second clause of FR:1670 guessed from the least-squares intercept (margin FOKL_GUESS_MARGIN, 2 %):
+                           # how far the chains' mean intercepts turned out to lie from it, relative (every guess is checked)
+                           'max_rel_distance_of_guessed_intercept_scale': guess_max_dev,
                            'chains_never_started_per_step': host['chains_cancelled'] / max(args.steps, 1),
                            'waiting_for_eigenpairs_s_per_step': host['t_settle'] / max(args.steps, 1)},
         'random_stream': {

@@ -791,6 +791,7 @@ class FoKL:
             self._rng_state_after = stream.as_numpy_state()
         self.fit_stats = dict(search.stats, seconds=time.perf_counter() - t0, searches_repeated=repeated)
         self.fit_trace = search.trace
+        self.fit_substage_stats = search.substage_stats
         _engine._mark('search_end')
         _engine._flush_marks()
 

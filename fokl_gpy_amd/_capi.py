@@ -828,7 +828,8 @@ SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain
                 'tapes_rewound', 'tapes_wasted', 'chains_ahead', 'chains_ahead_unused', 'chains_skipped',
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
                 'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device',
-                'spectral_updated', 'direct_tests', 'direct_max_rel', 'chains_cancelled', 't_settle')
+                'spectral_updated', 'direct_tests', 'direct_max_rel', 'chains_cancelled', 't_settle',
+                'guess_max_dev')
 
 
 class NativeSearch:
@@ -1015,9 +1016,9 @@ class NativeSearch:
 
     def trace(self):
         n = self._lib.fokl_search_trace(self._h, None, 0)
-        rec = np.zeros((max(1, n), 4))
+        rec = np.zeros((max(1, n), 5))
         self._lib.fokl_search_trace(self._h, _ptr(rec), n)
-        return [dict(cols=int(r[0]), built=int(r[1]), ev=float(r[2]), kill=bool(r[3])) for r in rec[:n]]
+        return [dict(cols=int(r[0]), built=int(r[1]), ev=float(r[2]), kill=bool(r[3]), b0=float(r[4])) for r in rec[:n]]
 
     def kill_tests(self, gram, columns, mean_abs, rel_std, slots, best, n_prev, vm_next, ahead, foresee=None,
                    idle_work=None, residual=None):

@@ -220,6 +220,8 @@ struct Outcome {
     bool lazy = false, cancelled = false;
     double s1 = NAN, s2 = NAN;              // residual moments the BIC was formed from
     double ls_intercept = NAN;              // least-squares intercept known at decision time (lazy outcomes)
+    double guess_margin = NAN;              // relative distance kept when guessing from it (NaN: the search's own)
+    int64_t trace_index = -1;               // its record in fokl_search::trace
     int refs = 1;                           // Python handle + the search's own lists
 };
 
@@ -236,7 +238,7 @@ enum Stat {
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
     S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_SPECTRAL_UPDATED,
-    S_DIRECT_TESTS, S_DIRECT_MAX_REL, S_CHAINS_CANCELLED, S_T_SETTLE,
+    S_DIRECT_TESTS, S_DIRECT_MAX_REL, S_CHAINS_CANCELLED, S_T_SETTLE, S_GUESS_MAX_DEV,
     S_COUNT
 };
 
@@ -333,7 +335,9 @@ struct fokl_search {
     };
     std::vector<WLimbo> chain_limbo;
     double stats[S_COUNT] = {};
-    std::vector<double> trace;              // 4 per evaluation: columns, built, ev, kill
+    // 5 per evaluation: columns, built, ev, kill, mean intercept draw over the rows half0 .. (FR:1671; NaN until / unless the
+    // search has looked at that chain's statistics)
+    std::vector<double> trace;
     double last_siglik = 0;
     std::string error;
     bool mispredicted = false;
@@ -836,6 +840,7 @@ void speculate(fokl_search *s, const std::vector<std::pair<int, bool>> &sizes)
 
 int ensure_started(fokl_search *s, Outcome *o);
 int settle_pending(fokl_search *s, bool block, Outcome *upto);
+void note_intercept(fokl_search *s, const Outcome *o, double mean);
 
 bool chain_done(Outcome *o)
 {
@@ -911,6 +916,7 @@ int intercept_scale(fokl_search *s, Outcome *o, double *out)
         const int rc = mean_intercept_draw(s, o, s->prm.half0, &m);
         if (rc != FOKL_OK) return rc;
         o->intercept_scale = std::fabs(m);
+        note_intercept(s, o, m);
     }
     *out = o->intercept_scale;
     return FOKL_OK;
@@ -1067,12 +1073,18 @@ double same_model_same_ev(fokl_search *s, const int32_t *idx, int p1, double ev)
     return s->ev_cache.emplace(std::move(key), ev).first->second;
 }
 
-void record(fokl_search *s, int p1, int n_prev, double ev, bool kill)
+int64_t record(fokl_search *s, int p1, int n_prev, double ev, bool kill)
 {
     s->stats[S_GIBBS_CALLS] += 1;
     s->stats[S_KILL_TESTS] += kill ? 1 : 0;
     s->stats[S_TERMS_LOGICAL] += p1 - n_prev;
-    s->trace.insert(s->trace.end(), {(double)p1, (double)(p1 - n_prev), ev, kill ? 1.0 : 0.0});
+    s->trace.insert(s->trace.end(), {(double)p1, (double)(p1 - n_prev), ev, kill ? 1.0 : 0.0, NAN});
+    return (int64_t)s->trace.size() / 5 - 1;
+}
+
+void note_intercept(fokl_search *s, const Outcome *o, double mean)
+{
+    if (o->trace_index >= 0 && (size_t)(5 * o->trace_index + 4) < s->trace.size()) s->trace[(size_t)(5 * o->trace_index + 4)] = mean;
 }
 
 // engine.ForwardSelection._commit: the chain of the evaluation (o->spec, which has run; o->tape) -- device engine for a
@@ -1266,8 +1278,8 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
     }
     if (!device_chain) return -1;
     const double threshold = s->prm.threshav * std::fabs(o->lazy ? o->ls_intercept : o->spec->betahat()[0]);
-    if (!(threshold > 0.0) || !std::isfinite(threshold) ||
-        std::fabs(value - threshold) <= s->prm.guess_margin * threshold) {
+    const double margin = std::isnan(o->guess_margin) ? s->prm.guess_margin : std::max(s->prm.guess_margin, o->guess_margin);
+    if (!(threshold > 0.0) || !std::isfinite(threshold) || std::fabs(value - threshold) <= margin * threshold) {
         // too close to call from the guess, and the device's answer is milliseconds away: the chain once more, in line on
         // this thread (same tape, same arithmetic up to the last bit of log()).  The tape is still there: the device job
         // is its reader until it has run.
@@ -1309,6 +1321,7 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
             }
             o->intercept_scale = std::fabs(total / (double)(t->draws - s->prm.half0));
             o->scale_inline = true;
+            note_intercept(s, o, total / (double)(t->draws - s->prm.half0));
         }
         give_buffer(w, classes, pinned);
         s->stats[S_T_CHAIN] += now_s() - t0;
@@ -1360,6 +1373,13 @@ int verify(fokl_search *s, bool block)
         if (rc != FOKL_OK) {
             unref(s, o);
             return rc;
+        }
+        {
+            // how far the chain's mean intercept lies from the least-squares intercept the guesses were taken from (relative):
+            // what the guess margin has to cover
+            const double guess = std::fabs(!std::isnan(o->ls_intercept) ? o->ls_intercept : o->spec->betahat()[0]);
+            if (guess > 0.0 && !o->checks.empty())
+                s->stats[S_GUESS_MAX_DEV] = std::max(s->stats[S_GUESS_MAX_DEV], std::fabs(scale / guess - 1.0));
         }
         for (const Check &c : o->checks) {
             if ((c.value < s->prm.threshav * scale) != c.decision) {
@@ -1446,6 +1466,17 @@ struct PathModel {
     }
 
     double ssr_without(int pos) const { return ssr + beta[(size_t)pos] * beta[(size_t)pos] / inv[(size_t)pos * ld + pos]; }
+
+    // How far the mean of the chain's intercept draws (draws of them) can be expected from the least-squares intercept,
+    // relative, times 32: the draws scatter with sigma^2 [(X'X + 1/tau^2)^-1]_00 <= siglik [(X'X)^-1]_00 around a mean that
+    // the prior shrinks by parts in 1e6 at these sizes -- the distance a guessed second clause of FR:1670 keeps from its
+    // threshold (on top of the search's floor).
+    double guess_margin_for(double n, int rows_averaged) const
+    {
+        const double b0 = std::fabs(beta[0]);
+        if (!(b0 > 0.0) || !(ssr > 0.0) || rows_averaged < 1) return INFINITY;
+        return 32.0 * std::sqrt((ssr / n) * inv[0] / (double)rows_averaged) / b0;
+    }
 
     void remove(int pos)
     {
@@ -1767,7 +1798,7 @@ extern "C" int fokl_search_score(fokl_search *s, fokl_outcome *h, double s1, dou
     o->siglik = s->last_siglik;
     o->s1 = s1;
     o->s2 = s2;
-    record(s, p1, n_prev, o->ev, kill != 0);
+    o->trace_index = record(s, p1, n_prev, o->ev, kill != 0);
     *ev = o->ev;
     return FOKL_OK;
 }
@@ -1923,8 +1954,8 @@ extern "C" int fokl_search_stats(const fokl_search *s, double *values, int count
 extern "C" int64_t fokl_search_trace(const fokl_search *s, double *records, int64_t capacity)
 {
     if (!s) return 0;
-    const int64_t have = (int64_t)s->trace.size() / 4;
-    if (records) std::memcpy(records, s->trace.data(), sizeof(double) * 4 * (size_t)std::min(have, capacity));
+    const int64_t have = (int64_t)s->trace.size() / 5;
+    if (records) std::memcpy(records, s->trace.data(), sizeof(double) * 5 * (size_t)std::min(have, capacity));
     return have;
 }
 
@@ -2155,6 +2186,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                         best->spec->lamb()[0] > 1e-9 * best->spec->lamb()[A - 1];
     auto run_direct = [&]() -> int {
         PathModel &m = committed;
+        best->guess_margin = m.guess_margin_for((double)s->prm.n, s->prm.draws - s->prm.half0);
         // Wide models (a decomposition takes tens of milliseconds, derivations are cut after two steps): G2 of an accepted
         // model is requested when something needs it, not when the model is accepted (Spectrum::deferred)
         const bool defer_g2 = A >= s->defer_from;
@@ -2259,7 +2291,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             const double siglik = s->last_siglik;
             s->stats[S_DIRECT_TESTS] += 1;
             lap(3);
-            if (ev < evmin) {
+            const bool ev_accepted = ev < evmin;
+            if (ev_accepted) {
                 if (!sp && !(sp = take_spectrum())) {
                     unref(s, tape);
                     return FOKL_ERR_STATE;
@@ -2276,6 +2309,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 m.remove(at);
                 m.ssr = s2;                                 // (the residual pass's, where that decided)
                 cand->ls_intercept = m.beta[0];
+                cand->guess_margin = m.guess_margin_for((double)s->prm.n, s->prm.draws - s->prm.half0);
                 cand->refs += 1;
                 s->pending.push_back(cand);
                 killed = trial;
@@ -2292,7 +2326,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 if (sp) unref(s, sp);
                 s->stats[S_CHAINS_SKIPPED] += 1;
             }
-            record(s, p1, a->n_prev, ev, true);
+            const int64_t rec = record(s, p1, a->n_prev, ev, true);
+            if (ev_accepted) best->trace_index = rec;
             lap(4);
             // bounded: accepted models waiting for G2 (their tapes hold the stream), tapes waiting for the walker
             const size_t bound = s->pending_limit(A);
@@ -2457,7 +2492,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             unref(s, tape);                                 // walked all the same: the stream advances as the reference's
             s->stats[S_CHAINS_SKIPPED] += 1;
         }
-        record(s, p1, a->n_prev, ev, true);
+        const int64_t rec = record(s, p1, a->n_prev, ev, true);
+        if (cand) cand->trace_index = rec;
         last_accepted = ev < evmin;
         const Step foreseen = step_at(pos);
         if (last_accepted) {

@@ -286,6 +286,8 @@ class ForwardSelection:
         self.candidate_sharded = bool(candidate_sharded) and comm is not None and (
             comm.world > 1 or os.environ.get('FOKL_CANDIDATE_SHARD_FORCE', '0') == '1')
         self._replicated_native = False     # a search replicated over ranks on the native driver (decided in run())
+        self.substage_stats = []            # per sub-stage: |mean beta| and std / |mean| of its new terms (FR:1656-1658)
+        self._update_args = None            # (from columns, depth, look-ahead) of the derived eigenpairs, when they are on
         # Both at once is the hybrid split: every rank holds N / G rows (K1, K2, K3 on its rows, the small Gram blocks and
         # residual moments all-reduced on the device -- the DEVICE work is divided by G) and the replicated search deals its
         # eigen-decompositions over the ranks as well (the HOST work that bounds configs[3] is divided by G too).  The Gram
@@ -368,7 +370,11 @@ class ForwardSelection:
         # configs[3] 1.76 -> 1.11 s per fit; FOKL_DCHAIN_ROWS=0 falls back to 256)
         self.device_chain_columns = int(os.environ.get(
             'FOKL_DCHAIN_MAX_COLUMNS', '768' if os.environ.get('FOKL_DCHAIN_ROWS', '1') != '0' else '256'))
-        self.guess_margin = float(os.environ.get('FOKL_GUESS_MARGIN', '0.02'))
+        # (under direct decisions the native loop widens this floor, per model, to 32 standard errors of the chain's mean
+        # intercept as its least-squares fit predicts them -- csrc/fokl_search.cpp guess_margin_for; measured on configs[2]:
+        # the chains' means lie within 2.6e-5 of the least-squares intercepts)
+        direct = os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and os.environ.get('FOKL_SEARCH', 'native') != 'python'
+        self.guess_margin = float(os.environ.get('FOKL_GUESS_MARGIN', '0.002' if direct else '0.02'))
         self._flip_guess = int(os.environ.get('FOKL_GUESS_TEST_FLIP', '0'))   # tests: the n-th guess is taken wrong
         self._unverified = collections.deque()   # (device-chained outcome, half0) whose checks are open, oldest first
         self._zombies = collections.deque()      # device jobs nobody will look at, released once they have run
@@ -1096,7 +1102,9 @@ class ForwardSelection:
                     # the loop waits for G2, FOKL_KILL_DECIDE=g2, a step every 0.1-0.2 ms is what it waits for: 6)
                     depth_default = '24' if os.environ.get('FOKL_KILL_DECIDE', 'direct') == 'direct' and \
                         getattr(self, 'allow_direct_decisions', True) else '6'
-                    self.native.set_update(update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', depth_default)), derived_ahead)
+                    self._update_args = (update_from, int(os.environ.get('FOKL_EIGH_UPDATE_DEPTH', depth_default)),
+                                         derived_ahead)
+                    self.native.set_update(*self._update_args)
                     self.stats['eigh_update_from'] = update_from
                 # Kill tests' BICs from the sub-stage's least-squares model downdated column by column (microseconds on the
                 # search thread; G2 then only feeds the accepted models' chains and confirms the BIC) instead of from G2 of every
@@ -1455,6 +1463,9 @@ class ForwardSelection:
             rel_std = np.divide(np.std(tail[half1 - half0:], axis=0), np.abs(np.mean(tail, axis=0)))
             _mark('full_statistics')
             lap('statistics')
+            # (what orders and gates this sub-stage's kill tests, in the order of the interaction matrix: kept for whoever
+            # wants to hold the chain's numbers -- not only the decisions they lead to -- against another implementation's)
+            self.substage_stats.append(dict(mean_abs=np.array(mean_abs), rel_std=np.array(rel_std)))
             order = np.argsort(mean_abs)
             cand_col = np.arange(dam - vm + 1, dam + 1)[order]     # active-column index of each proposal
             mean_abs, rel_std = mean_abs[order], rel_std[order]
@@ -1477,6 +1488,14 @@ class ForwardSelection:
                             evmin = res.ev
                             best = res
             else:
+                if self.native is not None and self._update_args is not None and self._update_args[1] > 6:
+                    # The sub-stage after which the stop rule may end the search (FR:1708-1718: `greater` has reached the
+                    # tolerance): the chains of its accepted models are what the search's last act -- confirming the guessed
+                    # decisions -- waits for, and those chains wait for G2.  Short pieces of derived models there (six steps
+                    # behind a decomposition: many pieces side by side), long ones everywhere else (nobody waits: less CPU).
+                    last_chance = evs.size > 0 and greater >= self.tolerance
+                    self.native.set_update(self._update_args[0], 6 if last_chance else self._update_args[1],
+                                           self._update_args[2])
                 killed, evmin, best = self._kill_tests_pipelined(gram, active_slots, n_prev, cand_col, mean_abs,
                                                                  rel_std, best, half0, foresee, early, vm_next,
                                                                  build_in_tests, coming_tests, chain_coming)

@@ -32,14 +32,20 @@ def _flush_marks():
         del _trace_log[:]
 
 
+_CPU_LISTS = {}                                             # sysfs path -> frozenset: the topology is the machine's
+
+
 def _cpu_list(path):
-    with open(path) as fh:
-        text = fh.read().strip()
-    cpus = set()
-    for part in text.split(','):
-        lo, _, hi = part.partition('-')
-        cpus.update(range(int(lo), int(hi or lo) + 1))
-    return cpus
+    cpus = _CPU_LISTS.get(path)
+    if cpus is None:
+        with open(path) as fh:
+            text = fh.read().strip()
+        found = set()
+        for part in text.split(','):
+            lo, _, hi = part.partition('-')
+            found.update(range(int(lo), int(hi or lo) + 1))
+        cpus = _CPU_LISTS[path] = frozenset(found)          # (every fit used to read two dozen of these files again)
+    return set(cpus)
 
 
 def _place_host_threads():
@@ -119,6 +125,31 @@ def _spectral_cpus(allowed, home, count):
         return None
 
 
+_QUOTA = []                                                 # [CPUs' worth of the cgroup quota or None], read once
+
+
+def _cgroup_quota():
+    if not _QUOTA:
+        quota = None
+        try:
+            with open('/sys/fs/cgroup/cpu.max') as fh:                       # cgroup v2: "<quota|max> <period>"
+                q, period = fh.read().split()
+                if q != 'max':
+                    quota = float(q) / float(period)
+        except (OSError, ValueError):
+            try:
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fh:      # cgroup v1
+                    q = float(fh.read())
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+                    period = float(fh.read())
+                if q > 0:
+                    quota = q / period
+            except (OSError, ValueError):
+                pass
+        _QUOTA.append(quota)
+    return _QUOTA[0]
+
+
 def _cpu_budget():
     """CPUs this process may keep busy: its affinity mask, capped by the cgroup CPU quota (a container that sees 256
     CPUs may be allowed 16 CPU-seconds per second) shared among the ranks of the node (LOCAL_WORLD_SIZE)."""
@@ -126,22 +157,7 @@ def _cpu_budget():
         budget = float(len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         budget = float(os.cpu_count() or 2)
-    quota = None
-    try:
-        with open('/sys/fs/cgroup/cpu.max') as fh:                       # cgroup v2: "<quota|max> <period>"
-            q, period = fh.read().split()
-            if q != 'max':
-                quota = float(q) / float(period)
-    except (OSError, ValueError):
-        try:
-            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fh:      # cgroup v1
-                q = float(fh.read())
-            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
-                period = float(fh.read())
-            if q > 0:
-                quota = q / period
-        except (OSError, ValueError):
-            pass
+    quota = _cgroup_quota()
     if quota is not None:
         try:
             ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))

@@ -648,8 +648,9 @@ int fokl_search_register_forecast(fokl_search *search, const int32_t *key, int k
 void fokl_search_clear_forecasts(fokl_search *search);
 int fokl_search_likely_first_tests(fokl_search *search, fokl_spectrum *spectrum, int n_new, double siglik,
                                    int32_t *columns_out, int32_t *accepted_out, int *count);
-/* counters / seconds in the order of csrc/fokl_search.cpp's Stat enumeration (-> their number); the trace: 4 doubles per
- * evaluation (columns, built, ev, kill) */
+/* counters / seconds in the order of csrc/fokl_search.cpp's Stat enumeration (-> their number); the trace: 5 doubles per
+ * evaluation (columns, built, ev, kill, the mean intercept draw over rows half0 .. of that evaluation's chain -- FR:1671's
+ * scale before the abs() -- or NaN where the search never looked at that chain's statistics) */
 int fokl_search_stats(const fokl_search *search, double *values, int count);
 int64_t fokl_search_trace(const fokl_search *search, double *records, int64_t capacity);
 /*

@@ -356,7 +356,10 @@ def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, 
 
     Returns (betas[-draws:], mtx, evs).  ``trace`` (optional list) receives one dict per gibbs() call with
     the number of columns, how many were (re)built, the BIC and whether it was a kill test -- the
-    "logical candidate-term" count of SURVEY 8(d) is ``sum(t['built'] for t in trace)``.
+    "logical candidate-term" count of SURVEY 8(d) is ``sum(t['built'] for t in trace)`` -- and what the kill tests read
+    from that call's chain (instrumentation only): ``b0`` = mean(betas[half0:, 0]), whose magnitude is the scale of
+    FR:1671 once the call's model is the accepted one, and, for a sub-stage's own call, ``mean_abs`` / ``rel_std`` of its new
+    terms in the order of the interaction matrix (betavs / betavs2, FR:1656-1658).
     """
     hp = dict(DEFAULT_HYPERS)
     for key, val in hypers.items():
@@ -384,7 +387,8 @@ def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, 
                     sigsqd0, tausqd0, dtd, eigh=eigh, build=build)
         if trace is not None:
             trace.append(dict(cols=discmtx.shape[0] + 1, built=discmtx.shape[0] + 1 - nxin, ev=float(res.ev),
-                              kill=kill, xtx=res.XtX if len(trace) < 12 else None))
+                              kill=kill, xtx=res.XtX if len(trace) < 12 else None,
+                              b0=float(np.mean(res.betas[int(np.ceil(draws / 2)):draws, 0]))))
         return res
 
     n, m = inputs.shape
@@ -417,6 +421,8 @@ def fit(inputs, data, phis, kernel, eigh=eigh_reference, build=build_columns_c, 
             rel_std = np.divide(np.std(np.array(beters[half1:draws, new]), axis=0),
                                 np.abs(np.mean(beters[half0:draws, dam - vm + 1:dam + 2], axis=0)))
             ids = np.array(range(dam - vm + 2, dam + 2))
+            if trace is not None:
+                trace[-1].update(mean_abs=np.array(mean_abs, dtype=np.float64), rel_std=np.array(rel_std, dtype=np.float64))
             table = np.transpose(np.array([mean_abs, rel_std, ids]))
             if table.shape[1] > 0:
                 table = table[np.argsort(table[:, 0])]

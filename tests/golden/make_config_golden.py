@@ -89,10 +89,29 @@ def run_case(name, config, unit=0, rows=None, **overrides):
                mtx=np.array(mtx, dtype=np.float64), evs=np.array(evs, dtype=np.float64), betas=np.array(betas),
                call_cols=np.array([t['cols'] for t in trace]), call_built=np.array([t['built'] for t in trace]),
                call_ev=np.array([t['ev'] for t in trace]), call_kill=np.array([t['kill'] for t in trace]),
+               # what the kill tests read from each call's chain (round 5): the mean intercept draw over the second half
+               # (FR:1671), and per sub-stage call the statistics of its new terms (FR:1656-1658), concatenated in call order
+               call_b0=np.array([t['b0'] for t in trace]),
+               stat_calls=np.array([i for i, t in enumerate(trace) if 'mean_abs' in t]),
+               stat_sizes=np.array([t['mean_abs'].shape[0] for t in trace if 'mean_abs' in t]),
+               stat_mean_abs=np.concatenate([t['mean_abs'] for t in trace if 'mean_abs' in t]),
+               stat_rel_std=np.concatenate([t['rel_std'] for t in trace if 'rel_std' in t]),
                rng_key=st[1], rng_pos=st[2], rng_has_gauss=st[3], rng_cached=st[4], b=float(b), btau=float(btau),
                oracle_seconds=secs, oracle_threads=THREADS,
                blas_threads=os.environ.get('OPENBLAS_NUM_THREADS', 'default'))
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    target = os.path.join(HERE, name + '.npz')
+    if os.path.exists(target):
+        # a regenerated fixture must say what the one in the repository says, bit for bit, in every field that one has (the
+        # fields added since come on top); otherwise it is written next to it for a look
+        old = np.load(target, allow_pickle=False)
+        same = all(np.array_equal(np.asarray(old[k]), np.asarray(out[k])) for k in old.files
+                   if k not in ('oracle_seconds', 'oracle_threads', 'blas_threads'))
+        if not same:
+            differing = [k for k in old.files if k not in ('oracle_seconds', 'oracle_threads', 'blas_threads')
+                         and not np.array_equal(np.asarray(old[k]), np.asarray(out[k]))]
+            target = os.path.join(HERE, name + '.regenerated.npz')
+            print(f"[{name}] differs from the committed fixture in {differing}: written to {target}", flush=True)
+    np.savez_compressed(target, **out)
     print(f"[{name}] {secs:.0f} s  terms={mtx.shape[0]} sub-stages={len(evs)} gibbs calls={len(trace)} "
           f"logical terms={int(np.sum(out['call_built']))}  max cols={int(np.max(out['call_cols']))}", flush=True)
 

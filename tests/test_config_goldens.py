@@ -74,6 +74,40 @@ def assert_matches_golden(g, model, betas, mtx, evs, state, draws_tol=1e-9):
     assert state[3] == int(g['rng_has_gauss']) and state[4] == float(g['rng_cached'])
     assert abs(model.b - float(g['b'])) <= 1e-15 * abs(float(g['b']))
     assert abs(model.btau - float(g['btau'])) <= 1e-15 * abs(float(g['btau']))
+    assert_chain_statistics_match(g, model)
+
+
+def assert_chain_statistics_match(g, model, tol=1e-9):
+    """What the kill tests READ from the chains, not only what they decided (fixtures regenerated in round 5 carry it):
+    per sub-stage the |mean beta| and std / |mean| of its new terms (FR:1656-1658) against the oracle's, 1e-9 of the
+    largest |mean beta| of the sub-stage / 1e-9 relative where the ratio is not ill-conditioned; per gibbs() call whose
+    chain the search looked at, the mean intercept draw of FR:1671 -- for a kill test that is the chain of a model whose
+    eigenpairs were derived from the model it was tested against and which ran on the device.  -> how many intercept
+    means were compared."""
+    if 'call_b0' not in g.files:
+        return 0
+    stats = model.fit_substage_stats
+    assert len(stats) == g['stat_sizes'].shape[0]
+    at = 0
+    for st, size in zip(stats, g['stat_sizes']):
+        want_mean, want_rel = g['stat_mean_abs'][at:at + size], g['stat_rel_std'][at:at + size]
+        at += int(size)
+        scale = max(float(np.max(want_mean)), 1e-300)
+        assert st['mean_abs'].shape == want_mean.shape
+        assert np.max(np.abs(st['mean_abs'] - want_mean)) <= tol * scale
+        # std / |mean|: a mean within 1e-3 of its sub-stage's largest may be cancellation noise relative to itself
+        firm = want_mean > 1e-3 * scale
+        assert np.all(np.abs(st['rel_std'][firm] - want_rel[firm]) <= 1e-6 * np.abs(want_rel[firm]))
+    have = np.array([t.get('b0', np.nan) for t in model.fit_trace])
+    seen = ~np.isnan(have)
+    want = g['call_b0']
+    assert have.shape == want.shape
+    assert np.all(np.abs(have[seen] - want[seen]) <= tol * np.abs(want[seen]))
+    if model.fit_stats.get('search_driver') == 'native':
+        # most of the accepted kill tests' chains have been looked at (guessed decisions are confirmed against them)
+        kills = g['call_kill'].astype(bool)
+        assert np.count_nonzero(seen & kills) >= 0.4 * np.count_nonzero(kills)
+    return int(np.count_nonzero(seen))
 
 
 def test_config_datasets_regenerate_bit_for_bit():
@@ -140,3 +174,57 @@ def test_kill_tests_eigenpairs_derived_from_the_tested_against_model(monkeypatch
     assert_matches_golden(g, model0, betas0, mtx0, evs0, state0)
     assert np.array_equal(mtx, mtx0) and betas.shape == betas0.shape
     assert np.abs(betas - betas0).max() <= 1e-9 * np.abs(betas0).max()
+
+
+# The knobs that change which code runs a fit (tools/knob_suite.sh walks all of them over every fit-level test by hand;
+# the default-changing ones are part of the GPU suite here, each on one golden): every mode must give the golden's model,
+# calls, stream, BICs and draws.
+MODES = [
+    (('FOKL_KILL_DECIDE', 'g2'),),                  # kill tests decided from G2 of every trial model (round 4's loop)
+    (('FOKL_EIGH_UPDATE', '0'),),                   # every model decomposed afresh
+    (('FOKL_CHAIN', 'host'),),                      # kill tests' chains on host threads
+    (('FOKL_SEARCH', 'python'),),                   # engine.py's statement of the kill-test loop
+    (('FOKL_EIGH', 'device'),),                     # G2 by the Jacobi kernels
+    (('FOKL_G2_DEFER_FROM', '8'),),                 # G2 of accepted models only when something needs it
+    (('FOKL_SPECULATE_ACROSS', '0'), ('FOKL_SPECULATION', '4')),   # a short order book, nothing ordered across the boundary
+    (('FOKL_K1_TOUCH', '1'),),                      # round 4's inputs_touch launch before every basis build
+    (('FOKL_DCHAIN_ROWS', '0'),),                   # tapes materialised on the host, read over the bus
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', MODES, ids=lambda m: '+'.join(f'{k}={v}' for k, v in m))
+def test_default_changing_modes_give_the_golden_fit(monkeypatch, mode):
+    g = load_golden('cfg4_unit0_n1e5_m8')
+    for key, value in mode:
+        monkeypatch.setenv(key, value)
+    model, betas, mtx, evs, state = fit_like_golden(g)
+    st = model.fit_stats
+    if ('FOKL_SEARCH', 'python') in mode:
+        assert st['search_driver'] == 'python'
+    else:
+        assert st['search_driver'] == 'native'
+        assert st['kill_decide'] == ('g2' if ('FOKL_KILL_DECIDE', 'g2') in mode else 'direct')
+    if ('FOKL_CHAIN', 'host') in mode:
+        assert st['chain_mode'] == 'host'
+    if ('FOKL_EIGH_UPDATE', '0') in mode:
+        assert st['spectral_updated'] == 0
+    if ('FOKL_EIGH', 'device') in mode:
+        assert st['eigh_mode'] == 'device' and st['spectral_device'] > 0
+    assert_matches_golden(g, model, betas, mtx, evs, state)
+
+
+@pytest.mark.gpu
+def test_direct_kill_decisions_are_confirmed_by_the_eigenpairs():
+    """The default: a kill test's BIC comes from the sub-stage's least-squares model downdated column by column; every
+    accepted model's eigenpairs bring a second BIC (Gram identity on their betahat) that is held against it.  On the
+    benchmarked fit: every kill test decided that way, the two BICs within 1e-12, a third of the accepted models replaced
+    before anything looked at their draws (no chain), and the chains that did run confirm the guessed decisions."""
+    g = load_golden('cfg2_n1e6_m8')
+    model, betas, mtx, evs, state = fit_like_golden(g)
+    st = model.fit_stats
+    assert st['kill_decide'] == 'direct' and st['direct_tests'] == st['kill_tests'] > 300
+    assert st['direct_max_rel'] < 1e-12
+    assert st['chains_cancelled'] > 50 and st['guesses_verified'] == st['guessed'] > 100
+    assert st['searches_repeated'] == 0
+    assert_matches_golden(g, model, betas, mtx, evs, state)
