@@ -544,6 +544,7 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
     # host threads that wait for the GPU sleep instead of spinning: with several processes on one GPU a wait is long, and
     # what it burns is CPU of the shared quota (measured: 0.37 -> 0.31 CPU-seconds per fit with six processes)
     os.environ.setdefault('FOKL_SYNC', 'blocking')
+    os.environ.setdefault('FOKL_SPIN', '0.05')            # ... and poll for tens of pauses, not thousands, before they sleep
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
                       ('FOKL_SPECTRAL_THREADS', '3' if device_chains or procs <= 2 else '2')):
         os.environ.setdefault(name, val)

@@ -39,6 +39,7 @@
 #include <sys/prctl.h>
 
 #include "../../include/fokl_hip.h"
+#include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 
@@ -594,7 +595,7 @@ int expand_tape_blocks(fokl_host_pool *pool, fokl_host_job *job)
     const int nblocks = (job->draws + job->block - 1) / job->block;
     int32_t ready = 0;
     if (fokl_host_job *tape = job->parent) {                // asleep until the walker gets to the tape
-        for (int spins = 0; spins < 200 && !tape->started.load(std::memory_order_acquire); ++spins) _mm_pause();
+        for (int spins = 0, lim = fokl_spin_budget(200); spins < lim && !tape->started.load(std::memory_order_acquire); ++spins) _mm_pause();
         if (!tape->started.load(std::memory_order_acquire)) {
             std::unique_lock<std::mutex> lock(pool->start_m);
             pool->start_cv.wait(lock, [&] { return tape->started.load(std::memory_order_acquire) != 0; });
@@ -607,7 +608,7 @@ int expand_tape_blocks(fokl_host_pool *pool, fokl_host_job *job)
             ready = __atomic_load_n(job->progress, __ATOMIC_ACQUIRE);
             if (ready < 0) break;
             if (ready < k1) {
-                if (++spins < 2000)
+                if (++spins < fokl_spin_budget(2000))
                     _mm_pause();
                 else
                     std::this_thread::sleep_for(std::chrono::microseconds(10));
@@ -920,7 +921,7 @@ void noise_worker(fokl_host_pool *pool)
                 return !queue->q.empty() && queue->q.front()->tentative;
             };
             for (int spins = 0; !settled(); ++spins) {
-                if (spins < 4000) {
+                if (spins < fokl_spin_budget(4000)) {
                     _mm_pause();
                     if ((spins & 63) == 63 && more()) break;
                 } else {
@@ -1317,7 +1318,7 @@ extern "C" int fokl_pool_wait(fokl_host_job *job)
         fokl_set_global_error("fokl_pool_wait: null job");
         return FOKL_ERR_ARG;
     }
-    for (int spins = 0; spins < 2000 && !job->done.load(std::memory_order_acquire); ++spins) _mm_pause();
+    for (int spins = 0, lim = fokl_spin_budget(2000); spins < lim && !job->done.load(std::memory_order_acquire); ++spins) _mm_pause();
     if (!job->done.load(std::memory_order_acquire)) {
         fokl_host_pool *pool = job->pool;
         std::unique_lock<std::mutex> lock(pool->done_m);

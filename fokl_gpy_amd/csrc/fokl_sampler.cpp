@@ -31,6 +31,7 @@
 #endif
 
 #include "../../include/fokl_hip.h"
+#include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 
@@ -758,7 +759,7 @@ namespace {
 // started yet may be far away (sleep in short steps rather than burn a core -- ranks may share a tight CPU quota).
 inline void follow_wait(int &spins)
 {
-    if (++spins < 2000) {
+    if (++spins < fokl_spin_budget(2000)) {
         __builtin_ia32_pause();
     } else {
         std::this_thread::sleep_for(std::chrono::microseconds(10));

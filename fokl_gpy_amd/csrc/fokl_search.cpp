@@ -38,6 +38,7 @@
 #include <immintrin.h>
 
 #include "../../include/fokl_hip.h"
+#include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 
@@ -349,8 +350,17 @@ int fail(fokl_search *s, int code, const std::string &msg)
 {
     if (s) s->error = msg;
     fokl_set_global_error(msg);
+    if (std::getenv("FOKL_SEARCH_PROFILE")) std::fprintf(stderr, "fokl_search: error %d: %s\n", code, msg.c_str());
     return code;
 }
+
+// (FOKL_SEARCH_PROFILE: where an error code that travels up the kill-test loop came from)
+#define FOKL_RET(s_, x)                                                                                              \
+    do {                                                                                                             \
+        const int r__ = (x);                                                                                         \
+        if (r__ != FOKL_OK && (s_)->profile) std::fprintf(stderr, "fokl_search: rc %d at line %d\n", r__, __LINE__);  \
+        return r__;                                                                                                  \
+    } while (0)
 
 // ---- tapes ----------------------------------------------------------------------------------------------------
 
@@ -426,7 +436,7 @@ Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
             if (rc != FOKL_OK) {
                 give_buffer(t->rows_mem, t->rows_classes, true);
                 delete t;
-                s->error = "fokl_search: the pool refused a noise tape";
+                (void)fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a noise tape");
                 return nullptr;
             }
             t->holds_stream = true;
@@ -447,7 +457,7 @@ Tape *request_tape(fokl_search *s, int p1, bool tentative, bool model)
     if (rc != FOKL_OK) {
         give_buffer(t->mem, t->classes, t->pinned);
         delete t;
-        s->error = "fokl_search: the pool refused a noise tape";
+        (void)fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a noise tape");
         return nullptr;
     }
     return t;
@@ -462,7 +472,7 @@ int materialise(fokl_search *s, Tape *t)
         const int32_t p = __atomic_load_n(t->progress, __ATOMIC_ACQUIRE);
         if (p < 0) return fail(s, FOKL_ERR_STATE, "fokl_search: the tape to materialise was sent back");
         if (p >= t->draws) break;
-        if (spins < 2000)
+        if (spins < fokl_spin_budget(2000))
             _mm_pause();
         else
             std::this_thread::sleep_for(std::chrono::microseconds(10));
@@ -582,7 +592,7 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
         // staged only: the entry point that ends this burst of requests launches them as one grid (flush_spectra)
         if (fokl_dspectral_submit(s->dspec, gram, ld, sp->idx.data(), p1, ld - 1, 0, &sp->ticket, &sp->buf) != FOKL_OK) {
             delete sp;
-            s->error = "fokl_search: the device refused a spectral job";
+            (void)fail(s, FOKL_ERR_STATE, "fokl_search: the device refused a spectral job");
             return nullptr;
         }
         sp->dev = s->dspec;
@@ -613,7 +623,7 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     if (rc != FOKL_OK) {
         give_spectrum_buffer(sp->buf, p1);
         delete sp;
-        s->error = "fokl_search: the pool refused a spectral job";
+        (void)fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a spectral job");
         return nullptr;
     }
     s->stats[S_SPECTRAL_SUBMITTED] += 1;
@@ -859,6 +869,8 @@ int wait_host_chain(fokl_search *s, Outcome *o)
     if (!o->chain_waited) {
         const double t0 = now_s();
         o->chain_status = o->chain ? fokl_pool_wait(o->chain) : FOKL_OK;
+        if (o->chain_status != FOKL_OK && s->profile)
+            std::fprintf(stderr, "fokl_search: host chain failed with %d: %s\n", o->chain_status, fokl_last_error(nullptr));
         o->chain = nullptr;
         o->chain_waited = true;
         s->stats[S_T_CHAIN] += now_s() - t0;
@@ -874,6 +886,9 @@ int wait_host_chain(fokl_search *s, Outcome *o)
 // mean over the rows from `first_row` on of the intercept draws (betas[:, 0] = w Q[0, :]')
 int mean_intercept_draw(fokl_search *s, Outcome *o, int first_row, double *out)
 {
+    if (s->profile && o->on_device == false && o->chain == nullptr && !o->chain_waited && !o->lazy)
+        std::fprintf(stderr, "fokl_search: mean_intercept_draw on an outcome without a chain (cancelled %d released %d)\n",
+                     (int)o->cancelled, (int)o->released);
     if (o->lazy || o->cancelled) {
         const int rc = ensure_started(s, o);
         if (rc != FOKL_OK) return rc;
@@ -988,6 +1003,12 @@ void release_outcome(fokl_search *s, Outcome *o)
         release_device_job(s, o);
         return;
     }
+    if (!o->checks.empty()) {
+        // a kill test decided before its chain existed may have had its second clause guessed like a device chain's and
+        // then got a host chain after all (every device slot alive): its statistics still have to confirm the guesses
+        o->release_wanted = true;
+        return;
+    }
     o->released = true;
     if (o->w) {
         if (o->chain_waited || !o->chain) {
@@ -1098,7 +1119,7 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
         __atomic_load_n(t->progress, __ATOMIC_ACQUIRE) > 0) {
         // (the very first tape of a stream handed over with a cached normal: that value exists on the host only)
         const int rc = materialise(s, t);
-        if (rc != FOKL_OK) return rc;
+        if (rc != FOKL_OK) FOKL_RET(s, rc);
     }
     if (test && t->rows_only) {
         const int rc = fokl_dchain_submit_rows(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
@@ -1112,9 +1133,9 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
             s->stats[S_ROWS_CHAINS] += 1;
             return FOKL_OK;
         }
-        if (rc != FOKL_ERR_STATE) return rc;                // FOKL_ERR_STATE: every slot is alive -> host chain
+        if (rc != FOKL_ERR_STATE) FOKL_RET(s, rc);                // FOKL_ERR_STATE: every slot is alive -> host chain
         const int rcm = materialise(s, t);
-        if (rcm != FOKL_OK) return rcm;
+        if (rcm != FOKL_OK) FOKL_RET(s, rcm);
     }
     if (test && s->dchain && !t->rows_mem && p1 <= s->prm.device_chain_columns && s->prechain.tape != t) {
         const int rc = fokl_dchain_submit(s->dchain, p1, t->draws, sp->lamb(), sp->qty(), s->prm.b, s->prm.btau, dtd,
@@ -1128,7 +1149,7 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
             s->stats[S_DEVICE_CHAINS] += 1;
             return FOKL_OK;
         }
-        if (rc != FOKL_ERR_STATE) return rc;                // FOKL_ERR_STATE: every slot is alive -> the host chain
+        if (rc != FOKL_ERR_STATE) FOKL_RET(s, rc);                // FOKL_ERR_STATE: every slot is alive -> the host chain
     }
     auto &pc = s->prechain;
     if (pc.tape) {
@@ -1151,7 +1172,7 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
     o->chain = submit_host_chain(s, sp, t, dtd, o->w, o->flag);
     if (!o->chain) {
         o->chain_waited = true;
-        return FOKL_ERR_STATE;
+        return fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a chain");
     }
     return FOKL_OK;
 }
@@ -1244,7 +1265,7 @@ int settle_pending(fokl_search *s, bool block, Outcome *upto)
         unref(s, o);                                        // the list's reference
         if (out != FOKL_OK) {
             flush();
-            return out;
+            FOKL_RET(s, out);
         }
         if (last) break;
     }
@@ -2211,10 +2232,10 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             lap(6);
             int rc2 = verify(s, false);                     // (also starts the chains whose G2 has arrived)
             lap(0);
-            if (rc2 != FOKL_OK) return rc2;
+            if (rc2 != FOKL_OK) FOKL_RET(s, rc2);
             if (!decided) {
                 const int quick = second_clause_now(s, best, a->mean_abs[i]);
-                if (quick < -1) return quick + 2;
+                if (quick < -1) FOKL_RET(s, quick + 2);
                 if (quick == 0) continue;
                 if (quick == 1) {
                     decided = true;
@@ -2223,7 +2244,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
             if (!decided) {
                 // no guess to be had (host chains; a borderline case whose tape is gone): the chain of `best` decides
-                if ((rc2 = intercept_scale(s, best, &scale_guess)) != FOKL_OK) return rc2;
+                if ((rc2 = intercept_scale(s, best, &scale_guess)) != FOKL_OK) FOKL_RET(s, rc2);
                 if (!(a->mean_abs[i] < threshav * scale_guess)) continue;
             }
             lap(1);
@@ -2233,12 +2254,12 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             const auto trial = with_column(killed, col);
             const int p1 = A - (int)trial.size();
             Tape *tape = tape_for(s, p1, false);            // the stream moves on at once
-            if (!tape) return FOKL_ERR_STATE;
+            if (!tape) FOKL_RET(s, FOKL_ERR_STATE);
             if (idle_pending) {
                 idle_pending = false;
                 if ((rc2 = a->idle_work(a->user)) != FOKL_OK) {
                     unref(s, tape);
-                    return rc2;
+                    FOKL_RET(s, rc2);
                 }
             }
             lap(2);
@@ -2271,7 +2292,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 // as in mode 0
                 if (!(sp = take_spectrum(true))) {
                     unref(s, tape);
-                    return FOKL_ERR_STATE;
+                    FOKL_RET(s, FOKL_ERR_STATE);
                 }
                 rc2 = wait_spectrum(s, sp);
                 const double t0 = now_s();
@@ -2281,7 +2302,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
                 if (rc2 != FOKL_OK) {
                     unref(s, sp);
                     unref(s, tape);
-                    return rc2;
+                    FOKL_RET(s, rc2);
                 }
                 s->stats[S_T_RESID] += now_s() - t0;
             } else {
@@ -2295,7 +2316,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             if (ev_accepted) {
                 if (!sp && !(sp = take_spectrum())) {
                     unref(s, tape);
-                    return FOKL_ERR_STATE;
+                    FOKL_RET(s, FOKL_ERR_STATE);
                 }
                 auto *cand = new Outcome();
                 cand->spec = sp;                            // takes over this block's reference
@@ -2332,7 +2353,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             // bounded: accepted models waiting for G2 (their tapes hold the stream), tapes waiting for the walker
             const size_t bound = s->pending_limit(A);
             while (s->pending.size() > bound)
-                if ((rc2 = settle_pending(s, true, s->pending.front())) != FOKL_OK) return rc2;
+                if ((rc2 = settle_pending(s, true, s->pending.front())) != FOKL_OK) FOKL_RET(s, rc2);
             if ((pos & 7) == 7) reap(s, false);
             while (s->tape_limbo.size() > 2 * bound) {
                 reap(s, false);
@@ -2342,7 +2363,7 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             }
         }
         // the model that survives the sub-stage is the caller's: its eigenpairs will be looked at
-        if (best->lazy && best->spec->deferred && (rc2_end = launch_deferred(s, best->spec)) != FOKL_OK) return rc2_end;
+        if (best->lazy && best->spec->deferred && (rc2_end = launch_deferred(s, best->spec)) != FOKL_OK) FOKL_RET(s, rc2_end);
         // the kill set is final: G2 of the coming sub-stage's model can start
         lap(6);
         if (a->foresee && !idle_pending) {

@@ -43,6 +43,7 @@
 #include <immintrin.h>
 
 #include "../../include/fokl_hip.h"
+#include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
 extern "C" __attribute__((visibility("hidden"))) void fokl_note_thread_cpu(int kind);   // fokl_hostpool.cpp
@@ -399,7 +400,7 @@ void bulk_worker(fokl_stream *e)
                 // a walker in the middle of a tape comes for the next segments within microseconds: look a few times
                 // before going to sleep (a sleep and a wake-up per segment cost more than the segment)
                 bool ready = false;
-                for (int spins = 0; spins < 400 && !ready; ++spins) {
+                for (int spins = 0, lim = fokl_spin_budget(400); spins < lim && !ready; ++spins) {
                     ready = room_now();
                     if (!ready) _mm_pause();
                 }
@@ -469,7 +470,7 @@ Segment *segment_of(fokl_stream *e, uint64_t D, bool walker)
     for (int spins = 0;; ++spins) {
         seg = e->table[index % kTable].load(std::memory_order_acquire);
         if (seg && seg->index == index) break;
-        if (spins < 4000)
+        if (spins < fokl_spin_budget(4000))
             _mm_pause();
         else
             std::this_thread::sleep_for(std::chrono::microseconds(5));

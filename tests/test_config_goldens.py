@@ -228,3 +228,23 @@ def test_direct_kill_decisions_are_confirmed_by_the_eigenpairs():
     assert st['chains_cancelled'] > 50 and st['guesses_verified'] == st['guessed'] > 100
     assert st['searches_repeated'] == 0
     assert_matches_golden(g, model, betas, mtx, evs, state)
+
+
+@pytest.mark.gpu
+def test_fit_with_a_chain_engine_of_few_slots_falls_back_to_host_chains(monkeypatch):
+    """Every device slot alive (here: an engine of six): a kill test's chain then runs on a host thread from the tape
+    materialised after all -- including chains of models whose second clause had been GUESSED as for a device chain (they
+    were decided before their chain existed): their statistics must still confirm the guesses before the outcome goes
+    (round 5: such an outcome used to be released with its checks open, and the final verification failed)."""
+    from fokl_gpy_amd import host_pipeline
+    g = load_golden('cfg4_unit0_n1e5_m8')
+    host_pipeline.close_chain_engines()
+    monkeypatch.setenv('FOKL_DCHAIN_SLOTS', '6')
+    try:
+        model, betas, mtx, evs, state = fit_like_golden(g)
+        st = model.fit_stats
+        assert st['tapes_materialised'] > 20 and st['guesses_verified'] == st['guessed'] > 0
+        assert st['searches_repeated'] == 0
+        assert_matches_golden(g, model, betas, mtx, evs, state)
+    finally:
+        host_pipeline.close_chain_engines()
