@@ -43,6 +43,7 @@ SIGNATURES = {
     'fokl_gram': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_gram_launch': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int]),
     'fokl_gram_fetch': (c_int, [c_vp, c_vp, c_i64]),
+    'fokl_gram_ready': (c_int, [c_vp]),
     'fokl_gram_plan': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     'fokl_bic_resid': (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
     'fokl_bic_resid_launch': (c_int, [c_vp, c_vp, c_int, c_vp]),
@@ -124,6 +125,7 @@ SIGNATURES = {
     'fokl_outcome_chain_ready': (c_int, [c_vp]),
     'fokl_outcome_draws': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_outcome_intercept_scale': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_outcome_new_term_stats': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     'fokl_outcome_release': (None, [c_vp, c_vp]),
     'fokl_outcome_drop': (None, [c_vp, c_vp]),
     'fokl_search_verify': (c_int, [c_vp, c_int]),
@@ -979,6 +981,15 @@ class NativeSearch:
         self._checked(self._lib.fokl_outcome_intercept_scale(self._h, c_vp(outcome), ctypes.byref(v)))
         return v.value
 
+    def outcome_new_term_stats(self, outcome, cols, half0, half1):
+        """(|mean beta| over rows half1 .., std over rows half1 .. / |mean over rows half0 ..|) of the model's active columns
+        `cols` (FR:1656-1658); waits for the chain."""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        mean_abs, rel_std = np.empty(cols.shape[0]), np.empty(cols.shape[0])
+        self._checked(self._lib.fokl_outcome_new_term_stats(self._h, c_vp(outcome), _ptr(cols), cols.shape[0], int(half0),
+                                                            int(half1), _ptr(mean_abs), _ptr(rel_std)))
+        return mean_abs, rel_std
+
     def outcome_release(self, outcome):
         if self._h:
             self._lib.fokl_outcome_release(self._h, c_vp(outcome))
@@ -1497,6 +1508,13 @@ class DeviceContext:
         self._ck(self._lib.fokl_gram_launch(self._h, _ptr(rs), rs.shape[0], _ptr(cs), cs.shape[0],
                                             int(bool(allreduce))))
         return rs.shape[0], cs.shape[0]
+
+    def gram_ready(self):
+        """True once gram_fetch would not wait."""
+        rc = self._lib.fokl_gram_ready(self._h)
+        if rc < 0:
+            self._ck(rc)
+        return rc == 1
 
     def gram_fetch(self, shape):
         out = np.empty(shape, dtype=np.float64)

@@ -1527,6 +1527,18 @@ extern "C" int fokl_gram_launch(fokl_ctx *ctx, const int32_t *row_slots, int nr,
     return FOKL_OK;
 }
 
+// 1: the block launched by fokl_gram_launch has arrived in host memory (fokl_gram_fetch will not wait), 0: not yet,
+// < 0: nothing launched / an error.
+extern "C" int fokl_gram_ready(fokl_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, FOKL_ERR_ARG, "fokl_gram_ready: null context");
+    if (!ctx->gram_pending) return fail(ctx, FOKL_ERR_STATE, "fokl_gram_ready: nothing launched");
+    const hipError_t st = hipEventQuery(ctx->gram_done);
+    if (st == hipSuccess) return 1;
+    if (st == hipErrorNotReady) return 0;
+    return fail(ctx, FOKL_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(st));
+}
+
 extern "C" int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count)
 {
     if (!ctx || !out) return fail(ctx, FOKL_ERR_ARG, "fokl_gram_fetch: null pointer");

@@ -1884,6 +1884,70 @@ extern "C" int fokl_outcome_draws(fokl_search *s, fokl_outcome *h, const double 
     return FOKL_OK;
 }
 
+// The statistics that order and gate a sub-stage's kill tests (FR:1656-1658) from the model's draws, without materialising
+// betas = w Q': for the active columns `cols`, mean_abs = |mean over rows half1 .. of beta|, rel_std = (population) standard
+// deviation over rows half1 .. / |mean over rows half0 ..| -- the reference's inconsistent pair of row ranges, on purpose.
+// beta[k][c] = sum_j w[k][j] Qt[j][cols[c]], summed over j ascending; means and squared deviations row after row, as numpy's
+// reduction along axis 0 does.  Waits for the chain.
+#define FOKL_STATS_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+namespace {
+FOKL_STATS_CLONES void betas_of_rows(const double *__restrict__ w, const double *__restrict__ B, int p1, int count, int k0,
+                                     int k1, double *__restrict__ out)
+{
+    for (int k = k0; k < k1; ++k) {
+        const double *__restrict__ row = w + (size_t)k * p1;
+        double *__restrict__ b = out + (size_t)(k - k0) * count;
+        for (int c = 0; c < count; ++c) b[c] = 0.0;
+        for (int j = 0; j < p1; ++j) {
+            const double wj = row[j];
+            const double *__restrict__ q = B + (size_t)j * count;
+            for (int c = 0; c < count; ++c) b[c] += wj * q[c];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int fokl_outcome_new_term_stats(fokl_search *s, fokl_outcome *h, const int32_t *cols, int count, int half0,
+                                           int half1, double *mean_abs, double *rel_std)
+{
+    if (!s || !h || !cols || count < 1 || !mean_abs || !rel_std || half0 < 0 || half1 < half0)
+        return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: bad arguments");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    const double *w = nullptr;
+    const int rc = fokl_outcome_draws(s, h, &w);
+    if (rc != FOKL_OK) return rc;
+    const int p1 = o->spec->p1, draws = s->prm.draws;
+    if (half1 >= draws) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: no rows to average");
+    for (int c = 0; c < count; ++c)
+        if (cols[c] < 0 || cols[c] >= p1) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: column out of range");
+    const double *Qt = o->spec->Qt();
+    std::vector<double> B((size_t)p1 * count), betas((size_t)(draws - half0) * count), sum0((size_t)count, 0.0),
+        sum1((size_t)count, 0.0), dev((size_t)count, 0.0);
+    for (int j = 0; j < p1; ++j)
+        for (int c = 0; c < count; ++c) B[(size_t)j * count + c] = Qt[(size_t)j * p1 + cols[c]];
+    betas_of_rows(w, B.data(), p1, count, half0, draws, betas.data());
+    for (int k = half0; k < draws; ++k) {
+        const double *b = betas.data() + (size_t)(k - half0) * count;
+        for (int c = 0; c < count; ++c) sum0[(size_t)c] += b[c];
+        if (k >= half1)
+            for (int c = 0; c < count; ++c) sum1[(size_t)c] += b[c];
+    }
+    const double rows0 = (double)(draws - half0), rows1 = (double)(draws - half1);
+    for (int c = 0; c < count; ++c) sum1[(size_t)c] /= rows1;             // the mean over rows half1 ..
+    for (int k = half1; k < draws; ++k) {
+        const double *b = betas.data() + (size_t)(k - half0) * count;
+        for (int c = 0; c < count; ++c) {
+            const double d = b[c] - sum1[(size_t)c];
+            dev[(size_t)c] += d * d;
+        }
+    }
+    for (int c = 0; c < count; ++c) {
+        mean_abs[c] = std::fabs(sum1[(size_t)c]);
+        rel_std[c] = std::sqrt(dev[(size_t)c] / rows1) / std::fabs(sum0[(size_t)c] / rows0);
+    }
+    return FOKL_OK;
+}
+
 extern "C" int fokl_outcome_intercept_scale(fokl_search *s, fokl_outcome *h, double *scale)
 {
     if (!s || !h || !scale) return fail(s, FOKL_ERR_ARG, "fokl_outcome_intercept_scale: null pointer");
@@ -2230,7 +2294,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             const int i = proposal[pos];
             bool decided = clause1[(size_t)i];
             lap(6);
-            int rc2 = verify(s, false);                     // (also starts the chains whose G2 has arrived)
+            // (every fourth turn: a turn takes microseconds, chains and eigenpairs arrive by the millisecond)
+            int rc2 = (pos & 3) == 0 ? verify(s, false) : FOKL_OK;      // (also starts the chains whose G2 has arrived)
             lap(0);
             if (rc2 != FOKL_OK) FOKL_RET(s, rc2);
             if (!decided) {

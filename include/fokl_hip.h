@@ -161,6 +161,7 @@ int fokl_gram(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *co
  */
 int fokl_gram_launch(fokl_ctx *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int allreduce);
 int fokl_gram_fetch(fokl_ctx *ctx, double *out, int64_t count);
+int fokl_gram_ready(fokl_ctx *ctx);      /* 1: fokl_gram_fetch will not wait, 0: the launched block is still on its way */
 /*
  * The launch plan path 2 would use for such a block -- host arithmetic only, no device needed (the CPU tests replay it
  * with numpy).  kind 0: gram_tiles_kernel (v_mfma_f64_16x16x4; what fokl_gram runs), kind 1: gram_tiles4s_kernel (the
@@ -640,6 +641,10 @@ int fokl_outcome_spectrum(fokl_search *search, fokl_outcome *outcome, fokl_spect
 int fokl_outcome_chain_ready(fokl_outcome *outcome);
 int fokl_outcome_draws(fokl_search *search, fokl_outcome *outcome, const double **w);
 int fokl_outcome_intercept_scale(fokl_search *search, fokl_outcome *outcome, double *scale);
+/* FR:1656-1658 for the active columns `cols` of the outcome's model, from its draws in the eigenbasis (waits for the chain):
+ * mean_abs[c] = |mean over rows half1 .. of beta_c|, rel_std[c] = std over rows half1 .. / |mean over rows half0 ..|. */
+int fokl_outcome_new_term_stats(fokl_search *search, fokl_outcome *outcome, const int32_t *cols, int count, int half0,
+                                int half1, double *mean_abs, double *rel_std);
 void fokl_outcome_release(fokl_search *search, fokl_outcome *outcome);
 void fokl_outcome_drop(fokl_search *search, fokl_outcome *outcome);
 int fokl_search_verify(fokl_search *search, int block);
