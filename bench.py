@@ -469,11 +469,11 @@ def kernel_report(kern, n, m, cfg):
             if kernels[name]:
                 kernels[name]['all_gram_launches'] = gram_all
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/pmc_r04.json, produced by tools/profile_r04.sh: separate
+    # rocprofv3 --pmc passes over this same command (profiles/pmc_r05.json, produced by tools/profile_r05.sh: separate
     # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
     # was recorded for exactly this workload.
     traffic_source = None
-    for cand in ('pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
+    for cand in ('pmc_r05.json', 'pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         pmc_path = os.path.join(ROOT, 'profiles', cand)
         if not os.path.exists(pmc_path):
             continue

@@ -930,7 +930,9 @@ void noise_worker(fokl_host_pool *pool)
                     std::unique_lock<std::mutex> lock(queue->m);
                     if (settled()) break;
                     if (open.size() < kMaxSpeculation && !queue->q.empty() && queue->q.front()->tentative) break;
-                    queue->cv.wait_for(lock, std::chrono::microseconds(200));
+                    // (system clock: libstdc++ then waits with pthread_cond_timedwait, which ThreadSanitizer follows; the
+                    // steady clock's pthread_cond_clockwait it does not, and reports the mutex as held across the wait)
+                    queue->cv.wait_until(lock, std::chrono::system_clock::now() + std::chrono::microseconds(200));
                     if (open.size() < kMaxSpeculation && !queue->q.empty() && queue->q.front()->tentative) break;
                 }
             }

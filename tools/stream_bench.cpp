@@ -3,6 +3,7 @@
 // there (warm: what the walk itself costs).  Build and run: see tools/stream_bench.sh.
 #include <string>
 void fokl_set_global_error(const std::string &) {}
+extern "C" void fokl_note_thread_cpu(int) {}            // (fokl_hostpool.cpp in the library: per-kind CPU accounting)
 #include "../fokl_gpy_amd/csrc/fokl_stream.cpp"
 #include <cstdio>
 #include <random>
