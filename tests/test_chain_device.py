@@ -110,7 +110,9 @@ def test_negative_bstar_is_flagged_and_goes_nan_like_the_host(engine, monkeypatc
     w, mean_w, negative = _capi.gibbs_chain_device(engine, *args, tape)
     assert flag and negative
     assert np.array_equal(np.isnan(w), np.isnan(want)) and np.isnan(w[1:]).all()
-    assert np.array_equal(w[0], want[0])
+    # (the first row is formed before anything goes NaN: the fast recursion's Newton-refined reciprocal square root is within
+    # a rounding or two of the host's 1 / x and sqrt)
+    assert np.allclose(w[0], want[0], rtol=1e-14, atol=0)
 
 
 def test_chains_follow_tapes_that_are_still_on_record_and_slots_are_recycled(engine):
