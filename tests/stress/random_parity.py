@@ -39,7 +39,8 @@ def fit(x, y, kw, seed, oracle):
             TALLY[key] += model.fit_stats.get(key, 0)
     return b, mtx, evs, hashlib.sha256(st[1].tobytes()).hexdigest() + str(st[2:])
 
-TALLY = dict(device_chains=0, guessed=0, guesses_verified=0, guess_waits=0, searches_repeated=0, kill_tests=0)
+TALLY = dict(device_chains=0, guessed=0, guesses_verified=0, guess_waits=0, searches_repeated=0, kill_tests=0, direct_tests=0,
+             chains_cancelled=0, spectral_submitted=0, spectral_updated=0)
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     x, y, kw = problem(seed)
