@@ -23,7 +23,17 @@ modes=(
   "FOKL_BUILD_AHEAD=tests"
   "FOKL_LOOKAHEAD_DERIVED=24"
   "FOKL_CLEAN=host"
-  "FOKL_K1_TOUCH=0"
+  "FOKL_K1_TOUCH=1"
+  "FOKL_KILL_DECIDE=g2"
+  "FOKL_G2_DEFER_FROM=8"
+  "FOKL_SPECULATION=4"
+  "FOKL_SPECULATE_ACROSS=0"
+  "FOKL_FORECAST_EARLY=0"
+  "FOKL_STATS=numpy"
+  "FOKL_SPIN=0"
+  "FOKL_GUESS_MARGIN=0.02"
+  "FOKL_EIGH_UPDATE_DEPTH=6"
+  "FOKL_SEARCH_DIST=python"
   "FOKL_K3=columns"
   "FOKL_KILL_BIC=device"
   "FOKL_KILL_BIC=check"
@@ -36,7 +46,10 @@ modes=(
   "FOKL_SAMPLER_ISA=base"
   "FOKL_SYNC=blocking"
 )
+# KNOB_PART=k/n: every n-th mode from the k-th on (a gpurun call is limited to 20 minutes)
+part=${KNOB_PART:-1/1}; k=${part%%/*}; n=${part##*/}; i=0
 for mode in "${modes[@]}"; do
+  i=$((i + 1)); if [ $(( (i - k) % n )) -ne 0 ] || [ $i -lt $k ]; then continue; fi
   echo "== $mode" | tee -a "$out"
   env $mode timeout -k 10 900 python -m pytest $TESTS -m gpu -q -x -k "$KEYS" 2>&1 | tail -2 | tee -a "$out"
   if [ "${PIPESTATUS[0]}" -ne 0 ]; then echo "FAILED under $mode" | tee -a "$out"; exit 1; fi
