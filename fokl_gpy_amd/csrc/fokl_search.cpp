@@ -304,7 +304,7 @@ struct fokl_search {
     // accepted models waiting for G2 at most (the loop then waits for the oldest).  The device expands a tape from the
     // stream's pre-states, which the bulk threads keep for the last 1024 segments of 79 872 doubles (fokl_dchain_prestate_ring;
     // the device's own ring of regenerated segments is as long): a chain must be issued before the walker is that far past
-    // its tape, so the bound follows the tape length -- 448 segments' worth of accepted models' tapes, 192 of tapes on order
+    // its tape, so the bound follows the tape length -- 448 segments' worth of accepted models' tapes, 320 of tapes on order
     // (speculate), together well inside the 1024
     size_t pending_limit(int p1) const
     {
@@ -314,7 +314,7 @@ struct fokl_search {
     size_t order_limit(int p1) const
     {
         const double per_tape = (double)prm.draws * (1.3 * p1 + 4.0) / 79872.0 + 1.0;
-        return (size_t)std::min(64.0, std::max(4.0, 192.0 / per_tape));
+        return (size_t)std::min(64.0, std::max(4.0, 320.0 / per_tape));
     }
     std::deque<Outcome *> pending;
     // FOKL_SEARCH_PROFILE=1: where the kill-test loop's own time goes (seconds per section, printed when the search ends)
@@ -827,6 +827,10 @@ void speculate(fokl_search *s, const std::vector<std::pair<int, bool>> &sizes)
     if (!s->prm.tentative_tapes) return;
     size_t k = 0;
     while (k < s->spec.size() && k < sizes.size() && s->spec[k]->p1 == sizes[k].first) ++k;
+    // (kill tests decided at once: a caller that names fewer models than are on order -- a model's own evaluation knows of
+    // its first test only -- does not take back what a better informed one ordered across the sub-stage boundary; a tape
+    // that turns out wrong is sent back when its turn comes and costs the walker nothing it had to do instead)
+    if (s->decide == 1 && k == sizes.size() && k <= s->spec.size()) return;
     if (k < s->spec.size()) drop_speculation(s, k);
     // (tapes on order hold the stream from where they begin, like the accepted models' tapes that wait for G2: the book is
     // as deep as the search allows or as half of pending_limit's segments are long, whichever is less)
