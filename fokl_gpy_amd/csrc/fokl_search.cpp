@@ -21,6 +21,7 @@
 // Everything in a fokl_search is touched by ONE thread (the driver); the pool's and the device engine's own threads are
 // reached through their C ABI only.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -131,7 +132,24 @@ void give_buffer(double *p, size_t classes, bool pinned)
 // the objects of a search
 // ---------------------------------------------------------------------------------------------------------------
 
-struct Tape {
+// live objects of each kind, process-wide (FOKL_SEARCH_PROFILE prints them when a search ends: a search that has been
+// destroyed leaves none of its own behind)
+struct Census {
+    std::atomic<int64_t> tapes{0}, spectra{0}, outcomes{0};
+};
+Census &census()
+{
+    static Census c;
+    return c;
+}
+template <typename T, std::atomic<int64_t> Census::*Member>
+struct Counted {
+    Counted() { (census().*Member).fetch_add(1, std::memory_order_relaxed); }
+    Counted(const Counted &) { (census().*Member).fetch_add(1, std::memory_order_relaxed); }
+    ~Counted() { (census().*Member).fetch_sub(1, std::memory_order_relaxed); }
+};
+
+struct Tape : Counted<Tape, &Census::tapes> {
     int p1 = 0, draws = 0;
     bool model = false;                     // ordered for a sub-stage's model (finished by host threads as it is walked)
     bool tentative = false, resolved = false, abandoned = false;
@@ -157,7 +175,7 @@ struct Tape {
     std::vector<fokl_host_job *> readers;   // host chains given up while they may still be reading the tape
 };
 
-struct Spectrum {
+struct Spectrum : Counted<Spectrum, &Census::spectra> {
     int p1 = 0;
     std::vector<int32_t> idx;
     double *buf = nullptr;                  // lamb | qty | betahat | Qt | moments
@@ -194,7 +212,7 @@ struct Check {
     bool decision;
 };
 
-struct Outcome {
+struct Outcome : Counted<Outcome, &Census::outcomes> {
     Spectrum *spec = nullptr;
     Tape *tape = nullptr;
     double ev = 0, siglik = 0, dtd = NAN;
@@ -300,6 +318,8 @@ struct fokl_search {
     // ends the search only where every rank finds out at the same point: in the blocking verification at the end.
     bool deterministic = false;
     bool misprediction_noted = false;
+    // derivations per decomposition in sub-stages of wide models (kWideDepth; FOKL_EIGH_UPDATE_DEPTH_WIDE for experiments)
+    int wide_depth = std::getenv("FOKL_EIGH_UPDATE_DEPTH_WIDE") ? std::max(1, std::atoi(std::getenv("FOKL_EIGH_UPDATE_DEPTH_WIDE"))) : 2;
     int defer_from = std::getenv("FOKL_G2_DEFER_FROM") ? std::atoi(std::getenv("FOKL_G2_DEFER_FROM")) : 192;   // (kWideModel)
     // accepted models waiting for G2 at most (the loop then waits for the oldest).  The device expands a tape from the
     // stream's pre-states, which the bulk threads keep for the last 1024 segments of 79 872 doubles (fokl_dchain_prestate_ring;
@@ -606,7 +626,7 @@ Spectrum *submit_spectrum(fokl_search *s, const double *gram, int ld, const int3
     const bool from_parent = sp->buf && parent && !parent->deferred && s->update_from > 0 && parent_pos >= 0 && parent_pos <= p1 &&
                              parent->p1 == p1 + 1 && parent->p1 >= s->update_from && !parent->dev && parent->buf &&
                              parent->status == FOKL_OK &&
-                             parent->depth < (parent->p1 >= kWideModel ? std::min(s->update_depth, kWideDepth) : s->update_depth);
+                             parent->depth < (parent->p1 >= kWideModel ? std::min(s->update_depth, s->wide_depth) : s->update_depth);
     if (from_parent) {
         rc = fokl_pool_submit_spectral_update(s->pool, gram, ld, sp->idx.data(), p1, ld - 1, parent->lamb(), parent->Qt(),
                                               parent_pos, parent->job, sp->lamb(), sp->Qt(), sp->qty(), sp->betahat(),
@@ -1369,10 +1389,23 @@ int second_clause_now(fokl_search *s, Outcome *o, double value)
 // statistics -- those that have arrived, or (block) all of them.  FOKL_ERR_STATE + s->mispredicted if one does not hold.
 int verify(fokl_search *s, bool block)
 {
+    const double t_in = s->profile && block ? now_s() : 0.0;
+    struct Note {                                           // (FOKL_SEARCH_PROFILE: what the blocking verification waited for)
+        fokl_search *s;
+        double t_in, t_settled = 0.0;
+        size_t pending, unverified;
+        ~Note()
+        {
+            if (t_in > 0.0)
+                std::fprintf(stderr, "fokl_search: blocking verify: %zu pending, %zu unverified; eigenpairs %.3f ms, chains %.3f ms\n",
+                             pending, unverified, 1e3 * (t_settled - t_in), 1e3 * (now_s() - t_settled));
+        }
+    } note{s, t_in, t_in, s->pending.size(), s->unverified.size()};
     if (!s->pending.empty()) {
         const int rc = settle_pending(s, block, nullptr);
         if (rc != FOKL_OK) return rc;
     }
+    if (t_in > 0.0) note.t_settled = now_s();
     while (!s->zombies.empty()) {
         Outcome *z = s->zombies.front();
         if (!z->device_released) {
@@ -1627,6 +1660,9 @@ extern "C" void fokl_search_destroy(fokl_search *s)
     s->device_outcomes.clear();
     reap(s, true);
     reap(s, true);                                          // tapes released by the chains of the first pass
+    if (s->profile)
+        std::fprintf(stderr, "fokl_search: alive after this search: %lld tapes, %lld spectra, %lld outcomes (handles the caller still holds)\n",
+                     (long long)census().tapes.load(), (long long)census().spectra.load(), (long long)census().outcomes.load());
     if (s->profile)
         std::fprintf(stderr, "fokl_search profile (ms): verify %.3f clause %.3f tape %.3f bic %.3f accept %.3f (spectrum %.3f) "
                              "bounds %.3f tail %.3f\n", 1e3 * s->prof[0], 1e3 * s->prof[1], 1e3 * s->prof[2], 1e3 * s->prof[3],
