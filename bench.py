@@ -779,9 +779,12 @@ def main():
     if (cfg == 2 and world == 1 and rank == 0 and not args.procs and not args.no_throughput and not args.mode
             and os.environ.get('FOKL_BENCH_FORCE_RCCL', '0') != '1'):
         # worker processes next to this one, which fits along as one more (six processes on the GPU at most, this one
-        # included): one fitting process per ~2.6 CPUs with the chains of the kill tests on the device (a fit then costs
-        # ~0.27 CPU-seconds per ~0.1 s), one per 4 CPUs with host chains (0.4 CPU-seconds)
-        per_proc = 4.0 if os.environ.get('FOKL_CHAIN', 'auto') == 'host' else 2.6
+        # included): one fitting process per ~3.9 CPUs of the budget.  A configs[2] fit costs 0.14-0.16 CPU-seconds in ~40 ms
+        # when it gets the CPUs it asks for: four processes use 15 of a 16-CPU quota and are never throttled (996 k terms/s,
+        # 41 ms per fit per process); a fifth and sixth push the container over its quota in most scheduler periods, and a
+        # period that ends throttled stops every thread of every fit (651 k / 886 k, 69-79 ms per fit:
+        # profiles/throughput_quota_r05.txt).  With host chains a fit costs twice the CPU: one process per 6 CPUs.
+        per_proc = 6.0 if os.environ.get('FOKL_CHAIN', 'auto') == 'host' else 3.9
         side_procs = int(os.environ.get('FOKL_BENCH_SIDE_PROCS', max(1, min(6, int(engine._cpu_budget() / per_proc))) - 1))
         if side_procs >= 1:
             try:
