@@ -1221,6 +1221,11 @@ void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, i
         __builtin_amdgcn_s_barrier();
     };
     int64_t chunk = blockIdx.x;
+#ifdef FOKL_GT_STAMP
+    // diagnostic build only (tools/k2_clock.sh; MI355X_MICROARCH.md, DVFS item 6): shader cycles and 100 MHz ticks around
+    // this workgroup's loop, to a buffer nothing else reads
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef FOKL_GD_STAMP
     // diagnostic build only (tools/k2_phases.sh): shader cycles of wavefronts 0 and 7 in the four phases of a chunk
     unsigned long long ph_issue = 0, ph_mult = 0, ph_wait = 0, ph_bar = 0;
@@ -1288,6 +1293,12 @@ void gram_tiles_dma_kernel(const GramGroup *__restrict__ groups, int ct_count, i
         }
     }
 
+#ifdef FOKL_GT_STAMP
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+        fokl_debug_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        fokl_debug_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
 #ifdef FOKL_GD_STAMP
     if (lane == 0 && (wave == 0 || wave == 7) && blockIdx.y == 0 && blockIdx.x < 512) {
         unsigned long long *st = fokl_debug_stamps + 8 * blockIdx.x + (wave == 7 ? 4 : 0);

@@ -5,7 +5,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, ROOT)
 from fokl_gpy_amd import _capi, getKernels, engine
 ctx = _capi.DeviceContext(0)
-n, m = 1_000_000, 8
+n, m = int(os.environ.get('K2_N', '1000000')), 8
 rng = np.random.default_rng(12)
 x = rng.random((n, m)); y = rng.standard_normal(n)
 packed, nb, width = getKernels.pack_phis(getKernels.bernoulli(), 1)
@@ -15,7 +15,10 @@ terms = np.vstack([engine.distinct_arrangements(p + [0] * 6) for p in ([2, 1], [
 slots = np.arange(2, 2 + terms.shape[0], dtype=np.int32)
 ctx.build_terms(terms, slots); ctx.sync()
 lib = ctypes.CDLL(_capi.LIB_PATH)
-for nr, nc in ((56, 58), (56, 128), (56, 176), (8, 150)):
+SHAPES = ((56, 58), (56, 128), (56, 176), (8, 150))
+if os.environ.get('K2_SHAPES'):
+    SHAPES = tuple(tuple(int(v) for v in item.split('x')) for item in os.environ['K2_SHAPES'].split(','))
+for nr, nc in SHAPES:
     rs = slots[:nr]; cs = np.concatenate([[0], slots[nr:nc - 2], rs, [1]]).astype(np.int32)
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 200):          # a second or so of back-to-back launches
         ctx.gram(rs, cs, path=2)
