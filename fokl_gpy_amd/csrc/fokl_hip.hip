@@ -1599,26 +1599,21 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
     return FOKL_OK;
 }
 
-typedef void (*resid_terms_fn)(const double *, int64_t, int64_t, const double *, int, const ResidTermsHeader *,
-                               const d2 *, int, const double *, double *);
+typedef void (*resid_quad_fn)(const double *, int64_t, int64_t, const double *, int, const ResidQuadTable *, const double *,
+                              double *);
 
-static resid_terms_fn pick_resid_terms(bool splines, int U)
-{
-    // up to 16 factors: table in one VGPR bank, two rows per lane; beyond: table in LDS, one row at a time (measured on
-    // MI355X, tools/k3_probe.py; the two- and three-bank register variants lose to it and are kept for A/B runs only,
-    // FOKL_K3_REGISTER_BANKS=1)
-    static const bool banks = getenv("FOKL_K3_REGISTER_BANKS") && atoi(getenv("FOKL_K3_REGISTER_BANKS")) != 0;
-    if (splines) {
-        if (U <= 16) return resid_terms_kernel<true, 1, 2>;
-        if (!banks) return resid_terms_lds_kernel<true>;
-        if (U <= 32) return resid_terms_kernel<true, 2, 1>;
-        return resid_terms_kernel<true, 3, 1>;
-    }
-    if (U <= 16) return resid_terms_kernel<false, 1, 2>;
-    if (!banks) return resid_terms_lds_kernel<false>;
-    if (U <= 32) return resid_terms_kernel<false, 2, 1>;
-    return resid_terms_kernel<false, 3, 1>;
-}
+// the slot layouts compiled: GM inputs x KM orders per input (smallest first); Bernoulli instances for orders up to 2
+// (what a search visits first) and up to RT_MAX_ORDER
+struct ResidQuadLayout {
+    int gm, km;
+    resid_quad_fn bernoulli2, bernoulli8, splines;
+};
+#define FOKL_RQ_LAYOUT(GM, KM)                                                                              \
+    {GM, KM, resid_quadratic_kernel<false, GM, KM, 2>, resid_quadratic_kernel<false, GM, KM, RT_MAX_ORDER>, \
+     resid_quadratic_kernel<true, GM, KM, 2>}
+static const ResidQuadLayout kResidQuadLayouts[] = {FOKL_RQ_LAYOUT(8, 1), FOKL_RQ_LAYOUT(16, 1), FOKL_RQ_LAYOUT(8, 2),
+                                                    FOKL_RQ_LAYOUT(4, 4), FOKL_RQ_LAYOUT(2, 8)};
+#undef FOKL_RQ_LAYOUT
 
 extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat)
 {
@@ -1631,8 +1626,8 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     const int m = ctx->m;
     const bool splines = ctx->kernel == FOKL_KERNEL_SPLINES;
 
-    // distinct (input, order) factors, ordered by input then order (std::map order, as in launch_basis)
-    std::map<std::pair<int, int>, int> fac_id;
+    // distinct (input, order) factors, ordered by input then order; a term has one or two of them
+    std::map<int, std::vector<int>> orders_of;                   // input -> its orders, ascending
     for (int j = 0; j < n_terms; ++j) {
         int nz = 0;
         for (int k = 0; k < m; ++k) {
@@ -1645,81 +1640,73 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
                     return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: Bernoulli order " + std::to_string(o) +
                                                        " beyond " + std::to_string(RT_MAX_ORDER) +
                                                        " (FOKL_RESID_TERMS_MAX_ORDER)");
-                fac_id.emplace(std::make_pair(k, o), 0);
+                std::vector<int> &os = orders_of[k];
+                auto at = std::lower_bound(os.begin(), os.end(), o);
+                if (at == os.end() || *at != o) os.insert(at, o);
                 ++nz;
             }
         }
         if (nz == 0) return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: term with no input (all-zero row)");
-        if (nz > 3)
-            return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: a term has more than three factors");
+        if (nz > 2)
+            return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: a term has more than two factors (the stored-column "
+                                           "pass, fokl_bic_resid_launch, takes such models)");
     }
-    int U = 0;
-    for (auto &kv : fac_id) kv.second = U++;
-    if (U > FOKL_RESID_TERMS_MAX_FACTORS)
-        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: model has " + std::to_string(U) +
-                                           " distinct (input, order) factors, limit " +
-                                           std::to_string(FOKL_RESID_TERMS_MAX_FACTORS));
-    int G = 0;
-    {
-        int last = -1;
-        for (auto &kv : fac_id)
-            if (kv.first.first != last) {
-                last = kv.first.first;
-                ++G;
-            }
+    const int G = (int)orders_of.size();
+    int K = 1, top_order = 1;
+    for (const auto &kv : orders_of) {
+        K = std::max(K, (int)kv.second.size());
+        top_order = std::max(top_order, kv.second.back());
     }
-    const int T = n_terms + 1;
-    const size_t table_bytes = (size_t)T * sizeof(ResidTerm) + (size_t)std::max(G, 1) * sizeof(ResidGroup) +
-                               (size_t)U * RT_COEF_STRIDE * sizeof(double);
-    if (table_bytes > 60 * 1024)
-        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: model too large for the tables in LDS");
+    const ResidQuadLayout *layout = nullptr;
+    for (const ResidQuadLayout &l : kResidQuadLayouts)
+        if (G <= l.gm && K <= l.km) {
+            layout = &l;
+            break;
+        }
+    if (!layout)
+        return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: " + std::to_string(G) + " inputs with up to " +
+                                           std::to_string(K) + " orders each fit none of the factor layouts (8 x 1, 16 x 1, "
+                                           "8 x 2, 4 x 4, 2 x 8: FOKL_RESID_TERMS_MAX_FACTORS slots)");
+    const int GM = layout->gm, KM = layout->km, UM = GM * KM;
 
-    const size_t tables_off = (sizeof(ResidTermsHeader) + 15) & ~(size_t)15;
-    const size_t arg_bytes = tables_off + table_bytes;
-    int rc = begin_args(ctx, arg_bytes);
+    int rc = begin_args(ctx, sizeof(ResidQuadTable));
     if (rc) return rc;
-    ResidTermsHeader *hdr = reinterpret_cast<ResidTermsHeader *>(ctx->h_args);
-    hdr->n_fac = U;
-    hdr->n_terms = T;
-    hdr->n_groups = G;
-    hdr->pad = 0;
-    ResidTerm *recs = reinterpret_cast<ResidTerm *>(ctx->h_args + tables_off);
-    ResidGroup *groups = reinterpret_cast<ResidGroup *>(recs + T);
-    double *coef = reinterpret_cast<double *>(groups + std::max(G, 1));
+    ResidQuadTable *tab = reinterpret_cast<ResidQuadTable *>(ctx->h_args);
+    std::memset(tab, 0, sizeof(ResidQuadTable));
+    tab->n_groups = G;
+    std::map<std::pair<int, int>, int> slot_of;                  // (input, order) -> slot
     double flops_per_row = 5.0;
     {
-        int g = -1;
-        for (auto &kv : fac_id) {
-            const int k = kv.first.first, o = kv.first.second, u = kv.second;
-            if (g < 0 || groups[g].input != k) {
-                if (g >= 0) flops_per_row += 8.0 * std::max(0, groups[g].omax - 1);   // the double-double power chain
-                ++g;
-                groups[g] = ResidGroup{k, u, 0, 0};
+        int g = 0;
+        for (const auto &kv : orders_of) {
+            tab->input[g] = kv.first;
+            tab->omax[g] = kv.second.back();
+            flops_per_row += 8.0 * std::max(0, kv.second.back() - 1);        // the double-double power chain
+            for (size_t k = 0; k < kv.second.size(); ++k) {
+                const int o = kv.second[k], u = g * KM + (int)k;
+                slot_of[std::make_pair(kv.first, o)] = u;
+                if (!splines)
+                    for (int q = 0; q <= o; ++q) tab->coef[u][q] = ctx->h_phis[(size_t)(o - 1) * ctx->width + q];
+                tab->coef[u][9] = (double)o;
+                flops_per_row += splines ? 14.0 : 2.0 * o;
             }
-            groups[g].count += 1;
-            groups[g].omax = std::max(groups[g].omax, o);
-            double *row = coef + (size_t)u * RT_COEF_STRIDE;
-            for (int q = 0; q <= RT_MAX_ORDER; ++q) row[q] = 0.0;
-            if (!splines)
-                for (int q = 0; q <= o; ++q) row[q] = ctx->h_phis[(size_t)(o - 1) * ctx->width + q];
-            row[9] = (double)o;
-            flops_per_row += splines ? 14.0 : 2.0 * o;
+            ++g;
         }
-        if (g >= 0) flops_per_row += 8.0 * std::max(0, groups[g].omax - 1);
-        if (G == 0) groups[0] = ResidGroup{0, 0, 0, 0};
     }
-    recs[0] = ResidTerm{betahat[0], 0u, 0};
+    tab->c0 = betahat[0];
     for (int j = 0; j < n_terms; ++j) {
-        uint32_t packed = 0;
-        int cnt = 0;
+        int fa = -1, fb = -1;
         for (int k = 0; k < m; ++k) {
             const int o = terms[(size_t)j * m + k];
-            if (o != 0) packed |= (uint32_t)fac_id[std::make_pair(k, o)] << (8 * cnt++);
+            if (o != 0) (fa < 0 ? fa : fb) = slot_of[std::make_pair(k, o)];
         }
-        recs[j + 1] = ResidTerm{betahat[j + 1], packed, cnt};
-        flops_per_row += cnt + 1;
+        if (fb < 0)
+            tab->lin[fa] += betahat[j + 1];
+        else                                                     // (ascending input order: fa < fb, different groups)
+            tab->quad[resid_quad_index(fa, fb, UM, KM)] += betahat[j + 1];
     }
-    rc = push_args(ctx, arg_bytes);
+    flops_per_row += 2.0 * 2.0 * (UM + UM * (UM - 1) / 2 - GM * (KM * (KM - 1) / 2));     // the form's fused multiply-adds
+    rc = push_args(ctx, sizeof(ResidQuadTable));
     if (rc) return rc;
 
     const int64_t n_row_blocks = (ctx->n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
@@ -1728,22 +1715,14 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     if (rc) return rc;
     rc = ensure_rout(ctx);
     if (rc) return rc;
-    resid_terms_fn fn = pick_resid_terms(splines, U);
-    size_t lds_bytes = table_bytes;
-    if (fn == (resid_terms_fn)resid_terms_lds_kernel<true> || fn == (resid_terms_fn)resid_terms_lds_kernel<false>) {
-        lds_bytes += (size_t)U * RS_THREADS * sizeof(double);          // + the factor table [U][lane]
-        if (lds_bytes > 64 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    }
+    resid_quad_fn fn = splines ? layout->splines : top_order <= 2 ? layout->bernoulli2 : layout->bernoulli8;
     {
         {
             TimedRegion timed(ctx, FOKL_K_RESID_MF, 8.0 * (double)ctx->n * (double)(G + 1),
                               (double)ctx->n * flops_per_row);
-            hipLaunchKernelGGL(fn, dim3(S), dim3(RS_THREADS), lds_bytes, ctx->stream, ctx->d_x, ctx->ld, ctx->n,
-                               ctx->d_phis, ctx->width, reinterpret_cast<const ResidTermsHeader *>(ctx->d_args),
-                               reinterpret_cast<const d2 *>(ctx->d_args + tables_off), (int)(table_bytes / sizeof(d2)),
-                               ctx->slot_ptr[FOKL_SLOT_Y], ctx->d_slab);
+            hipLaunchKernelGGL(fn, dim3(S), dim3(RS_THREADS), 0, ctx->stream, ctx->d_x, ctx->ld, ctx->n, ctx->d_phis,
+                               ctx->width, reinterpret_cast<const ResidQuadTable *>(ctx->d_args), ctx->slot_ptr[FOKL_SLOT_Y],
+                               ctx->d_slab);
         }
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1), dim3(RD_THREADS), 0, ctx->stream, ctx->d_slab, S, 1, 2, 1, 2,

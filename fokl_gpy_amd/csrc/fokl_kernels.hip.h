@@ -1615,120 +1615,72 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
 
 
 // ---------------------------------------------------------------------------------------------------------
-// K3, matrix-free: the same residual moments without reading the basis columns back
+// K3, matrix-free: the residual moments as a quadratic form in the model's distinct factors
 // ---------------------------------------------------------------------------------------------------------
 //
 // A residual pass over stored columns reads 8 N (P + 2) bytes; the columns are products of a handful of basis
-// functions of the inputs, and the inputs (8 N M_used bytes, often resident in the 256 MB Infinity Cache) are all it
-// takes to form them again.  Every lane owns the same two consecutive rows as in resid_kernel, evaluates the U distinct
-// (input, order) factors of the model once -- same separately-rounded operations as K1, so the column values are the
-// stored columns' bit for bit -- keeps them in VGPRs (wave-uniform indices -> s_set_gpr_idx, no scratch), and
-// accumulates fit = fma(beta_j, column_j, fit) in column order exactly like resid_kernel: the two kernels return the
-// same bits (tests/test_gpu_parity.py).  The power chain RN(x**j) of an input is shared by all its orders.
+// functions of the inputs, and the inputs (8 N M_used bytes, resident in the 256 MB Infinity Cache at the headline size)
+// are all it takes to form them again.  With f_0 .. f_{U-1} the model's distinct (input, order) factors at a row, a model
+// of one- and two-factor terms is
 //
-// Per-term records and the flattened factor lists sit in LDS (wave-uniform broadcast reads).
-
-// Everything the kernel needs to know about the model sits in LDS in fixed-size records, so that no step of the
-// per-row work waits on a dependent chain of scalar loads:
-struct ResidTerm {           // one model column (16 bytes: one broadcast ds_read_b128)
-    double beta;
-    uint32_t fac;            // up to three factor indices, 8 bits each, in ascending input order
-    int cnt;                 // number of factors (0 = the intercept column of ones)
-};
-
-struct ResidGroup {          // the factors of one input: first .. first + count - 1, orders ascending
-    int input;
-    int first;
-    int count;
-    int omax;                // largest order of the group
-};
+//     fit = c0 + sum_a f_a * ( l_a + sum_{b > a} Q_ab f_b )          l_a = beta of the term {a}, Q_ab = beta of {a, b}
+//
+// -- U (U + 1) / 2 fused multiply-adds per row whatever the number of terms, on operands with COMPILE-TIME register
+// numbers: factor slot = GM inputs x KM orders per input, every loop below is unrolled, the coefficients are wave-uniform
+// scalar loads (s_load, SGPR operands of v_fma_f64: no VGPR, no LDS).  Round 2-4's form of this pass walked the term list
+// and fetched each term's factors from a per-lane table in VGPRs through s_set_gpr_idx -- some thirty instructions per
+// term, 0.23 of its roof; this one is bounded by the input stream.  The factors are evaluated with K1's separately
+// rounded operations (so f_a is the stored column's value bit for bit); the SUM is associated differently from
+// resid_kernel's fit = fma(beta_j, column_j, fit) in column order, so the two passes agree to rounding, not to the bit
+// (tests/test_gpu_parity.py: 1e-13 of the moments' scale).  Models with a three-factor term, or whose factors do not fit
+// a slot layout, take the stored-column pass (fokl_bic_resid_terms_launch says FOKL_ERR_ARG; engine.resid_terms_supported).
 
 constexpr int RT_MAX_ORDER = 8;            // Bernoulli orders the matrix-free pass handles (coefficient row: 9 doubles)
-constexpr int RT_COEF_STRIDE = 10;         // doubles per factor: c[0 .. 8] + the order (as a double), 16-byte aligned rows
+constexpr int RT_COEF_STRIDE = 10;         // doubles per factor: c[0 .. 8] + the order (as a double; 0 = empty slot)
+constexpr int RQ_MAX_SLOTS = 16;
 
-struct ResidTermsHeader {
-    int n_fac;       // U distinct (input, order) factors, sorted by input then order
-    int n_terms;     // model columns, intercept included
-    int n_groups;    // inputs used
-    int pad;
-    // followed, each 16-byte aligned, by ResidTerm[n_terms], ResidGroup[n_groups], double coef[U][RT_COEF_STRIDE]
-    // (splines: coef[v][9] = order only)
+struct ResidQuadTable {
+    int32_t n_groups;                      // inputs used (<= GM of the kernel the host picked)
+    int32_t pad;
+    int32_t input[RQ_MAX_SLOTS];           // group g reads input column input[g]
+    int32_t omax[RQ_MAX_SLOTS];            // largest order among the group's factors
+    double c0;                             // the intercept's coefficient (+ any term without factors)
+    double coef[RQ_MAX_SLOTS][RT_COEF_STRIDE];   // slot g * KM + k: the k-th order of group g (splines: [9] = order only)
+    double lin[RQ_MAX_SLOTS];
+    double quad[RQ_MAX_SLOTS * (RQ_MAX_SLOTS - 1) / 2];   // pairs a < b of different groups, in the kernel's loop order
 };
 
-// The per-lane factor table: banks of 16 doubles, each small enough for hipcc to keep in VGPRs and index with
-// s_set_gpr_idx (one 32- or 48-entry array goes to scratch instead); the bank is picked by a wave-uniform branch.
-// (Each arm carries its own empty volatile asm: arms that differ and cannot be speculated stay branches.  Merged into
-// a select between the banks' addresses -- which is what the optimiser makes of a plain if / else -- the arrays can no
-// longer be promoted to registers and land in scratch memory.)
-// R = rows a lane works on at once.  Every lane owns two consecutive rows, as in resid_kernel; with one bank it takes
-// both together (R = 2: every table read serves two rows), with two or three banks one after the other (R = 1: half
-// the registers, twice the wavefronts per SIMD -- this kernel lives on latency hiding, not on VALU throughput).
-#define FOKL_FAC_GET(u, out)                                                                                \
-    do {                                                                                                    \
-        const int b_ = (u) >> 4;                                                                            \
-        if (NB == 1 || b_ == 0) {                                                                           \
-            out[0] = fx0[(u) & 15];                                                                         \
-            if (R == 2) out[R - 1] = fy0[(u) & 15];                                                         \
-            asm volatile("; bank 0" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
-        } else if (NB == 2 || b_ == 1) {                                                                    \
-            out[0] = fx1[(u) & 15];                                                                         \
-            if (R == 2) out[R - 1] = fy1[(u) & 15];                                                         \
-            asm volatile("; bank 1" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
-        } else {                                                                                            \
-            out[0] = fx2[(u) & 15];                                                                         \
-            if (R == 2) out[R - 1] = fy2[(u) & 15];                                                         \
-            asm volatile("; bank 2" : "+v"(out[0]), "+v"(out[R - 1]));                                      \
-        }                                                                                                   \
-    } while (0)
-#define FOKL_FAC_SET(u, val)                                                                                \
-    do {                                                                                                    \
-        const int b_ = (u) >> 4;                                                                            \
-        if (NB == 1 || b_ == 0) {                                                                           \
-            fx0[(u) & 15] = val[0];                                                                         \
-            if (R == 2) fy0[(u) & 15] = val[R - 1];                                                         \
-            asm volatile("; bank 0");                                                                       \
-        } else if (NB == 2 || b_ == 1) {                                                                    \
-            fx1[(u) & 15] = val[0];                                                                         \
-            if (R == 2) fy1[(u) & 15] = val[R - 1];                                                         \
-            asm volatile("; bank 1");                                                                       \
-        } else {                                                                                            \
-            fx2[(u) & 15] = val[0];                                                                         \
-            if (R == 2) fy2[(u) & 15] = val[R - 1];                                                         \
-            asm volatile("; bank 2");                                                                       \
-        }                                                                                                   \
-    } while (0)
-
-template <int R>
-__device__ __forceinline__ void load_rows(const double *p, double (&out)[R])
+// position of the pair (a, b), a < b, in ResidQuadTable::quad for a layout of KM orders per input (host and device)
+__host__ __device__ constexpr int resid_quad_index(int a, int b, int UM, int KM)
 {
-    if (R == 2) {
-        const d2 v = load_d2(p);
-        out[0] = v.x;
-        out[R - 1] = v.y;
-    } else {
-        out[0] = *(global_d_ptr)(p);
-    }
+    int q = 0;
+    for (int i = 0; i < UM; ++i)
+        for (int j = i + 1; j < UM; ++j) {
+            if (i / KM == j / KM) continue;
+            if (i == a && j == b) return q;
+            ++q;
+        }
+    return -1;
 }
 
-template <bool SPLINES, int NB, int R>
-__global__ __launch_bounds__(RS_THREADS) void resid_terms_kernel(
+typedef __attribute__((address_space(4))) const ResidQuadTable *const_quad_ptr;      // constant address space: scalar loads
+
+// OT: the highest Bernoulli order the instance evaluates (2 or RT_MAX_ORDER).  Everything a row does between its loads and
+// its two sums is straight-line code: a factor of lower order carries zero coefficients beyond its own (val + 0 * x**j
+// leaves val as it is), an empty slot carries only zeros -- so the scalar loads of the coefficients are scheduled ahead in
+// bulk (s_load_dwordx8 / x16) instead of one by one inside wave-uniform branches, each waited for on the spot.
+template <bool SPLINES, int GM, int KM, int OT>
+__global__ __launch_bounds__(RS_THREADS) void resid_quadratic_kernel(
     const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
-    const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
-    const double *__restrict__ y, double *__restrict__ slab)
+    const ResidQuadTable *__restrict__ table, const double *__restrict__ y, double *__restrict__ slab)
 {
+    constexpr int UM = GM * KM;
+    static_assert(UM <= RQ_MAX_SLOTS && OT >= 2 && OT <= RT_MAX_ORDER, "slot layout");
     __builtin_amdgcn_s_setprio(3);
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     __shared__ double red[RS_THREADS / WAVE][2];
-    const int T = hdr->n_terms, G = hdr->n_groups;
+    const const_quad_ptr tab = (const_quad_ptr)(uintptr_t)table;
     const int tid = threadIdx.x;
-    {
-        d2 *dst = reinterpret_cast<d2 *>(lds_raw);
-        for (int i = tid; i < table_d2s; i += RS_THREADS) dst[i] = tables[i];
-    }
-    const ResidTerm *terms = reinterpret_cast<const ResidTerm *>(lds_raw);
-    const ResidGroup *groups = reinterpret_cast<const ResidGroup *>(terms + T);
-    const double *coef = reinterpret_cast<const double *>(groups + G);
-    __syncthreads();
+    const int G = tab->n_groups;
 
     double s1 = 0.0, s2 = 0.0;
     const int64_t n_tiles = (n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
@@ -1736,275 +1688,89 @@ __global__ __launch_bounds__(RS_THREADS) void resid_terms_kernel(
         const int64_t r = (tile * RS_THREADS + tid) * 2;
         const bool in0 = r < n, in1 = r + 1 < n;
         if (!in0) continue;                                     // ld is a multiple of 64 rows: the pair stays in bounds
-        double resid[2] = {0.0, 0.0};
-#pragma unroll 1
-        for (int pass = 0; pass < 2 / R; ++pass) {
-            const int64_t rr = r + pass;                        // first row of this pass
-            double fx0[16], fy0[R == 2 ? 16 : 1], fx1[NB > 1 ? 16 : 1], fy1[NB > 1 && R == 2 ? 16 : 1];
-            double fx2[NB > 2 ? 16 : 1], fy2[NB > 2 && R == 2 ? 16 : 1];
-            double x_next[R];
-            load_rows<R>(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[0].input) * ld + rr, x_next);
-            for (int g = 0; g < G; ++g) {
-                const ResidGroup gr = groups[g];
-                const int first = __builtin_amdgcn_readfirstlane(gr.first);
-                const int count = __builtin_amdgcn_readfirstlane(gr.count);
-                const int omax = __builtin_amdgcn_readfirstlane(gr.omax);
-                double x[R];
+        // every input of the model first (all loads in flight together), y with them; an unused group reads the first
+        // group's column again (a cache hit) and multiplies it by zeros
+        d2 xv[GM];
 #pragma unroll
-                for (int q = 0; q < R; ++q) x[q] = x_next[q];
-                if (g + 1 < G)                                  // the next input is on its way while this one is worked on
-                    load_rows<R>(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[g + 1].input) * ld + rr, x_next);
-                if (SPLINES) {
-                    int piece[R];
-                    double t[R];
+        for (int g = 0; g < GM; ++g) xv[g] = load_d2(xT + (size_t)tab->input[g < G ? g : 0] * ld + r);
+        const d2 yv = load_d2(y + r);
+
+        double f[UM][2];
 #pragma unroll
-                    for (int q = 0; q < R; ++q) spline_locate(x[q], width, false, piece[q], t[q]);
-                    for (int v = first; v < first + count; ++v) {
-                        const int order = __builtin_amdgcn_readfirstlane((int)coef[(size_t)v * RT_COEF_STRIDE + 9]);
-                        const global_d_ptr sl = (global_d_ptr)(phis + (size_t)(order - 1) * 4 * width);
-                        double c[R][4];
+        for (int g = 0; g < GM; ++g) {
+            const double x[2] = {xv[g].x, xv[g].y};
+            if (SPLINES) {
+                int piece[2];
+                double t[2];
 #pragma unroll
-                        for (int q = 0; q < R; ++q)
+                for (int q = 0; q < 2; ++q) spline_locate(x[q], width, false, piece[q], t[q]);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) c[q][e] = sl[e * width + piece[q]];
-                        double val[R];
+                for (int k = 0; k < KM; ++k) {
+                    const int order = (int)tab->coef[g * KM + k][9];          // 0: empty slot (evaluated as order 1, times 0)
+                    const global_cd_ptr sl = (global_cd_ptr)(phis + (size_t)((order > 0 ? order : 1) - 1) * 4 * width);
 #pragma unroll
-                        for (int q = 0; q < R; ++q) val[q] = cubic_basis(c[q][0], c[q][1], c[q][2], c[q][3], t[q]);
-                        FOKL_FAC_SET(v, val);
-                    }
-                } else {
-                    // RN(x**j), j = 1 .. omax, once per input (double-double chain, as bernoulli_basis forms them)
-                    double pw[RT_MAX_ORDER + 1][R];
-                    {
-                        double ph[R], pl[R];
-#pragma unroll
-                        for (int q = 0; q < R; ++q) {
-                            pw[1][q] = ph[q] = x[q];
-                            pl[q] = 0.0;
-                        }
-#pragma unroll
-                        for (int j = 2; j <= RT_MAX_ORDER; ++j) {
-                            if (j <= omax) {
-#pragma unroll
-                                for (int q = 0; q < R; ++q) dd_mul_d(ph[q], pl[q], x[q]);
-                            }
-#pragma unroll
-                            for (int q = 0; q < R; ++q) pw[j][q] = ph[q];
-                        }
-                    }
-                    // c0 + sum_{j>=1} c_j RN(x**j), the sum taken from 0 in ascending j with every product and addition
-                    // rounded (bernoulli_basis); the coefficient row of a factor is five broadcast 16-byte LDS reads
-                    for (int v = first; v < first + count; ++v) {
-                        const d2 *row = reinterpret_cast<const d2 *>(coef + (size_t)v * RT_COEF_STRIDE);
-                        const d2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3], c8o = row[4];
-                        const int order = __builtin_amdgcn_readfirstlane((int)c8o.y);
-                        const double c[RT_MAX_ORDER + 1] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y, c8o.x};
-                        double val[R];
-#pragma unroll
-                        for (int q = 0; q < R; ++q) val[q] = c[1] * pw[1][q];
-#pragma unroll
-                        for (int j = 2; j <= RT_MAX_ORDER; ++j)
-                            if (j <= order) {
-#pragma unroll
-                                for (int q = 0; q < R; ++q) val[q] = val[q] + c[j] * pw[j][q];
-                            }
-#pragma unroll
-                        for (int q = 0; q < R; ++q) val[q] = c[0] + val[q];
-                        FOKL_FAC_SET(v, val);
+                    for (int q = 0; q < 2; ++q) {
+                        const double v = cubic_basis(sl[piece[q]], sl[width + piece[q]], sl[2 * width + piece[q]],
+                                                     sl[3 * width + piece[q]], t[q]);
+                        f[g * KM + k][q] = order > 0 ? v : 0.0;
                     }
                 }
-            }
-
-            double fit[R];
+            } else {
+                // RN(x**j), j = 1 .. OT (double-double chain, as bernoulli_basis forms them)
+                double pw[OT + 1][2];
+                {
+                    double ph[2], pl[2];
 #pragma unroll
-            for (int q = 0; q < R; ++q) fit[q] = 0.0;
-#define FOKL_APPLY_TERM(t)                                                                   \
-    do {                                                                                     \
-        const int cnt_ = __builtin_amdgcn_readfirstlane((t).cnt);                            \
-        const uint32_t fac_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t).fac);        \
-        double p_[R], g_[R];                                                                 \
-        _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = 1.0;                           \
-        if (cnt_ > 0) {                                                                      \
-            const int a_ = fac_ & 255;                                                       \
-            FOKL_FAC_GET(a_, p_);                    /* 1 * first factor */                   \
-            if (cnt_ > 1) {                                                                  \
-                const int b2_ = (fac_ >> 8) & 255;                                           \
-                FOKL_FAC_GET(b2_, g_);                                                       \
-                _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = p_[q] * g_[q];         \
-                if (cnt_ > 2) {                                                              \
-                    const int c2_ = (fac_ >> 16) & 255;                                      \
-                    FOKL_FAC_GET(c2_, g_);                                                   \
-                    _Pragma("unroll") for (int q = 0; q < R; ++q) p_[q] = p_[q] * g_[q];     \
-                }                                                                            \
-            }                                                                                \
-        }                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < R; ++q) fit[q] = __builtin_fma((t).beta, p_[q], fit[q]);  \
-    } while (0)
-            int j = 0;
-            for (; j + 4 <= T; j += 4) {                        // four records in flight per wait
-                const ResidTerm ta = terms[j], tb = terms[j + 1], tc = terms[j + 2], td = terms[j + 3];
-                FOKL_APPLY_TERM(ta);
-                FOKL_APPLY_TERM(tb);
-                FOKL_APPLY_TERM(tc);
-                FOKL_APPLY_TERM(td);
-            }
-            for (; j < T; ++j) {
-                const ResidTerm ta = terms[j];
-                FOKL_APPLY_TERM(ta);
-            }
-#undef FOKL_APPLY_TERM
-            double yv[R];
-            load_rows<R>(y + rr, yv);
+                    for (int q = 0; q < 2; ++q) {
+                        pw[1][q] = ph[q] = x[q];
+                        pl[q] = 0.0;
+                    }
 #pragma unroll
-            for (int q = 0; q < R; ++q) resid[pass * R + q] = yv[q] - fit[q];
+                    for (int j = 2; j <= OT; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            dd_mul_d(ph[q], pl[q], x[q]);
+                            pw[j][q] = ph[q];
+                        }
+                    }
+                }
+                // c0 + sum_{j>=1} c_j RN(x**j), the sum taken from 0 in ascending j with every product and addition
+                // rounded (bernoulli_basis)
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    double val[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) val[q] = tab->coef[g * KM + k][1] * pw[1][q];
+#pragma unroll
+                    for (int j = 2; j <= OT; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) val[q] = val[q] + tab->coef[g * KM + k][j] * pw[j][q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) f[g * KM + k][q] = tab->coef[g * KM + k][0] + val[q];
+                }
+            }
         }
-        const double r0 = resid[0];
-        const double r1 = in1 ? resid[1] : 0.0;
+
+        double fit[2] = {tab->c0, tab->c0};
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < UM; ++a) {
+            double inner[2] = {tab->lin[a], tab->lin[a]};
+#pragma unroll
+            for (int b = a + 1; b < UM; ++b) {
+                if (a / KM == b / KM) continue;                 // two orders of one input never meet in a term
+                const double c = tab->quad[q++];
+                inner[0] = __builtin_fma(c, f[b][0], inner[0]);
+                inner[1] = __builtin_fma(c, f[b][1], inner[1]);
+            }
+            fit[0] = __builtin_fma(f[a][0], inner[0], fit[0]);
+            fit[1] = __builtin_fma(f[a][1], inner[1], fit[1]);
+        }
+        const double r0 = yv.x - fit[0];
+        const double r1 = in1 ? yv.y - fit[1] : 0.0;
         s1 += r0 + r1;
         s2 += r0 * r0 + r1 * r1;
-    }
-    const int wave = tid / WAVE, lane = tid % WAVE;
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (lane == 0) {
-        red[wave][0] = s1;
-        red[wave][1] = s2;
-    }
-    __syncthreads();
-    if (tid < 2) {
-        double s = red[0][tid];
-#pragma unroll
-        for (int w = 1; w < RS_THREADS / WAVE; ++w) s += red[w][tid];
-        slab[(size_t)blockIdx.x * 2 + tid] = s;
-    }
-}
-#undef FOKL_FAC_GET
-#undef FOKL_FAC_SET
-
-// The same pass for models with more than 16 distinct factors: the per-row factor table lives in LDS as
-// [factor][lane] (8 bytes per lane and factor, the lane's own column: conflict-free ds_read_b64 / ds_write_b64, no
-// register indexing, no bank branches).  A lane takes its two rows one after the other so that 48 factors fit
-// (96 KB + the records); rows, accumulation order and the block reduction are those of resid_kernel, so the bits are too.
-template <bool SPLINES>
-__global__ __launch_bounds__(RS_THREADS) void resid_terms_lds_kernel(
-    const double *__restrict__ xT, int64_t ld, int64_t n, const double *__restrict__ phis, int width,
-    const ResidTermsHeader *__restrict__ hdr, const d2 *__restrict__ tables, int table_d2s,
-    const double *__restrict__ y, double *__restrict__ slab)
-{
-    __builtin_amdgcn_s_setprio(3);
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    __shared__ double red[RS_THREADS / WAVE][2];
-    const int U = hdr->n_fac, T = hdr->n_terms, G = hdr->n_groups;
-    const int tid = threadIdx.x;
-    {
-        d2 *dst = reinterpret_cast<d2 *>(lds_raw);
-        for (int i = tid; i < table_d2s; i += RS_THREADS) dst[i] = tables[i];
-    }
-    const ResidTerm *terms = reinterpret_cast<const ResidTerm *>(lds_raw);
-    const ResidGroup *groups = reinterpret_cast<const ResidGroup *>(terms + T);
-    const double *coef = reinterpret_cast<const double *>(groups + G);
-    double *fac = reinterpret_cast<double *>(lds_raw) + 2 * (size_t)table_d2s + tid;     // fac[u * RS_THREADS]: this lane's column
-    (void)U;
-    __syncthreads();
-
-    double s1 = 0.0, s2 = 0.0;
-    const int64_t n_tiles = (n + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r = (tile * RS_THREADS + tid) * 2;
-        const bool in0 = r < n, in1 = r + 1 < n;
-        double resid[2] = {0.0, 0.0};
-        if (in0) {                                              // no barrier below: every lane reads only its own column
-#pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                const int64_t rr = r + pass;                    // ld is a multiple of 64 rows: stays in bounds
-                double x_next = *(global_cd_ptr)(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[0].input) * ld + rr);
-                for (int g = 0; g < G; ++g) {
-                    const ResidGroup gr = groups[g];
-                    const int first = __builtin_amdgcn_readfirstlane(gr.first);
-                    const int count = __builtin_amdgcn_readfirstlane(gr.count);
-                    const int omax = __builtin_amdgcn_readfirstlane(gr.omax);
-                    const double x = x_next;
-                    if (g + 1 < G)
-                        x_next = *(global_cd_ptr)(xT + (size_t)__builtin_amdgcn_readfirstlane(groups[g + 1].input) * ld + rr);
-                    if (SPLINES) {
-                        int piece;
-                        double t;
-                        spline_locate(x, width, false, piece, t);
-                        for (int v = first; v < first + count; ++v) {
-                            const int order = __builtin_amdgcn_readfirstlane((int)coef[(size_t)v * RT_COEF_STRIDE + 9]);
-                            const global_cd_ptr sl = (global_cd_ptr)(phis + (size_t)(order - 1) * 4 * width);
-                            const double c0 = sl[piece], c1 = sl[width + piece], c2 = sl[2 * width + piece],
-                                         c3 = sl[3 * width + piece];
-                            fac[(size_t)v * RS_THREADS] = cubic_basis(c0, c1, c2, c3, t);
-                        }
-                    } else {
-                        double pw[RT_MAX_ORDER + 1];
-                        {
-                            double ph = x, pl = 0.0;
-                            pw[1] = x;
-#pragma unroll
-                            for (int j = 2; j <= RT_MAX_ORDER; ++j) {
-                                if (j <= omax) dd_mul_d(ph, pl, x);
-                                pw[j] = ph;
-                            }
-                        }
-                        for (int v = first; v < first + count; ++v) {
-                            const d2 *row = reinterpret_cast<const d2 *>(coef + (size_t)v * RT_COEF_STRIDE);
-                            const d2 c01 = row[0], c23 = row[1], c45 = row[2], c67 = row[3], c8o = row[4];
-                            const int order = __builtin_amdgcn_readfirstlane((int)c8o.y);
-                            const double c[RT_MAX_ORDER + 1] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y, c67.x, c67.y, c8o.x};
-                            double val = c[1] * pw[1];
-#pragma unroll
-                            for (int j = 2; j <= RT_MAX_ORDER; ++j)
-                                if (j <= order) val = val + c[j] * pw[j];
-                            fac[(size_t)v * RS_THREADS] = c[0] + val;
-                        }
-                    }
-                }
-
-                double fit = 0.0;
-                // four records, then their (up to twelve) factor reads, in flight per wait; absent factors read factor 0
-                // and multiply by one instead (a select, no branch)
-#define FOKL_LOAD_TERM(t, fa, fb, fc)                                                        \
-    const uint32_t w_##t = (t).fac;                                                          \
-    const double fa = fac[(size_t)(w_##t & 255u) * RS_THREADS];                              \
-    const double fb = fac[(size_t)((w_##t >> 8) & 255u) * RS_THREADS];                       \
-    const double fc = fac[(size_t)((w_##t >> 16) & 255u) * RS_THREADS];
-#define FOKL_USE_TERM(t, fa, fb, fc)                                                         \
-    {                                                                                        \
-        double p_ = (t).cnt > 0 ? fa : 1.0;                                                  \
-        if ((t).cnt > 1) p_ = p_ * fb;                                                       \
-        if ((t).cnt > 2) p_ = p_ * fc;                                                       \
-        fit = __builtin_fma((t).beta, p_, fit);                                              \
-    }
-                int j = 0;
-                for (; j + 4 <= T; j += 4) {
-                    const ResidTerm ta = terms[j], tb = terms[j + 1], tc = terms[j + 2], td = terms[j + 3];
-                    FOKL_LOAD_TERM(ta, a0, a1, a2)
-                    FOKL_LOAD_TERM(tb, b0, b1, b2)
-                    FOKL_LOAD_TERM(tc, c0, c1, c2)
-                    FOKL_LOAD_TERM(td, d0, d1, d2)
-                    FOKL_USE_TERM(ta, a0, a1, a2)
-                    FOKL_USE_TERM(tb, b0, b1, b2)
-                    FOKL_USE_TERM(tc, c0, c1, c2)
-                    FOKL_USE_TERM(td, d0, d1, d2)
-                }
-                for (; j < T; ++j) {
-                    const ResidTerm ta = terms[j];
-                    FOKL_LOAD_TERM(ta, a0, a1, a2)
-                    FOKL_USE_TERM(ta, a0, a1, a2)
-                }
-#undef FOKL_LOAD_TERM
-#undef FOKL_USE_TERM
-                resid[pass] = *(global_cd_ptr)(y + rr) - fit;
-            }
-        }
-        if (in0) {
-            const double r0 = resid[0];
-            const double r1 = in1 ? resid[1] : 0.0;
-            s1 += r0 + r1;
-            s2 += r0 * r0 + r1 * r1;
-        }
     }
     const int wave = tid / WAVE, lane = tid % WAVE;
     s1 = wave_sum(s1);

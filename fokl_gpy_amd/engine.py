@@ -182,21 +182,28 @@ class HipBackend:
 
     def resid_terms_supported(self, terms):
         """Can a model made of (a subset of) these terms take the matrix-free residual pass?  (The limits of
-        fokl_bic_resid_terms_launch, include/fokl_hip.h.)"""
+        fokl_bic_resid_terms_launch, include/fokl_hip.h: one or two inputs per term, the distinct (input, order) factors
+        within one of the kernel's slot layouts.)  Measured on MI355X (tools/k3_probe.py, profiles/k3_ab_r05.txt)."""
         nz = terms != 0
-        if not nz.any() or int(nz.sum(axis=1).max()) > 3:
+        if not nz.any() or int(nz.sum(axis=1).max()) > 2:
             return False
         if getattr(self, 'kernel_id', 1) != 0 and int(terms.max()) > _capi.RESID_TERMS_MAX_ORDER:
             return False
-        k = np.nonzero(terms)[1]
-        n_factors = np.unique(k.astype(np.int64) * 65536 + terms[nz]).shape[0]
-        table = 16 * (terms.shape[0] + 1) + 16 * terms.shape[1] + 80 * n_factors
-        # Measured on MI355X (tools/k3_probe.py, N = 1e6): with at most 16 distinct factors -- one register bank, two rows
-        # per lane -- the matrix-free pass beats the stored-column pass by 1.2 x (37 columns) to 2.5 x (101 columns);
-        # with two banks it breaks even, with three it loses (481 vs 296 us at 201 columns): bank selection and the
-        # one-row-at-a-time passes cost more than the column reads they save.  FOKL_K3_MAX_FACTORS overrides.
-        limit = min(int(os.environ.get('FOKL_K3_MAX_FACTORS', '16')), _capi.RESID_TERMS_MAX_FACTORS)
-        return n_factors <= limit and table <= 60 * 1024
+        orders = [np.unique(col[col != 0]).shape[0] for col in terms.T]
+        inputs, deepest = sum(1 for c in orders if c), max(orders)
+        return any(inputs <= gm and deepest <= km for gm, km in _capi.RESID_TERMS_LAYOUTS)
+
+    def resid_terms_pay_from(self, terms):
+        """Model columns from which the matrix-free pass is the faster one (its time depends on the factor slots of its
+        layout, the stored pass's on the columns it reads: profiles/k3_quadratic_r05.txt -- Bernoulli factors: always;
+        spline factors, four table gathers each: 38 us at 8 slots / 72 us at 16 against 1.4 us per stored column at
+        N = 1e6)."""
+        if getattr(self, 'kernel_id', 1) != 0:
+            return 0
+        orders = [np.unique(col[col != 0]).shape[0] for col in terms.T]
+        inputs, deepest = sum(1 for c in orders if c), max(orders)
+        slots = min(gm * km for gm, km in _capi.RESID_TERMS_LAYOUTS if inputs <= gm and deepest <= km)
+        return int(3.5 * slots)
 
     def predict(self, slots, betas, cut=None):
         return self.ctx.predict(slots, betas, cut)
@@ -315,6 +322,7 @@ class ForwardSelection:
         self._matrix_free = (hasattr(backend, 'bic_resid_terms_launch') and
                              os.environ.get('FOKL_K3', 'matrixfree') != 'columns')
         self._terms_arr = None              # [A, m] int32 terms of the active columns (row 0 = intercept) or None
+        self._terms_pay_from = 0            # ... and the model size from which the matrix-free pass is the faster one
         # spectral jobs submitted ahead of the kill tests: three along the guessed path (the Python loop: every miss costs
         # the jobs); the native loop predicts its path (csrc/fokl_search.cpp PathModel) and goes twelve deep
         self.lookahead = int(os.environ.get('FOKL_LOOKAHEAD', '3'))
@@ -445,7 +453,7 @@ class ForwardSelection:
         return spec, idx, cand_slots, gram[ycol, ycol], slots
 
     def _launch_resid(self, cand_slots, idx, betahat):
-        if self._terms_arr is not None:
+        if self._terms_arr is not None and len(idx) >= self._terms_pay_from:
             self.backend.bic_resid_terms_launch(self._terms_arr[idx[1:]], betahat)
             self.stats['resid_matrix_free'] += 1
         else:
@@ -469,6 +477,7 @@ class ForwardSelection:
             arr = np.ascontiguousarray(damtx, dtype=np.int32)
             if self.backend.resid_terms_supported(arr):
                 self._terms_arr = np.vstack([np.zeros((1, arr.shape[1]), dtype=np.int32), arr])
+                self._terms_pay_from = getattr(self.backend, 'resid_terms_pay_from', lambda a: 0)(arr)
 
     def _request_noise(self, p1, tentative=False, model=True):
         """model: the tape is meant for a sub-stage's model (host chain: finished by host threads while it is recorded);
@@ -1059,6 +1068,7 @@ class ForwardSelection:
                 import warnings
                 warnings.warn(f"host thread pipeline unavailable ({exc}); running the search in line", RuntimeWarning)
                 self.host = None
+        self.stats['t_pool_create'] = time.perf_counter() - t_begin_run
         if self.host is not None and self._native_wanted():
             try:
                 half0 = int(math.ceil(self.draws / 2))
@@ -1165,6 +1175,7 @@ class ForwardSelection:
                 self._outcomes, self._retiring = [], []
                 self.native.close()         # sends back what is on order, waits for what is in flight
                 self.native = None
+                self.stats['t_teardown_search'] = time.perf_counter() - t_down
             if self.host is not None:
                 # every device chain of this search gives its slot back (the engine outlives the fit); idempotent, and
                 # a chain that has not run yet is waited for -- its tape is committed, so it will
@@ -1176,7 +1187,9 @@ class ForwardSelection:
                 if self.chain_engine is not None:
                     now = self.chain_engine.stats()               # the engine outlives the fit: this fit's share
                     self.stats.update({'dchain_' + k: v - self._dchain_stats0.get(k, 0) for k, v in now.items()})
+                t_close = time.perf_counter()
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
+                self.stats['t_teardown_pool'] = time.perf_counter() - t_close
                 self.stats.update(pool_bulk_s=busy.get('bulk', 0.0), walker_wait_s=busy.get('walker_wait', 0.0),
                                   stream_segments=busy.get('stream_segments', 0),
                                   gamma_attempts_exact=busy.get('gamma_attempts_exact', 0),

@@ -199,14 +199,16 @@ int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce);
 /*
  * Matrix-free form of fokl_bic_resid_launch: the model is given by its terms (rows of the interaction matrix,
  * [n_terms, M] int32 as for fokl_build_terms; betahat[0] belongs to the intercept, betahat[1 + j] to terms[j]) and the
- * kernel forms X betahat (FR:1551: `np.matmul(X, betahat)`) from the resident inputs, recomputing every basis column
- * with the operations of fokl_build_terms instead of reading it back: 8 N (M_used + 1) bytes of HBM traffic instead
- * of 8 N (P + 2), and no column needs to exist.  Same moments, bit for bit, as the stored-column pass over columns
- * built by fokl_build_terms.  Limits: at most FOKL_RESID_TERMS_MAX_FACTORS distinct (input, order) pairs in the model,
- * at most three inputs per term, Bernoulli orders up to FOKL_RESID_TERMS_MAX_ORDER (FOKL_ERR_ARG beyond; callers
- * fall back to the stored-column pass).  Fetch with fokl_bic_resid_fetch.
+ * kernel forms X betahat (FR:1551: `np.matmul(X, betahat)`) from the resident inputs: 8 N (M_used + 1) bytes of HBM
+ * traffic instead of 8 N (P + 2), and no column needs to exist.  The model's distinct (input, order) factors are
+ * evaluated once per row with the operations of fokl_build_terms, and the fit is their quadratic form
+ * c0 + sum_a f_a (l_a + sum_{b > a} Q_ab f_b) -- the same moments as the stored-column pass up to the association of
+ * the sum (agreement ~1e-15 of the moments' scale, not bit for bit).  Limits: one or two inputs per term; the factors
+ * must fit one of the slot layouts (inputs x orders per input) 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8
+ * (FOKL_RESID_TERMS_MAX_FACTORS slots); Bernoulli orders up to FOKL_RESID_TERMS_MAX_ORDER.  FOKL_ERR_ARG beyond:
+ * callers take the stored-column pass.  Fetch with fokl_bic_resid_fetch.
  */
-#define FOKL_RESID_TERMS_MAX_FACTORS 48
+#define FOKL_RESID_TERMS_MAX_FACTORS 16
 #define FOKL_RESID_TERMS_MAX_ORDER 8
 int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat);
 

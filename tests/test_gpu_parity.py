@@ -292,45 +292,55 @@ def test_k3_residual_moments(device_ctx):
 
 
 @pytest.mark.parametrize('kid', [O.KERNEL_BERNOULLI, O.KERNEL_SPLINES])
-def test_k3_matrix_free_returns_the_bits_of_the_stored_column_pass(device_ctx, kid):
-    """fokl_bic_resid_terms_launch re-forms every basis column from the inputs with the operations of
-    fokl_build_terms and accumulates in the column order of resid_kernel: the two residual passes must agree bit for
-    bit -- for models whose factor table takes one, two and three register banks (<= 16 / 32 / 48 distinct
-    (input, order) pairs), ragged row counts, 1-, 2- and 3-way terms, and against the oracle's columns to rounding."""
+def test_k3_matrix_free_agrees_with_the_stored_column_pass(device_ctx, kid):
+    """fokl_bic_resid_terms_launch re-forms the model's distinct factors from the inputs with the operations of
+    fokl_build_terms and evaluates the fit as their quadratic form: the same moments as the stored-column pass up to
+    the association of the sum (1e-13 of the moments' scale; the oracle's columns to 1e-11) -- for every slot layout
+    (inputs x orders per input: 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8), ragged row counts, one- and two-way terms,
+    duplicated terms, subsets of a sub-stage's terms; models outside the layouts are refused, not overrun."""
     rng = np.random.default_rng(14)
-    m = 8
-    for n, orders, n_terms in ((1, 2, 5), (777, 2, 12), (20001, 4, 60), (65536 + 3, 6, 140), (5000, 3, 300),
-                               (3001, 8, 25)):
+    # (rows, inputs in the dataset, inputs used, orders per input used, highest order, terms)
+    for n, m, used, per_input, top, n_terms in ((1, 8, 3, 1, 2, 5), (777, 8, 8, 1, 1, 36), (20001, 8, 8, 2, 4, 60),
+                                                (65536 + 3, 16, 16, 1, 3, 120), (5000, 8, 4, 4, 6, 80),
+                                                (3001, 8, 2, 8, 8, 25), (4099, 8, 8, 2, 2, 128)):
         x = rng.random((n, m))
         y = rng.standard_normal(n)
         phis = upload(device_ctx, x, y, kid)
+        inputs = rng.choice(m, size=used, replace=False)
+        orders = {int(k): rng.choice(np.arange(1, top + 1), size=min(per_input, top), replace=False) for k in inputs}
         terms = np.zeros((n_terms, m), dtype=np.int32)
         for j in range(n_terms):
-            ways = int(rng.integers(1, 4))
-            for k in rng.choice(m, size=ways, replace=False):
-                terms[j, k] = int(rng.integers(1, orders + 1))
-        n_factors = len({(k, int(o)) for row in terms for k, o in enumerate(row) if o})
-        assert n_factors <= _capi.RESID_TERMS_MAX_FACTORS
+            ways = int(rng.integers(1, 3)) if used > 1 else 1
+            for k in rng.choice(inputs, size=ways, replace=False):
+                terms[j, k] = int(rng.choice(orders[int(k)]))
         device_ctx.reserve_slots(2 + n_terms)
         slots = np.arange(2, 2 + n_terms, dtype=np.int32)
         device_ctx.build_terms(terms, slots)
         beta = rng.standard_normal(n_terms + 1)
-        want = device_ctx.bic_resid(np.concatenate([[0], slots]).astype(np.int32), beta)
-        device_ctx.bic_resid_terms_launch(terms, beta)
-        got = device_ctx.bic_resid_fetch()
-        assert got == want, (n, n_factors, got, want)
         cols = oracle_columns(x, kid, phis, terms)
-        r = y - (beta[0] + cols @ beta[1:])
-        assert abs(got[0] - r.sum()) <= 1e-11 * np.abs(r).sum() + 1e-300 and abs(got[1] - r @ r) <= 1e-11 * (r @ r)
+        for keep in (np.arange(n_terms), np.sort(rng.choice(n_terms, size=max(1, n_terms // 3), replace=False))):
+            b = np.concatenate([beta[:1], beta[1 + keep]])
+            want = device_ctx.bic_resid(np.concatenate([[0], slots[keep]]).astype(np.int32), b)
+            device_ctx.bic_resid_terms_launch(terms[keep], b)
+            got = device_ctx.bic_resid_fetch()
+            r = y - (b[0] + cols[:, keep] @ b[1:])
+            scale1, scale2 = np.abs(r).sum() + 1e-300, r @ r
+            assert abs(got[0] - want[0]) <= 1e-13 * scale1 and abs(got[1] - want[1]) <= 1e-13 * scale2, (n, got, want)
+            assert abs(got[0] - r.sum()) <= 1e-11 * scale1 and abs(got[1] - r @ r) <= 1e-11 * scale2
+            device_ctx.bic_resid_terms_launch(terms[keep], b)            # the same launch again: the same bits
+            assert device_ctx.bic_resid_fetch() == got
     # intercept-only model, and the limits are reported, not overrun
     device_ctx.bic_resid_terms_launch(np.zeros((0, m), dtype=np.int32), [0.25])
     s1, s2 = device_ctx.bic_resid_fetch()
     assert abs(s1 - (y - 0.25).sum()) <= 1e-12 * np.abs(y - 0.25).sum()
-    too_many = np.zeros((56, m), dtype=np.int32)
-    for j in range(56):
-        too_many[j, j % m] = 1 + j // m
-    with pytest.raises(_capi.FoklNativeError):
-        device_ctx.bic_resid_terms_launch(too_many, np.zeros(57))
+    three_way = np.zeros((1, m), dtype=np.int32)
+    three_way[0, :3] = 1
+    too_deep = np.zeros((24, m), dtype=np.int32)                          # 8 inputs x 3 orders: no layout
+    for j in range(24):
+        too_deep[j, j % 8] = 1 + j // 8
+    for bad in (three_way, too_deep):
+        with pytest.raises(_capi.FoklNativeError):
+            device_ctx.bic_resid_terms_launch(bad, np.zeros(bad.shape[0] + 1))
 
 
 def test_predict_mean_and_order_statistics(device_ctx):

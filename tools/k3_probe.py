@@ -1,5 +1,5 @@
 """K3 A/B on the device: stored-column residual pass vs the matrix-free pass (fokl_bic_resid_terms_launch) on
-configs[2]-shaped models (N rows, M = 8, Bernoulli, 2-way): time per launch from HIP events, bitwise comparison."""
+configs[2]-shaped models (N rows, M = 8, Bernoulli, 2-way): time per launch from HIP events, difference of the moments."""
 import os, sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, ROOT)
@@ -34,14 +34,23 @@ for label, pats in shapes.items():
     beta = rng.standard_normal(T + 1)
     sl = np.concatenate([[0], slots]).astype(np.int32)
     want = ctx.bic_resid(sl, beta)
-    ctx.bic_resid_terms_launch(terms, beta)
-    got = ctx.bic_resid_fetch()
+    try:
+        ctx.bic_resid_terms_launch(terms, beta)
+        got = ctx.bic_resid_fetch()
+    except _capi.FoklNativeError:
+        got = None                                            # outside the matrix-free pass's factor layouts
     ctx.sync(); ctx.timing_reset()
     for _ in range(20):
         ctx.bic_resid(sl, beta)
-    for _ in range(20):
+    for _ in range(20 if got is not None else 0):
         ctx.bic_resid_terms_launch(terms, beta); ctx.bic_resid_fetch()
     a, b = ctx.timing_get(_capi.K_RESID), ctx.timing_get(_capi.K_RESID_MF)
-    print(f"{label:32s} columns {1e3 * a['ms'] / a['launches']:8.1f} us ({a['bytes'] / a['ms'] / 1e6:7.0f} GB/s)   "
-          f"matrix-free {1e3 * b['ms'] / b['launches']:8.1f} us ({b['bytes'] / b['ms'] / 1e6:7.0f} GB/s, "
-          f"{b['flops'] / b['ms'] / 1e9:6.2f} TFLOP/s)   same bits: {got == want}", flush=True)
+    line = f"{label:32s} columns {1e3 * a['ms'] / a['launches']:8.1f} us ({a['bytes'] / a['ms'] / 1e6:7.0f} GB/s)   "
+    if got is None:
+        line += "matrix-free: not offered (stored columns only)"
+    else:
+        line += (f"matrix-free {1e3 * b['ms'] / b['launches']:8.1f} us ({b['bytes'] / b['ms'] / 1e6:7.0f} GB/s of its own "
+                 f"8 N (M_used + 1) bytes, {a['bytes'] / a['launches'] / (b['ms'] / b['launches']) / 1e6:7.0f} GB/s of the stored "
+                 f"pass's 8 N (P + 2); {b['flops'] / b['ms'] / 1e9:6.2f} TFLOP/s)   relative difference of the moments: "
+                 f"{abs(got[0] - want[0]) / max(abs(want[0]), 1e-300):.1e} {abs(got[1] - want[1]) / want[1]:.1e}")
+    print(line, flush=True)
