@@ -44,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SIDE_FITS = int(os.environ.get('FOKL_BENCH_SIDE_FITS', '12'))   # fits per process in the throughput side measurement
+THROUGHPUT_SPECULATION = '24'    # FOKL_SPECULATION of the processes that share a GPU (throughput mode; a fit alone: 48)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense fp64 matrix peak
 
@@ -545,6 +546,10 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
     # what it burns is CPU of the shared quota (measured: 0.37 -> 0.31 CPU-seconds per fit with six processes)
     os.environ.setdefault('FOKL_SYNC', 'blocking')
     os.environ.setdefault('FOKL_SPIN', '0.05')            # ... and poll for tens of pauses, not thousands, before they sleep
+    # tapes walked ahead of the decisions: 24 deep instead of 48 -- a fit alone takes the same time within the spread of the
+    # boxes, 50 instead of 160 tapes per fit are walked for nothing, and that CPU is what the quota is short of
+    # (tools/r05_spec.sh: 4 processes 854-913 k terms/s at 48, 952-981 k at 24, 961-965 k at 12, 709-944 k at 6)
+    os.environ.setdefault('FOKL_SPECULATION', THROUGHPUT_SPECULATION)
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
                       ('FOKL_SPECTRAL_THREADS', '3' if device_chains or procs <= 2 else '2')):
         os.environ.setdefault(name, val)
@@ -1100,10 +1105,16 @@ def main():
             cg0 = cgroup_cpu()
             t_side = time.perf_counter()
             own_terms = 0
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                for _ in range(SIDE_FITS):                  # this process fits along: one more fitting process on the GPU
-                    own_terms += sum(st['terms_logical'] for st in one_step())
+            own_speculation = os.environ.get('FOKL_SPECULATION')
+            os.environ.setdefault('FOKL_SPECULATION', THROUGHPUT_SPECULATION)     # (as the workers: read per search)
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    for _ in range(SIDE_FITS):              # this process fits along: one more fitting process on the GPU
+                        own_terms += sum(st['terms_logical'] for st in one_step())
+            finally:
+                if own_speculation is None:
+                    os.environ.pop('FOKL_SPECULATION', None)
             side_res = [done_q.get(timeout=300) for _ in side_workers]
             t_side = time.perf_counter() - t_side
             cg1 = cgroup_cpu()
@@ -1115,6 +1126,7 @@ def main():
                 procs=side_procs + 1, value=side_terms / t_side, unit='candidate-terms/s', fits_per_s=side_fits / t_side,
                 seconds=t_side, ms_per_fit_per_process=1e3 * t_side / SIDE_FITS,
                 chain_mode=os.environ.get('FOKL_CHAIN', 'auto'),
+                order_book_depth=int(own_speculation or THROUGHPUT_SPECULATION),   # FOKL_SPECULATION of every process
                 worker_s_per_fit={key: sum(r['stats'].get(key, 0.0) for r in side_res) / max(1, side_procs * SIDE_FITS)
                                   for key in ('t_eigh', 't_chain', 'pool_noise_s', 'pool_spectral_s', 'noise_verdict_wait_s',
                                               'noise_queue_wait_s', 'seconds', 'cpu_s')},
