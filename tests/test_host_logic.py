@@ -755,3 +755,28 @@ def test_lookahead_knobs_are_bounded_to_what_was_verified():
         _warnings.simplefilter('always')
         assert [_engine._bounded_lookahead('FOKL_LOOKAHEAD', v) for v in ('0', '12', '24', '-5')] == [0, 12, 24, 0]
     assert not seen
+
+
+def test_matrix_free_residual_pass_is_offered_only_inside_its_slot_layouts():
+    """engine.HipBackend.resid_terms_supported mirrors fokl_bic_resid_terms_launch's limits (include/fokl_hip.h): one or
+    two inputs per term, the distinct (input, order) factors inside one of the layouts inputs x orders-per-input
+    8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8; spline factors pay only from 3.5 model columns per slot on."""
+    import types
+    from fokl_gpy_amd import engine
+    bern, spl = types.SimpleNamespace(kernel_id=1), types.SimpleNamespace(kernel_id=0)
+    ok = lambda be, t: engine.HipBackend.resid_terms_supported(be, np.asarray(t, dtype=np.int32))
+    pay = lambda be, t: engine.HipBackend.resid_terms_pay_from(be, np.asarray(t, dtype=np.int32))
+    mains = np.eye(8, dtype=np.int32)
+    pairs = engine.distinct_arrangements([1, 1] + [0] * 6)
+    assert ok(bern, mains) and ok(bern, np.vstack([mains, pairs]))                      # 8 x 1
+    second = np.vstack([mains, 2 * mains, engine.distinct_arrangements([2, 1] + [0] * 6)])
+    assert ok(bern, second)                                                              # 8 x 2
+    assert not ok(bern, np.vstack([second, 3 * mains]))                                  # 8 inputs x 3 orders: no layout
+    assert ok(bern, np.vstack([k * np.eye(4, 8, dtype=np.int32) for k in (1, 2, 3, 4)]))  # 4 x 4
+    assert ok(bern, np.eye(16, dtype=np.int32)) and not ok(bern, np.eye(17, dtype=np.int32))
+    three_way = np.zeros((1, 8), dtype=np.int32)
+    three_way[0, :3] = 1
+    assert not ok(bern, three_way) and not ok(bern, np.zeros((1, 8)))
+    assert not ok(bern, 9 * mains[:1]) and ok(spl, 9 * mains[:1])                        # Bernoulli orders stop at 8
+    assert pay(bern, second) == 0
+    assert pay(spl, mains) == 28 and pay(spl, second) == 56 and pay(spl, np.eye(16, dtype=np.int32)) == 56

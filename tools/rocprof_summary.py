@@ -24,7 +24,7 @@ def short(name):
     name = name.replace('void ', '')
     for key in ('basis_build_reg_kernel', 'basis_build_kernel', 'gram_tiles_dma_kernel', 'gram_tiles4s_kernel', 'gram_tiles_kernel',
                 'gram_mfma_kernel', 'gram_valu_kernel',
-                'resid_terms_lds_kernel', 'resid_terms_kernel', 'resid_kernel', 'reduce_slabs_sym_kernel', 'reduce_slabs_kernel',
+                'resid_quadratic_kernel', 'resid_terms_lds_kernel', 'resid_terms_kernel', 'resid_kernel', 'reduce_slabs_sym_kernel', 'reduce_slabs_kernel',
                 'transpose_inputs_kernel', 'predict_mfma_kernel', 'predict_kernel', 'gibbs_chain_kernel', 'tape_gather_kernel'):
         if key in name:
             tag = ''
@@ -82,7 +82,7 @@ def family(name):
     for key, fam in (('basis_build_reg_kernel', 'basis_build'), ('basis_build_kernel', 'basis_build'),
                      ('gram_tiles_dma_kernel', 'gram'), ('gram_tiles4s_kernel', 'gram'), ('gram_tiles_kernel', 'gram'),
                      ('gram_mfma_kernel', 'gram'), ('gram_valu_kernel', 'gram'),
-                     ('resid_terms_lds_kernel', 'resid_matrix_free'), ('resid_terms_kernel', 'resid_matrix_free'),
+                     ('resid_quadratic_kernel', 'resid_matrix_free'), ('resid_terms_lds_kernel', 'resid_matrix_free'), ('resid_terms_kernel', 'resid_matrix_free'),
                      ('resid_kernel', 'resid'), ('gibbs_chain_kernel', 'gibbs_chain'), ('tape_gather_kernel', 'tape_gather')):
         if key in name:
             return fam
