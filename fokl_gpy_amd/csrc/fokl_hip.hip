@@ -1843,4 +1843,10 @@ extern "C" int fokl_debug_stamps_read(unsigned long long *out, int count)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fokl::fokl_debug_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
 }
+
+extern "C" int fokl_debug_stamps_clear()
+{
+    static const unsigned long long zeros[8192] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fokl::fokl_debug_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+}
 #endif

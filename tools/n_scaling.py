@@ -10,6 +10,28 @@ from fokl_gpy_amd import FoKLRoutines, _capi
 
 rows = [int(float(a)) for a in sys.argv[1:]] or [100_000, 1_000_000, 10_000_000]
 REPS = int(os.environ.get('N_SCALING_REPS', '5'))
+TRACE = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'fokl_gram_trace_{os.getpid()}.txt')
+os.environ['FOKL_GRAM_TRACE'] = TRACE      # one line per Gram launch: rows x columns and the roof it was booked under
+
+
+def flops_run_over_algorithmic(trace_lines):
+    """The matrix-core flops the MFMA-bound Gram launches of a fit really issue (16 x 16 tiles of the plan, half tiles on a
+    ragged last row tile, the symmetric part's lower tiles skipped) over the algorithmic 2 N nr nc they are booked with."""
+    run = alg = 0.0
+    for line in trace_lines:
+        nr, nc, _, klass = line.split()
+        nr, nc = int(nr), int(nc)
+        if klass != 'gram_mfma':
+            continue
+        rs = np.arange(2, 2 + nr, dtype=np.int32)                                 # the fit's shape: new columns against
+        cs = np.concatenate([[0], np.arange(1000, 1000 + nc - nr - 2), rs, [1]])   # [ones | model | new | y]
+        plan = _capi.gram_plan(rs, cs.astype(np.int32))
+        real = plan['tiles'][..., 2] >= 0
+        run += 512.0 * (np.count_nonzero(real & ~plan['half']) + 0.5 * np.count_nonzero(real & plan['half']))
+        alg += 2.0 * nr * nc
+    return run / alg if alg else float('nan')
+
+
 for n in rows:
     x, y = bench.make_workload(12, n, 8)
     with warnings.catch_warnings():
@@ -21,6 +43,7 @@ for n in rows:
             np.random.seed(1000); model._search(be, nn, m)
         ctx = be.ctx
         ctx.timing_enable(True); ctx.timing_reset()
+        open(TRACE, 'w').close()
         ts = []
         for rep in range(REPS):
             np.random.seed(1000)
@@ -34,5 +57,11 @@ for n in rows:
     print(f"N={n:>11,d}: {min(ts):.3f} s/fit (median {sorted(ts)[len(ts) // 2]:.3f}), device kernels {dev_ms:.1f} ms/fit, "
           f"{st['terms_logical'] / min(ts):,.0f} candidate terms/s, evaluations {st['gibbs_calls']}, BIC from Gram "
           f"{st['bic_from_gram']}, matrix-free K3 {st['resid_matrix_free']}; roofline fractions "
-          + ' '.join(f"{k} {v:.2f}" for k, v in frac.items()), flush=True)
+          + ' '.join(f"{k} {v:.2f}" for k, v in frac.items())
+          + f"; MFMA flops issued / algorithmic on the MFMA-bound Gram launches {flops_run_over_algorithmic(open(TRACE).read().splitlines()):.3f}",
+          flush=True)
     ctx.upload(np.zeros((1, 1)), np.zeros(1), 1, np.zeros(2), 1, 2)          # let go of the big dataset
+try:
+    os.remove(TRACE)
+except OSError:
+    pass
