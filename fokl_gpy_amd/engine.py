@@ -189,9 +189,17 @@ class HipBackend:
             return False
         if getattr(self, 'kernel_id', 1) != 0 and int(terms.max()) > _capi.RESID_TERMS_MAX_ORDER:
             return False
-        orders = [np.unique(col[col != 0]).shape[0] for col in terms.T]
-        inputs, deepest = sum(1 for c in orders if c), max(orders)
+        inputs, deepest = self._factor_shape(terms)
         return any(inputs <= gm and deepest <= km for gm, km in _capi.RESID_TERMS_LAYOUTS)
+
+    @staticmethod
+    def _factor_shape(terms):
+        """(inputs used, most distinct orders on one input) of a set of terms."""
+        rows, cols = np.nonzero(terms)
+        present = np.zeros((terms.shape[1], int(terms.max()) + 1), dtype=bool)
+        present[cols, terms[rows, cols]] = True
+        per_input = present.sum(axis=1)
+        return int(np.count_nonzero(per_input)), int(per_input.max())
 
     def resid_terms_pay_from(self, terms):
         """Model columns from which the matrix-free pass is the faster one (its time depends on the factor slots of its
@@ -200,8 +208,7 @@ class HipBackend:
         N = 1e6)."""
         if getattr(self, 'kernel_id', 1) != 0:
             return 0
-        orders = [np.unique(col[col != 0]).shape[0] for col in terms.T]
-        inputs, deepest = sum(1 for c in orders if c), max(orders)
+        inputs, deepest = self._factor_shape(terms)
         slots = min(gm * km for gm, km in _capi.RESID_TERMS_LAYOUTS if inputs <= gm and deepest <= km)
         return int(3.5 * slots)
 

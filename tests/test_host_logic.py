@@ -763,7 +763,8 @@ def test_matrix_free_residual_pass_is_offered_only_inside_its_slot_layouts():
     8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8; spline factors pay only from 3.5 model columns per slot on."""
     import types
     from fokl_gpy_amd import engine
-    bern, spl = types.SimpleNamespace(kernel_id=1), types.SimpleNamespace(kernel_id=0)
+    shape = staticmethod(engine.HipBackend._factor_shape)
+    bern, spl = types.SimpleNamespace(kernel_id=1, _factor_shape=shape), types.SimpleNamespace(kernel_id=0, _factor_shape=shape)
     ok = lambda be, t: engine.HipBackend.resid_terms_supported(be, np.asarray(t, dtype=np.int32))
     pay = lambda be, t: engine.HipBackend.resid_terms_pay_from(be, np.asarray(t, dtype=np.int32))
     mains = np.eye(8, dtype=np.int32)
