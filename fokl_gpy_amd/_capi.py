@@ -15,9 +15,9 @@ LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.s
 
 UNIQUE_ID_BYTES = 128
 K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA, K_GRAM_REDUCE, K_TOUCH = 0, 1, 2, 3, 4, 5, 6, 7
-RESID_TERMS_MAX_FACTORS = 16
+RESID_TERMS_MAX_FACTORS = 32
 RESID_TERMS_MAX_ORDER = 8
-RESID_TERMS_LAYOUTS = ((8, 1), (16, 1), (8, 2), (4, 4), (2, 8))    # inputs x orders per input (csrc/fokl_hip.hip)
+RESID_TERMS_LAYOUTS = ((8, 1), (16, 1), (8, 2), (4, 4), (2, 8), (8, 4), (16, 2), (4, 8))    # inputs x orders per input (csrc/fokl_hip.hip)
 SLOT_ONES, SLOT_Y, SLOT_FIRST_FREE = 0, 1, 2
 
 c_int, c_i32, c_i64, c_dbl, c_vp = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p

@@ -1602,17 +1602,18 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
 typedef void (*resid_quad_fn)(const double *, int64_t, int64_t, const double *, int, const ResidQuadTable *, const double *,
                               double *);
 
-// the slot layouts compiled: GM inputs x KM orders per input (smallest first); Bernoulli instances for orders up to 2
-// (what a search visits first) and up to RT_MAX_ORDER
+// the slot layouts compiled: GM inputs x KM orders per input (fewest slots first); Bernoulli instances for orders up to 2, 4
+// (what a search visits first) and RT_MAX_ORDER
 struct ResidQuadLayout {
     int gm, km;
-    resid_quad_fn bernoulli2, bernoulli8, splines;
+    resid_quad_fn bernoulli2, bernoulli4, bernoulli8, splines;
 };
-#define FOKL_RQ_LAYOUT(GM, KM)                                                                              \
-    {GM, KM, resid_quadratic_kernel<false, GM, KM, 2>, resid_quadratic_kernel<false, GM, KM, RT_MAX_ORDER>, \
-     resid_quadratic_kernel<true, GM, KM, 2>}
+#define FOKL_RQ_LAYOUT(GM, KM)                                                                          \
+    {GM, KM, resid_quadratic_kernel<false, GM, KM, 2>, resid_quadratic_kernel<false, GM, KM, 4>,        \
+     resid_quadratic_kernel<false, GM, KM, RT_MAX_ORDER>, resid_quadratic_kernel<true, GM, KM, 2>}
 static const ResidQuadLayout kResidQuadLayouts[] = {FOKL_RQ_LAYOUT(8, 1), FOKL_RQ_LAYOUT(16, 1), FOKL_RQ_LAYOUT(8, 2),
-                                                    FOKL_RQ_LAYOUT(4, 4), FOKL_RQ_LAYOUT(2, 8)};
+                                                    FOKL_RQ_LAYOUT(4, 4), FOKL_RQ_LAYOUT(2, 8), FOKL_RQ_LAYOUT(8, 4),
+                                                    FOKL_RQ_LAYOUT(16, 2), FOKL_RQ_LAYOUT(4, 8)};
 #undef FOKL_RQ_LAYOUT
 
 extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat)
@@ -1666,7 +1667,7 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     if (!layout)
         return fail(ctx, FOKL_ERR_ARG, "fokl_bic_resid_terms_launch: " + std::to_string(G) + " inputs with up to " +
                                            std::to_string(K) + " orders each fit none of the factor layouts (8 x 1, 16 x 1, "
-                                           "8 x 2, 4 x 4, 2 x 8: FOKL_RESID_TERMS_MAX_FACTORS slots)");
+                                           "8 x 2, 4 x 4, 2 x 8, 8 x 4, 16 x 2, 4 x 8: FOKL_RESID_TERMS_MAX_FACTORS slots)");
     const int GM = layout->gm, KM = layout->km, UM = GM * KM;
 
     int rc = begin_args(ctx, sizeof(ResidQuadTable));
@@ -1715,7 +1716,7 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
     if (rc) return rc;
     rc = ensure_rout(ctx);
     if (rc) return rc;
-    resid_quad_fn fn = splines ? layout->splines : top_order <= 2 ? layout->bernoulli2 : layout->bernoulli8;
+    resid_quad_fn fn = splines ? layout->splines : top_order <= 2 ? layout->bernoulli2 : top_order <= 4 ? layout->bernoulli4 : layout->bernoulli8;
     {
         {
             TimedRegion timed(ctx, FOKL_K_RESID_MF, 8.0 * (double)ctx->n * (double)(G + 1),

@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(RS_THREADS) void resid_kernel(double *const *__rest
 
 constexpr int RT_MAX_ORDER = 8;            // Bernoulli orders the matrix-free pass handles (coefficient row: 9 doubles)
 constexpr int RT_COEF_STRIDE = 10;         // doubles per factor: c[0 .. 8] + the order (as a double; 0 = empty slot)
-constexpr int RQ_MAX_SLOTS = 16;
+constexpr int RQ_MAX_SLOTS = 32;
 
 struct ResidQuadTable {
     int32_t n_groups;                      // inputs used (<= GM of the kernel the host picked)
@@ -1665,7 +1665,7 @@ __host__ __device__ constexpr int resid_quad_index(int a, int b, int UM, int KM)
 
 typedef __attribute__((address_space(4))) const ResidQuadTable *const_quad_ptr;      // constant address space: scalar loads
 
-// OT: the highest Bernoulli order the instance evaluates (2 or RT_MAX_ORDER).  Everything a row does between its loads and
+// OT: the highest Bernoulli order the instance evaluates (2, 4 or RT_MAX_ORDER).  Everything a row does between its loads and
 // its two sums is straight-line code: a factor of lower order carries zero coefficients beyond its own (val + 0 * x**j
 // leaves val as it is), an empty slot carries only zeros -- so the scalar loads of the coefficients are scheduled ahead in
 // bulk (s_load_dwordx8 / x16) instead of one by one inside wave-uniform branches, each waited for on the spot.

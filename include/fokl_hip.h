@@ -204,11 +204,11 @@ int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce);
  * evaluated once per row with the operations of fokl_build_terms, and the fit is their quadratic form
  * c0 + sum_a f_a (l_a + sum_{b > a} Q_ab f_b) -- the same moments as the stored-column pass up to the association of
  * the sum (agreement ~1e-15 of the moments' scale, not bit for bit).  Limits: one or two inputs per term; the factors
- * must fit one of the slot layouts (inputs x orders per input) 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8
+ * must fit one of the slot layouts (inputs x orders per input) 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8, 8 x 4, 16 x 2, 4 x 8
  * (FOKL_RESID_TERMS_MAX_FACTORS slots); Bernoulli orders up to FOKL_RESID_TERMS_MAX_ORDER.  FOKL_ERR_ARG beyond:
  * callers take the stored-column pass.  Fetch with fokl_bic_resid_fetch.
  */
-#define FOKL_RESID_TERMS_MAX_FACTORS 16
+#define FOKL_RESID_TERMS_MAX_FACTORS 32
 #define FOKL_RESID_TERMS_MAX_ORDER 8
 int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, int n_terms, const double *betahat);
 

@@ -296,13 +296,14 @@ def test_k3_matrix_free_agrees_with_the_stored_column_pass(device_ctx, kid):
     """fokl_bic_resid_terms_launch re-forms the model's distinct factors from the inputs with the operations of
     fokl_build_terms and evaluates the fit as their quadratic form: the same moments as the stored-column pass up to
     the association of the sum (1e-13 of the moments' scale; the oracle's columns to 1e-11) -- for every slot layout
-    (inputs x orders per input: 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8), ragged row counts, one- and two-way terms,
+    (inputs x orders per input: 8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8, 8 x 4, 16 x 2, 4 x 8), ragged row counts, one- and two-way terms,
     duplicated terms, subsets of a sub-stage's terms; models outside the layouts are refused, not overrun."""
     rng = np.random.default_rng(14)
     # (rows, inputs in the dataset, inputs used, orders per input used, highest order, terms)
     for n, m, used, per_input, top, n_terms in ((1, 8, 3, 1, 2, 5), (777, 8, 8, 1, 1, 36), (20001, 8, 8, 2, 4, 60),
                                                 (65536 + 3, 16, 16, 1, 3, 120), (5000, 8, 4, 4, 6, 80),
-                                                (3001, 8, 2, 8, 8, 25), (4099, 8, 8, 2, 2, 128)):
+                                                (3001, 8, 2, 8, 8, 25), (4099, 8, 8, 2, 2, 128), (9001, 8, 8, 4, 4, 200),
+                                                (2500, 16, 16, 2, 3, 150), (1300, 8, 4, 8, 8, 90), (7000, 8, 8, 3, 5, 110)):
         x = rng.random((n, m))
         y = rng.standard_normal(n)
         phis = upload(device_ctx, x, y, kid)
@@ -335,8 +336,8 @@ def test_k3_matrix_free_agrees_with_the_stored_column_pass(device_ctx, kid):
     assert abs(s1 - (y - 0.25).sum()) <= 1e-12 * np.abs(y - 0.25).sum()
     three_way = np.zeros((1, m), dtype=np.int32)
     three_way[0, :3] = 1
-    too_deep = np.zeros((24, m), dtype=np.int32)                          # 8 inputs x 3 orders: no layout
-    for j in range(24):
+    too_deep = np.zeros((40, m), dtype=np.int32)                          # 8 inputs x 5 orders: no layout
+    for j in range(40):
         too_deep[j, j % 8] = 1 + j // 8
     for bad in (three_way, too_deep):
         with pytest.raises(_capi.FoklNativeError):

@@ -760,7 +760,8 @@ def test_lookahead_knobs_are_bounded_to_what_was_verified():
 def test_matrix_free_residual_pass_is_offered_only_inside_its_slot_layouts():
     """engine.HipBackend.resid_terms_supported mirrors fokl_bic_resid_terms_launch's limits (include/fokl_hip.h): one or
     two inputs per term, the distinct (input, order) factors inside one of the layouts inputs x orders-per-input
-    8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8; spline factors pay only from 3.5 model columns per slot on."""
+    8 x 1, 16 x 1, 8 x 2, 4 x 4, 2 x 8 (16 slots), 8 x 4, 16 x 2, 4 x 8 (32); spline factors pay only from 3.5 model
+    columns per slot on."""
     import types
     from fokl_gpy_amd import engine
     shape = staticmethod(engine.HipBackend._factor_shape)
@@ -772,7 +773,10 @@ def test_matrix_free_residual_pass_is_offered_only_inside_its_slot_layouts():
     assert ok(bern, mains) and ok(bern, np.vstack([mains, pairs]))                      # 8 x 1
     second = np.vstack([mains, 2 * mains, engine.distinct_arrangements([2, 1] + [0] * 6)])
     assert ok(bern, second)                                                              # 8 x 2
-    assert not ok(bern, np.vstack([second, 3 * mains]))                                  # 8 inputs x 3 orders: no layout
+    assert ok(bern, np.vstack([second, 3 * mains, 4 * mains]))                           # 8 x 4 (32 slots)
+    assert not ok(bern, np.vstack([second, 3 * mains, 4 * mains, 5 * mains]))            # 8 inputs x 5 orders: no layout
+    wide = np.eye(16, dtype=np.int32)
+    assert ok(bern, np.vstack([wide, 2 * wide])) and not ok(bern, np.vstack([wide, 2 * wide, 3 * wide]))   # 16 x 2
     assert ok(bern, np.vstack([k * np.eye(4, 8, dtype=np.int32) for k in (1, 2, 3, 4)]))  # 4 x 4
     assert ok(bern, np.eye(16, dtype=np.int32)) and not ok(bern, np.eye(17, dtype=np.int32))
     three_way = np.zeros((1, 8), dtype=np.int32)
