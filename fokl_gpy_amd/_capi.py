@@ -261,6 +261,35 @@ def gram_plan(row_slots, col_slots, kind=0):
                 perm=perm, staged=staged, tiles=tiles, half=half)
 
 
+class TraceRecords:
+    """The evaluations of a search in order, one dict(cols, built, ev, kill, b0) each -- formed when somebody looks (a fit has
+    hundreds of them and the search's last half millisecond is no place to build them)."""
+
+    def __init__(self, rec):
+        self._rec = rec
+
+    def __len__(self):
+        return self._rec.shape[0]
+
+    @staticmethod
+    def _record(r):
+        return dict(cols=int(r[0]), built=int(r[1]), ev=float(r[2]), kill=bool(r[3]), b0=float(r[4]))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._record(r) for r in self._rec[i]]
+        return self._record(self._rec[i])
+
+    def __iter__(self):
+        return (self._record(r) for r in self._rec)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(list(self))
+
+
 class LegacyStream:
     """Mutable copy of numpy's global legacy RNG state in the layout the C sampler updates in place."""
 
@@ -1030,7 +1059,7 @@ class NativeSearch:
         n = self._lib.fokl_search_trace(self._h, None, 0)
         rec = np.zeros((max(1, n), 5))
         self._lib.fokl_search_trace(self._h, _ptr(rec), n)
-        return [dict(cols=int(r[0]), built=int(r[1]), ev=float(r[2]), kill=bool(r[3]), b0=float(r[4])) for r in rec[:n]]
+        return TraceRecords(rec[:n])
 
     def kill_tests(self, gram, columns, mean_abs, rel_std, slots, best, n_prev, vm_next, ahead, foresee=None,
                    idle_work=None, residual=None):

@@ -1629,8 +1629,17 @@ extern "C" int fokl_search_create(fokl_host_pool *pool, fokl_dchain *dchain, con
 extern "C" void fokl_search_destroy(fokl_search *s)
 {
     if (!s) return;
+    double lap[5] = {0.0, 0.0, 0.0, 0.0, 0.0};             // FOKL_SEARCH_PROFILE: where the teardown's time goes
+    double t_lap = s->profile ? now_s() : 0.0;
+    auto mark = [&](int i) {
+        if (!s->profile) return;
+        const double t = now_s();
+        lap[i] += t - t_lap;
+        t_lap = t;
+    };
     drop_speculation(s, 0);
     if (s->prechain.tape) drop_prechain(s);
+    mark(0);
     while (!s->pending.empty()) {                           // chains that were never started: their tapes were walked, that is all
         Outcome *o = s->pending.front();
         s->pending.pop_front();
@@ -1649,7 +1658,9 @@ extern "C" void fokl_search_destroy(fokl_search *s)
         o->checks.clear();
         unref(s, o);
     }
+    mark(1);
     (void)verify(s, true);                                  // zombies
+    mark(2);
     for (Outcome *o : s->device_outcomes) {
         if (!o->device_released) {
             (void)fokl_dchain_release(s->dchain, o->ticket);
@@ -1658,8 +1669,14 @@ extern "C" void fokl_search_destroy(fokl_search *s)
         unref(s, o);
     }
     s->device_outcomes.clear();
+    mark(3);
     reap(s, true);
     reap(s, true);                                          // tapes released by the chains of the first pass
+    mark(4);
+    if (s->profile)
+        std::fprintf(stderr, "fokl_search teardown (ms): orders sent back %.3f, pending / forecasts / unverified let go %.3f, zombies %.3f, "
+                             "device slots %.3f, waiting for jobs in flight %.3f\n", 1e3 * lap[0], 1e3 * lap[1], 1e3 * lap[2],
+                     1e3 * lap[3], 1e3 * lap[4]);
     if (s->profile)
         std::fprintf(stderr, "fokl_search: alive after this search: %lld tapes, %lld spectra, %lld outcomes (handles the caller still holds)\n",
                      (long long)census().tapes.load(), (long long)census().spectra.load(), (long long)census().outcomes.load());

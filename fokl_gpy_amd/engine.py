@@ -1047,6 +1047,15 @@ class ForwardSelection:
         chains and the eigen-decompositions run on native threads (HostPipeline); otherwise every chain runs in line."""
         pipelined = self.b > 0 and os.environ.get('FOKL_NOISE_PIPELINE', '1') != '0'
         t_begin_run = time.perf_counter()
+        # Head start: the seed Gram and K1 + K2 of the first sub-stage (its pattern is known before anything else is) go to
+        # the device now, and run while the host threads of the pipeline are being created (0.6 ms) -- the first sub-stage
+        # then finds its Gram block waiting, like every later one whose columns were built ahead.  Single-process searches
+        # (a split over ranks gathers rows: a collective, kept where the other collectives are).  FOKL_HEAD_START=0: off.
+        self._head = None
+        if (pipelined and hasattr(self.backend, 'gram_launch') and not (self.allreduce or self.candidate_sharded)
+                and os.environ.get('FOKL_HEAD_START', '1') != '0'):
+            base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], False)
+            self._head = (base, self._build_ahead(next(self._patterns())[1], [SLOT_ONES]))
         if pipelined:
             try:
                 # device chains: one search per process at a time drives an engine's guesses.  Searches replicated over ranks
@@ -1151,6 +1160,10 @@ class ForwardSelection:
                     self.native = None
                 self.host.close()
                 self.host = None
+                if self._head is not None:          # the block launched ahead is fetched: the context outlives this search
+                    self._ahead_block(self._head[1])
+                    self.pool.give(self._head[1]['slots'])
+                    self._head = None
                 raise
         self.stats['search_driver'] = 'native' if self.native is not None else 'python'
         if self.native is None and self.host is not None and os.environ.get('FOKL_SEARCH', 'native') != 'python':
@@ -1339,7 +1352,12 @@ class ForwardSelection:
         # Gram of [ones, y] seeds the cache: n, sum y, y'y
         model_slots = []                            # device slots of accepted terms (aligned with damtx rows)
         damtx = np.zeros((0, m))
-        base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], self.allreduce)
+        head = getattr(self, '_head', None)
+        self._head = None
+        if head is not None:
+            base = head[0]
+        else:
+            base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], self.allreduce)
         gram = np.array(base, dtype=np.float64)     # Gram over [ones] + model columns + y
         keep = [0]
 
@@ -1350,7 +1368,7 @@ class ForwardSelection:
         greater = 0
         patterns = self._patterns()
         pattern = next(patterns)
-        ahead = None                                # the coming sub-stage, built early (pipelined search only)
+        ahead = head[1] if head is not None else None   # the coming sub-stage, built early (pipelined search only)
         forecasts = {}                              # survivors' slots -> (G2 job of the coming model, its Gram)
         look_ahead = self.host is not None and self.foresight > 0
 

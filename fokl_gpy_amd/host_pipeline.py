@@ -774,19 +774,38 @@ class NativeOutcome:
     """One model evaluation of a NativeSearch (csrc/fokl_search.cpp): GibbsOutcome's interface over a native handle.  The
     spectrum, the draws and their buffers belong to the search; the arrays here are views that live as long as this
     object is not released / dropped."""
-    __slots__ = ('_ns', 'h', 'lamb', 'qty', 'Qt', 'betahat', 'ev', 'idx', 'siglik', '_w', '_betas', '_scale', '_owner')
+    __slots__ = ('_ns', 'h', '_spec', '_idx', '_p1', '_spectrum_at', '_idx_at', 'ev', 'siglik', '_w', '_betas', '_scale',
+                 '_owner')
 
     def __init__(self, owner, ns, handle):
         self._owner, self._ns, self.h = owner, ns, handle
         view = ns.outcome_info(handle)
-        p1 = view.p1
-        import ctypes
-        buf = np.ctypeslib.as_array((ctypes.c_double * _capi.SpectralResult.doubles(p1)).from_address(view.spectrum))
-        spec = _capi.SpectralResult(p1, buf)
-        self.lamb, self.qty, self.Qt, self.betahat = spec.lamb, spec.qty, spec.Qt, spec.betahat
-        self.idx = np.array(np.ctypeslib.as_array((ctypes.c_int32 * p1).from_address(view.idx)))
+        # (the views of the spectrum are formed when somebody reads them: most outcomes of a search are only ever asked
+        # for their BIC and their handle -- 28 per configs[2] fit, 23 us each)
+        self._p1, self._spectrum_at, self._idx_at = view.p1, view.spectrum, view.idx
+        self._spec = self._idx = None
         self.ev, self.siglik = view.ev, view.siglik
         self._w = self._betas = self._scale = None
+
+    def _spectrum(self):
+        if self._spec is None:
+            import ctypes
+            buf = np.ctypeslib.as_array(
+                (ctypes.c_double * _capi.SpectralResult.doubles(self._p1)).from_address(self._spectrum_at))
+            self._spec = _capi.SpectralResult(self._p1, buf)
+        return self._spec
+
+    lamb = property(lambda self: self._spectrum().lamb)
+    qty = property(lambda self: self._spectrum().qty)
+    Qt = property(lambda self: self._spectrum().Qt)
+    betahat = property(lambda self: self._spectrum().betahat)
+
+    @property
+    def idx(self):
+        if self._idx is None:
+            import ctypes
+            self._idx = np.array(np.ctypeslib.as_array((ctypes.c_int32 * self._p1).from_address(self._idx_at)))
+        return self._idx
 
     @property
     def on_device(self):
