@@ -329,6 +329,7 @@ class ForwardSelection:
         self._matrix_free = (hasattr(backend, 'bic_resid_terms_launch') and
                              os.environ.get('FOKL_K3', 'matrixfree') != 'columns')
         self._terms_arr = None              # [A, m] int32 terms of the active columns (row 0 = intercept) or None
+        self._arrangement_memo = {}         # pattern -> its distinct arrangements (this search's)
         self._terms_pay_from = 0            # ... and the model size from which the matrix-free pass is the faster one
         # spectral jobs submitted ahead of the kill tests: three along the guessed path (the Python loop: every miss costs
         # the jobs); the native loop predicts its path (csrc/fokl_search.cpp PathModel) and goes twelve deep
@@ -1295,10 +1296,20 @@ class ForwardSelection:
         mine, share = self._share_of(new_slots)
         return self._gather_rows(self.backend.gram(mine, col_slots, False), len(new_slots), share)
 
+    def _arrangements(self, indvec):
+        """distinct_arrangements(indvec), enumerated once per search (a sub-stage's pattern is looked at when it is the coming
+        one -- how many terms will it bring -- and again when its columns are built)."""
+        key = tuple(float(v) for v in indvec)
+        hit = self._arrangement_memo.get(key)
+        if hit is None:
+            hit = self._arrangement_memo[key] = distinct_arrangements(indvec)
+            hit.setflags(write=False)
+        return hit
+
     def _build_ahead(self, indvec, active_slots):
         """K1 + K2 of a coming sub-stage while the current one is still being decided: its columns, and their Gram
         block against every column that can still be in the model then (all of the current sub-stage's) and y."""
-        vecs = distinct_arrangements(indvec)
+        vecs = self._arrangements(indvec)
         slots = self.pool.take(vecs.shape[0])
         self.backend.build_terms(vecs.astype(np.int32), slots)
         self.stats['terms_physical'] += vecs.shape[0]
@@ -1401,7 +1412,7 @@ class ForwardSelection:
                 ahead, forecasts = None, {}
             else:
                 # K1 + K2: build the new columns once, extend the Gram
-                vecs = distinct_arrangements(indvec)
+                vecs = self._arrangements(indvec)
                 new_slots = self.pool.take(vecs.shape[0])
                 self.backend.build_terms(vecs.astype(np.int32), new_slots)
                 self.stats['terms_physical'] += vecs.shape[0]
@@ -1420,7 +1431,7 @@ class ForwardSelection:
             early, then = None, [A - 1] if vm > 0 and A > 1 else []
             vm_next = None
             if pipelined and pattern is not None:
-                vm_next = distinct_arrangements(pattern[1]).shape[0]
+                vm_next = self._arrangements(pattern[1]).shape[0]
             if pipelined and self.lookahead > 0 and spectral_job is not None and getattr(
                     spectral_job, 'done', lambda: False)():
                 early, then = self._guess_first_tests(gram, spectral_job.wait(), vm, before_model=True,
