@@ -1619,14 +1619,19 @@ class ForwardSelection:
             self._ahead_block(ahead)
             self.pool.give(ahead['slots'])
 
-        t0 = time.perf_counter()
-        self._verify(block=True)                   # every decision taken from a guess is confirmed before anything returns
-        self.stats['t_final_verify'] = time.perf_counter() - t0
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx
+        # The returned model's draws are formed while the last confirmations are still on their way (eigenpairs of the last
+        # sub-stage's accepted models, then their chains on the device: 3-4 ms in which this thread only waits); should a
+        # confirmation fail, Misprediction discards them with everything else.
         t0 = time.perf_counter()
+        self._verify(block=False)                  # (starts the chains whose eigenpairs have arrived)
+        t1 = time.perf_counter()
         out_betas = betas.betas[-self.draws_keep::, :]
-        self.stats['t_final_draws'] = time.perf_counter() - t0
+        t2 = time.perf_counter()
+        self.stats['t_final_draws'] = t2 - t1
+        self._verify(block=True)                   # every decision taken from a guess is confirmed before anything returns
+        self.stats['t_final_verify'] = (t1 - t0) + (time.perf_counter() - t2)
         for keep_alive in (betas, last):           # the returned draws are on the host now: the device slots go back
             if getattr(keep_alive, 'on_device', False):
                 keep_alive.release()
