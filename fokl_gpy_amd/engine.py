@@ -190,16 +190,14 @@ class HipBackend:
         if getattr(self, 'kernel_id', 1) != 0 and int(terms.max()) > _capi.RESID_TERMS_MAX_ORDER:
             return False
         inputs, deepest = self._factor_shape(terms)
+        self._shape_of_last = (terms, inputs, deepest)          # (resid_terms_pay_from is asked about the same terms next)
         return any(inputs <= gm and deepest <= km for gm, km in _capi.RESID_TERMS_LAYOUTS)
 
     @staticmethod
     def _factor_shape(terms):
         """(inputs used, most distinct orders on one input) of a set of terms."""
-        rows, cols = np.nonzero(terms)
-        present = np.zeros((terms.shape[1], int(terms.max()) + 1), dtype=bool)
-        present[cols, terms[rows, cols]] = True
-        per_input = present.sum(axis=1)
-        return int(np.count_nonzero(per_input)), int(per_input.max())
+        per_input = [len(set(col) - {0}) for col in terms.T.tolist()]     # (a few hundred small ints: no numpy call pays)
+        return sum(1 for c in per_input if c), max(per_input)
 
     def resid_terms_pay_from(self, terms):
         """Model columns from which the matrix-free pass is the faster one (its time depends on the factor slots of its
@@ -208,7 +206,8 @@ class HipBackend:
         N = 1e6)."""
         if getattr(self, 'kernel_id', 1) != 0:
             return 0
-        inputs, deepest = self._factor_shape(terms)
+        last = getattr(self, '_shape_of_last', None)
+        inputs, deepest = last[1:] if last is not None and last[0] is terms else self._factor_shape(terms)
         slots = min(gm * km for gm, km in _capi.RESID_TERMS_LAYOUTS if inputs <= gm and deepest <= km)
         return int(3.5 * slots)
 

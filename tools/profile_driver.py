@@ -37,6 +37,7 @@ def main():
     out = io.StringIO()
     st = pstats.Stats(prof, stream=out)
     st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('cumulative').print_stats(45)
     print(out.getvalue().replace(ROOT + '/', ''))
     print(f"per fit: {1e3 * model.fit_stats['seconds']:.1f} ms (under the profiler)")
 
