@@ -67,6 +67,9 @@ SIGNATURES = {
     'fokl_pool_stream': (c_vp, [c_vp]),
     'fokl_pool_use_dsyevd': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_use_dgemm': (c_int, [c_vp, c_vp]),
+    'fokl_device_dgemm': (None, [c_vp] * 13),               # (called by the pool's threads through its address, not from here)
+    'fokl_device_dgemm_configure': (c_int, [c_int, c_vp, c_int, c_vp]),
+    'fokl_device_dgemm_stats': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_pool_spectral_affinity': (c_int, [c_vp, c_vp, c_int]),
     'fokl_pool_release_hold': (c_int, [c_vp, ctypes.c_uint64]),
     'fokl_pool_destroy': (None, [c_vp]),
@@ -259,6 +262,14 @@ def gram_plan(row_slots, col_slots, kind=0):
     return dict(nci=int(info[0]), i_tiles=int(info[1]), j_tiles=int(info[2]), nt=int(info[4]), ct=int(info[5]),
                 rows_per_chunk=32 << int(info[6]), ks=int(info[7]), depth=int(info[8]), waves=int(info[9]), icols=icols,
                 perm=perm, staged=staged, tiles=tiles, half=half)
+
+
+def device_dgemm_stats():
+    """(calls of fokl_device_dgemm so far in this process, of which ran on the device, device attempts that fell back)"""
+    v = [ctypes.c_int64(0) for _ in range(3)]
+    if load().fokl_device_dgemm_stats(*[ctypes.byref(x) for x in v]) != 0:
+        return 0, 0, 0
+    return tuple(x.value for x in v)
 
 
 class TraceRecords:
@@ -709,9 +720,10 @@ class HostPool:
     spectral threads of one fit."""
 
     def __init__(self, stream, chain_threads=2, finish_threads=2, spectral_threads=3, noise_cpu=-1, bulk_threads=2,
-                 prestates=None):
+                 prestates=None, device_dgemm=None):
         """prestates: (address, entries) of a pre-state ring (DeviceChainEngine.prestate_ring()) for a device that
-        regenerates the stream itself."""
+        regenerates the stream itself.  device_dgemm: (device, columns) -- the eigen-update's product on that device's matrix
+        cores for models of at least that many columns (fokl_device_dgemm), scipy's dgemm below."""
         self._lib = load()
         self.stream = stream
         self._h = None
@@ -736,6 +748,12 @@ class HostPool:
         self.has_dgemm = False
         if spectral_threads > 0:
             fg = _scipy_dgemm_address()
+            self.device_dgemm_from = 0
+            if fg and device_dgemm is not None:
+                entry = c_vp(0)
+                if self._lib.fokl_device_dgemm_configure(int(device_dgemm[0]), c_vp(fg), int(device_dgemm[1]),
+                                                         ctypes.byref(entry)) == 0 and entry.value:
+                    fg, self.device_dgemm_from = entry.value, int(device_dgemm[1])
             if fg:
                 _check(self._lib.fokl_pool_use_dgemm(self._h, c_vp(fg)))
                 self.has_dgemm = True

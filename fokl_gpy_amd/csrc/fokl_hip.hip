@@ -1837,6 +1837,7 @@ extern "C" int fokl_timing_get(fokl_ctx *ctx, int kernel_id, double *total_ms, i
 #include "fokl_spectral_device.inc"
 #include "fokl_predict.inc"
 #include "fokl_probe.inc"
+#include "fokl_dgemm_device.inc"
 
 #if defined(FOKL_GT_STAMP) || defined(FOKL_GD_STAMP)
 // diagnostic builds only (tools/k2_clock.sh, tools/k2_phases.sh): the clock stamps of the last Gram launch

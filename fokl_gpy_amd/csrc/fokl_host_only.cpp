@@ -62,6 +62,12 @@ extern "C" int fokl_dchain_release(fokl_dchain *, int64_t) { return FOKL_ERR_HIP
 extern "C" int fokl_dchain_try_release(fokl_dchain *, int64_t) { return 1; }
 extern "C" int fokl_dchain_flush(fokl_dchain *) { return FOKL_ERR_HIP; }
 // ... nor does the device's eigen-solver: a search in these builds is never bound to one.
+extern "C" void fokl_device_dgemm(char *, char *, int *, int *, int *, double *, double *, int *, double *, int *, double *, double *,
+                                  int *)
+{
+}
+extern "C" int fokl_device_dgemm_configure(int, void *, int, void **) { return FOKL_ERR_HIP; }
+extern "C" int fokl_device_dgemm_stats(int64_t *, int64_t *, int64_t *) { return FOKL_ERR_HIP; }
 extern "C" int fokl_dspectral_max_columns(void) { return 0; }
 extern "C" int fokl_dspectral_submit(fokl_dspectral *, const double *, int, const int32_t *, int, int, int, int64_t *, double **)
 {

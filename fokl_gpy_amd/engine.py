@@ -1077,7 +1077,8 @@ class ForwardSelection:
                 # driver's splits the Gram launches instead, _gram_of_new_columns, and keeps every G2 job at home)
                 self.host = HostPipeline(self.stream, self.draws,
                                          self.comm if self.candidate_sharded and not self._replicated_native else None,
-                                         chain_engine=self.chain_engine, wide_models=wide)
+                                         chain_engine=self.chain_engine, wide_models=wide,
+                                         device=getattr(getattr(self.backend, 'ctx', None), 'device', None))
             except (ImportError, KeyError, AttributeError, _capi.FoklNativeError) as exc:
                 # e.g. a scipy without the cython_lapack capsule the spectral threads call through: same results in
                 # line, only slower
@@ -1172,6 +1173,7 @@ class ForwardSelection:
                           "stand-in chain engine): it runs on the Python statement of the loop, several times slower -- "
                           "fit_stats['search_driver'] says which", RuntimeWarning)
         _mark('pool_up')
+        dgemm0 = _capi.device_dgemm_stats() if self.host is not None else (0, 0, 0)
         self.stats['t_pool_up'] = time.perf_counter() - t_begin_run
         # which arithmetic produced the draws (the stream is numpy's either way): libmvec's vector log or libm's scalar
         # one for the normals finished on the host, host threads or the device for the kill tests' chains
@@ -1210,6 +1212,9 @@ class ForwardSelection:
                 t_close = time.perf_counter()
                 busy = self.host.close()     # all requested tapes are recorded -> the stream ends where it must
                 self.stats['t_teardown_pool'] = time.perf_counter() - t_close
+                dgemm1 = _capi.device_dgemm_stats()
+                self.stats.update(eigen_update_products=dgemm1[0] - dgemm0[0], eigen_update_products_on_device=dgemm1[1] - dgemm0[1],
+                                  eigen_update_products_fell_back=dgemm1[2] - dgemm0[2])
                 self.stats.update(pool_bulk_s=busy.get('bulk', 0.0), walker_wait_s=busy.get('walker_wait', 0.0),
                                   stream_segments=busy.get('stream_segments', 0),
                                   gamma_attempts_exact=busy.get('gamma_attempts_exact', 0),

@@ -335,7 +335,7 @@ class HostPipeline:
     The driver thread keeps what needs Python or the device: the sequential decisions, the K1 / K2 / K3 launches.
     """
 
-    def __init__(self, stream, draws, comm=None, chain_engine=None, wide_models=False):
+    def __init__(self, stream, draws, comm=None, chain_engine=None, wide_models=False, device=None):
         self.stream, self.draws = stream, int(draws)
         self.dchain = chain_engine          # G3 of kill-test candidates on the device (None: host chain threads)
         self._pinned = chain_engine is not None and getattr(chain_engine, 'wants_pinned_tapes', True)
@@ -366,8 +366,15 @@ class HostPipeline:
             except _capi.FoklNativeError:
                 prestates = None
         try:
+            # The product that ends a derived decomposition (0.4 GFLOP at 585 columns: 3.6 of a 5.1 ms step on a host core)
+            # on the device's matrix cores from FOKL_EIGH_DGEMM_FROM columns on: 2.6 ms a step at 585 columns, break-even near
+            # 200 (tools/eigen_update_bench.py).  Opt-in (default 0: scipy's dgemm for every size): no BASELINE config derives
+            # models that wide -- configs[3] defers the G2 of its 585-column models, which leaves them without a parent to
+            # derive from (tools/r05_cfg3b.sh: 348-358 ms per fit either way).
+            dgemm_from = int(os.environ.get('FOKL_EIGH_DGEMM_FROM', '0'))
             self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads(wide_models=wide_models),
-                                       prestates=prestates)
+                                       prestates=prestates,
+                                       device_dgemm=(device, dgemm_from) if device is not None and dgemm_from > 0 else None)
             if prestates is not None:
                 chain_engine.bind(self.pool.stream_handle())
                 self.device_rows = True

@@ -438,6 +438,17 @@ int fokl_pool_use_dsyevd(fokl_host_pool *pool, void *fn, int from_columns);
 /* BLAS dgemm (fn: its address, Fortran ABI with 32-bit integers, e.g. scipy.linalg.cython_blas's) for the product of
  * fokl_pool_submit_spectral_update; NULL: those jobs decompose afresh.  Call before the first spectral job. */
 int fokl_pool_use_dgemm(fokl_host_pool *pool, void *fn);
+/* The same product on the device (csrc/fokl_dgemm_device.inc): fokl_device_dgemm has BLAS dgemm's signature and runs
+ * C = A B ('N', 'N', alpha 1, beta 0; N and K of at least `from`, M of at least 16) as fp64 MFMA tiles on `device` through
+ * page-locked staging buffers of the calling thread; every other call, and any device failure, goes to host_dgemm.
+ * fokl_device_dgemm_configure returns its address through *entry -- what to give fokl_pool_use_dgemm for searches whose
+ * models have hundreds of columns (585: 0.4 GFLOP per derived model, 8-10 ms on a host core).  One configuration per
+ * process.  Replaces the call of scipy's dgemm inside the eigen-update (no reference line: the reference decomposes every
+ * model afresh, FR:1499). */
+void fokl_device_dgemm(char *transa, char *transb, int *m, int *n, int *k, double *alpha, double *a, int *lda, double *b,
+                       int *ldb, double *beta, double *c, int *ldc);
+int fokl_device_dgemm_configure(int device, void *host_dgemm, int from, void **entry);
+int fokl_device_dgemm_stats(int64_t *calls, int64_t *on_device, int64_t *failed);
 
 /* CPUs for the spectral threads alone (they share no data with the threads around the random stream: another last-level
  * cache domain keeps them off those threads' cores) */

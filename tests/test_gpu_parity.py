@@ -344,6 +344,57 @@ def test_k3_matrix_free_agrees_with_the_stored_column_pass(device_ctx, kid):
             device_ctx.bic_resid_terms_launch(bad, np.zeros(bad.shape[0] + 1))
 
 
+def test_device_dgemm_is_the_host_dgemm_to_rounding(device_ctx):
+    """fokl_device_dgemm (the eigen-update's product on the matrix cores, BLAS dgemm's signature): C = A B for column-major
+    operands with leading dimensions larger than the matrices, ragged sizes on either side of the 64 x 64 x 16 tiling, within
+    a few ulp of |A| |B| of numpy's product; calls it does not take (a transpose, beta != 0, small sizes) reach the host
+    dgemm it wraps and return ITS bits; the counters say which way each call went."""
+    import ctypes
+    lib = _capi.load()
+    host = _capi._scipy_dgemm_address()
+    assert host
+    entry = ctypes.c_void_p(0)
+    assert lib.fokl_device_dgemm_configure(0, ctypes.c_void_p(host), 48, ctypes.byref(entry)) == 0 and entry.value
+    proto = ctypes.CFUNCTYPE(None, *([ctypes.c_void_p] * 13))
+    device_dgemm, host_dgemm = proto(entry.value), proto(host)
+
+    def call(fn, ta, tb, a, b, c, m, n, k, alpha=1.0, beta=0.0):
+        args = [ctypes.c_char(ta), ctypes.c_char(tb), ctypes.c_int(m), ctypes.c_int(n), ctypes.c_int(k), ctypes.c_double(alpha),
+                None, ctypes.c_int(a.shape[1]), None, ctypes.c_int(b.shape[1]), ctypes.c_double(beta), None, ctypes.c_int(c.shape[1])]
+        ptr = lambda v: ctypes.cast(ctypes.byref(v), ctypes.c_void_p)
+        fn(ptr(args[0]), ptr(args[1]), ptr(args[2]), ptr(args[3]), ptr(args[4]), ptr(args[5]), a.ctypes.data, ptr(args[7]),
+           b.ctypes.data, ptr(args[9]), ptr(args[10]), c.ctypes.data, ptr(args[12]))
+
+    def counters():
+        v = [ctypes.c_int64(0) for _ in range(3)]
+        assert lib.fokl_device_dgemm_stats(*[ctypes.byref(x) for x in v]) == 0
+        return [x.value for x in v]
+
+    rng = np.random.default_rng(21)
+    for m, n, k in ((16, 48, 48), (64, 64, 64), (65, 129, 67), (292, 585, 586), (293, 585, 586), (100, 200, 50), (17, 49, 1000)):
+        # column-major with padding: array[col, row], leading dimension = shape[1]
+        a = rng.standard_normal((k, m + 3))
+        b = rng.standard_normal((n, k + 5))
+        c = np.full((n, m + 2), np.nan)
+        before = counters()
+        call(device_dgemm, b'N', b'N', a, b, c, m, n, k)
+        after = counters()
+        assert after[0] == before[0] + 1 and after[1] == before[1] + 1 and after[2] == before[2]
+        want = b[:, :k] @ a[:, :m]                                        # (C' = B' A' in this layout)
+        bound = np.abs(b[:, :k]) @ np.abs(a[:, :m])
+        assert np.all(np.abs(c[:, :m] - want) <= 8 * np.finfo(float).eps * bound)
+        assert np.all(np.isnan(c[:, m:]))                                 # nothing written beyond the m rows
+    # what it does not take goes to the host routine: the same bits as calling that directly
+    a, b = rng.standard_normal((40, 40)), rng.standard_normal((40, 40))
+    for ta, tb, m, n, k, beta in ((b'T', b'N', 40, 40, 40, 0.0), (b'N', b'N', 40, 40, 40, 0.5), (b'N', b'N', 24, 24, 24, 0.0),
+                                  (b'N', b'N', 8, 40, 40, 0.0)):
+        c1, c2 = np.ones((40, 40)), np.ones((40, 40))
+        before = counters()
+        call(device_dgemm, ta, tb, a, b, c1, m, n, k, beta=beta)
+        call(host_dgemm, ta, tb, a, b, c2, m, n, k, beta=beta)
+        assert counters()[1] == before[1] and np.array_equal(c1, c2)
+
+
 def test_predict_mean_and_order_statistics(device_ctx):
     rng = np.random.default_rng(11)
     n = 3000

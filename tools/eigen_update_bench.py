@@ -34,10 +34,14 @@ def main():
 def measure():
     rng = np.random.default_rng(5)
     np.random.seed(1)
-    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1)
-    print(f"dgemm bound: {pool.has_dgemm}; dsyevd from {pool.dsyevd_from} columns")
+    # EUB_DEVICE_DGEMM=columns: the update's product on the device (fokl_device_dgemm) from that many columns on
+    dev = os.environ.get('EUB_DEVICE_DGEMM')
+    pool = _capi.HostPool(_capi.LegacyStream(), chain_threads=1, spectral_threads=1,
+                          device_dgemm=(0, int(dev)) if dev else None)
+    print(f"dgemm bound: {pool.has_dgemm} (on the device from {getattr(pool, 'device_dgemm_from', 0)} columns; 0: never); "
+          f"dsyevd from {pool.dsyevd_from} columns")
     print(f"{'columns':>8s} {'update ms':>10s} {'fresh ms':>9s} {'ratio':>6s} {'map deviation':>14s} {'orthogonality':>14s}")
-    for n in (24, 48, 66, 80, 96, 112, 128, 144):
+    for n in [int(v) for v in os.environ.get('EUB_SIZES', '24,48,66,80,96,112,128,144').split(',')]:
         gram = gram_like(n + 1, rng)
         idx = np.arange(n, dtype=np.int32)
         par = pool.submit_spectral(gram, idx, n).wait()
