@@ -45,6 +45,8 @@ modes=(
   "FOKL_PIN_L3=0"
   "FOKL_SAMPLER_ISA=base"
   "FOKL_SYNC=blocking"
+  "FOKL_HEAD_START=0"
+  "FOKL_EIGH_DGEMM_FROM=32"
 )
 # KNOB_PART=k/n: every n-th mode from the k-th on (a gpurun call is limited to 20 minutes)
 part=${KNOB_PART:-1/1}; k=${part%%/*}; n=${part##*/}; i=0
