@@ -166,6 +166,26 @@ def compare_with_golden(name, model, betas, mtx, evs, state):
     return out
 
 
+def mfma_flops_issued_over_algorithmic(trace_lines):
+    """What the MFMA-bound Gram launches of a fit issue on the matrix cores (16 x 16 tiles of the launch plan; half tiles on a
+    ragged last row tile; the symmetric part's lower tiles never computed) over the algorithmic 2 N nr nc they are booked with
+    (SURVEY 8(d)).  trace_lines: FOKL_GRAM_TRACE's, one per launch: `nr nc distinct class`."""
+    from fokl_gpy_amd import _capi
+    run = alg = 0.0
+    for line in trace_lines:
+        nr, nc, _, klass = line.split()
+        nr, nc = int(nr), int(nc)
+        if klass != 'gram_mfma':
+            continue
+        rs = np.arange(2, 2 + nr, dtype=np.int32)                                 # the fit's shape: new columns against
+        cs = np.concatenate([[0], np.arange(1000, 1000 + nc - nr - 2), rs, [1]])   # [ones | model | new | y]
+        plan = _capi.gram_plan(rs, cs.astype(np.int32))
+        real = plan['tiles'][..., 2] >= 0
+        run += 512.0 * (np.count_nonzero(real & ~plan['half']) + 0.5 * np.count_nonzero(real & plan['half']))
+        alg += 2.0 * nr * nc
+    return run / alg if alg else None
+
+
 def cgroup_cpu():
     """What the container's CPU controller says (cgroup v2): quota in CPUs (None: unlimited / unknown) and the counters of
     cpu.stat -- usage_usec, nr_periods, nr_throttled, throttled_usec.  Fits side by side on one GPU are bounded by this quota
@@ -1048,7 +1068,7 @@ def main():
     # normalisation, defaults, H2D upload + transposition, the search) -- after the timed region, on a warm process,
     # rank 0, the same dataset and chain seed (so the same search).  Never `value`: the metric's denominator starts
     # after `clean` with the inputs resident in HBM.
-    fit_call = None
+    fit_call, issued_ratio = None, None
     if rank == 0 and mode == 'fits' and cfg != 4 and not args.inputs:
         model0, backend0, x0, y0, sp0, _ = fits[0]
         with warnings.catch_warnings():
@@ -1057,9 +1077,21 @@ def main():
             user = FoKLRoutines.FoKL(kernel=kernel, phis=phis, UserWarnings=False, ConsoleOutput=False, **sp0['fit'])
             user._backend_override = backend0
             np.random.seed(sp0['seed_fit'])
+            trace_path = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'fokl_gram_trace_{os.getpid()}.txt')
+            trace_was = os.environ.get('FOKL_GRAM_TRACE')
+            if trace_was is None:                          # (one line per Gram launch of this untimed fit: shapes and classes)
+                os.environ['FOKL_GRAM_TRACE'] = trace_path
+                open(trace_path, 'w').close()
             t0 = time.perf_counter()
             user.fit(x0, y0, clean=True)
             backend0.ctx.sync()
+            if trace_was is None:
+                os.environ.pop('FOKL_GRAM_TRACE', None)
+                try:
+                    issued_ratio = mfma_flops_issued_over_algorithmic(open(trace_path).read().splitlines())
+                    os.remove(trace_path)
+                except (OSError, ValueError):
+                    issued_ratio = None
             fit_call = dict(fit_call_ms=1e3 * (time.perf_counter() - t0), clean_ms=1e3 * user.prepare_stats['clean_s'],
                             upload_ms=1e3 * user.prepare_stats['upload_s'], search_ms=1e3 * user.fit_stats['seconds'],
                             note='one FoKL.fit(inputs, data, clean=True) from host arrays, warm process, after the timed '
@@ -1334,7 +1366,11 @@ def main():
             'gamma_attempts_needing_libm_per_step': host['gamma_attempts_exact'] / max(args.steps, 1),
             'kill_test_path_repredicted_per_step': host['path_repredicted'] / max(args.steps, 1)},
         'cpu_pinning': pinned,
-        'roofline': dominant,
+        # (`achieved` books the algorithmic 2 N nr nc of SURVEY 8(d); what the MFMA-bound launches issue on the matrix cores
+        # is this fraction of it -- the symmetric part's lower tiles are never computed, ragged tiles are padded: measured on
+        # the launches of the untimed fit_call pass)
+        'roofline': dict(dominant, mfma_flops_issued_over_algorithmic=issued_ratio) if dominant.get('bound') == 'mfma'
+        else dominant,
         'kernels': kernels,
         'basis_build_sustained': hot,
         'device_sustains': sustained,

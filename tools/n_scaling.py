@@ -14,22 +14,7 @@ TRACE = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'fokl_gram_trace_{os.get
 os.environ['FOKL_GRAM_TRACE'] = TRACE      # one line per Gram launch: rows x columns and the roof it was booked under
 
 
-def flops_run_over_algorithmic(trace_lines):
-    """The matrix-core flops the MFMA-bound Gram launches of a fit really issue (16 x 16 tiles of the plan, half tiles on a
-    ragged last row tile, the symmetric part's lower tiles skipped) over the algorithmic 2 N nr nc they are booked with."""
-    run = alg = 0.0
-    for line in trace_lines:
-        nr, nc, _, klass = line.split()
-        nr, nc = int(nr), int(nc)
-        if klass != 'gram_mfma':
-            continue
-        rs = np.arange(2, 2 + nr, dtype=np.int32)                                 # the fit's shape: new columns against
-        cs = np.concatenate([[0], np.arange(1000, 1000 + nc - nr - 2), rs, [1]])   # [ones | model | new | y]
-        plan = _capi.gram_plan(rs, cs.astype(np.int32))
-        real = plan['tiles'][..., 2] >= 0
-        run += 512.0 * (np.count_nonzero(real & ~plan['half']) + 0.5 * np.count_nonzero(real & plan['half']))
-        alg += 2.0 * nr * nc
-    return run / alg if alg else float('nan')
+flops_run_over_algorithmic = bench.mfma_flops_issued_over_algorithmic
 
 
 for n in rows:
