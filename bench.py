@@ -1090,7 +1090,7 @@ def main():
                 try:
                     issued_ratio = mfma_flops_issued_over_algorithmic(open(trace_path).read().splitlines())
                     os.remove(trace_path)
-                except (OSError, ValueError):
+                except Exception:                          # (a diagnostic: never the reason a bench line is lost)
                     issued_ratio = None
             fit_call = dict(fit_call_ms=1e3 * (time.perf_counter() - t0), clean_ms=1e3 * user.prepare_stats['clean_s'],
                             upload_ms=1e3 * user.prepare_stats['upload_s'], search_ms=1e3 * user.fit_stats['seconds'],
