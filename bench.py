@@ -1138,15 +1138,22 @@ def main():
             t_side = time.perf_counter()
             own_terms = 0
             own_speculation = os.environ.get('FOKL_SPECULATION')
-            os.environ.setdefault('FOKL_SPECULATION', THROUGHPUT_SPECULATION)     # (as the workers: read per search)
+            # this process fits along under the workers' settings where they are read per search (order book, thread plan;
+            # the polling budgets are fixed when the library loads): the measurement ends when the slowest process has done
+            # its fits, and with a single fit's thread plan (2 / 2 / 8 host threads against the workers' 1 / 1 / 3) that was
+            # this one (48 ms per fit against the workers' 39-45)
+            side_env = {'FOKL_SPECULATION': THROUGHPUT_SPECULATION, 'FOKL_CHAIN_THREADS': '1', 'FOKL_FINISH_THREADS': '1',
+                        'FOKL_SPECTRAL_THREADS': '3' if os.environ.get('FOKL_CHAIN', 'auto') != 'host' or side_procs + 1 <= 2 else '2'}
+            side_env = {k: v for k, v in side_env.items() if k not in os.environ}
+            os.environ.update(side_env)
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     for _ in range(SIDE_FITS):              # this process fits along: one more fitting process on the GPU
                         own_terms += sum(st['terms_logical'] for st in one_step())
             finally:
-                if own_speculation is None:
-                    os.environ.pop('FOKL_SPECULATION', None)
+                for k in side_env:
+                    os.environ.pop(k, None)
             side_res = [done_q.get(timeout=300) for _ in side_workers]
             t_side = time.perf_counter() - t_side
             cg1 = cgroup_cpu()
