@@ -879,7 +879,7 @@ SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
                 'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device',
                 'spectral_updated', 'direct_tests', 'direct_max_rel', 'chains_cancelled', 't_settle',
-                'guess_max_dev')
+                'guess_max_dev', 'direct_in_band')
 
 
 class NativeSearch:

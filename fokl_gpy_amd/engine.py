@@ -307,6 +307,8 @@ class ForwardSelection:
         self._predicted_kills = None        # columns the current sub-stage's tests will probably remove (_guess_first_tests)
         # FOKL_FORECAST_EARLY=0: G2 of the coming sub-stage's model is requested when the kill set is final, not before
         self._forecast_early = os.environ.get('FOKL_FORECAST_EARLY', '1') != '0'
+        # two ctypes calls per look, ~1 us: the model's chain takes ~1.2 ms; FOKL_SPIN scales it like the native spins
+        self._forecast_polls = int(2000 * float(os.environ.get('FOKL_SPIN', '1') or 1))
         # Both at once is the hybrid split: every rank holds N / G rows (K1, K2, K3 on its rows, the small Gram blocks and
         # residual moments all-reduced on the device -- the DEVICE work is divided by G) and the replicated search deals its
         # eigen-decompositions over the ranks as well (the HOST work that bounds configs[3] is divided by G too).  The Gram
@@ -1524,7 +1526,11 @@ class ForwardSelection:
             if (self._forecast_early and pipelined and self.native is not None and ahead is not None
                     and 'pending' in ahead and 'share' not in ahead and self._predicted_kills is not None
                     and hasattr(self.backend, 'gram_ready') and not forecasts):
-                while not full.chain_ready():
+                # (a bounded look, not a wait: a Gram block that is late leaves this to the tests -- and processes that share
+                # a CPU quota, FOKL_SYNC=blocking, do not spin here at all)
+                polls = 0 if os.environ.get('FOKL_SYNC') == 'blocking' else self._forecast_polls
+                while polls > 0 and not full.chain_ready():
+                    polls -= 1
                     if self.backend.gram_ready():
                         foresee(self._predicted_kills)
                         self.stats['forecasts_early'] = self.stats.get('forecasts_early', 0) + 1

@@ -122,6 +122,14 @@ CASES = {
     # one unit of configs[4] (dataset seed 100, chain seed 1000)
     'cfg4': lambda: run_case('cfg4_unit0_n1e5_m8', 4, unit=0),
     'cfg4b': lambda: run_case('cfg4_unit5_n1e5_m8', 4, unit=5),
+    # round 6: four more units of configs[4] (of its 64: 0, 5, 17, 29, 42, 63 are pinned) ...
+    'cfg4c': lambda: run_case('cfg4_unit17_n1e5_m8', 4, unit=17),
+    'cfg4d': lambda: run_case('cfg4_unit29_n1e5_m8', 4, unit=29),
+    'cfg4e': lambda: run_case('cfg4_unit42_n1e5_m8', 4, unit=42),
+    'cfg4f': lambda: run_case('cfg4_unit63_n1e5_m8', 4, unit=63),
+    # ... and the configs[2] family on another dataset / chain seed (dataset seed 12 + 7, chain seed 1000 + 7), so that the
+    # timed fit is not the only full-size Bernoulli search pinned
+    'cfg2b': lambda: run_case('cfg2_unit7_n1e6_m8', 2, unit=7),
     # configs[1] at its full size and the reference's default draws
     'cfg1': lambda: run_case('cfg1_n1e5_m4_splines', 1),
     # configs[3] family (M = 16, 3-way, stages capped at 3) at the largest N / draws the oracle finishes in ~1/2 h:
