@@ -32,8 +32,10 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -87,6 +89,18 @@ inline bool cpu_is_wide()
 struct alignas(64) Segment {
     uint32_t buf[MT_N + kSegWords + kSegTail];
     alignas(64) uint64_t mask[2][kSegMaskWords];
+    // Round 6, the walk in RANK space (walk_tape_ranked below).  Accepted attempts of alignment a are numbered 0, 1, .. in
+    // stream order ("rank"); cum[a][w] = how many lie in mask words < w.  Indexed by rank i (bit i of a plane):
+    //   g0[a]      the slot right behind attempt i (same alignment) is accepted;
+    //   g1[.][a]   three bit planes of G1(i) = how far the rank moves over the two gamma draws that follow attempt i when its
+    //              x1 half is cached: the accepted a-slots behind it up to the one under the second draw's uniform
+    //              (0 .. 6; 7 = more than four rejected attempts in a row there: not tabulated, the position walk decides).
+    // Entries of attempts closer than 24 slots to the segment's end look into the next segment and are not valid:
+    // safe[a] = the first such rank.  Made by the AVX-512 / BMI2 build only (finish_segment_wide).
+    alignas(64) uint64_t g0[2][kSegMaskWords + 1];
+    alignas(64) uint64_t g1[3][2][kSegMaskWords + 1];
+    uint16_t cum[2][kSegMaskWords + 2];
+    int32_t safe[2];
     int64_t index;
     std::atomic<int> ready;
 
@@ -173,6 +187,8 @@ void finish_segment_portable(Segment *seg, int o, const uint32_t *raw)
     }
 }
 
+void build_rank_tables(Segment *seg);
+
 FOKL_WIDE_TARGET inline __m512d polar_squares(const uint32_t *p)
 {
     // eight doubles from sixteen tempered words: lane = wa | wb << 32; v = (wa >> 5) 2^26 + (wb >> 6) < 2^53;
@@ -222,6 +238,48 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
         }
         m0[word] = even;
         m1[word] = odd;
+    }
+    build_rank_tables(seg);
+}
+
+// The rank tables of a finished segment (see Segment): word by word, bit-sliced.  For the attempt in a-slot j the second
+// gamma draw of an iteration that ends there looks for the first accepted attempt of the OTHER alignment from slot
+// j + 1 + a on; with m rejected ones in front of it the walk comes back to alignment a behind a-slot j + 2 + m, so
+// G1 = acc(j+1) + acc(j+2) + sum_{m >= 1} [the first m rejected] acc(j+2+m): six one-bit planes added by full adders, then
+// compressed from slot order to rank order (pext by the word's own mask) and appended at bit cum[w].
+FOKL_WIDE_TARGET void build_rank_tables(Segment *seg)
+{
+    for (int a = 0; a < 2; ++a) {
+        const uint64_t *M = seg->mask[a], *X = seg->mask[a ^ 1];
+        uint64_t *planes[4] = {seg->g0[a], seg->g1[0][a], seg->g1[1][a], seg->g1[2][a]};
+        for (auto *pl : planes) std::memset(pl, 0, sizeof(uint64_t) * (kSegMaskWords + 1));
+        uint32_t c = 0;
+        for (int w = 0; w < kSegMaskWords; ++w) {
+            seg->cum[a][w] = (uint16_t)c;
+            const uint64_t m = M[w], mn = w + 1 < kSegMaskWords ? M[w + 1] : 0;
+            const uint64_t x = X[w], xn = w + 1 < kSegMaskWords ? X[w + 1] : 0;
+#define FOKL_WIN(lo, hi, sh) (((lo) >> (sh)) | ((hi) << (64 - (sh))))
+            const uint64_t A1 = FOKL_WIN(m, mn, 1), A2 = FOKL_WIN(m, mn, 2), A3 = FOKL_WIN(m, mn, 3), A4 = FOKL_WIN(m, mn, 4),
+                           A5 = FOKL_WIN(m, mn, 5), A6 = FOKL_WIN(m, mn, 6);
+            const uint64_t E1 = ~FOKL_WIN(x, xn, 1 + a), E2 = E1 & ~FOKL_WIN(x, xn, 2 + a), E3 = E2 & ~FOKL_WIN(x, xn, 3 + a),
+                           E4 = E3 & ~FOKL_WIN(x, xn, 4 + a), E5 = E4 & ~FOKL_WIN(x, xn, 5 + a);
+#undef FOKL_WIN
+            const uint64_t t3 = E1 & A3, t4 = E2 & A4, t5 = E3 & A5, t6 = E4 & A6;
+            const uint64_t s1 = A1 ^ A2 ^ t3, c1 = (A1 & A2) | (t3 & (A1 ^ A2));
+            const uint64_t s2 = t4 ^ t5 ^ t6, c2 = (t4 & t5) | (t6 & (t4 ^ t5));
+            const uint64_t c3 = s1 & s2;
+            const uint64_t value[4] = {A1, (s1 ^ s2) | E5, (c1 ^ c2 ^ c3) | E5, ((c1 & c2) | (c3 & (c1 ^ c2))) | E5};
+            const int at = (int)(c >> 6), sh = (int)(c & 63);
+            for (int pl = 0; pl < 4; ++pl) {
+                const uint64_t bits = _pext_u64(value[pl], m);
+                planes[pl][at] |= bits << sh;
+                if (sh) planes[pl][at + 1] |= bits >> (64 - sh);
+            }
+            c += (uint32_t)__builtin_popcountll(m);
+        }
+        seg->cum[a][kSegMaskWords] = seg->cum[a][kSegMaskWords + 1] = (uint16_t)c;
+        seg->safe[a] = (int32_t)seg->cum[a][kSegMaskWords - 1] +
+                       __builtin_popcountll(M[kSegMaskWords - 1] & ((1ull << 40) - 1));   // attempts in slots < 39936 - 24
     }
 }
 
@@ -303,6 +361,7 @@ struct fokl_stream {
     std::atomic<int64_t> walker_wait_ns{0};
     std::atomic<int64_t> exact_draws{0}, gamma_draws{0};    // gamma attempts that needed libm / all of them
     std::atomic<int64_t> rollbacks{0};                      // iterations the wide walk had to redo draw by draw
+    std::atomic<int64_t> position_iterations{0};            // iterations the rank walk left to the position walk
     bool wide = false;
     std::string error;
 };
@@ -366,6 +425,7 @@ void bulk_worker(fokl_stream *e)
     struct Note {
         ~Note() { fokl_note_thread_cpu(4); }
     } note;
+
     void *scratch_mem = nullptr;
     if (posix_memalign(&scratch_mem, 64, sizeof(uint32_t) * (size_t)(MT_N + kSegWords + kSegTail + 64)) != 0) {
         std::lock_guard<std::mutex> lock(e->token_m);
@@ -910,11 +970,21 @@ static inline __attribute__((always_inline)) void walk_iteration(Walk &w, int p1
     row.gamma[1] = w.marsaglia_tsang(b_tau, c_tau);
 }
 
+int walk_tape_ranked(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                     int32_t *progress);
+
 FOKL_WIDE_TARGET int walk_tape_wide(fokl_stream *e, int p1, int draws, double astar, double atau_star,
                                     fokl_tape_row *rows, double *gam_sig, double *gam_tau, int32_t *progress)
 {
-    if (!(astar > 1.0) || !(atau_star > 1.0) || std::getenv("FOKL_STREAM_SCALAR_WALK"))
+    static const bool scalar_walk = std::getenv("FOKL_STREAM_SCALAR_WALK") != nullptr;
+    // FOKL_STREAM_WALK=positions: round 4/5's walk (positions first, tests afterwards) instead of the walk in rank space
+    static const bool position_walk = [] {
+        const char *v = std::getenv("FOKL_STREAM_WALK");
+        return v && std::strcmp(v, "positions") == 0;
+    }();
+    if (!(astar > 1.0) || !(atau_star > 1.0) || scalar_walk)
         return walk_body<true>(e, p1, draws, astar, atau_star, rows, gam_sig, gam_tau, progress);
+    if (p1 >= 2 && !position_walk) return walk_tape_ranked(e, p1, draws, astar, atau_star, rows, progress);
     constexpr int B = FOKL_TAPE_BLOCK;
     Walk w(e);
     Walk checker(e);                                        // its reader serves the values of the accept tests
@@ -1051,6 +1121,306 @@ FOKL_WIDE_TARGET int walk_tape_wide(fokl_stream *e, int p1, int draws, double as
     return FOKL_OK;
 }
 
+// ---- the walk in rank space (round 6) ---------------------------------------------------------------------------
+// What made the walk serial was "advance over k accepted attempts": a popcount loop and a select per iteration, every one
+// depending on the one before (21.7 ns per Gibbs iteration, 20 ms of a 29 ms configs[2] fit).  Counted in ACCEPTED ATTEMPTS
+// of the current alignment instead of doubles, that step is `r += k`.  What is left of an iteration's dependence is how far
+// the two gamma draws move the rank, and that is a function of the attempt the normals ended on alone -- tabulated per
+// segment by the bulk threads (Segment::g0 / g1).  So a block of iterations is walked in three passes:
+//   1. the CHASE: r -> r + k + table[r + k ..], one or three bit loads per iteration (~3 ns), nothing else;
+//   2. POSITIONS: the ranks back to stream positions (a monotone cursor over cum[] + pdep / tzcnt), the tape rows and the
+//      sources of the gamma draws -- iterations independent of each other: the core overlaps them;
+//   3. the accept TESTS of the gamma draws, sixteen at a time in vector registers (check_tests, as in walk_tape_wide).
+// Whatever the tables do not cover -- the last attempts of a segment, more than four rejected attempts in a row at a
+// gamma site, a gamma draw that does not accept its first attempt -- is walked by the position walk (walk_iteration) from
+// the exact state, which passes 2 and 3 always know.  Rows, positions and consumption are those of the scalar walk bit for
+// bit (tests/test_stream_engine.py: the builds against each other, against the one-thread recorder and numpy).
+constexpr int kChase = 128;                                 // iterations per block (a multiple of FOKL_TAPE_BLOCK)
+// FOKL_WALK_PROFILE=1: nanoseconds per pass (chase, positions, tests, position walk), printed when a stream is destroyed
+static const bool g_walk_profile = std::getenv("FOKL_WALK_PROFILE") != nullptr;
+// FOKL_ROW_STORES=cached: ordinary stores for the tape rows (A/B; default: non-temporal)
+static const bool g_row_stream = !(std::getenv("FOKL_ROW_STORES") && std::strcmp(std::getenv("FOKL_ROW_STORES"), "cached") == 0);
+static std::atomic<int64_t> g_walk_ns[4];
+static std::atomic<int64_t> g_walk_iterations{0}, g_walk_by_position{0};
+#define FOKL_LAP(i)                                                          \
+    do {                                                                     \
+        if (g_walk_profile) {                                                \
+            const int64_t t_ = now_ns();                                     \
+            g_walk_ns[i].fetch_add(t_ - lap_, std::memory_order_relaxed);    \
+            lap_ = t_;                                                       \
+        }                                                                    \
+    } while (0)
+
+// What the chase leaves of a block of iterations, and what passes 2 and 3 make of it.
+struct BlockIn {
+    const Segment *seg;
+    uint64_t lo;                                            // first double of seg
+    int a;                                                  // alignment the block's normals are read in
+    uint32_t wc0;                                           // a mask word at or before the first rank's
+    uint64_t D0, gsrc0;                                     // the walker's exact state at the block's first iteration
+    int count;
+    double b_sig, c_sig, b_tau, c_tau;
+    fokl_tape_row *rows;                                    // the block's rows
+    int32_t e[kChase];                                      // rank of the last attempt of each iteration's normals
+    uint8_t hs[kChase], h[kChase];                          // cached normal at the gamma site / at the iteration's start
+};
+struct BlockOut {
+    uint64_t source[2 * kChase], upos[2 * kChase];
+    IterationStart after[kChase];                           // the walker's state behind each iteration
+};
+
+// first iteration (0-based, within [0, count)) one of whose gamma draws does not accept its first attempt, or -1
+FOKL_WIDE_TARGET static inline int check_tests(Walk &checker, int o, const uint64_t *source, const uint64_t *upos, int count,
+                                               __m512d bvec, __m512d cvec, double b_sig, double c_sig, double b_tau,
+                                               double c_tau, int64_t &exact)
+{
+    Reader &rv = checker.r;
+    alignas(64) uint64_t first[2 * FOKL_TAPE_BLOCK], second[2 * FOKL_TAPE_BLOCK], uniform[2 * FOKL_TAPE_BLOCK];
+    uint64_t src_pad[2 * FOKL_TAPE_BLOCK];
+    for (int i0 = 0; i0 < count; i0 += FOKL_TAPE_BLOCK) {
+        const int tests = 2 * std::min(FOKL_TAPE_BLOCK, count - i0);
+        const uint64_t *src = source + 2 * i0, *up = upos + 2 * i0;
+        for (int n = 0; n < tests; ++n) {
+            const uint64_t at = src[n] & ~kCachedHalf;
+            src_pad[n] = src[n];
+            if (!rv.locate(at)) return -2;
+            const uint32_t *p = rv.seg->words() + o + 2 * (at - rv.lo);
+            std::memcpy(&first[n], p, 8);
+            std::memcpy(&second[n], p + 2, 8);
+            if (!rv.locate(up[n])) return -2;
+            std::memcpy(&uniform[n], rv.seg->words() + o + 2 * (up[n] - rv.lo), 8);
+        }
+        for (int n = tests; n < ((tests + 7) & ~7); ++n) {
+            first[n] = first[0];
+            second[n] = second[0];
+            uniform[n] = uniform[0];
+            src_pad[n] = src_pad[0];
+        }
+        unsigned sure = 0;
+        for (int v = 0; v < tests; v += 8) {
+            unsigned cached = 0;
+            for (int l = 0; l < 8; ++l) cached |= (unsigned)((src_pad[v + l] >> 63) & 1) << l;
+            sure |= sure_accepts8(_mm512_load_si512(first + v), _mm512_load_si512(second + v), _mm512_load_si512(uniform + v),
+                                  (__mmask8)cached, bvec, cvec)
+                    << v;
+        }
+        unsigned open = ~sure & (tests >= 32 ? 0xffffffffu : ((1u << tests) - 1u));
+        while (open) {
+            const int n = __builtin_ctz(open);
+            open &= open - 1;
+            ++exact;
+            const double b = (n & 1) ? b_tau : b_sig, c = (n & 1) ? c_tau : c_sig;
+            const double X = checker.value_of(src[n]);
+            double V = 1.0 + c * X;
+            bool accepted = false;
+            if (V > 0.0) {
+                const double U = rv.dbl(up[n]);
+                V = V * V * V;
+                accepted = U < 1.0 - 0.0331 * (X * X) * (X * X) || std::log(U) < 0.5 * X * X + b * (1.0 - V + std::log(V));
+            }
+            if (rv.failed) return -2;
+            if (!accepted) return i0 + (n >> 1);
+        }
+    }
+    return -1;
+}
+
+// pass 1.  From rank r / cached normal h: up to `want` iterations inside the segment.  -> count; r, h move on.
+static inline int chase_block(const Segment *seg, int a, int p1, int want, int64_t &r, int &h, BlockIn &in)
+{
+    const int64_t limit = seg->safe[a];
+    const uint64_t *G0 = seg->g0[a], *P0 = seg->g1[0][a], *P1 = seg->g1[1][a], *P2 = seg->g1[2][a];
+    int count = 0;
+    while (count < want) {
+        const int rest = p1 - h, hs = rest & 1;
+        const int64_t last = r + ((rest + 1) >> 1) - 1;
+        if (last + 2 >= limit) break;
+        int64_t next;
+        if (hs) {
+            const int sh = (int)(last & 63);
+            const size_t at = (size_t)(last >> 6);
+            const int g = (int)((P0[at] >> sh) & 1) | (int)(((P1[at] >> sh) & 1) << 1) | (int)(((P2[at] >> sh) & 1) << 2);
+            if (g == 7) break;
+            next = last + 1 + g;
+        } else {
+            next = last + 2 + (int64_t)((G0[(size_t)((last + 1) >> 6)] >> ((last + 1) & 63)) & 1);
+        }
+        in.e[count] = (int32_t)last;
+        in.hs[count] = (uint8_t)hs;
+        in.h[count] = (uint8_t)h;
+        ++count;
+        r = next;
+        h = hs;
+    }
+    in.count = count;
+    return count;
+}
+
+// Where iteration (e, hs) of alignment a ends: the two gamma draws' sources and uniforms, the state behind it.  wc: cursor
+// over the mask words (ranks only grow within a block).
+FOKL_WIDE_TARGET static inline __attribute__((always_inline)) void iteration_sites(const Segment *seg, uint64_t lo, int a,
+                                                                                   uint32_t &wc, int32_t e, int hs,
+                                                                                   uint64_t src[2], uint64_t up[2],
+                                                                                   IterationStart &after)
+{
+    const uint16_t *cum = seg->cum[a];
+    const uint32_t idx = (uint32_t)e + (hs ? 0u : 1u);
+    while (cum[wc + 1] <= idx) ++wc;
+    const uint64_t slot = 64ull * wc + (uint64_t)_tzcnt_u64(_pdep_u64(1ull << (idx - cum[wc]), seg->mask[a][wc]));
+    const uint64_t A = lo + 2 * slot + (uint64_t)a;
+    if (hs) {
+        // the x1 half of the normals' last attempt is cached: the first draw uses it, the second takes the next accepted
+        // attempt of the other alignment (at most four rejected ones in front of it: g < 7)
+        const uint64_t *X = seg->mask[a ^ 1];
+        uint64_t t = slot + 1 + (uint64_t)a;
+        uint64_t mm = X[t >> 6] >> (t & 63);
+        if (!mm) {
+            t = (t | 63) + 1;
+            mm = X[t >> 6];
+        }
+        t += (uint64_t)_tzcnt_u64(mm);
+        const uint64_t Q = lo + 2 * t + (uint64_t)(a ^ 1);
+        src[0] = A | kCachedHalf;
+        up[0] = A + 2;
+        src[1] = Q;
+        up[1] = Q + 2;
+        after = {Q + 3, Q, 1};
+    } else {
+        src[0] = A;
+        up[0] = A + 2;
+        src[1] = A | kCachedHalf;
+        up[1] = A + 3;
+        after = {A + 4, A, 0};
+    }
+}
+
+// pass 2: the block's rows, the sources of its gamma draws, the state behind every iteration
+FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut &out, const Reader &prefetcher)
+{
+    uint32_t wc = in.wc0;
+    uint64_t D = in.D0, gsrc = in.gsrc0;
+    const bool stream_rows = g_row_stream && (reinterpret_cast<uintptr_t>(in.rows) & 31) == 0;
+    for (int i = 0; i < in.count; ++i) {
+        const int lead = in.h[i];
+        iteration_sites(in.seg, in.lo, in.a, wc, in.e[i], in.hs[i], out.source + 2 * i, out.upos + 2 * i, out.after[i]);
+        // (a row is written once and read by another agent -- the device over the bus, a finish thread: streamed past the
+        // cache, no line is fetched to be overwritten; callers fence before they publish progress)
+        const __m256i rowv = _mm256_set_epi64x((long long)out.source[2 * i + 1], (long long)out.source[2 * i],
+                                               (long long)(lead ? gsrc : 0), (long long)(D | (lead ? kLeadBit : 0)));
+        if (stream_rows)
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(in.rows + i), rowv);
+        else
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(in.rows + i), rowv);
+        D = out.after[i].D;
+        gsrc = out.after[i].gauss_src;
+        prefetcher.prefetch_words(out.source[2 * i] & ~kCachedHalf);
+    }
+}
+
+FOKL_WIDE_TARGET int walk_tape_ranked(fokl_stream *e, int p1, int draws, double astar, double atau_star,
+                                      fokl_tape_row *rows, int32_t *progress)
+{
+    Walk w(e);                                              // the exact state; its reader keeps the producers ahead
+    Walk checker(e);                                        // its reader serves the values of the accept tests
+    checker.r.walker = false;
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
+    const __m512d bvec = _mm512_setr_pd(b_sig, b_tau, b_sig, b_tau, b_sig, b_tau, b_sig, b_tau);
+    const __m512d cvec = _mm512_setr_pd(c_sig, c_tau, c_sig, c_tau, c_sig, c_tau, c_sig, c_tau);
+    const int o = e->o;
+    int64_t exact = 0, rolled_back = 0, by_position = 0;
+    int k = 0, published = 0;                               // iterations that stand / that `progress` has announced
+    auto publish = [&](int upto) {
+        const int whole = upto == draws ? draws : upto - upto % FOKL_TAPE_BLOCK;
+        if (progress && whole > published) {
+            _mm_sfence();                                   // the rows were streamed (block_positions)
+            __atomic_store_n(progress, whole, __ATOMIC_RELEASE);
+        }
+        published = std::max(published, whole);
+    };
+    BlockIn in;
+    std::unique_ptr<BlockOut> out(new BlockOut());
+    in.b_sig = b_sig;
+    in.c_sig = c_sig;
+    in.b_tau = b_tau;
+    in.c_tau = c_tau;
+    while (k < draws && !w.r.failed) {
+        int64_t lap_ = g_walk_profile ? now_ns() : 0;
+        // ---- pass 1: the chase, inside the segment under the walker ----
+        if (w.r.locate(w.D) && w.D - w.r.lo < (uint64_t)kSegDoubles - 64) {
+            const Segment *seg = w.r.seg;
+            const int a = (int)(w.D & 1);
+            const uint64_t q = (w.D - w.r.lo) >> 1;         // attempts of alignment a from slot q on are unread
+            int64_t r = (int64_t)seg->cum[a][q >> 6] + __builtin_popcountll(seg->mask[a][q >> 6] & ~(~0ull << (q & 63)));
+            int h = w.has_gauss;
+            const int want = std::min(kChase, draws - k);
+            const int count = chase_block(seg, a, p1, want, r, h, in);
+            FOKL_LAP(0);
+            if (count > 0) {
+                in.seg = seg;
+                in.lo = w.r.lo;
+                in.a = a;
+                in.wc0 = (uint32_t)(q >> 6);
+                in.D0 = w.D;
+                in.gsrc0 = w.gauss_src;
+                in.rows = rows + k;
+                // ---- pass 2: positions, rows, the sources of the gamma draws ----
+                block_positions(in, *out, w.r);
+                FOKL_LAP(1);
+                // ---- pass 3: the accept tests ----
+                const int redo = check_tests(checker, o, out->source, out->upos, count, bvec, cvec, b_sig, c_sig, b_tau, c_tau,
+                                             exact);
+                FOKL_LAP(2);
+                if (redo == -2) {
+                    w.r.failed = true;
+                    break;
+                }
+                const int good = redo < 0 ? count : redo;   // iterations k .. k + good - 1 stand
+                if (good > 0) {
+                    w.D = out->after[good - 1].D;
+                    w.gauss_src = out->after[good - 1].gauss_src;
+                    w.has_gauss = out->after[good - 1].has_gauss;
+                    k += good;
+                }
+                if (redo >= 0) ++rolled_back;
+                if (redo < 0 && count == want) {
+                    publish(k);
+                    continue;
+                }
+            }
+        }
+        if (w.r.failed) break;
+        // ---- one iteration by the position walk: where the block stopped (a draw to redo, the segment's end, a long run of
+        // rejected attempts), from the exact state ----
+        if (k < draws) {
+            if (g_walk_profile) lap_ = now_ns();
+            walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k]);
+            ++k;
+            ++by_position;
+            FOKL_LAP(3);
+        }
+        publish(k);
+    }
+    e->exact_draws.fetch_add(exact + w.exact, std::memory_order_relaxed);
+    e->gamma_draws.fetch_add(2 * (int64_t)draws, std::memory_order_relaxed);
+    e->rollbacks.fetch_add(rolled_back, std::memory_order_relaxed);
+    e->position_iterations.fetch_add(by_position, std::memory_order_relaxed);
+    if (g_walk_profile) {
+        g_walk_iterations.fetch_add(k, std::memory_order_relaxed);
+        g_walk_by_position.fetch_add(by_position, std::memory_order_relaxed);
+    }
+    if (w.r.failed || checker.r.failed) {
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        fokl_set_global_error("fokl_stream_walk: the stream's producers stopped (" + e->error + ")");
+        return FOKL_ERR_STATE;
+    }
+    publish(draws);
+    e->D = w.D;
+    e->has_gauss = w.has_gauss;
+    e->gauss_src = w.gauss_src;
+    return FOKL_OK;
+}
+
 int walk_tape_base(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
                    double *gam_sig, double *gam_tau, int32_t *progress)
 {
@@ -1110,6 +1480,14 @@ extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_
 extern "C" void fokl_stream_destroy(fokl_stream *e)
 {
     if (!e) return;
+    if (g_walk_profile && g_walk_iterations.load() > 0) {
+        const double n = (double)g_walk_iterations.exchange(0);
+        std::fprintf(stderr, "fokl_stream: rank walk, %.0f iterations: chase %.2f positions %.2f tests %.2f ns per iteration; "
+                             "position walk %.0f iterations, %.1f ns each\n", n, g_walk_ns[0].exchange(0) / n,
+                     g_walk_ns[1].exchange(0) / n, g_walk_ns[2].exchange(0) / n, (double)g_walk_by_position.load(),
+                     g_walk_ns[3].exchange(0) / std::max(1.0, (double)g_walk_by_position.load()));
+        g_walk_by_position.store(0);
+    }
     {
         std::lock_guard<std::mutex> lock(e->token_m);
         e->stop = true;
