@@ -102,6 +102,11 @@ GOLDENS = {  # (config, unit, rows, fit overrides) -> fixture made by tests/gold
     (2, 0, 1_000_000): ('cfg2_n1e6_m8', {}),
     (4, 0, 100_000): ('cfg4_unit0_n1e5_m8', {}),
     (4, 5, 100_000): ('cfg4_unit5_n1e5_m8', {}),
+    (4, 17, 100_000): ('cfg4_unit17_n1e5_m8', {}),
+    (4, 29, 100_000): ('cfg4_unit29_n1e5_m8', {}),
+    (4, 42, 100_000): ('cfg4_unit42_n1e5_m8', {}),
+    (4, 63, 100_000): ('cfg4_unit63_n1e5_m8', {}),
+    (2, 7, 1_000_000): ('cfg2_unit7_n1e6_m8', {}),
     (1, 0, 100_000): ('cfg1_n1e5_m4_splines', {}),
     (3, 0, 100_000): ('cfg3_n1e5_m16_way3', dict(burnin=30, draws=30)),
     (3, 0, 1_000_000): ('cfg3_n1e6_m16_way3', dict(burnin=30, draws=30)),
@@ -422,8 +427,7 @@ def KERNEL_SLOTS():
     """(name in the JSON line, timing slot of the library) of every kernel a fit launches."""
     from fokl_gpy_amd import _capi
     return (('basis_build', _capi.K_BASIS), ('gram', _capi.K_GRAM), ('gram_mfma', _capi.K_GRAM_MFMA),
-            ('gram_reduce', _capi.K_GRAM_REDUCE), ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF),
-            ('inputs_touch', _capi.K_TOUCH))
+            ('gram_reduce', _capi.K_GRAM_REDUCE), ('resid', _capi.K_RESID), ('resid_matrix_free', _capi.K_RESID_MF))
 
 
 def kernel_report(kern, n, m, cfg):
@@ -449,18 +453,7 @@ def kernel_report(kern, n, m, cfg):
     kernels = {'basis_build': roof('basis_build', 'hbm'), 'gram': roof('gram', 'hbm'),
                'gram_mfma': roof('gram_mfma', 'mfma'), 'gram_reduce': roof('gram_reduce', 'hbm'),
                'resid': roof('resid', 'hbm'),
-               'resid_matrix_free': roof('resid_matrix_free', 'hbm'),
-               'inputs_touch': roof('inputs_touch', 'hbm')}
-    if kernels['inputs_touch'] and kernels['basis_build']:
-        # the read of the inputs ahead of every basis build (it leaves them in the Infinity Cache) belongs to the price of
-        # the build: both launches together against the build's algorithmic bytes
-        # (FOKL_K1_TOUCH=1 runs only: `frac` / `achieved` ARE the pair then, the build launch alone goes under kernel_only_*)
-        kb, kt = kern['basis_build'], kern['inputs_touch']
-        together = kb['bytes'] / ((kb['ms'] + kt['ms']) * 1e-3) / 1e9
-        alone = kernels['basis_build']
-        alone.update(kernel_only_gbs=alone['achieved'], kernel_only_frac=alone['frac'], achieved=together,
-                     frac=together / HBM_PEAK_GBS, with_inputs_touch_gbs=together,
-                     with_inputs_touch_frac=together / HBM_PEAK_GBS)
+               'resid_matrix_free': roof('resid_matrix_free', 'hbm')}
     mf = kernels['resid_matrix_free']
     if mf:
         # the matrix-free residual pass trades the column reads for fp64 vector arithmetic: re-forming the columns
@@ -513,6 +506,45 @@ def kernel_report(kern, n, m, cfg):
     return kernels, dominant, gpu_ms
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this one -- the same
+    command line, RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would (no torch needed on the box; the ranks find each
+    other through fokl_gpy_amd.dist's own rendezvous, which is keyed on MASTER_PORT and the run id).  This process never
+    touches the GPU; rank 0 prints the JSON line.  -> exit code (the first failing rank's; the others are ended then)."""
+    import socket
+    import subprocess
+    import time
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]                             # free now; only names this launch (dist._rendezvous_path)
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                TORCHELASTIC_RUN_ID=f'bench_{port}', TORCHELASTIC_RESTART_COUNT='0')
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    ranks = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    code = 0
+    try:
+        alive = list(ranks)
+        while alive:
+            for p in list(alive):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                alive.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc
+                    for q in alive:                           # one rank failed: the others would wait for it for ever
+                        q.terminate()
+            time.sleep(0.05)
+    except BaseException:
+        for p in ranks:
+            if p.poll() is None:
+                p.kill()
+        raise
+    return code
+
+
 def device_of(local):
     """HIP device of the rank with this LOCAL_RANK.  FOKL_BENCH_SHARE_GPU=1 (launcher rehearsals on a box with fewer GPUs
     than ranks) wraps the ranks round the devices there are -- RCCL then refuses to initialise (two ranks on one device) and
@@ -545,6 +577,49 @@ def bring_up_comm(ctx, rank, world, use_rccl, need_rccl):
     if world == 1:                                            # FOKL_BENCH_FORCE_RCCL=1: RCCL in a world of one
         return dist.RcclComm(ctx, rank, world), 'RCCL'
     return dist.bring_up(ctx, rank, world, need_rccl, log=lambda msg: print(f"bench.py: {msg}", file=sys.stderr))
+
+
+def _host_reduced_backend():
+    from fokl_gpy_amd import engine
+
+    class HostReduced(engine.HipBackend):
+        """Rehearsal only (ranks sharing one GPU, no RCCL): the row-sharded modes' sums over the ranks -- Gram blocks,
+        residual moments, what fokl_gram(allreduce=1) / fokl_bic_resid(allreduce=1) do with ncclAllReduce on the device --
+        are formed on the host over the control plane.  Same call order on every rank (the replicated search)."""
+
+        def __init__(self, ctx, comm):
+            super().__init__(ctx)
+            self.comm, self._launched_reduced = comm, False
+
+        def gram(self, row_slots, col_slots, allreduce=False):
+            g = self.ctx.gram(row_slots, col_slots, 0, False)
+            return self.comm.allreduce_sum(g) if allreduce else g
+
+        def gram_launch(self, row_slots, col_slots, allreduce=False):
+            self._launched_reduced = bool(allreduce)
+            return self.ctx.gram_launch(row_slots, col_slots, False)
+
+        def gram_fetch(self, shape):
+            g = self.ctx.gram_fetch(shape)
+            return self.comm.allreduce_sum(g) if self._launched_reduced else g
+
+        def _moments(self, pair, allreduce):
+            if not allreduce:
+                return pair
+            s = self.comm.allreduce_sum(np.array(pair, dtype=np.float64))
+            return float(s[0]), float(s[1])
+
+        def bic_resid(self, slots, betahat, allreduce=False):
+            return self._moments(self.ctx.bic_resid(slots, betahat, False), allreduce)
+
+        def bic_resid_fetch(self, allreduce=False):
+            return self._moments(self.ctx.bic_resid_fetch(False), allreduce)
+
+    return HostReduced
+
+
+def HostReducedBackend(ctx, comm):
+    return _host_reduced_backend()(ctx, comm)
 
 
 def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done, gate=None, domain=None):
@@ -773,15 +848,29 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-throughput', action='store_true',
                     help='skip the secondary measurement of the default run (several fits sharing the GPU)')
+    ap.add_argument('--launch-check', action='store_true', help=argparse.SUPPRESS)    # tests: bring the ranks up, nothing else
     args = ap.parse_args()
 
     from fokl_gpy_amd import dist
     rank, world, local = dist.env_rank_world()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started by hand: this process becomes the launcher of its own ranks (before anything here touches the GPU)
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it without WORLD_SIZE (it launches its own "
+                  f"ranks) or with a launcher that starts {args.gpus} of them", file=sys.stderr)
             sys.exit(2)
+    if args.launch_check:
+        # (no GPU involved: the ranks of the launch meet over the control plane and say who they are)
+        tcp = dist.TcpComm(rank, world)
+        seen = tcp.allgather([float(rank), float(local)]) if world > 1 else np.array([[0.0, 0.0]])
+        tcp.barrier()
+        tcp.close()
+        if rank == 0:
+            print(json.dumps({'launch_check': [int(v) for v in seen[:, 0]], 'world': world,
+                              'local_world': int(os.environ.get('LOCAL_WORLD_SIZE', '1'))}), flush=True)
+        return
     os.environ['FOKL_DEVICE'] = str(device_of(local))
     from fokl_gpy_amd import FoKLRoutines, _capi, engine
     cfg = args.config
@@ -874,7 +963,13 @@ def main():
     for _ in range(fits_per_step - 1):                        # one resident dataset (and stream) per fit of a step
         backends.append(engine.HipBackend(_capi.DeviceContext(device_of(local))))
     ctx = backends[0].ctx
-    comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=one_fit_for_all)
+    # launcher rehearsals with the ranks on one GPU (FOKL_BENCH_SHARE_GPU=1; RCCL refuses two ranks on a device):
+    # FOKL_BENCH_SHARDED_OVER_TCP=1 lets the sharded modes carry their exchange steps over the control plane instead
+    over_tcp = os.environ.get('FOKL_BENCH_SHARDED_OVER_TCP', '0') == '1'
+    comm, comm_kind = bring_up_comm(ctx, rank, world, use_rccl, need_rccl=one_fit_for_all and not over_tcp)
+    if one_fit_for_all and world > 1 and comm_kind != 'RCCL':
+        comm_kind = 'TCP control plane carries the exchange steps (rehearsal: FOKL_BENCH_SHARDED_OVER_TCP=1)'
+        backends = [HostReducedBackend(b.ctx, comm) for b in backends]
     # barriers and the gathers of timing figures go over the TCP control plane when there is one (N > 1): a launch of
     # independent fits then runs no RCCL collective at all, RCCL carries the data path of the sharded modes only
     control = getattr(comm, 'control', None) or comm
@@ -1063,6 +1158,38 @@ def main():
                                      f'iteration), fitted after the timed region'
                 parity_checked = True
                 side._backend_override.ctx.close()
+    if cfg == 3 and world > 1 and one_fit_for_all and not args.inputs and not args.no_parity and n == 1_000_000:
+        # N > 1, one fit for all ranks: the SHARDED fit itself once more with the golden's chain length (burnin 250 + draws
+        # 250, see above), on the data every rank already holds -- compared on EVERY rank, the verdicts gathered
+        name, over = GOLDENS[(3, 0, 1_000_000)]
+        if os.path.exists(os.path.join(ROOT, 'tests', 'golden', name + '.npz')):
+            model0, backend0, _, _, _, n_local0 = fits[0]
+            kept = model0.burnin, model0.draws
+            model0.burnin, model0.draws = over['burnin'], over['draws']
+            np.random.seed(spec0['seed_fit'])
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                if mode == 'rows':
+                    model0._search(backend0, n_local0, m, n_global=spec0['rows'], row_sharded=True)
+                elif mode == 'hybrid':
+                    model0._search(backend0, n_local0, m, n_global=spec0['rows'], row_sharded=True, comm=comm,
+                                   candidate_sharded=True)
+                else:
+                    model0._search(backend0, n_local0, m, comm=comm, candidate_sharded=True)
+            backend0.ctx.sync()
+            mine = compare_with_golden(name, model0, model0.betas, model0.mtx, model0.evs, np.random.get_state())
+            model0.burnin, model0.draws = kept
+            verdicts = control.allgather([1.0 if mine.get('ok') else 0.0, float(mine.get('max_rel_bic', 1.0)),
+                                          float(mine.get('max_draw_err_over_scale', 1.0))])
+            if rank == 0:
+                parity = mine
+                parity['workload'] = (f'the {mode}-sharded fit of configs[3] over {world} ranks with burnin {over["burnin"]} + '
+                                      f'draws {over["draws"]} (the golden\'s chain length), after the timed region')
+                parity['ok_on_every_rank'] = bool(np.all(verdicts[:, 0] == 1.0))
+                parity['max_rel_bic_by_rank'] = verdicts[:, 1].tolist()
+                parity['max_draw_err_over_scale_by_rank'] = verdicts[:, 2].tolist()
+                parity['ok'] = bool(parity.get('ok')) and parity['ok_on_every_rank']
+                parity_checked = True
 
     # What a drop-in user sees: one `fit(inputs, data, clean=True)` call from host arrays to returned draws (formatting,
     # normalisation, defaults, H2D upload + transposition, the search) -- after the timed region, on a warm process,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FOKL_HIP_LIBRARY', os.path.join(_HERE, 'libfokl_hip.so'))   # override: A/B builds
 
 UNIQUE_ID_BYTES = 128
-K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA, K_GRAM_REDUCE, K_TOUCH = 0, 1, 2, 3, 4, 5, 6, 7
+K_BASIS, K_GRAM, K_RESID, K_PREDICT, K_RESID_MF, K_GRAM_MFMA, K_GRAM_REDUCE = 0, 1, 2, 3, 4, 5, 6
 RESID_TERMS_MAX_FACTORS = 32
 RESID_TERMS_MAX_ORDER = 8
 RESID_TERMS_LAYOUTS = ((8, 1), (16, 1), (8, 2), (4, 4), (2, 8), (8, 4), (16, 2), (4, 8))    # inputs x orders per input (csrc/fokl_hip.hip)

@@ -14,7 +14,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/fokl_hip.h"
+#include "../../include/fokl_hip_internal.h"
 #include "fokl_kernels.hip.h"
 
 using namespace fokl;
@@ -699,19 +699,10 @@ static int launch_basis(fokl_ctx *ctx, const int32_t *terms, const int32_t *slot
                 ++m_used;
             }
     }
-    // In a fit K1 comes behind Gram and residual launches that stream 0.5-1 GB of columns.  While those went through the 256 MB
-    // Infinity Cache with the default policy they evicted the inputs, whose 8 N m_used bytes then came from HBM IN BETWEEN
-    // K1's 8 N T bytes of stores (a mixed stream runs at 4.3-4.6 TB/s where stores alone run at 5.5,
-    // profiles/hbm_write_ceiling_r03.txt).  Round 4 read the inputs once just before, in a launch of its own (0.53 -> 0.65 for
-    // K1 alone, 0.49-0.51 with that launch charged to it); round 5 marks the column streams non-temporal instead
-    // (FOKL_STREAM_NT, fokl_kernels.hip.h): 0.65 with no extra launch.  FOKL_K1_TOUCH=1 brings the launch back (A/B runs).
-    if (deriv.order == 0 && env_int("FOKL_K1_TOUCH", 0) != 0 && ctx->n >= 65536) {
-        const int64_t words = ctx->n / 2;                   // 16-byte loads
-        TimedRegion timed(ctx, FOKL_K_TOUCH, 8.0 * (double)ctx->n * (double)m, 0.0);
-        hipLaunchKernelGGL(inputs_touch_kernel, dim3((unsigned)(cu_count(ctx) * 4)), dim3(256), 0, ctx->stream, ctx->d_x,
-                           ctx->ld, words, m, ctx->d_zero);
-        HIP_TRY(ctx, hipGetLastError());
-    }
+    // (In a fit K1 comes behind Gram and residual launches that stream 0.5-1 GB of columns.  Those streams are marked
+    // non-temporal, FOKL_STREAM_NT in fokl_kernels.hip.h, so that they do not evict the 8 N m bytes of inputs from the 256 MB
+    // Infinity Cache: K1 reads them from there, 0.61-0.65 of the HBM roof with no helper launch.  Round 4's separate read of
+    // the inputs ahead of every build -- 0.50-0.54 for the pair -- is gone.)
     const double alg_bytes = 8.0 * (double)ctx->n * (double)(m_used + T);
     TimedRegion timed(ctx, FOKL_K_BASIS, alg_bytes, 0.0);
     typedef void (*basis_fn)(const double *, int64_t, int64_t, const double *, int, const BasisPlan *, const int *,

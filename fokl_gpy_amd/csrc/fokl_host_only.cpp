@@ -7,7 +7,7 @@
 #include <mutex>
 #include <string>
 
-#include "../../include/fokl_hip.h"
+#include "../../include/fokl_hip_internal.h"
 
 static std::mutex g_err_mutex;
 static std::string g_err;

@@ -38,7 +38,7 @@
 #include <sched.h>
 #include <sys/prctl.h>
 
-#include "../../include/fokl_hip.h"
+#include "../../include/fokl_hip_internal.h"
 #include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip

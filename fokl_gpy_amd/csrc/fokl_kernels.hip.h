@@ -167,24 +167,6 @@ __device__ __forceinline__ void spline_locate(double x, int width, bool twice_no
 
 // What a launch differentiates: the factor of input `input` is replaced by its `order`-th derivative divided by
 // `div` (= (span / l) ** order, FR:758-759, 781-782); input < 0 = plain basis build.
-// Reads the m input rows once (16-byte loads, nothing kept): they are then in the Infinity Cache for the basis build that
-// follows (fokl_hip.hip build_terms_impl).  `sink` is written only if the sum of everything read is a value it cannot be.
-__global__ __launch_bounds__(256) void inputs_touch_kernel(const double *__restrict__ x, int64_t ld, int64_t words, int m,
-                                                           double *__restrict__ sink)
-{
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-    double acc = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int k = 0; k < m; ++k) {
-        const double2_t *row = reinterpret_cast<const double2_t *>(x + (int64_t)k * ld);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
-            const double2_t v = row[i];
-            acc += v.x + v.y;
-        }
-    }
-    if (acc == 1.2345678901234567e300) sink[0] = acc;
-}
-
 struct DerivSpec {
     int input;
     int order;

@@ -44,7 +44,7 @@
 
 #include <immintrin.h>
 
-#include "../../include/fokl_hip.h"
+#include "../../include/fokl_hip_internal.h"
 #include "fokl_spin.h"
 
 extern void fokl_set_global_error(const std::string &msg);   // fokl_hip.hip
@@ -56,7 +56,7 @@ constexpr int MT_N = 624, MT_SHIFT = 227;                   // 227 = 624 - 397
 constexpr int kSegBlocks = FOKL_SEGMENT_BLOCKS;
 constexpr int kSegWords = kSegBlocks * MT_N;                // 159 744 words
 constexpr int kSegDoubles = kSegWords / 2;                  // 79 872 doubles (attempts may start at each of them)
-static_assert(kSegDoubles == FOKL_SEGMENT_DOUBLES, "include/fokl_hip.h and this file disagree on the segment size");
+static_assert(kSegDoubles == FOKL_SEGMENT_DOUBLES, "include/fokl_hip_internal.h and this file disagree on the segment size");
 constexpr int kSegSlots = kSegDoubles / 2;                  // 39 936 attempts per alignment
 constexpr int kSegMaskWords = kSegSlots / 64;               // 624 mask words per alignment
 constexpr int kSegTail = 32;                                // words of the next segment kept behind this one's

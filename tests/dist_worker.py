@@ -80,8 +80,64 @@ def synth(seed, n, m):
     return x, y
 
 
+def many_ranks(out_dir):
+    """`dist_worker.py OUT many`: more ranks than a forward step has candidates.  M = 3 inputs, 2-way: the sub-stages bring
+    T = 3 or 6 candidate terms (one per input or pair; two orders over a pair), so with 4 or 8 ranks T < world or T % world != 0 -- shares of one
+    column on some ranks and PADDING-only shares on the others (engine._share_of).  Candidates and hybrid: model, calls, stream
+    = the single-process fit's, ranks bitwise alike."""
+    tdist.init_process_group('gloo')
+    comm = GlooComm()
+    rank, world = comm.rank, comm.world
+    res = {'world': world}
+    n, m = 640, 3
+    rng = np.random.default_rng(23)
+    x = rng.random((n, m))
+    y = np.sin(4 * x[:, 0]) + x[:, 1] * x[:, 2] + 0.05 * rng.standard_normal(n)
+    hy = dict(kernel='Bernoulli Polynomials', burnin=40, draws=40, a=4, atau=4, UserWarnings=False, ConsoleOutput=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        single = FoKLRoutines.FoKL(**hy)
+        single._backend_override = OracleBackend()
+        np.random.seed(4)
+        sb, sm, se = single.fit(x, y, clean=True)
+        single_state = np.random.get_state()
+        res['new_terms'] = sorted({int(t['built']) for t in single.fit_trace if not t['kill']})
+        for mode in ('cand', 'hybrid'):
+            if mode == 'cand':
+                fit = FoKLRoutines.FoKL(**hy)
+                backend = OracleBackend()
+                fit._backend_override = backend
+                fit._prepare_fit(x, y, dict(clean=True))
+                np.random.seed(4)
+                fb, fm, fe = fit._search(backend, n, m, comm=comm, candidate_sharded=True)
+            else:
+                lo, hi = dist.shard_range(n, rank, world)
+                fit = FoKLRoutines.FoKL(b=single.b, btau=single.btau, **hy)
+                backend = ShardedOracleBackend(comm)
+                fit.inputs, fit.data = single.inputs[lo:hi], single.data[lo:hi]
+                fit._upload(backend, fit.inputs, fit.data)
+                np.random.seed(4)
+                fb, fm, fe = fit._search(backend, hi - lo, m, n_global=n, row_sharded=True, comm=comm, candidate_sharded=True)
+            state = np.random.get_state()
+            res[mode + '_driver'] = fit.fit_stats['search_driver']
+            res[mode + '_mtx_equal'] = bool(fm.shape == sm.shape and np.array_equal(fm, sm))
+            res[mode + '_calls_equal'] = [t['cols'] for t in fit.fit_trace] == [t['cols'] for t in single.fit_trace]
+            res[mode + '_stream_equal'] = bool(np.array_equal(single_state[1], state[1]) and single_state[2:] == state[2:])
+            res[mode + '_evs_err'] = float(np.max(np.abs(fe - se) / np.abs(se))) if len(fe) == len(se) else 1.0
+            res[mode + '_betas_err'] = float(np.max(np.abs(fb - sb) / np.max(np.abs(sb), axis=0))) if fb.shape == sb.shape else 1.0
+            res[mode + '_gathers'] = int(fit.fit_stats.get('candidate_gathers', 0))
+            digest = comm.allgather([float(np.sum(fb)), float(np.sum(fe)), float(fm.sum())])
+            res[mode + '_ranks_bitwise_equal'] = bool(np.all(digest == digest[0]))
+    comm.barrier()
+    with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as fh:
+        json.dump(res, fh)
+    tdist.destroy_process_group()
+
+
 def main():
     out_dir = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == 'many':
+        return many_ranks(out_dir)
     tdist.init_process_group('gloo')
     comm = GlooComm()
     rank, world = comm.rank, comm.world

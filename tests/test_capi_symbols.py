@@ -1,4 +1,5 @@
-"""The C-ABI shared library loads on a GPU-less host and exports exactly what include/fokl_hip.h declares."""
+"""The C-ABI shared library loads on a GPU-less host and exports exactly what include/fokl_hip.h (the boundary) and
+include/fokl_hip_internal.h (this package's own plumbing) declare."""
 import ctypes
 import os
 import re
@@ -8,11 +9,12 @@ import pytest
 from helpers import ROOT
 from fokl_gpy_amd import _capi
 
-HEADER = os.path.join(ROOT, 'include', 'fokl_hip.h')
+HEADER = os.path.join(ROOT, 'include', 'fokl_hip.h')                       # the C ABI: what a maintainer binds
+INTERNAL = os.path.join(ROOT, 'include', 'fokl_hip_internal.h')            # this package's own plumbing (_capi.py only)
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+def declared_symbols(path=HEADER):
+    text = open(path).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(fokl_[a-z0-9_]+)\s*\(', text)))
 
@@ -24,14 +26,33 @@ def test_header_declares_the_documented_entry_points():
         assert must in syms
 
 
+def test_the_boundary_is_separate_from_the_plumbing():
+    """include/fokl_hip.h is the stable boundary (SURVEY 8(b)'s set + the K1-K3 launch forms, predict, derivatives, clean,
+    GP_Integrate, comm); the search / pool / stream / device-engine plumbing lives in fokl_hip_internal.h and nowhere else."""
+    public, internal = declared_symbols(HEADER), declared_symbols(INTERNAL)
+    assert not set(public) & set(internal)
+    prefixes = ('fokl_search_', 'fokl_pool_', 'fokl_stream_', 'fokl_dchain_', 'fokl_dspectral_', 'fokl_outcome_',
+                'fokl_spectrum_')
+    assert not [s for s in public if s.startswith(prefixes)]
+    assert len(public) <= 50
+    # both headers are plain C (the boundary needs nothing of the plumbing)
+    import shutil
+    import subprocess
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc:
+        for header in (HEADER, INTERNAL):
+            res = subprocess.run([cc, '-fsyntax-only', '-x', 'c', '-std=c99', '-Wall', header], capture_output=True, text=True)
+            assert res.returncode == 0, res.stderr
+
+
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_capi.LIB_PATH)
-    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    missing = [s for s in declared_symbols(HEADER) + declared_symbols(INTERNAL) if not hasattr(lib, s)]
     assert missing == []
 
 
 def test_binding_table_matches_header():
-    assert sorted(_capi.SIGNATURES.keys()) == declared_symbols()
+    assert sorted(_capi.SIGNATURES.keys()) == sorted(declared_symbols(HEADER) + declared_symbols(INTERNAL))
 
 
 def test_no_device_is_reported_not_hidden():

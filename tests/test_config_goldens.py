@@ -20,7 +20,9 @@ from helpers import GOLDEN, OracleBackend
 from fokl_gpy_amd import FoKLRoutines, getKernels
 
 CASES = ['cfg4_unit0_n1e5_m8', 'cfg4_unit5_n1e5_m8', 'cfg2_n1e6_m8', 'cfg1_n1e5_m4_splines', 'cfg3_n1e5_m16_way3',
-         'cfg3_n1e6_m16_way3', 'cfg3_n1e6_m16_way3_d250']
+         'cfg3_n1e6_m16_way3', 'cfg3_n1e6_m16_way3_d250',
+         # round 6: four more of configs[4]'s 64 units, and the configs[2] family on another dataset / chain seed
+         'cfg4_unit17_n1e5_m8', 'cfg4_unit29_n1e5_m8', 'cfg4_unit42_n1e5_m8', 'cfg4_unit63_n1e5_m8', 'cfg2_unit7_n1e6_m8']
 
 
 def _sha(a):
@@ -185,7 +187,6 @@ MODES = [
     (('FOKL_EIGH', 'device'),),                     # G2 by the Jacobi kernels
     (('FOKL_G2_DEFER_FROM', '8'),),                 # G2 of accepted models only when something needs it
     (('FOKL_SPECULATE_ACROSS', '0'), ('FOKL_SPECULATION', '4')),   # a short order book, nothing ordered across the boundary
-    (('FOKL_K1_TOUCH', '1'),),                      # round 4's inputs_touch launch before every basis build
     (('FOKL_DCHAIN_ROWS', '0'),),                   # tapes materialised on the host, read over the bus
 ]
 

@@ -1,9 +1,12 @@
-"""N > 1 host logic on CPU: two ranks, gloo backend, launched exactly like the driver launches bench.py."""
+"""N > 1 host logic on CPU: two ranks, gloo backend, launched exactly like the driver launches bench.py; four and eight
+ranks on a dataset whose forward steps have fewer candidates than there are ranks."""
 import json
 import os
 import socket
 import subprocess
 import sys
+
+import pytest
 
 from helpers import ROOT
 
@@ -54,3 +57,25 @@ def test_two_rank_collectives_rowshard_and_replicas(tmp_path):
     assert results[0]['replica_terms'] == results[1]['replica_terms']
     assert results[0]['replica_terms'][0] == results[0]['replica_own_terms']
     assert results[1]['replica_terms'][1] == results[1]['replica_own_terms']
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_more_ranks_than_candidates(tmp_path, world):
+    """T = 3 or 6 candidate terms per forward step over 4 and 8 ranks (T < world, T % world != 0): ranks whose share of the
+    candidates is padding only (engine._share_of); candidates and hybrid (rows + candidates) under the native driver --
+    the single-process model, call sequence and stream, every rank the same bits."""
+    env = dict(os.environ, OPENBLAS_NUM_THREADS='1', OMP_NUM_THREADS='1', FOKL_SPIN='0.05')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+           '127.0.0.1', '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path), 'many']
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    results = [json.load(open(tmp_path / f'rank{r}.json')) for r in range(world)]
+    for res in results:
+        # forward steps of 3 and of 6 candidates: fewer than ranks, or not a multiple of their number
+        assert res['world'] == world and res['new_terms'] == [3, 6]
+        for mode in ('cand', 'hybrid'):
+            assert res[mode + '_driver'] == 'native'
+            assert res[mode + '_mtx_equal'] and res[mode + '_calls_equal'] and res[mode + '_stream_equal'], mode
+            assert res[mode + '_evs_err'] < 1e-10 and res[mode + '_betas_err'] < 1e-8, mode
+            assert res[mode + '_ranks_bitwise_equal'], mode
+        assert res['cand_gathers'] >= 1

@@ -164,3 +164,24 @@ def test_attach_happens_only_when_every_rank_is_up():
     assert all(one.get('kind') == 'RCCL' and one['context'] == ['attached', 'closed'] for one in res), res
     res = _launch(['ok', 'fail', 'ok'], need_rccl=False)
     assert [one['context'] for one in res] == [['dropped'], [], ['dropped']], res
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): the process starts its N ranks itself --
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them, no torch involved -- and the ranks
+    meet over dist.TcpComm.  --launch-check stops there (no GPU needed); a launcher that started the wrong number of ranks
+    is still refused."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE',
+                                                             'MASTER_PORT', 'TORCHELASTIC_RUN_ID')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--launch-check'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line == {'launch_check': [0, 1, 2, 3], 'world': 4, 'local_world': 4}
+    wrong = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--launch-check'],
+                           env=dict(env, WORLD_SIZE='2', RANK='0'), capture_output=True, text=True, timeout=300)
+    assert wrong.returncode == 2 and 'WORLD_SIZE=2' in wrong.stderr

@@ -81,7 +81,9 @@ def check_job(job, gram, idx):
     return job.info()
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 8, 17, 31, 32, 33, 47, 48, 49, 64, 65, 66, 95, 96, 97, 127, 128, 129, 130, 144, 191, 192])
+# (the engine is opt-in -- FOKL_EIGH=device | hybrid, an honest negative result of round 4, DESIGN section 5 -- and keeps a
+# handful of tests: the sizes around its tile edges and its largest model)
+@pytest.mark.parametrize('n', [1, 3, 66, 129, 192])
 def test_decomposition_against_lapack(engine, n):
     rng = np.random.default_rng(100 + n)
     gram = gram_like(n + 3, rng)
@@ -93,21 +95,6 @@ def test_decomposition_against_lapack(engine, n):
         info = check_job(job, gram, idx)
         assert not info['not_converged'] and (n < 2 or 1 <= info["sweeps"] <= 24)
     finally:
-        job.release()
-
-
-def test_more_jobs_than_work_areas(engine):
-    """A job in flight holds one of 64 device work areas: the 65th launch waits for the oldest to finish."""
-    rng = np.random.default_rng(17)
-    gram = gram_like(40, rng)
-    jobs = []
-    for k in range(150):
-        idx = np.concatenate([[0], 1 + np.sort(rng.choice(38, size=int(rng.integers(3, 38)), replace=False))]).astype(np.int32)
-        jobs.append((engine.submit(gram, idx, launch=(k % 7 == 0)), idx))
-    engine.flush()
-    for job, idx in jobs[::5]:
-        check_job(job, gram, idx)
-    for job, idx in jobs:
         job.release()
 
 
@@ -128,16 +115,6 @@ def test_many_jobs_of_mixed_sizes_in_one_grid(engine):
         job.release()
 
 
-def test_a_staged_job_is_launched_by_its_first_wait(engine):
-    rng = np.random.default_rng(8)
-    gram = gram_like(12, rng)
-    idx = np.arange(11, dtype=np.int32)
-    job = engine.submit(gram, idx, launch=False)
-    check_job(job, gram, idx)                                         # wait() flushes
-    job.release()
-    job.release()                                                     # idempotent
-
-
 def test_degenerate_spectra(engine):
     # identity: nothing to rotate, order by index; a diagonal matrix in descending order: only the sort acts;
     # exactly repeated eigenvalues (identical 2 x 2 blocks): any orthonormal basis of each eigenspace is right
@@ -155,30 +132,6 @@ def test_degenerate_spectra(engine):
         assert np.abs(Qt @ Qt.T - np.eye(n)).max() <= 1e-14
         assert np.abs(betahat - np.linalg.solve(A, gram[:n, n])).max() <= 1e-13 * n
         job.release()
-
-
-def test_lapack_sign_mode_leaves_the_rotations_signs(engine):
-    rng = np.random.default_rng(9)
-    gram = gram_like(9, rng)
-    idx = np.arange(8, dtype=np.int32)
-    engine.set_signs(False)
-    try:
-        job = engine.submit(gram, idx)
-        lamb, Qt, qty, betahat, moments = job.wait()
-        raw = Qt.copy()
-        job.release()
-    finally:
-        engine.set_signs(True)
-    job = engine.submit(gram, idx)
-    lamb2, Qt2, *_ = job.wait()
-    assert np.array_equal(canonical(raw), Qt2) and np.array_equal(lamb, lamb2)
-    job.release()
-
-
-def test_too_large_a_model_is_refused(engine):
-    gram = np.eye(engine.max_columns + 3)
-    with pytest.raises(_capi.FoklNativeError):
-        engine.submit(gram, np.arange(engine.max_columns + 1, dtype=np.int32))
 
 
 def test_against_the_host_spectral_job_on_a_fit_like_gram(engine):

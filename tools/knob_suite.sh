@@ -23,7 +23,6 @@ modes=(
   "FOKL_BUILD_AHEAD=tests"
   "FOKL_LOOKAHEAD_DERIVED=24"
   "FOKL_CLEAN=host"
-  "FOKL_K1_TOUCH=1"
   "FOKL_KILL_DECIDE=g2"
   "FOKL_G2_DEFER_FROM=8"
   "FOKL_SPECULATION=4"
