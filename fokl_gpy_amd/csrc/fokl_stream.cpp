@@ -189,6 +189,17 @@ void finish_segment_portable(Segment *seg, int o, const uint32_t *raw)
 
 void build_rank_tables(Segment *seg);
 
+// x^2 of sixteen doubles in single precision, from the doubles' upper words alone (q: the first of their 32 tempered words):
+// x = (wa >> 5) / 2^26 - 1 to 2e-7
+FOKL_WIDE_TARGET inline __m512 polar_squares16(const uint32_t *q)
+{
+    const __m512i even_words = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
+    const __m512i hi = _mm512_permutex2var_epi32(_mm512_loadu_si512(q), even_words, _mm512_loadu_si512(q + 16));
+    const __m512 x = _mm512_fmadd_ps(_mm512_cvtepi32_ps(_mm512_srli_epi32(hi, 5)), _mm512_set1_ps(1.0f / 67108864.0f),
+                                     _mm512_set1_ps(-1.0f));
+    return _mm512_mul_ps(x, x);
+}
+
 FOKL_WIDE_TARGET inline __m512d polar_squares(const uint32_t *p)
 {
     // eight doubles from sixteen tempered words: lane = wa | wb << 32; v = (wa >> 5) 2^26 + (wb >> 6) < 2^53;
@@ -206,31 +217,55 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
 {
     uint32_t *w = seg->words();
     const __m512i m7 = _mm512_set1_epi32((int)0x9d2c5680u), m15 = _mm512_set1_epi32((int)0xefc60000u);
-    for (int i = 0; i < kSegWords + kSegTail; i += 16) {
-        __m512i y = _mm512_loadu_si512(raw + i);
-        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
-        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), m7));
-        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), m15));
-        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
-        _mm512_storeu_si512(w + i, y);
-    }
-    const __m512d one = _mm512_set1_pd(1.0), zero = _mm512_setzero_pd();
+    // tempering runs a few groups ahead of the flags that read its output (one pass over the segment: the flags find the
+    // words in the first-level cache instead of fetching 640 KB a second time)
+    int tempered = 0;
+    auto temper_to = [&](int upto) FOKL_WIDE_TARGET {
+        upto = std::min(upto, kSegWords + kSegTail);
+        for (; tempered < upto; tempered += 16) {
+            __m512i y = _mm512_loadu_si512(raw + tempered);
+            y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+            y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 7), m7, 0x78);      // y ^ (shifted & mask)
+            y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 15), m15, 0x78);
+            y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+            _mm512_storeu_si512(w + tempered, y);
+        }
+    };
+    temper_to(128);
+    // The accept flag of the attempt that starts at each double, 0 < x_l^2 + x_{l+1}^2 < 1, sixteen at a time in SINGLE precision
+    // from the doubles' upper words (x to 2e-7, the sum to 1.2e-6): whatever lies further than 8e-6 from both bounds is decided
+    // (round 6: a third of the double-precision form's instructions); the one attempt per segment that does not is decided
+    // by the exact expressions -- conversion and 2 d - 1 exact, x * x and the sum one rounding each, as numpy forms them.
     const uint32_t *p = w + o;
-    __m512d cur = polar_squares(p);
+    const __m512 below = _mm512_set1_ps(1.0f - 8e-6f), above = _mm512_set1_ps(1.0f + 8e-6f), tiny = _mm512_set1_ps(8e-6f);
+    auto exact_flag = [&](int l) -> uint64_t {
+        const double x1 = 2.0 * to_double(p[2 * l], p[2 * l + 1]) - 1.0, x2 = 2.0 * to_double(p[2 * l + 2], p[2 * l + 3]) - 1.0;
+        const double r2 = x1 * x1 + x2 * x2;
+        return (uint64_t)((r2 < 1.0) & (r2 != 0.0));
+    };
+    __m512 cur = polar_squares16(p);
     uint64_t *m0 = seg->mask[0], *m1 = seg->mask[1];
     for (int word = 0; word < kSegMaskWords; ++word) {      // 128 doubles -> one mask word per alignment
         uint64_t even = 0, odd = 0;
         for (int half = 0; half < 2; ++half) {
             uint64_t bits = 0;
-            for (int j = 0; j < 8; ++j) {
-                p += 16;
-                const __m512d nxt = polar_squares(p);
-                // r2 of the attempt starting at double l = sq[l] + sq[l + 1]
-                const __m512d shifted = _mm512_castsi512_pd(
-                    _mm512_alignr_epi64(_mm512_castpd_si512(nxt), _mm512_castpd_si512(cur), 1));
-                const __m512d r2 = _mm512_add_pd(cur, shifted);
-                const unsigned m = _mm512_cmp_pd_mask(r2, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(r2, zero, _CMP_NEQ_OQ);
-                bits |= (uint64_t)m << (8 * j);
+            for (int j = 0; j < 4; ++j) {
+                const int l0 = 128 * word + 64 * half + 16 * j;                  // first double of the group
+                // (the last group's successor lies in the tail words behind the segment: 32 of them, 16 doubles)
+                temper_to(2 * (l0 + 32) + 16);                                   // (nxt reads words up to o + 2 l0 + 63)
+                const __m512 nxt = polar_squares16(p + 2 * (l0 + 16));
+                const __m512 r2 = _mm512_add_ps(cur, _mm512_castsi512_ps(_mm512_alignr_epi32(_mm512_castps_si512(nxt),
+                                                                                              _mm512_castps_si512(cur), 1)));
+                const unsigned yes = _mm512_cmp_ps_mask(r2, below, _CMP_LT_OQ) & _mm512_cmp_ps_mask(r2, tiny, _CMP_GT_OQ);
+                const unsigned no = _mm512_cmp_ps_mask(r2, above, _CMP_GT_OQ);
+                uint64_t group = yes;
+                unsigned open = ~(yes | no) & 0xffffu;
+                while (open) {
+                    const int i = __builtin_ctz(open);
+                    open &= open - 1;
+                    group |= exact_flag(l0 + i) << i;
+                }
+                bits |= group << (16 * j);
                 cur = nxt;
             }
             even |= _pext_u64(bits, 0x5555555555555555ull) << (32 * half);
@@ -239,6 +274,7 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
         m0[word] = even;
         m1[word] = odd;
     }
+    temper_to(kSegWords + kSegTail);
     build_rank_tables(seg);
 }
 
@@ -250,32 +286,49 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
 FOKL_WIDE_TARGET void build_rank_tables(Segment *seg)
 {
     for (int a = 0; a < 2; ++a) {
-        const uint64_t *M = seg->mask[a], *X = seg->mask[a ^ 1];
+        // mask words with one zero word behind them (windows of the last word look into it: those entries are not valid
+        // anyway, see Segment::safe)
+        alignas(64) uint64_t M[kSegMaskWords + 8], X[kSegMaskWords + 8];
+        std::memcpy(M, seg->mask[a], sizeof(uint64_t) * kSegMaskWords);
+        std::memcpy(X, seg->mask[a ^ 1], sizeof(uint64_t) * kSegMaskWords);
+        for (int i = kSegMaskWords; i < kSegMaskWords + 8; ++i) M[i] = X[i] = 0;
         uint64_t *planes[4] = {seg->g0[a], seg->g1[0][a], seg->g1[1][a], seg->g1[2][a]};
         for (auto *pl : planes) std::memset(pl, 0, sizeof(uint64_t) * (kSegMaskWords + 1));
         uint32_t c = 0;
-        for (int w = 0; w < kSegMaskWords; ++w) {
-            seg->cum[a][w] = (uint16_t)c;
-            const uint64_t m = M[w], mn = w + 1 < kSegMaskWords ? M[w + 1] : 0;
-            const uint64_t x = X[w], xn = w + 1 < kSegMaskWords ? X[w + 1] : 0;
-#define FOKL_WIN(lo, hi, sh) (((lo) >> (sh)) | ((hi) << (64 - (sh))))
-            const uint64_t A1 = FOKL_WIN(m, mn, 1), A2 = FOKL_WIN(m, mn, 2), A3 = FOKL_WIN(m, mn, 3), A4 = FOKL_WIN(m, mn, 4),
-                           A5 = FOKL_WIN(m, mn, 5), A6 = FOKL_WIN(m, mn, 6);
-            const uint64_t E1 = ~FOKL_WIN(x, xn, 1 + a), E2 = E1 & ~FOKL_WIN(x, xn, 2 + a), E3 = E2 & ~FOKL_WIN(x, xn, 3 + a),
-                           E4 = E3 & ~FOKL_WIN(x, xn, 4 + a), E5 = E4 & ~FOKL_WIN(x, xn, 5 + a);
+        for (int w0 = 0; w0 < kSegMaskWords; w0 += 8) {     // eight mask words at a time (624 = 78 * 8)
+            const __m512i m = _mm512_load_si512(M + w0), mn = _mm512_loadu_si512(M + w0 + 1);
+            const __m512i x = _mm512_load_si512(X + w0), xn = _mm512_loadu_si512(X + w0 + 1);
+#define FOKL_WIN(lo, hi, sh) _mm512_or_si512(_mm512_srli_epi64(lo, sh), _mm512_slli_epi64(hi, 64 - (sh)))
+            const __m512i A1 = FOKL_WIN(m, mn, 1), A2 = FOKL_WIN(m, mn, 2), A3 = FOKL_WIN(m, mn, 3), A4 = FOKL_WIN(m, mn, 4),
+                          A5 = FOKL_WIN(m, mn, 5), A6 = FOKL_WIN(m, mn, 6);
+            // (ternary logic 0x10: E & ~window -- "still rejected")
+            const __m512i ones = _mm512_set1_epi64(-1);
+            const __m512i E1 = _mm512_xor_si512(FOKL_WIN(x, xn, 1 + a), ones);
+            const __m512i E2 = _mm512_andnot_si512(FOKL_WIN(x, xn, 2 + a), E1), E3 = _mm512_andnot_si512(FOKL_WIN(x, xn, 3 + a), E2),
+                          E4 = _mm512_andnot_si512(FOKL_WIN(x, xn, 4 + a), E3), E5 = _mm512_andnot_si512(FOKL_WIN(x, xn, 5 + a), E4);
 #undef FOKL_WIN
-            const uint64_t t3 = E1 & A3, t4 = E2 & A4, t5 = E3 & A5, t6 = E4 & A6;
-            const uint64_t s1 = A1 ^ A2 ^ t3, c1 = (A1 & A2) | (t3 & (A1 ^ A2));
-            const uint64_t s2 = t4 ^ t5 ^ t6, c2 = (t4 & t5) | (t6 & (t4 ^ t5));
-            const uint64_t c3 = s1 & s2;
-            const uint64_t value[4] = {A1, (s1 ^ s2) | E5, (c1 ^ c2 ^ c3) | E5, ((c1 & c2) | (c3 & (c1 ^ c2))) | E5};
-            const int at = (int)(c >> 6), sh = (int)(c & 63);
-            for (int pl = 0; pl < 4; ++pl) {
-                const uint64_t bits = _pext_u64(value[pl], m);
-                planes[pl][at] |= bits << sh;
-                if (sh) planes[pl][at + 1] |= bits >> (64 - sh);
+            const __m512i t3 = _mm512_and_si512(E1, A3), t4 = _mm512_and_si512(E2, A4), t5 = _mm512_and_si512(E3, A5),
+                          t6 = _mm512_and_si512(E4, A6);
+            // full adders: 0x96 = a ^ b ^ c, 0xe8 = majority
+            const __m512i s1 = _mm512_ternarylogic_epi64(A1, A2, t3, 0x96), c1 = _mm512_ternarylogic_epi64(A1, A2, t3, 0xe8);
+            const __m512i s2 = _mm512_ternarylogic_epi64(t4, t5, t6, 0x96), c2 = _mm512_ternarylogic_epi64(t4, t5, t6, 0xe8);
+            const __m512i c3 = _mm512_and_si512(s1, s2);
+            alignas(64) uint64_t value[4][8], own[8];
+            _mm512_store_si512(own, m);
+            _mm512_store_si512(value[0], A1);
+            _mm512_store_si512(value[1], _mm512_or_si512(_mm512_xor_si512(s1, s2), E5));
+            _mm512_store_si512(value[2], _mm512_or_si512(_mm512_ternarylogic_epi64(c1, c2, c3, 0x96), E5));
+            _mm512_store_si512(value[3], _mm512_or_si512(_mm512_ternarylogic_epi64(c1, c2, c3, 0xe8), E5));
+            for (int k = 0; k < 8; ++k) {
+                seg->cum[a][w0 + k] = (uint16_t)c;
+                const int at = (int)(c >> 6), sh = (int)(c & 63);
+                for (int pl = 0; pl < 4; ++pl) {
+                    const uint64_t bits = _pext_u64(value[pl][k], own[k]);
+                    planes[pl][at] |= bits << sh;
+                    if (sh) planes[pl][at + 1] |= bits >> (64 - sh);
+                }
+                c += (uint32_t)__builtin_popcountll(own[k]);
             }
-            c += (uint32_t)__builtin_popcountll(m);
         }
         seg->cum[a][kSegMaskWords] = seg->cum[a][kSegMaskWords + 1] = (uint16_t)c;
         seg->safe[a] = (int32_t)seg->cum[a][kSegMaskWords - 1] +

@@ -7,8 +7,11 @@ Tolerances: with FOKL_DCHAIN_RECURSION=exact a tape whose normals were finished 
 recursion BIT FOR BIT (same IEEE operations in the same order, the quadratic forms summed in the host's order); with the
 finishing on the device the normals differ from libm's in the last bit of log(), and the default recursion folds its
 reciprocals (three long operations on the critical path instead of nine), each fold a rounding or two away from the
-host's: both reach the draws at the 1e-16 .. 1e-15 level, bounded here by 1e-13 of the column scale over the full 2000
-iterations of a fit's chain.
+host's: both reach the draws at the 1e-16 .. 1e-15 level.  Round 6's recursion forms bstar as
+b + (dtd - sum d qty^2 + sigma^2 sum v^2) / 2 -- two of its three sums off the critical path -- where the host forms
+b + (w'Lw - 2 w'qty + dtd + w'w / tau^2) / 2: the same cancellation against dtd reached through different roundings, a
+digit's worth on models whose fit is nearly exact.  Bounded here by TOL = 1e-12 of the column scale over the full 2000
+iterations of a fit's chain (the reference's draws are held to 1e-9, tests/test_config_goldens.py).
 """
 import os
 
@@ -18,6 +21,8 @@ import pytest
 from fokl_gpy_amd import _capi
 
 pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
 
 
 @pytest.fixture(scope='module')
@@ -72,8 +77,8 @@ def test_device_chain_equals_the_host_chain_on_the_same_tape(engine, exact_engin
     w, mean_w, negative = _capi.gibbs_chain_device(engine, *args, tape, stat_first=half0)
     assert not negative and not flag
     scale = np.max(np.abs(want), axis=0)
-    assert np.max(np.abs(w - want) / scale) < 1e-13
-    assert np.max(np.abs(mean_w - want[half0:].mean(axis=0)) / scale) < 1e-13
+    assert np.max(np.abs(w - want) / scale) < TOL
+    assert np.max(np.abs(mean_w - want[half0:].mean(axis=0)) / scale) < TOL
 
 
 @pytest.mark.parametrize('p1', [3, 60, 150])
@@ -154,8 +159,8 @@ def check(entry, draws, s_ref):
     job.release()
     want = _capi.gibbs_chain(args[0], args[1], 500.0 + p / 2, 4 + (p - 1) / 2, *args[2:], draws, s_ref)
     scale = np.max(np.abs(want), axis=0)
-    assert flag[0] == 0 and np.max(np.abs(w - want) / scale) < 1e-13
-    assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+    assert flag[0] == 0 and np.max(np.abs(w - want) / scale) < TOL
+    assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < TOL
 
 
 @pytest.mark.parametrize('draws', [1, 2, 7, 8, 9, 17, 129])
@@ -172,8 +177,8 @@ def test_short_chains_and_ring_boundaries(engine, exact_engine, draws, monkeypat
         for eng in (engine, exact_engine):
             w, mean_w, negative = _capi.gibbs_chain_device(eng, *args, tape, stat_first=draws // 2)
             scale = np.max(np.abs(want), axis=0)
-            assert not negative and np.max(np.abs(w - want) / scale) < 1e-13
-            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+            assert not negative and np.max(np.abs(w - want) / scale) < TOL
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < TOL
 
 
 def test_largest_model_and_beyond(engine, monkeypatch):
@@ -186,7 +191,7 @@ def test_largest_model_and_beyond(engine, monkeypatch):
     args = (lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9)
     want, _ = _capi.gibbs_chain_from_tape(*args, tape)
     w, _, negative = _capi.gibbs_chain_device(engine, *args, tape)
-    assert not negative and np.max(np.abs(w - want) / np.max(np.abs(want), axis=0)) < 1e-13
+    assert not negative and np.max(np.abs(w - want) / np.max(np.abs(want), axis=0)) < TOL
     lamb, qty = model(769, rng)
     with pytest.raises(_capi.FoklNativeError) as err:
         engine.submit(lamb, qty, 900.0, 2.0, 5e5, 0.3, 0.9, host_tape(769, 10, 1), follow=False)
@@ -251,8 +256,8 @@ def test_rows_expanded_on_the_device_equal_the_tape_expanded_on_the_host(p1, pos
             w = job.fetch_w()
             scale = np.max(np.abs(want), axis=0)
             assert not flag[0]
-            assert np.max(np.abs(w - want) / scale) < 1e-13
-            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+            assert np.max(np.abs(w - want) / scale) < TOL
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < TOL
             job.release()
         assert eng.stream_stats()['rows_jobs'] == 3 and eng.stream_stats()['segments_made'] >= 1
         for hold in holds:
@@ -307,8 +312,8 @@ def test_sixteen_wide_chains_at_once_at_the_full_chain_length(p1, monkeypatch):
             w = job.fetch_w()
             scale = np.max(np.abs(want), axis=0)
             assert not flag[0]
-            assert np.max(np.abs(w - want) / scale) < 1e-13
-            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < 1e-13
+            assert np.max(np.abs(w - want) / scale) < TOL
+            assert np.max(np.abs(mean_w - want[draws // 2:].mean(axis=0)) / scale) < TOL
             job.release()
         for hold in holds:
             se.release(hold)
