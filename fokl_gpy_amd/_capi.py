@@ -78,7 +78,7 @@ SIGNATURES = {
     'fokl_tape_ready': (c_int, [c_vp, c_int, c_vp, c_int]),
     'fokl_pool_resolve': (c_int, [c_vp, c_int]),
     'fokl_pool_submit_chain': (c_int, [c_vp, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_vp, c_vp,
-                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+                                       c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_pool_submit_spectral': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp]),
     'fokl_pool_submit_spectral_update': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp,
@@ -122,7 +122,7 @@ SIGNATURES = {
     'fokl_spectrum_release': (None, [c_vp, c_vp]),
     'fokl_spectrum_retain': (c_int, [c_vp, c_vp]),
     'fokl_search_model_begin': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
-    'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_vp]),
+    'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_int, c_vp]),
     'fokl_search_score': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp]),
     'fokl_outcome_info': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_outcome_spectrum': (c_int, [c_vp, c_vp, c_vp]),
@@ -803,7 +803,7 @@ class HostPool:
                                                 float(sigsqd0), float(tausqd0), tape.draws, *tape.pointers(),
                                                 tape.progress_pointer(), tape.block_done_pointer(),
                                                 tape.BLOCK, int(tape.finishing_requested), _ptr(w), _ptr(flag),
-                                                ctypes.byref(h)))
+                                                None, None, ctypes.byref(h)))
         return PoolJob(h, (lamb, qty, tape, w, flag), (w, flag))
 
     def submit_spectral(self, gram, idx, ycol):
@@ -879,7 +879,7 @@ SEARCH_STATS = ('gibbs_calls', 'kill_tests', 'terms_logical', 't_eigh', 't_chain
                 'spectral_submitted', 'device_chains', 'chains_fetched', 'guessed', 'guess_waits', 'guesses_verified',
                 'dchain_kernel_s', 'dchain_timed', 't_resid', 't_kill_loop', 'tapes_materialised', 'rows_chains', 'path_repredicted', 'spectral_device',
                 'spectral_updated', 'direct_tests', 'direct_max_rel', 'chains_cancelled', 't_settle',
-                'guess_max_dev', 'direct_in_band')
+                'guess_max_dev', 'direct_in_band', 'stats_by_chain_thread')
 
 
 class NativeSearch:
@@ -994,9 +994,11 @@ class NativeSearch:
                                                         len(then), ctypes.byref(sp), ctypes.byref(tape)))
         return sp.value, tape.value
 
-    def model_commit(self, spectrum, tape, dtd):
+    def model_commit(self, spectrum, tape, dtd, new_terms=0):
+        """new_terms: the model's last `new_terms` active columns are a sub-stage's new terms -- their statistics
+        (outcome_new_term_stats) are formed by the chain thread as soon as the chain has run."""
         out = c_vp(0)
-        self._checked(self._lib.fokl_search_model_commit(self._h, c_vp(spectrum), c_vp(tape), float(dtd),
+        self._checked(self._lib.fokl_search_model_commit(self._h, c_vp(spectrum), c_vp(tape), float(dtd), int(new_terms),
                                                          ctypes.byref(out)))
         return out.value
 

@@ -105,6 +105,8 @@ struct Queue {
 }  // namespace
 
 struct fokl_host_job {
+    void (*then)(void *) = nullptr;         // chain jobs: run by the chain thread behind a chain that succeeded
+    void *then_arg = nullptr;
     Kind kind;
     fokl_host_pool *pool = nullptr;
     std::atomic<int> done{0};
@@ -679,6 +681,7 @@ fokl_host_job *run(fokl_host_pool *pool, fokl_host_job *job)
                                                      job->gam_sig, job->gam_tau, job->block_done, job->block,
                                                      job->w_out, nullptr, nullptr, job->bstar_negative);
             if (rc != FOKL_OK) err = "chain: invalid arguments or the tape producer failed";
+            if (rc == FOKL_OK && job->then) job->then(job->then_arg);       // (the draws are complete: what follows from them)
             busy = &pool->chain_busy_ns;
             break;
         }
@@ -687,6 +690,7 @@ fokl_host_job *run(fokl_host_pool *pool, fokl_host_job *job)
                                               job->gam_sig, job->gam_tau, job->raw_block_done, job->block, job->w_out,
                                               job->bstar_negative);
         if (rc != FOKL_OK) err = "chain: invalid arguments or the tape producer failed";
+        if (rc == FOKL_OK && job->then) job->then(job->then_arg);
         busy = &pool->chain_busy_ns;
         break;
     case Kind::spectral:
@@ -1138,7 +1142,7 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
                                       const double *normals, const double *pair_r2, const int32_t *lead,
                                       const double *gam_sig, const double *gam_tau, const int32_t *progress,
                                       int32_t *block_done, int block, int finishing_requested, double *w_out,
-                                      int32_t *bstar_negative, fokl_host_job **out)
+                                      int32_t *bstar_negative, void (*then)(void *), void *then_arg, fokl_host_job **out)
 {
     if (!pool || !out || !lamb || !qty || p1 <= 0 || draws < 0 || !normals || !pair_r2 || !lead || !gam_sig ||
         !gam_tau || !progress || !w_out || !bstar_negative || !block_done || block < 1) {
@@ -1166,6 +1170,8 @@ extern "C" int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, 
     job->w_out = w_out;
     job->bstar_negative = bstar_negative;
     job->block = block;
+    job->then = then;
+    job->then_arg = then_arg;
     if (finishing_requested)
         job->block_done = block_done;                       // the finish threads complete the normals in place
     else

@@ -213,6 +213,16 @@ struct Check {
     bool decision;
 };
 
+// The statistics of a sub-stage model's new terms (FR:1656-1658), formed by the chain thread the moment its chain has run
+// (round 6: the driver used to form them when it got there, 0.1-0.2 ms per sub-stage on the thread everything waits for).
+// The new terms are the model's last `count` active columns.
+struct TermStats {
+    int count = 0, p1 = 0, draws = 0, half0 = 0, half1 = 0;
+    const double *w = nullptr;              // the chain's draws in the eigenbasis [draws][p1]
+    const double *Qt = nullptr;             // the model's eigenvectors (row e = eigenvector e); kept alive by the chain's owner
+    std::vector<double> mean_abs, rel_std;
+};
+
 struct Outcome : Counted<Outcome, &Census::outcomes> {
     Spectrum *spec = nullptr;
     Tape *tape = nullptr;
@@ -243,6 +253,8 @@ struct Outcome : Counted<Outcome, &Census::outcomes> {
     double ls_intercept = NAN;              // least-squares intercept known at decision time (lazy outcomes)
     double guess_margin = NAN;              // relative distance kept when guessing from it (NaN: the search's own)
     int64_t trace_index = -1;               // its record in fokl_search::trace
+    int new_terms = 0;                      // a sub-stage model: its last new_terms columns are the new terms
+    TermStats *tstats = nullptr;            // ... and their statistics, if a host chain thread forms them
     int refs = 1;                           // Python handle + the search's own lists
 };
 
@@ -259,7 +271,7 @@ enum Stat {
     S_TAPES_REWOUND, S_TAPES_WASTED, S_CHAINS_AHEAD, S_CHAINS_AHEAD_UNUSED, S_CHAINS_SKIPPED, S_SPECTRAL_SUBMITTED,
     S_DEVICE_CHAINS, S_CHAINS_FETCHED, S_GUESSED, S_GUESS_WAITS, S_GUESSES_VERIFIED, S_DCHAIN_KERNEL_S, S_DCHAIN_TIMED,
     S_T_RESID, S_T_KILL_LOOP, S_TAPES_MATERIALISED, S_ROWS_CHAINS, S_PATH_REPREDICTED, S_SPECTRAL_DEVICE, S_SPECTRAL_UPDATED,
-    S_DIRECT_TESTS, S_DIRECT_MAX_REL, S_CHAINS_CANCELLED, S_T_SETTLE, S_GUESS_MAX_DEV, S_DIRECT_IN_BAND,
+    S_DIRECT_TESTS, S_DIRECT_MAX_REL, S_CHAINS_CANCELLED, S_T_SETTLE, S_GUESS_MAX_DEV, S_DIRECT_IN_BAND, S_STATS_BY_CHAIN_THREAD,
     S_COUNT
 };
 
@@ -302,6 +314,7 @@ struct fokl_search {
         size_t w_classes = 0;
         bool w_pinned = false;
         int32_t *flag = nullptr;
+        TermStats *tstats = nullptr;
     } prechain;
     std::map<std::vector<int64_t>, double> ev_cache;
     std::vector<int64_t> active_ids;        // term id of every active column of the sub-stage (column 0: the intercept)
@@ -356,6 +369,7 @@ struct fokl_search {
         Tape *tape;
         int32_t *flag;
         Spectrum *spec;
+        TermStats *tstats;
     };
     std::vector<WLimbo> chain_limbo;
     double stats[S_COUNT] = {};
@@ -758,23 +772,48 @@ void drop_prechain(fokl_search *s)
     if (!pc.tape) return;
     // a chain started ahead that nobody will look at: its buffer goes back when it has run, and the tape it reads is
     // not reused before that (the chain's reference on the tape passes to the limbo entry)
-    s->chain_limbo.push_back({pc.job, pc.w, pc.w_classes, pc.w_pinned, pc.tape, pc.flag, pc.spec});
+    s->chain_limbo.push_back({pc.job, pc.w, pc.w_classes, pc.w_pinned, pc.tape, pc.flag, pc.spec, pc.tstats});
     pc = {};
     s->stats[S_CHAINS_AHEAD_UNUSED] += 1;
 }
 
-fokl_host_job *submit_host_chain(fokl_search *s, Spectrum *sp, Tape *t, double dtd, double *w, int32_t *flag)
+void term_stats_now(void *arg);
+
+// new_terms > 0: the chain thread forms the statistics of the model's last new_terms columns behind the chain (*tstats_out)
+fokl_host_job *submit_host_chain(fokl_search *s, Spectrum *sp, Tape *t, double dtd, double *w, int32_t *flag,
+                                 int new_terms = 0, TermStats **tstats_out = nullptr)
 {
     fokl_host_job *job = nullptr;
+    TermStats *ts = nullptr;
+    if (new_terms > 0 && new_terms < sp->p1 && tstats_out) {
+        ts = new TermStats();
+        ts->count = new_terms;
+        ts->p1 = sp->p1;
+        ts->draws = t->draws;
+        ts->half0 = s->prm.half0;
+        ts->half1 = (int)std::ceil(t->draws / 2.0 + 1.0);                   // FR:1656
+        ts->w = w;
+        ts->Qt = sp->Qt();
+        if (ts->half1 >= ts->draws) {
+            delete ts;
+            ts = nullptr;
+        }
+    }
     const int rc = fokl_pool_submit_chain(s->pool, sp->lamb(), sp->qty(), sp->p1, s->prm.b, s->prm.btau, dtd, s->sigsqd0,
                                           s->tausqd0, t->draws, t->normals, t->pair_r2, t->lead, t->gam_sig, t->gam_tau,
-                                          t->progress, t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, w, flag, &job);
-    return rc == FOKL_OK ? job : nullptr;
+                                          t->progress, t->block_done, FOKL_TAPE_BLOCK, t->finishing ? 1 : 0, w, flag,
+                                          ts ? term_stats_now : nullptr, ts, &job);
+    if (rc != FOKL_OK) {
+        delete ts;
+        return nullptr;
+    }
+    if (tstats_out) *tstats_out = ts;
+    return job;
 }
 
 // Start the chain of the evaluation expected next -- G2 `sp`, p1 columns -- if its G2 has run and its tape is the oldest on
 // order (engine.ForwardSelection._chain_ahead).
-void chain_ahead(fokl_search *s, Spectrum *sp, int p1, double dtd)
+void chain_ahead(fokl_search *s, Spectrum *sp, int p1, double dtd, int new_terms = 0)
 {
     if (s->spec.empty() || s->spec.front()->p1 != p1 || !spectrum_done(sp)) return;
     Tape *t = s->spec.front();
@@ -790,7 +829,8 @@ void chain_ahead(fokl_search *s, Spectrum *sp, int p1, double dtd)
     double *w = take_w(s, p1, &classes, &pinned);
     if (!w) return;
     auto *flag = new int32_t(0);
-    fokl_host_job *job = submit_host_chain(s, sp, t, dtd, w, flag);
+    TermStats *ts = nullptr;
+    fokl_host_job *job = submit_host_chain(s, sp, t, dtd, w, flag, new_terms, &ts);
     if (!job) {
         give_buffer(w, classes, pinned);
         delete flag;
@@ -798,6 +838,7 @@ void chain_ahead(fokl_search *s, Spectrum *sp, int p1, double dtd)
     }
     sp->refs += 1;
     t->refs += 1;                                           // the chain reads the tape whatever becomes of the order
+    pc.tstats = ts;
     pc.tape = t;
     pc.spec = sp;
     pc.job = job;
@@ -988,7 +1029,8 @@ void destroy_outcome(fokl_search *s, Outcome *o)
     } else if (o->w) {
         if (o->chain && !o->chain_waited) {                 // still running: buffers, tape and spectrum go when it has
             o->spec->refs += 1;
-            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec});
+            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec, o->tstats});
+            o->tstats = nullptr;
             o->tape = nullptr;
         } else {
             give_buffer(o->w, o->w_classes, o->w_pinned);
@@ -999,6 +1041,7 @@ void destroy_outcome(fokl_search *s, Outcome *o)
     } else {
         delete o->flag;
     }
+    delete o->tstats;
     unref(s, o->spec);
     unref(s, o->tape);
     delete o;
@@ -1078,6 +1121,7 @@ void reap(fokl_search *s, bool block)
             (void)fokl_pool_wait(c.job);
             give_buffer(c.w, c.classes, c.pinned);
             delete c.flag;
+            delete c.tstats;
             Tape *t = c.tape;
             Spectrum *sp = c.spec;
             s->chain_limbo[i] = s->chain_limbo.back();
@@ -1187,6 +1231,7 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
             o->w_classes = pc.w_classes;
             o->w_pinned = pc.w_pinned;
             o->flag = pc.flag;
+            o->tstats = pc.tstats;
             unref(s, pc.spec);
             unref(s, pc.tape);                              // the chain's reference: the outcome holds the tape now
             pc = {};
@@ -1197,7 +1242,7 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
     o->w = take_w(s, p1, &o->w_classes, &o->w_pinned);
     o->flag = new int32_t(0);
     if (!o->w) return fail(s, FOKL_ERR_STATE, "fokl_search: out of memory for a chain's draws");
-    o->chain = submit_host_chain(s, sp, t, dtd, o->w, o->flag);
+    o->chain = submit_host_chain(s, sp, t, dtd, o->w, o->flag, o->new_terms, &o->tstats);
     if (!o->chain) {
         o->chain_waited = true;
         return fail(s, FOKL_ERR_STATE, "fokl_search: the pool refused a chain");
@@ -1205,9 +1250,10 @@ int start_chain(fokl_search *s, Outcome *o, double dtd, bool test)
     return FOKL_OK;
 }
 
-Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test)
+Outcome *commit(fokl_search *s, Spectrum *sp, Tape *t, double dtd, bool test, int new_terms = 0)
 {
     auto *o = new Outcome();
+    o->new_terms = new_terms;
     o->spec = sp;
     sp->refs += 1;
     o->tape = t;                                            // takes over the caller's reference
@@ -1866,12 +1912,13 @@ extern "C" int fokl_search_model_begin(fokl_search *s, const double *gram, int l
     return FOKL_OK;
 }
 
-extern "C" int fokl_search_model_commit(fokl_search *s, fokl_spectrum *spectrum, fokl_tape *tape, double dtd,
+extern "C" int fokl_search_model_commit(fokl_search *s, fokl_spectrum *spectrum, fokl_tape *tape, double dtd, int new_terms,
                                         fokl_outcome **out)
 {
-    if (!s || !spectrum || !tape || !out) return fail(s, FOKL_ERR_ARG, "fokl_search_model_commit: null pointer");
+    if (!s || !spectrum || !tape || !out || new_terms < 0)
+        return fail(s, FOKL_ERR_ARG, "fokl_search_model_commit: null pointer or negative count");
     Spectrum *sp = reinterpret_cast<Spectrum *>(spectrum);
-    Outcome *o = commit(s, sp, reinterpret_cast<Tape *>(tape), dtd, false);
+    Outcome *o = commit(s, sp, reinterpret_cast<Tape *>(tape), dtd, false, new_terms);
     unref(s, sp);                                           // model_begin's reference: the outcome holds its own
     if (!o) return FOKL_ERR_STATE;
     *out = reinterpret_cast<fokl_outcome *>(o);
@@ -1977,20 +2024,11 @@ FOKL_STATS_CLONES void betas_of_rows(const double *__restrict__ w, const double 
 }
 }  // namespace
 
-extern "C" int fokl_outcome_new_term_stats(fokl_search *s, fokl_outcome *h, const int32_t *cols, int count, int half0,
-                                           int half1, double *mean_abs, double *rel_std)
+namespace {
+// mean_abs / rel_std of the active columns `cols` from the draws w [draws][p1] and the eigenvectors Qt
+void term_stats(const double *w, const double *Qt, int p1, int draws, const int32_t *cols, int count, int half0, int half1,
+                double *mean_abs, double *rel_std)
 {
-    if (!s || !h || !cols || count < 1 || !mean_abs || !rel_std || half0 < 0 || half1 < half0)
-        return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: bad arguments");
-    Outcome *o = reinterpret_cast<Outcome *>(h);
-    const double *w = nullptr;
-    const int rc = fokl_outcome_draws(s, h, &w);
-    if (rc != FOKL_OK) return rc;
-    const int p1 = o->spec->p1, draws = s->prm.draws;
-    if (half1 >= draws) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: no rows to average");
-    for (int c = 0; c < count; ++c)
-        if (cols[c] < 0 || cols[c] >= p1) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: column out of range");
-    const double *Qt = o->spec->Qt();
     std::vector<double> B((size_t)p1 * count), betas((size_t)(draws - half0) * count), sum0((size_t)count, 0.0),
         sum1((size_t)count, 0.0), dev((size_t)count, 0.0);
     for (int j = 0; j < p1; ++j)
@@ -2015,6 +2053,45 @@ extern "C" int fokl_outcome_new_term_stats(fokl_search *s, fokl_outcome *h, cons
         mean_abs[c] = std::fabs(sum1[(size_t)c]);
         rel_std[c] = std::sqrt(dev[(size_t)c] / rows1) / std::fabs(sum0[(size_t)c] / rows0);
     }
+}
+
+// on the chain thread, behind a chain that has run (fokl_pool_submit_chain's `then`)
+void term_stats_now(void *arg)
+{
+    auto *ts = static_cast<TermStats *>(arg);
+    std::vector<int32_t> cols((size_t)ts->count);
+    for (int c = 0; c < ts->count; ++c) cols[(size_t)c] = ts->p1 - ts->count + c;
+    ts->mean_abs.resize((size_t)ts->count);
+    ts->rel_std.resize((size_t)ts->count);
+    term_stats(ts->w, ts->Qt, ts->p1, ts->draws, cols.data(), ts->count, ts->half0, ts->half1, ts->mean_abs.data(),
+               ts->rel_std.data());
+}
+}  // namespace
+
+extern "C" int fokl_outcome_new_term_stats(fokl_search *s, fokl_outcome *h, const int32_t *cols, int count, int half0,
+                                           int half1, double *mean_abs, double *rel_std)
+{
+    if (!s || !h || !cols || count < 1 || !mean_abs || !rel_std || half0 < 0 || half1 < half0)
+        return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: bad arguments");
+    Outcome *o = reinterpret_cast<Outcome *>(h);
+    const double *w = nullptr;
+    const int rc = fokl_outcome_draws(s, h, &w);            // (waits for the chain -- and for what its thread formed behind it)
+    if (rc != FOKL_OK) return rc;
+    const int p1 = o->spec->p1, draws = s->prm.draws;
+    if (half1 >= draws) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: no rows to average");
+    for (int c = 0; c < count; ++c)
+        if (cols[c] < 0 || cols[c] >= p1) return fail(s, FOKL_ERR_ARG, "fokl_outcome_new_term_stats: column out of range");
+    if (const TermStats *ts = o->tstats) {
+        bool same = !ts->mean_abs.empty() && ts->count == count && ts->half0 == half0 && ts->half1 == half1 && ts->w == w;
+        for (int c = 0; same && c < count; ++c) same = cols[c] == p1 - count + c;
+        if (same) {
+            std::memcpy(mean_abs, ts->mean_abs.data(), sizeof(double) * (size_t)count);
+            std::memcpy(rel_std, ts->rel_std.data(), sizeof(double) * (size_t)count);
+            s->stats[S_STATS_BY_CHAIN_THREAD] += 1;
+            return FOKL_OK;
+        }
+    }
+    term_stats(w, o->spec->Qt(), p1, draws, cols, count, half0, half1, mean_abs, rel_std);
     return FOKL_OK;
 }
 
@@ -2290,7 +2367,8 @@ extern "C" int fokl_search_kill_tests(fokl_search *s, const fokl_kill_tests_args
             auto it = ahead.find(with_column(killed, a->columns[nxt]));
             if (it != ahead.end()) chain_ahead(s, it->second, A - (int)killed.size() - 1, dtd);
         } else if (a->vm_next >= 0) {
-            if (Forecast *f = find_forecast(killed)) chain_ahead(s, f->spec, A - (int)killed.size() + a->vm_next, f->dtd);
+            if (Forecast *f = find_forecast(killed))
+                chain_ahead(s, f->spec, A - (int)killed.size() + a->vm_next, f->dtd, a->vm_next);
         }
     };
     // G2 of the models on the predicted path, `lookahead` tests deep beyond the one at `pos` (which is submitted whatever

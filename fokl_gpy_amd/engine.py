@@ -632,7 +632,8 @@ class ForwardSelection:
             self.stats['bic_gram_max_rel'] = max(self.stats['bic_gram_max_rel'], abs(other - ev) / abs(ev))
         return self._same_model_same_ev(idx, ev)
 
-    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None, then=(), after_begin=None):
+    def _evaluate(self, gram, slots, idx, n_prev_cols, kill, spectral_job=None, overlap=None, then=(), after_begin=None,
+                  new_terms=0):
         """
         gram  : Gram of the sub-stage's active columns, last row/column = y   [(A + 1) x (A + 1)]
         slots : device slot of each active column
@@ -641,6 +642,7 @@ class ForwardSelection:
         overlap : called once G2 is under way -- work for the driver thread in its shadow (pipelined search)
         then  : sizes of the models that will probably be evaluated after this one (tapes ordered ahead, _speculate)
         after_begin : (native search) called with the model's spectrum handle once G2 has run and K3 is launched
+        new_terms : (native search) how many of the model's last columns are the sub-stage's new terms (their statistics)
         """
         idx = np.asarray(idx, dtype=np.int32)
         p1 = idx.shape[0]
@@ -659,7 +661,7 @@ class ForwardSelection:
                 if after_begin is not None:
                     after_begin(spectrum)       # G2 is there, the device is busy with K3: what can be ordered ahead now
                 ycol = gram.shape[0] - 1
-                handle = ns.model_commit(spectrum, tape, gram[ycol, ycol])
+                handle = ns.model_commit(spectrum, tape, gram[ycol, ycol], 0 if kill else new_terms)
             except BaseException:
                 ns.spectrum_release(spectrum)
                 raise
@@ -1465,7 +1467,8 @@ class ForwardSelection:
 
             full = self._evaluate(gram, active_slots, np.arange(A), n_prev, kill=False, spectral_job=spectral_job,
                                   overlap=None if pipelined else build_next, then=then,
-                                  after_begin=first_tests_now if pipelined and self.native is not None else None)
+                                  after_begin=first_tests_now if pipelined and self.native is not None else None,
+                                  new_terms=vm)
             best = full
             ev = full.ev
             _mark('full_evaluated', str(A))

@@ -183,13 +183,14 @@ int fokl_pool_resolve(fokl_host_job *job, int commit);
 /*
  * The draws of one candidate from its tape (whose noise job must have been submitted with the same block_done): the
  * recursion follows the flags of the finish threads -- on normals they completed in place (finishing_requested != 0:
- * the tape was submitted with finish != 0) or completing each row itself.
+ * the tape was submitted with finish != 0) or completing each row itself.  then (may be NULL): called with then_arg by the
+ * chain thread once the chain has run without error, before the job counts as done (what follows from the complete draws).
  */
 int fokl_pool_submit_chain(fokl_host_pool *pool, const double *lamb, const double *qty, int p1, double b, double btau,
                            double dtd, double sigsqd0, double tausqd0, int draws, const double *normals,
                            const double *pair_r2, const int32_t *lead, const double *gam_sig, const double *gam_tau,
                            const int32_t *progress, int32_t *block_done, int block, int finishing_requested,
-                           double *w_out, int32_t *bstar_negative, fokl_host_job **out);
+                           double *w_out, int32_t *bstar_negative, void (*then)(void *), void *then_arg, fokl_host_job **out);
 /*
  * G2 for the candidate model made of columns idx[0..p1) of `gram` (row-major, leading dimension ld, y in column
  * ycol): XtX = gram[idx][:, idx], Xty = gram[idx, ycol].  Outputs: lamb_out [p1] ascending eigenvalues,
@@ -332,7 +333,8 @@ void fokl_spectrum_release(fokl_search *search, fokl_spectrum *spectrum);
 int fokl_search_model_begin(fokl_search *search, const double *gram, int ld, const int32_t *idx, int p1,
                             fokl_spectrum *given, const int32_t *then_sizes, const int32_t *then_model, int then_count,
                             fokl_spectrum **spectrum_out, fokl_tape **tape_out);
-int fokl_search_model_commit(fokl_search *search, fokl_spectrum *spectrum, fokl_tape *tape, double dtd, fokl_outcome **out);
+int fokl_search_model_commit(fokl_search *search, fokl_spectrum *spectrum, fokl_tape *tape, double dtd, int new_terms,
+                             fokl_outcome **out);
 int fokl_search_score(fokl_search *search, fokl_outcome *outcome, double sum_r, double sum_r2, int n_prev, int kill,
                       double *ev);
 typedef struct fokl_outcome_view {
