@@ -483,11 +483,11 @@ def kernel_report(kern, n, m, cfg):
             if kernels[name]:
                 kernels[name]['all_gram_launches'] = gram_all
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figures come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/pmc_r05.json, produced by tools/profile_r05.sh: separate
+    # rocprofv3 --pmc passes over this same command (profiles/pmc_r06.json, produced by tools/profile_r06.sh: separate
     # FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) and are attached only when that file
     # was recorded for exactly this workload.
     traffic_source = None
-    for cand in ('pmc_r05.json', 'pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
+    for cand in ('pmc_r06.json', 'pmc_r05.json', 'pmc_r04.json', 'pmc_r03.json', 'pmc_r02.json', 'pmc_r01.json'):
         pmc_path = os.path.join(ROOT, 'profiles', cand)
         if not os.path.exists(pmc_path):
             continue
@@ -794,6 +794,10 @@ def fits_with_worker_processes(args, cfg, rank, world, local, procs):
                                   f'{procs} worker processes per GPU', 'collectives': comm_kind,
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
         'value_physical': tot_physical / t_max,
+        'what_is_counted': {'logical_terms_per_fit': tot_logical / fits_total,
+                            'columns_built_on_the_device_per_fit': tot_physical / fits_total,
+                            'value_logical_terms_per_s': tot_logical / t_max,
+                            'value_physical_columns_per_s': tot_physical / t_max},
         'parity_checked': parity_checked,
         'parity': parity,
         'fits_per_s': fits_total / t_max,
@@ -1460,6 +1464,18 @@ def main():
                    'config_index': cfg, 'rows': n, 'inputs': m, 'parallelism': parallelism, 'collectives': comm_kind,
                    'terms_counted': 'logical (reference-equivalent, FoKLRoutines.py:1461)'},
         'value_physical': tot_physical / t_max,
+        # both numbers wherever the headline stands.  `value` counts LOGICAL terms -- the columns the
+        # reference would have built for this sequence of gibbs() calls; the device builds each candidate column
+        # once per sub-stage (kill tests read sub-blocks of the sub-stage's Gram) and runs a chain only for the
+        # accepted kill tests whose draws something looks at (the stream position of the others is still advanced)
+        'what_is_counted': {
+            'logical_terms_per_fit': tot_logical / fits_total,
+            'columns_built_on_the_device_per_fit': tot_physical / fits_total,
+            'value_logical_terms_per_s': tot_logical / t_max,
+            'value_physical_columns_per_s': tot_physical / t_max,
+            'kill_tests_per_fit': host.get('direct_tests', 0.0) / max(args.steps, 1) / max(fits_per_step, 1),
+            'kill_test_chains_never_run_per_fit': host.get('chains_cancelled', 0.0) / max(args.steps, 1) / max(fits_per_step, 1),
+        },
         'parity_checked': parity_checked,
         'parity': parity,
         'fits_per_s': fits_total / t_max,
