@@ -3,7 +3,7 @@
 # spectral threads and the search's use of them under ThreadSanitizer and under AddressSanitizer + UBSan.
 #   tools/sanitize_host.sh [tsan|asan] [pytest args ...]
 # Builds fokl_gpy_amd/libfokl_host_<kind>.so (csrc/Makefile) and runs tests/test_sampler_host.py plus the pool / search
-# tests of tests/test_host_logic.py on it; reports go to profiles/sanitize_<kind>_r05.txt.
+# tests of tests/test_host_logic.py on it; reports go to profiles/sanitize_<kind>_r06.txt.
 set -u
 cd "$(dirname "$0")/.."
 kind=${1:-tsan}; shift || true
@@ -15,7 +15,7 @@ case $kind in
         export ASAN_OPTIONS="detect_leaks=0 abort_on_error=0 halt_on_error=0" UBSAN_OPTIONS="print_stacktrace=1" ;;
   *) echo "tsan or asan"; exit 2 ;;
 esac
-out=profiles/sanitize_${kind}_r05.txt
+out=profiles/sanitize_${kind}_r06.txt
 # (tests that start other processes are left out: a fork from a sanitized, multi-threaded interpreter does not come back)
 tests=${*:-"tests/test_sampler_host.py tests/test_stream_engine.py tests/test_native_search.py tests/test_eigen_update.py tests/test_host_logic.py -k '(native_search or eigen or pool or pipelined or device_chains or reap or tape or sampler or stream or chain or numpy or legacy or gibbs or fit) and not recorders_agree and not statements_agree and not rendezvous and not stale_file'"}
 {
