@@ -123,6 +123,13 @@ SIGNATURES = {
     'fokl_spectrum_retain': (c_int, [c_vp, c_vp]),
     'fokl_search_model_begin': (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     'fokl_search_model_commit': (c_int, [c_vp, c_vp, c_vp, c_dbl, c_int, c_vp]),
+    'fokl_run_create': (c_int, [c_vp, c_vp, c_vp]),
+    'fokl_run_set_update': (c_int, [c_vp, c_int, c_int, c_int]),
+    'fokl_run_search': (c_int, [c_vp, c_vp]),
+    'fokl_run_result': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_run_arrays': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_run_error': (ctypes.c_char_p, [c_vp]),
+    'fokl_run_destroy': (None, [c_vp]),
     'fokl_search_score': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_vp]),
     'fokl_outcome_info': (c_int, [c_vp, c_vp, c_vp]),
     'fokl_outcome_spectrum': (c_int, [c_vp, c_vp, c_vp]),
@@ -1441,6 +1448,177 @@ def gibbs_chain_device(engine, lamb, qty, b, btau, dtd, sigsqd0, tausqd0, tape, 
 # ---------------------------------------------------------------------------------------------------------
 # device context
 # ---------------------------------------------------------------------------------------------------------
+
+_OPS_SIGS = (('reserve_slots', [c_vp, c_int]),
+             ('build_terms', [c_vp, c_vp, c_int, c_vp]),
+             ('gram', [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int]),
+             ('gram_launch', [c_vp, c_vp, c_int, c_vp, c_int, c_int]),
+             ('gram_fetch', [c_vp, c_vp, c_i64]),
+             ('gram_ready', [c_vp]),
+             ('bic_resid', [c_vp, c_vp, c_int, c_vp, c_vp, c_int]),
+             ('bic_resid_launch', [c_vp, c_vp, c_int, c_vp]),
+             ('bic_resid_fetch', [c_vp, c_vp, c_int]),
+             ('bic_resid_terms_launch', [c_vp, c_vp, c_int, c_vp]))
+_OPS_TYPES = {name: ctypes.CFUNCTYPE(c_int, *args) for name, args in _OPS_SIGS}
+
+
+class _BackendOps(ctypes.Structure):
+    _fields_ = [('ctx', c_vp)] + [(name, c_vp) for name, _ in _OPS_SIGS] + [('kernel_id', c_i32)]
+
+
+class _RunParams(ctypes.Structure):
+    _fields_ = [(name, c_i32) for name in (
+        'm', 'n_phis', 'way3', 'tolerance', 'gimmie', 'draws', 'half0', 'lookahead', 'lookahead_native', 'foresight',
+        'speculate_across', 'forecast_early', 'forecast_polls', 'matrix_free', 'update_from', 'update_depth',
+        'update_lookahead', 'head_start', 'slot_capacity')]
+
+
+RUN_STATS = ('terms_physical', 'substages', 'forecasts_used', 'forecasts_early', 'resid_matrix_free', 't_resid',
+             'phase_prepare', 'phase_model', 'phase_statistics', 'phase_tests', 'phase_wrap_up')
+
+
+def backend_ops(backend, kernel_id):
+    """include/fokl_hip_internal.h fokl_backend_ops for a search backend -> (struct, what must stay alive with it).
+    A backend on a DeviceContext hands over the library's own entry points (nothing of the loop passes through Python); any
+    other object with HipBackend's methods (the checker backend of the CPU tests) is reached through callbacks."""
+    lib = load()
+    ops = _BackendOps()
+    ops.kernel_id = int(kernel_id)
+    ctx = getattr(backend, 'ctx', None)
+    if isinstance(ctx, DeviceContext):
+        ops.ctx = ctx._h
+        for name, _ in _OPS_SIGS:
+            setattr(ops, name, ctypes.cast(getattr(lib, 'fokl_' + name), c_vp).value)
+        return ops, (ctx,)
+    pending, raised = {}, []
+
+    def arr(ptr, count, ctype, dtype):
+        return np.array(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype * count)).contents), dtype=dtype)
+
+    def guard(fn):
+        def call(*args):
+            try:
+                fn(*args)
+                return 0
+            except BaseException as exc:                     # noqa: B902 -- carried over the native frame
+                raised.append(exc)
+                return -3
+        return call
+
+    def out(ptr, values):
+        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        ctypes.memmove(ptr, values.ctypes.data, values.nbytes)
+
+    def reserve_slots(_c, n):
+        backend.reserve_slots(int(n))
+
+    def build_terms(_c, terms, T, slots):
+        sl = arr(slots, T, ctypes.c_int32, np.int32)
+        m = pending['m']
+        backend.build_terms(arr(terms, T * m, ctypes.c_int32, np.int32).reshape(T, m), [int(v) for v in sl])
+
+    def gram(_c, rows, nr, cols, nc, dst, _path, allreduce):
+        out(dst, backend.gram([int(v) for v in arr(rows, nr, ctypes.c_int32, np.int32)],
+                              [int(v) for v in arr(cols, nc, ctypes.c_int32, np.int32)], bool(allreduce)))
+
+    def gram_launch(_c, rows, nr, cols, nc, allreduce):
+        pending['gram'] = backend.gram([int(v) for v in arr(rows, nr, ctypes.c_int32, np.int32)],
+                                       [int(v) for v in arr(cols, nc, ctypes.c_int32, np.int32)], bool(allreduce))
+
+    def gram_fetch(_c, dst, count):
+        block = pending.pop('gram')
+        assert block.size == count
+        out(dst, block)
+
+    def bic_resid(_c, slots, nc, betahat, dst, allreduce):
+        out(dst, backend.bic_resid([int(v) for v in arr(slots, nc, ctypes.c_int32, np.int32)],
+                                   arr(betahat, nc, ctypes.c_double, np.float64), bool(allreduce)))
+
+    def bic_resid_launch(_c, slots, nc, betahat):
+        pending['resid'] = backend.bic_resid([int(v) for v in arr(slots, nc, ctypes.c_int32, np.int32)],
+                                             arr(betahat, nc, ctypes.c_double, np.float64), False)
+
+    def bic_resid_fetch(_c, dst, _allreduce):
+        out(dst, pending.pop('resid'))
+
+    table = dict(reserve_slots=reserve_slots, build_terms=build_terms, gram=gram, gram_launch=gram_launch,
+                 gram_fetch=gram_fetch, bic_resid=bic_resid, bic_resid_launch=bic_resid_launch,
+                 bic_resid_fetch=bic_resid_fetch)
+    keep = [pending, raised]
+    for name, fn in table.items():
+        cb = _OPS_TYPES[name](guard(fn))
+        keep.append(cb)
+        setattr(ops, name, ctypes.cast(cb, c_vp).value)
+    return ops, tuple(keep)
+
+
+class NativeRun:
+    """include/fokl_hip_internal.h: fokl_run_* -- the sub-stage loop of a fit (csrc/fokl_run.cpp) on a NativeSearch.
+    Created BEFORE the pool (its head start puts the first sub-stage's columns and Gram block under way)."""
+
+    def __init__(self, backend, kernel_id, **params):
+        self._lib = load()
+        self._h = None
+        self._ops, self._keep = backend_ops(backend, kernel_id)
+        if isinstance(self._keep[0], dict):
+            self._keep[0]['m'] = int(params['m'])
+        self._prm = _RunParams(**{k: int(v) for k, v in params.items()})
+        self.m = int(params['m'])
+        h = c_vp(0)
+        _check(self._lib.fokl_run_create(ctypes.byref(self._ops), ctypes.byref(self._prm), ctypes.byref(h)))
+        self._h = h
+        self._reraise()
+
+    def _reraise(self):
+        raised = self._keep[1] if isinstance(self._keep[0], dict) else None
+        if raised:
+            exc = raised[0]
+            del raised[:]
+            raise exc
+
+    def set_update(self, from_columns, depth, lookahead):
+        _check(self._lib.fokl_run_set_update(self._h, int(from_columns), int(depth), int(lookahead)))
+
+    def search(self, native_search):
+        """The loop.  Raises what a backend callback raised, or FoklNativeError with the search's / the run's message."""
+        rc = self._lib.fokl_run_search(self._h, native_search._h)
+        self._reraise()
+        if rc != 0:
+            native_search._checked(rc)
+        return self
+
+    def result(self):
+        """-> (mtx [rows, m] float64, evs, per sub-stage (mean_abs, rel_std), handle of the returned model, handle of the
+        last sub-stage's survivor, stats)"""
+        rows, n_evs, subs = c_i32(0), c_i32(0), c_i32(0)
+        best, last = c_vp(0), c_vp(0)
+        _check(self._lib.fokl_run_result(self._h, ctypes.byref(rows), ctypes.byref(n_evs), ctypes.byref(subs),
+                                         ctypes.byref(best), ctypes.byref(last)))
+        mtx = np.zeros((max(rows.value, 0), self.m), dtype=np.int32)
+        evs = np.zeros(n_evs.value)
+        sizes = np.zeros(max(subs.value, 1), dtype=np.int32)
+        stats = np.zeros(16)
+        total = self._lib.fokl_run_arrays(self._h, _ptr(mtx) if mtx.size else None, _ptr(evs) if evs.size else None,
+                                          _ptr(sizes), None, None, _ptr(stats))
+        mean_abs, rel_std = np.zeros(max(total, 1)), np.zeros(max(total, 1))
+        self._lib.fokl_run_arrays(self._h, None, None, None, _ptr(mean_abs), _ptr(rel_std), None)
+        per, at = [], 0
+        for size in sizes[:subs.value]:
+            per.append(dict(mean_abs=mean_abs[at:at + size].copy(), rel_std=rel_std[at:at + size].copy()))
+            at += int(size)
+        return (mtx.astype(np.float64), evs, per, best.value, last.value, dict(zip(RUN_STATS, stats[:len(RUN_STATS)])))
+
+    def close(self):
+        if self._h is not None and self._h:
+            self._lib.fokl_run_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class DeviceContext:
     """One HIP stream on one MI355X plus the resident dataset and column slots."""

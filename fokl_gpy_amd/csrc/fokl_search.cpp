@@ -201,6 +201,10 @@ struct Spectrum : Counted<Spectrum, &Census::spectra> {
     int32_t updated = -1;
     int status = FOKL_OK;
     int refs = 1;
+    // (X'X)^-1 of the model, formed from the eigenpairs the first time a least-squares predictor starts from this model
+    // (PathModel::init: p^3 operations, 0.1-0.25 ms at 100-144 columns) and kept: a sub-stage model is started from two or
+    // three times -- the likely first tests before and after its evaluation, the kill tests themselves (search thread only)
+    mutable std::vector<double> inverse;
     double *lamb() const { return buf; }
     double *qty() const { return buf + p1; }
     double *betahat() const { return buf + 2 * p1; }
@@ -1570,9 +1574,12 @@ struct PathModel {
         beta.assign(sp->betahat(), sp->betahat() + p);
         ssr = sp->moments()[1];
         s1 = sp->moments()[0];
-        inv.resize((size_t)p * p);
-        std::vector<double> scaled((size_t)p);
-        inverse_from_spectrum(sp->Qt(), sp->lamb(), p, inv.data(), scaled.data());
+        if (sp->inverse.empty()) {
+            sp->inverse.resize((size_t)p * p);
+            std::vector<double> scaled((size_t)p);
+            inverse_from_spectrum(sp->Qt(), sp->lamb(), p, sp->inverse.data(), scaled.data());
+        }
+        inv = sp->inverse;
     }
 
     int position(int32_t col) const

@@ -1056,7 +1056,29 @@ class ForwardSelection:
         # then finds its Gram block waiting, like every later one whose columns were built ahead.  Single-process searches
         # (a split over ranks gathers rows: a collective, kept where the other collectives are).  FOKL_HEAD_START=0: off.
         self._head = None
-        if (pipelined and hasattr(self.backend, 'gram_launch') and not (self.allreduce or self.candidate_sharded)
+        # The sub-stage loop itself as native code (csrc/fokl_run.cpp, round 6) where the search is the common case: one
+        # process, the native search, look-ahead on, default build-ahead / statistics.  Its head start replaces the one
+        # below.  FOKL_SUBSTAGE_LOOP=python: this file's _run (what every other search runs, and the statement the native
+        # loop is tested against).
+        self._nrun = None
+        if (pipelined and not (self.allreduce or self.candidate_sharded) and self._native_planned()
+                and self.lookahead > 0 and self.tentative_tapes and not self._test_rewinds and not self.console
+                and not (self.way3 and self.m == 2)        # (FR:1724 reads indvec[2]: the reference raises -- this file's loop too)
+                and os.environ.get('FOKL_SUBSTAGE_LOOP', 'native') != 'python'
+                and os.environ.get('FOKL_BUILD_AHEAD', 'model') == 'model'
+                and os.environ.get('FOKL_STATS', 'native') == 'native'
+                and not os.environ.get('FOKL_POOL_TRACE')):
+            self._nrun = _capi.NativeRun(
+                self.backend, getattr(self.backend, 'kernel_id', getattr(self.backend, 'kernel', 1)),
+                m=self.m, n_phis=self.n_phis, way3=int(self.way3), tolerance=self.tolerance, gimmie=int(bool(self.gimmie)),
+                draws=self.draws, half0=int(math.ceil(self.draws / 2)), lookahead=self.lookahead,
+                lookahead_native=self._lookahead_native, foresight=self.foresight,
+                speculate_across=int(self._speculate_across), forecast_early=int(self._forecast_early),
+                forecast_polls=0 if os.environ.get('FOKL_SYNC') == 'blocking' else self._forecast_polls,
+                matrix_free=int(self._matrix_free), update_from=0, update_depth=0, update_lookahead=0,
+                head_start=int(os.environ.get('FOKL_HEAD_START', '1') != '0'), slot_capacity=self.pool.capacity)
+        if (self._nrun is None and pipelined and hasattr(self.backend, 'gram_launch')
+                and not (self.allreduce or self.candidate_sharded)
                 and os.environ.get('FOKL_HEAD_START', '1') != '0'):
             base = self.backend.gram([SLOT_ONES, SLOT_Y], [SLOT_ONES, SLOT_Y], False)
             self._head = (base, self._build_ahead(next(self._patterns())[1], [SLOT_ONES]))
@@ -1362,7 +1384,39 @@ class ForwardSelection:
         out[n_prev:A2, A2] = out[A2, n_prev:A2] = block[:, over + vm]
         return out
 
+    def _run_native(self):
+        """csrc/fokl_run.cpp: the sub-stage loop as native code on this search's NativeSearch; this side keeps what follows
+        the loop (_finish)."""
+        nrun, self._nrun = self._nrun, None
+        if self._update_args is not None:
+            nrun.set_update(*self._update_args)
+        try:
+            nrun.search(self.native)
+            mtx, evs, per_substage, best_h, last_h, st = nrun.result()
+        finally:
+            nrun.close()
+        self.substage_stats = per_substage
+        for key in ('terms_physical', 'substages', 'forecasts_used', 'resid_matrix_free'):
+            self.stats[key] += int(st[key])
+        self.stats['forecasts_early'] = self.stats.get('forecasts_early', 0) + int(st['forecasts_early'])
+        self.stats['t_resid'] += st['t_resid']
+        self.stats['substage_loop'] = 'native'
+        phase = self.stats.setdefault('phases', dict(prepare=0.0, model=0.0, statistics=0.0, tests=0.0, wrap_up=0.0))
+        for key in phase:
+            phase[key] += st['phase_' + key]
+        betas = NativeOutcome(self, self.native, best_h)
+        last = betas if last_h == best_h else NativeOutcome(self, self.native, last_h)
+        self._outcomes = [betas] if last is betas else [betas, last]
+        if self.chain_engine is not None and hasattr(self.chain_engine, 'flush'):
+            self.chain_engine.flush()              # the last kill tests' chains go out now, not when their batch has aged
+        return self._finish(betas, mtx, evs, last)
+
     def _run(self):
+        if getattr(self, '_nrun', None) is not None:
+            if self.native is not None:
+                return self._run_native()
+            self._nrun.close()                      # the native search did not come up after all: this file's loop from scratch
+            self._nrun = None
         m, n = self.m, self.n
         draws = self.draws
         half1 = int(math.ceil(draws / 2 + 1))      # FR:1656
@@ -1634,6 +1688,10 @@ class ForwardSelection:
 
         if self.gimmie:                            # FR:1751-1753
             betas, mtx = last, last_damtx
+        return self._finish(betas, mtx, evs, last)
+
+    def _finish(self, betas, mtx, evs, last):
+        """What follows the sub-stage loop: the returned model's draws, the confirmation of every guessed decision."""
         # The returned model's draws are formed while the last confirmations are still on their way (eigenpairs of the last
         # sub-stage's accepted models, then their chains on the device: 3-4 ms in which this thread only waits); should a
         # confirmation fail, Misprediction discards them with everything else.

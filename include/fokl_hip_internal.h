@@ -399,6 +399,60 @@ typedef struct fokl_kill_tests_result {
 int fokl_search_kill_tests(fokl_search *search, const fokl_kill_tests_args *args, fokl_kill_tests_result *result);
 
 /* ------------------------------------------------------------------------------------------------------ */
+/* The sub-stage loop next to the kill-test loop (round 6; csrc/fokl_run.cpp).  Replaces the bookkeeping of    */
+/* FR:1602-1748 around the calls above: enumeration, build-ahead, model evaluation, statistics, stop rule.     */
+/* ------------------------------------------------------------------------------------------------------ */
+/* The device as a table of entry points with the signatures of fokl_hip.h (ctx is handed back as their first
+ * argument): the library's own functions on a fokl_ctx, or a checker backend's callbacks (CPU tests). */
+typedef struct fokl_backend_ops {
+    void *ctx;
+    int (*reserve_slots)(void *ctx, int n_slots);
+    int (*build_terms)(void *ctx, const int32_t *terms, int T, const int32_t *slots);
+    int (*gram)(void *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, double *out, int path,
+                int allreduce);
+    int (*gram_launch)(void *ctx, const int32_t *row_slots, int nr, const int32_t *col_slots, int nc, int allreduce);
+    int (*gram_fetch)(void *ctx, double *out, int64_t count);
+    int (*gram_ready)(void *ctx);                                       /* may be NULL */
+    int (*bic_resid)(void *ctx, const int32_t *slots, int nc, const double *betahat, double *out, int allreduce);
+    int (*bic_resid_launch)(void *ctx, const int32_t *slots, int nc, const double *betahat);
+    int (*bic_resid_fetch)(void *ctx, double *out, int allreduce);
+    int (*bic_resid_terms_launch)(void *ctx, const int32_t *terms, int n_terms, const double *betahat);   /* may be NULL */
+    int32_t kernel_id;                                                  /* FOKL_KERNEL_* of the uploaded dataset */
+} fokl_backend_ops;
+typedef struct fokl_run_params {
+    int32_t m, n_phis;                          /* inputs; orders the kernel offers (FR:1747) */
+    int32_t way3, tolerance, gimmie;            /* FR:208-212 */
+    int32_t draws, half0;                       /* iterations per chain; first row of the intercept statistic */
+    int32_t lookahead, lookahead_native, foresight, speculate_across;   /* engine.py's knobs of the same names */
+    int32_t forecast_early, forecast_polls;
+    int32_t matrix_free;                        /* K3 without the stored columns where the terms allow it */
+    int32_t update_from, update_depth, update_lookahead;   /* fokl_search_set_update's arguments (update_depth 0: never set) */
+    int32_t head_start;                         /* fokl_run_create launches the first sub-stage's K1 + K2 */
+    int32_t slot_capacity;                      /* device column slots to start with */
+} fokl_run_params;
+#define FOKL_RUN_STATS 16
+typedef struct fokl_run fokl_run;
+/* Seed Gram + (head_start) the first sub-stage's columns and Gram block under way: before the caller creates its pool. */
+int fokl_run_create(const fokl_backend_ops *ops, const fokl_run_params *params, fokl_run **out);
+/* fokl_search_set_update's arguments as the caller configured its search (the loop shortens the derivation depth in the
+ * sub-stage after which the stop rule may end the search; depth 0: never touched). */
+int fokl_run_set_update(fokl_run *run, int from_columns, int depth, int lookahead);
+/* The loop, on `search` (fokl_search_create on the caller's pool; decisions, update depth etc. configured by the caller). */
+int fokl_run_search(fokl_run *run, fokl_search *search);
+/* What it found: rows of the interaction matrix, length of the BIC trace, sub-stages; the outcome handles of the returned
+ * model and of the last sub-stage's survivor (the caller owns them: fokl_outcome_drop; they may be one and the same). */
+int fokl_run_result(const fokl_run *run, int32_t *mtx_rows, int32_t *evs_count, int32_t *substages,
+                    fokl_outcome **best_model, fokl_outcome **last_model);
+/* mtx [mtx_rows][m], evs, per sub-stage the number of new terms and -- concatenated -- their |mean beta| and std / |mean|
+ * (FR:1656-1658), stats [FOKL_RUN_STATS]: columns built, sub-stages, forecasts used / early, matrix-free residual passes,
+ * seconds waiting for K3, seconds by phase (prepare, model, statistics, tests, wrap-up).  NULL: skipped.  -> length of the
+ * statistics arrays */
+int fokl_run_arrays(const fokl_run *run, int32_t *mtx, double *evs, int32_t *stat_sizes, double *stat_mean_abs,
+                    double *stat_rel_std, double *stats);
+const char *fokl_run_error(const fokl_run *run);
+void fokl_run_destroy(fokl_run *run);
+
+/* ------------------------------------------------------------------------------------------------------ */
 /* G3 on the device: finishing of the polar normals + the D-iteration recursion (FoKLRoutines.py:1519-1548)  */
 /* ------------------------------------------------------------------------------------------------------ */
 

@@ -89,21 +89,42 @@ def test_native_objects_are_released(monkeypatch):
 
 
 def test_a_callback_that_raises_surfaces_after_the_native_loop(monkeypatch):
+    """The device stand-in fails in the middle of a search -- inside a callback of the native sub-stage loop
+    (csrc/fokl_run.cpp), or inside this file's loop (FOKL_SUBSTAGE_LOOP=python): the exception surfaces once the native
+    frames have returned, and the next fit in the process works: nothing was left half torn down."""
     problem = _random_problem(3)
-    monkeypatch.setenv('FOKL_SEARCH', 'native')
     boom = RuntimeError('device gone')
-    real = engine.ForwardSelection._build_ahead
-    calls = []
+    real = OracleBackend.build_terms
+    for loop in ('native', 'python'):
+        monkeypatch.setenv('FOKL_SUBSTAGE_LOOP', loop)
+        calls = []
 
-    def failing(self, indvec, active_slots):
-        calls.append(1)
-        if len(calls) == 3:
-            raise boom
-        return real(self, indvec, active_slots)
+        def failing(self, terms, slots, calls=calls):
+            calls.append(1)
+            if len(calls) == 3:
+                raise boom
+            return real(self, terms, slots)
 
-    monkeypatch.setattr(engine.ForwardSelection, '_build_ahead', failing)
-    with pytest.raises(RuntimeError, match='device gone'):
+        monkeypatch.setattr(OracleBackend, 'build_terms', failing)
+        with pytest.raises(RuntimeError, match='device gone'):
+            _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
+        monkeypatch.setattr(OracleBackend, 'build_terms', real)
         _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
-    # and the next fit in this process works: nothing was left half torn down
-    monkeypatch.setattr(engine.ForwardSelection, '_build_ahead', real)
-    _fit(monkeypatch, 'native', problem=problem, draws=40, burnin=40)
+
+
+@pytest.mark.parametrize('name', ['bern_m3', 'bern_m4_way3', 'bern_m8_capped', 'splines_m4'])
+def test_native_substage_loop_equals_the_python_one(monkeypatch, name):
+    """csrc/fokl_run.cpp against engine.ForwardSelection._run, both on the native search: the same sequence of evaluations,
+    model, draws, statistics of every sub-stage and end state of numpy's stream."""
+    monkeypatch.setenv('FOKL_SUBSTAGE_LOOP', 'native')
+    a = _fit(monkeypatch, 'native', name)
+    monkeypatch.setenv('FOKL_SUBSTAGE_LOOP', 'python')
+    b = _fit(monkeypatch, 'native', name)
+    assert a[0].fit_stats.get('substage_loop') == 'native' and b[0].fit_stats.get('substage_loop') != 'native'
+    assert [(t['cols'], t['built'], t['kill']) for t in a[0].fit_trace] == [(t['cols'], t['built'], t['kill']) for t in b[0].fit_trace]
+    assert np.array_equal([t['ev'] for t in a[0].fit_trace], [t['ev'] for t in b[0].fit_trace])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[4][0], b[4][0]) and a[4][1:] == b[4][1:]
+    assert len(a[0].fit_substage_stats) == len(b[0].fit_substage_stats)
+    for x, y in zip(a[0].fit_substage_stats, b[0].fit_substage_stats):
+        assert np.array_equal(x['mean_abs'], y['mean_abs']) and np.array_equal(x['rel_std'], y['rel_std'])
