@@ -645,6 +645,7 @@ def fits_worker(cfg, k, procs, local, unit_ids, rows, steps, warmup, start, done
     # boxes, 50 instead of 160 tapes per fit are walked for nothing, and that CPU is what the quota is short of
     # (tools/r05_spec.sh: 4 processes 854-913 k terms/s at 48, 952-981 k at 24, 961-965 k at 12, 709-944 k at 6)
     os.environ.setdefault('FOKL_SPECULATION', THROUGHPUT_SPECULATION)
+    os.environ.setdefault('FOKL_WALK_HELPERS', '0')       # (helpers of the serial walk buy latency with CPU: not here)
     for name, val in (('FOKL_CHAIN_THREADS', '1'), ('FOKL_FINISH_THREADS', '1'),
                       ('FOKL_SPECTRAL_THREADS', '3' if device_chains or procs <= 2 else '2')):
         os.environ.setdefault(name, val)
@@ -1274,6 +1275,7 @@ def main():
             # its fits, and with a single fit's thread plan (2 / 2 / 8 host threads against the workers' 1 / 1 / 3) that was
             # this one (48 ms per fit against the workers' 39-45)
             side_env = {'FOKL_SPECULATION': THROUGHPUT_SPECULATION, 'FOKL_CHAIN_THREADS': '1', 'FOKL_FINISH_THREADS': '1',
+                        'FOKL_WALK_HELPERS': '0',
                         'FOKL_SPECTRAL_THREADS': '3' if os.environ.get('FOKL_CHAIN', 'auto') != 'host' or side_procs + 1 <= 2 else '2'}
             side_env = {k: v for k, v in side_env.items() if k not in os.environ}
             os.environ.update(side_env)

@@ -102,6 +102,7 @@ SIGNATURES = {
     'fokl_stream_state': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_expand': (c_int, [c_vp, c_int, c_dbl, c_dbl, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'fokl_stream_set_helpers': (c_int, [c_vp, c_int, c_vp]),
     'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
@@ -772,6 +773,14 @@ class HostPool:
     def stream_handle(self):
         """The pool's fokl_stream (for DeviceChainEngine.bind)."""
         return self._lib.fokl_pool_stream(self._h)
+
+    def set_walk_helpers(self, count, cpus=None):
+        """fokl_stream_set_helpers on the pool's stream: helper threads for the serial walk (positions + accept tests of the
+        blocks the walking thread chases), each on the logical CPU given for it."""
+        arr = None
+        if cpus is not None:
+            arr = np.ascontiguousarray(list(cpus)[:count] + [-1] * max(0, count - len(cpus)), dtype=np.int32)
+        _check(self._lib.fokl_stream_set_helpers(c_vp(self.stream_handle()), int(count), _ptr(arr) if arr is not None else None))
 
     def close(self):
         """Runs everything still queued (each submitted tape advances the stream), then stops the threads."""

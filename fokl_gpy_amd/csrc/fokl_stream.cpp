@@ -43,6 +43,7 @@
 #include <vector>
 
 #include <immintrin.h>
+#include <sched.h>
 
 #include "../../include/fokl_hip_internal.h"
 #include "fokl_spin.h"
@@ -374,7 +375,12 @@ void give_segment(Segment *s)
 
 }  // namespace
 
+namespace {
+struct WalkCrew;
+}
+
 struct fokl_stream {
+    WalkCrew *crew = nullptr;                               // helper threads of the walk in rank space (walk_tape_crew)
     // the stream as it was handed over (numpy's get_state()): block 0 is mt_key, the first unread word is pos0
     uint32_t key0[MT_N];
     int pos0 = 0;
@@ -1348,7 +1354,7 @@ FOKL_WIDE_TARGET static inline __attribute__((always_inline)) void iteration_sit
 }
 
 // pass 2: the block's rows, the sources of its gamma draws, the state behind every iteration
-FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut &out, const Reader &prefetcher)
+FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut &out, int o)
 {
     uint32_t wc = in.wc0;
     uint64_t D = in.D0, gsrc = in.gsrc0;
@@ -1366,13 +1372,287 @@ FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut 
             _mm256_storeu_si256(reinterpret_cast<__m256i *>(in.rows + i), rowv);
         D = out.after[i].D;
         gsrc = out.after[i].gauss_src;
-        prefetcher.prefetch_words(out.source[2 * i] & ~kCachedHalf);
+        // the words of this iteration's gamma site (both draws' attempts and uniforms lie within a few doubles of each other,
+        // inside the block's own segment): written by another core a moment ago, read by the tests that follow
+        const char *site = reinterpret_cast<const char *>(in.seg->words() + o + 2 * ((out.source[2 * i] & ~kCachedHalf) - in.lo));
+        __builtin_prefetch(site);
+        __builtin_prefetch(site + 24);
     }
+}
+
+// ---- the walk crew: passes 2 and 3 on other threads ------------------------------------------------------------------
+// With the sub-stage loop native (csrc/fokl_run.cpp) a fit is bound by the walk: its thread is busy 18.6 of 23.3 ms.  The chase
+// is 4 ns per iteration of its 19-20; positions and tests -- every gamma site a cache line another core wrote a moment ago --
+// are the rest and do not depend on each other from block to block.  With helper threads (fokl_stream_set_helpers) the
+// walking thread only chases: it publishes each block's ranks and exact first state (one select per block gives it the
+// state behind the block) and goes on, taking the block to be good, which 899 in 900 iterations are; helpers form the rows,
+// run the accept tests and report the first iteration to redo, if any.  Verdicts are read in order; a block that is not good
+// takes everything issued behind it with it (the walker waits for those helpers, walks the one iteration by positions and
+// chases on from there).  Rows, positions and consumption are the one-thread walk's bit for bit.
+constexpr int kCrewRing = 8;                                // blocks in flight at most
+constexpr int kCrewMax = 4;
+
+struct alignas(64) CrewSlot {
+    BlockIn in;
+    int redo = -1;                                          // the helper's verdict: -1 good, >= 0 first iteration to redo, -2 failure
+    IterationStart redo_from{};                             // the exact state at that iteration's start
+    int64_t exact = 0;
+    alignas(64) std::atomic<uint64_t> ready{0};             // number of the block in `in` (published by the walker)
+    alignas(64) std::atomic<uint64_t> done{0};              // number of the block whose verdict stands here
+};
+
+struct WalkCrew {
+    fokl_stream *e = nullptr;
+    int helpers = 0;
+    CrewSlot slots[kCrewRing];
+    uint64_t issued = 0;                                    // blocks are numbered 1, 2, ..: block n lives in slot n % kCrewRing
+    alignas(64) std::atomic<uint64_t> claimed{0};           // blocks 1 .. claimed have a worker (helpers and, when it would
+                                                            // only wait, the walking thread take the next published one)
+    std::unique_ptr<BlockOut> walker_out;                   // the walking thread's own work area, when it lends a hand
+    alignas(64) std::atomic<bool> stop{false};
+    std::atomic<int> sleepers{0};
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::thread> threads;
+    std::vector<int> cpus;                                  // helper i runs on cpus[i] (empty: wherever its creator may)
+};
+
+// passes 2 and 3 of block n (published, claimed by the caller)
+FOKL_WIDE_TARGET static void crew_process(WalkCrew *crew, uint64_t n, BlockOut &out, Walk &checker)
+{
+    CrewSlot &slot = crew->slots[n % kCrewRing];
+    const BlockIn &in = slot.in;
+    const int o = crew->e->o;
+    checker.r.failed = false;
+    const int64_t t0 = g_walk_profile ? now_ns() : 0;
+    block_positions(in, out, o);
+    const int64_t t1 = g_walk_profile ? now_ns() : 0;
+    const __m512d bvec = _mm512_setr_pd(in.b_sig, in.b_tau, in.b_sig, in.b_tau, in.b_sig, in.b_tau, in.b_sig, in.b_tau);
+    const __m512d cvec = _mm512_setr_pd(in.c_sig, in.c_tau, in.c_sig, in.c_tau, in.c_sig, in.c_tau, in.c_sig, in.c_tau);
+    int64_t exact = 0;
+    const int redo = check_tests(checker, o, out.source, out.upos, in.count, bvec, cvec, in.b_sig, in.c_sig, in.b_tau, in.c_tau,
+                                 exact);
+    if (g_walk_profile) {
+        g_walk_ns[1].fetch_add(t1 - t0, std::memory_order_relaxed);
+        g_walk_ns[2].fetch_add(now_ns() - t1, std::memory_order_relaxed);
+    }
+    slot.redo = redo;
+    slot.exact = exact;
+    if (redo > 0)
+        slot.redo_from = out.after[redo - 1];
+    else if (redo == 0)
+        slot.redo_from = {in.D0, in.gsrc0, (int)in.h[0]};
+    _mm_sfence();                                           // the rows were streamed
+    slot.done.store(n, std::memory_order_release);
+}
+
+// the next published block nobody has taken yet -> its number, or 0
+static inline uint64_t crew_claim(WalkCrew *crew)
+{
+    uint64_t n = crew->claimed.load(std::memory_order_acquire);
+    while (crew->slots[(n + 1) % kCrewRing].ready.load(std::memory_order_acquire) == n + 1)
+        if (crew->claimed.compare_exchange_weak(n, n + 1, std::memory_order_acq_rel)) return n + 1;
+    return 0;
+}
+
+FOKL_WIDE_TARGET void crew_helper(WalkCrew *crew, int which)
+{
+    struct Note {
+        ~Note() { fokl_note_thread_cpu(0); }
+    } note;
+    if (which < (int)crew->cpus.size() && crew->cpus[(size_t)which] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(crew->cpus[(size_t)which], &set);
+        (void)sched_setaffinity(0, sizeof(set), &set);
+    }
+    Walk checker(crew->e, Walk::ReaderOnly{});
+    std::unique_ptr<BlockOut> out(new BlockOut());
+    for (;;) {
+        uint64_t n = 0;
+        for (int spins = 0; (n = crew_claim(crew)) == 0; ++spins) {
+            if (crew->stop.load(std::memory_order_acquire)) return;
+            if (spins < fokl_spin_budget(20000)) {
+                _mm_pause();
+            } else {
+                std::unique_lock<std::mutex> lock(crew->m);
+                crew->sleepers.fetch_add(1, std::memory_order_seq_cst);
+                crew->cv.wait(lock, [&] {
+                    if (crew->stop.load(std::memory_order_seq_cst)) return true;
+                    const uint64_t c = crew->claimed.load(std::memory_order_seq_cst);
+                    return crew->slots[(c + 1) % kCrewRing].ready.load(std::memory_order_seq_cst) == c + 1;
+                });
+                crew->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+                spins = 0;
+            }
+        }
+        crew_process(crew, n, *out, checker);
+    }
+}
+
+void crew_stop(fokl_stream *e)
+{
+    WalkCrew *crew = e->crew;
+    if (!crew) return;
+    {
+        std::lock_guard<std::mutex> lock(crew->m);
+        crew->stop.store(true, std::memory_order_seq_cst);
+    }
+    crew->cv.notify_all();
+    for (auto &t : crew->threads) t.join();
+    delete crew;
+    e->crew = nullptr;
+}
+
+// the tape walked by the crew: the calling thread chases, the helpers do the rest
+FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
+                                    int32_t *progress)
+{
+    WalkCrew *crew = e->crew;
+    Walk w(e);
+    const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
+    const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
+    int64_t exact = 0, rolled_back = 0, by_position = 0;
+    int k = 0, k_issued = 0, published = 0;                 // iterations that stand / that were chased / that `progress` announced
+    auto publish = [&](int upto) {
+        const int whole = upto == draws ? draws : upto - upto % FOKL_TAPE_BLOCK;
+        if (progress && whole > published) __atomic_store_n(progress, whole, __ATOMIC_RELEASE);    // (helpers fenced their rows)
+        published = std::max(published, whole);
+    };
+    uint64_t first_open = crew->issued + 1;                 // the oldest block without a verdict
+    Walk lender(e, Walk::ReaderOnly{});                     // (reader of the blocks this thread processes itself)
+    // a verdict this thread has to wait for: it takes published blocks nobody has claimed yet instead of only waiting
+    auto wait_done = [&](uint64_t n) -> CrewSlot & {
+        CrewSlot &slot = crew->slots[n % kCrewRing];
+        for (int spins = 0; slot.done.load(std::memory_order_acquire) != n; ++spins) {
+            if (const uint64_t mine = crew_claim(crew)) {
+                crew_process(crew, mine, *crew->walker_out, lender);
+                spins = 0;
+            } else if (spins < 50000) {
+                _mm_pause();
+            } else {
+                std::this_thread::yield();
+            }
+        }
+        return slot;
+    };
+    // the oldest open block's verdict (waited for).  -> false: it was not good: the walker stands at the iteration to redo
+    auto judge_oldest = [&]() -> bool {
+        CrewSlot &slot = wait_done(first_open);
+        exact += slot.exact;
+        const int redo = slot.redo;
+        if (redo == -1) {
+            k += slot.in.count;
+            ++first_open;
+            publish(k);
+            return true;
+        }
+        for (uint64_t n = first_open + 1; n <= crew->issued; ++n) (void)wait_done(n);      // what was issued behind it goes with it
+        first_open = crew->issued + 1;
+        if (redo == -2) {
+            w.r.failed = true;
+            return false;
+        }
+        k += redo;
+        w.D = slot.redo_from.D;
+        w.gauss_src = slot.redo_from.gauss_src;
+        w.has_gauss = slot.redo_from.has_gauss;
+        k_issued = k;
+        ++rolled_back;
+        publish(k);
+        return false;
+    };
+    while (k < draws && !w.r.failed) {
+        int64_t lap_ = g_walk_profile ? now_ns() : 0;
+        bool exact_state = true;                            // w is the state behind the last iteration that stands
+        if (k_issued < draws && w.r.locate(w.D) && w.D - w.r.lo < (uint64_t)kSegDoubles - 64) {
+            if (crew->issued - first_open + 1 >= (uint64_t)kCrewRing) {     // the ring is full: the oldest verdict first
+                if (judge_oldest()) continue;
+            } else {
+                const Segment *seg = w.r.seg;
+                const int a = (int)(w.D & 1);
+                const uint64_t q = (w.D - w.r.lo) >> 1;
+                int64_t r = (int64_t)seg->cum[a][q >> 6] + __builtin_popcountll(seg->mask[a][q >> 6] & ~(~0ull << (q & 63)));
+                int h = w.has_gauss;
+                const int want = std::min(kChase, draws - k_issued);
+                BlockIn &in = crew->slots[(crew->issued + 1) % kCrewRing].in;
+                const int count = chase_block(seg, a, p1, want, r, h, in);
+                FOKL_LAP(0);
+                if (count > 0) {
+                    in.seg = seg;
+                    in.lo = w.r.lo;
+                    in.a = a;
+                    in.wc0 = (uint32_t)(q >> 6);
+                    in.D0 = w.D;
+                    in.gsrc0 = w.gauss_src;
+                    in.rows = rows + k_issued;
+                    in.b_sig = b_sig;
+                    in.c_sig = c_sig;
+                    in.b_tau = b_tau;
+                    in.c_tau = c_tau;
+                    // the state behind the block (exact unless one of its draws turns out not to accept): one select
+                    uint32_t wc = in.wc0;
+                    uint64_t src[2], up[2];
+                    IterationStart after;
+                    iteration_sites(seg, in.lo, a, wc, in.e[count - 1], in.hs[count - 1], src, up, after);
+                    const uint64_t n = ++crew->issued;
+                    crew->slots[n % kCrewRing].ready.store(n, std::memory_order_seq_cst);
+                    if (crew->sleepers.load(std::memory_order_seq_cst) > 0) {
+                        { std::lock_guard<std::mutex> lock(crew->m); }
+                        crew->cv.notify_all();
+                    }
+                    w.D = after.D;
+                    w.gauss_src = after.gauss_src;
+                    w.has_gauss = after.has_gauss;
+                    k_issued += count;
+                    // verdicts that have arrived meanwhile
+                    bool good = true;
+                    while (good && first_open <= crew->issued &&
+                           crew->slots[first_open % kCrewRing].done.load(std::memory_order_acquire) == first_open)
+                        good = judge_oldest();
+                    if (good && count == want) continue;
+                    exact_state = good;                     // (not good: w stands at the iteration to redo already)
+                }
+            }
+        }
+        // the chase stopped (the segment's end, a long run of rejected attempts, the tape's end) or a block was not good: the
+        // position walk needs the exact state, i.e. every block judged
+        while (exact_state && first_open <= crew->issued) exact_state = judge_oldest();
+        if (w.r.failed) break;
+        if (k < draws) {
+            if (g_walk_profile) lap_ = now_ns();
+            walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k]);
+            ++k;
+            k_issued = k;
+            ++by_position;
+            FOKL_LAP(3);
+        }
+        publish(k);
+    }
+    e->exact_draws.fetch_add(exact + w.exact, std::memory_order_relaxed);
+    e->gamma_draws.fetch_add(2 * (int64_t)draws, std::memory_order_relaxed);
+    e->rollbacks.fetch_add(rolled_back, std::memory_order_relaxed);
+    e->position_iterations.fetch_add(by_position, std::memory_order_relaxed);
+    if (g_walk_profile) {
+        g_walk_iterations.fetch_add(k, std::memory_order_relaxed);
+        g_walk_by_position.fetch_add(by_position, std::memory_order_relaxed);
+    }
+    if (w.r.failed) {
+        if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
+        fokl_set_global_error("fokl_stream_walk: the stream's producers stopped (" + e->error + ")");
+        return FOKL_ERR_STATE;
+    }
+    publish(draws);
+    e->D = w.D;
+    e->has_gauss = w.has_gauss;
+    e->gauss_src = w.gauss_src;
+    return FOKL_OK;
 }
 
 FOKL_WIDE_TARGET int walk_tape_ranked(fokl_stream *e, int p1, int draws, double astar, double atau_star,
                                       fokl_tape_row *rows, int32_t *progress)
 {
+    if (e->crew) return walk_tape_crew(e, p1, draws, astar, atau_star, rows, progress);
     Walk w(e);                                              // the exact state; its reader keeps the producers ahead
     Walk checker(e);                                        // its reader serves the values of the accept tests
     checker.r.walker = false;
@@ -1418,7 +1698,7 @@ FOKL_WIDE_TARGET int walk_tape_ranked(fokl_stream *e, int p1, int draws, double 
                 in.gsrc0 = w.gauss_src;
                 in.rows = rows + k;
                 // ---- pass 2: positions, rows, the sources of the gamma draws ----
-                block_positions(in, *out, w.r);
+                block_positions(in, *out, o);
                 FOKL_LAP(1);
                 // ---- pass 3: the accept tests ----
                 const int redo = check_tests(checker, o, out->source, out->upos, count, bvec, cvec, b_sig, c_sig, b_tau, c_tau,
@@ -1550,9 +1830,36 @@ extern "C" void fokl_stream_destroy(fokl_stream *e)
         e->stop_flag.store(true, std::memory_order_release);
     }
     e->room_cv.notify_all();
+    crew_stop(e);
     for (auto &t : e->threads) t.join();
     for (auto &t : e->table) give_segment(t.exchange(nullptr));
     delete e;
+}
+
+// Helper threads for the walk (walk_tape_crew): `count` of them (0: none; at most 4), helper i pinned to logical CPU cpus[i]
+// (cpus NULL or an entry < 0: not pinned).  Before the first walk; the AVX-512 build only (elsewhere: no effect).
+extern "C" int fokl_stream_set_helpers(fokl_stream *e, int count, const int32_t *cpus)
+{
+    if (!e || count < 0) {
+        fokl_set_global_error("fokl_stream_set_helpers: null stream or negative count");
+        return FOKL_ERR_ARG;
+    }
+    crew_stop(e);
+    if (count == 0 || !e->wide) return FOKL_OK;
+    auto *crew = new WalkCrew();
+    crew->e = e;
+    crew->helpers = std::min(count, kCrewMax);
+    crew->walker_out.reset(new BlockOut());
+    for (int i = 0; i < crew->helpers; ++i) crew->cpus.push_back(cpus ? (int)cpus[i] : -1);
+    e->crew = crew;
+    try {
+        for (int i = 0; i < crew->helpers; ++i) crew->threads.emplace_back(crew_helper, crew, i);
+    } catch (const std::exception &ex) {
+        crew_stop(e);
+        fokl_set_global_error(std::string("fokl_stream_set_helpers: ") + ex.what());
+        return FOKL_ERR_STATE;
+    }
+    return FOKL_OK;
 }
 
 extern "C" int fokl_stream_walk(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,

@@ -167,6 +167,13 @@ def _cpu_budget():
     return budget
 
 
+def _walk_helpers_default():
+    """Helper threads of the walk for a process that has the CPUs for them (a fit alone on a 16-CPU budget: two -- same-box
+    sweep 0 / 1 / 2 / 3 / 4: 27.2 / 22.2 / 21.0 / 21.4 / 21.4 ms per configs[2] fit, +15 ms of CPU per helper); fits side by
+    side are bounded by their CPU-seconds and get none."""
+    return 2 if _cpu_budget() >= 12 else 0
+
+
 def _bulk_threads(budget=None, wide_models=False):
     """Threads that produce the random stream ahead of the noise thread's walk (csrc/fokl_stream.cpp): the walk consumes a
     segment of 79 872 doubles in 10-30 us, a bulk thread makes one in 20-40 us (AVX-512).  FOKL_BULK_THREADS overrides."""
@@ -378,6 +385,21 @@ class HostPipeline:
             if prestates is not None:
                 chain_engine.bind(self.pool.stream_handle())
                 self.device_rows = True
+            # Helper threads for the serial walk of the random stream (csrc/fokl_stream.cpp walk_tape_crew): with the sub-stage
+            # loop native the walk bounds a fit.  On physical cores of their OWN, outside this process's last-level-cache domain
+            # -- next to the bulk threads, two to a core, their passes ran at half speed and bought nothing.  FOKL_WALK_HELPERS
+            # overrides the count (0: the walking thread does everything), FOKL_WALK_CPUS=same leaves them unpinned.
+            helpers = int(os.environ.get('FOKL_WALK_HELPERS', str(_walk_helpers_default())))
+            if helpers > 0:
+                cpus = None
+                if self._saved_affinity is not None and os.environ.get('FOKL_WALK_CPUS', 'other') != 'same':
+                    picked = _spectral_cpus(self._saved_affinity, os.sched_getaffinity(0), spectral + helpers)
+                    if picked is not None:
+                        cpus = sorted(picked)[-helpers:]      # (behind the cores the spectral threads get)
+                try:
+                    self.pool.set_walk_helpers(helpers, cpus)
+                except _capi.FoklNativeError:
+                    pass
             # the eigen-decompositions share nothing with the stream's threads: on a CPU with several last-level-cache
             # domains they get the next one to themselves (FOKL_SPECTRAL_DOMAIN=0: they stay where the others are)
             if self._saved_affinity is not None and os.environ.get('FOKL_SPECTRAL_DOMAIN', '1') != '0':

@@ -94,6 +94,10 @@ int fokl_stream_expand(fokl_stream *stream, int p1, double astar, double atau_st
                        double *gam_tau_out);
 /* seconds the bulk threads worked, seconds the walker waited for them, segments (79 872 doubles each) produced, gamma
  * attempts walked and how many of them needed the exact expressions */
+/* Helper threads for the walk: the walking thread then only counts accepted attempts (the chase) and hands blocks of 128
+ * iterations out; helpers turn ranks into positions / rows and run the gamma draws' accept tests.  count 0: none (default),
+ * at most 4; cpus (may be NULL): the logical CPU of each helper (< 0: not pinned).  Call before the first walk. */
+int fokl_stream_set_helpers(fokl_stream *stream, int count, const int32_t *cpus);
 int fokl_stream_stats(const fokl_stream *stream, double *bulk_busy_s, double *walker_wait_s, int64_t *segments,
                       int64_t *gamma_attempts, int64_t *gamma_attempts_exact);
 /* max |fast_ln(y) - log(y)| over a sweep of (0, 1): the approximation the walker's bounds are built on (tests) */

@@ -30,9 +30,11 @@ def _old_tapes(state, sizes, draws, shapes=_shapes):
     return [_capi.record_noise_tape(_capi.NoiseTape(p1, draws), *shapes(p1), stream) for p1 in sizes], stream
 
 
-def _new_tapes(state, sizes, draws, shapes=_shapes, bulk_threads=2):
+def _new_tapes(state, sizes, draws, shapes=_shapes, bulk_threads=2, helpers=0):
     stream = _capi.LegacyStream(state)
     eng = _capi.StreamEngine(stream, bulk_threads)
+    if helpers:
+        _capi._check(_capi.load().fokl_stream_set_helpers(eng._h, helpers, None))
     tapes = []
     for p1 in sizes:
         tape = _capi.NoiseTape(p1, draws)
@@ -70,6 +72,25 @@ def test_walk_and_expansion_equal_the_one_thread_recorder(seed, pos):
     for a, b in zip(new, old):
         _assert_same_tape(a, b)
     assert _same_state(sn.as_numpy_state(), so.as_numpy_state())
+
+
+@pytest.mark.parametrize('helpers', [1, 2, 3])
+def test_walk_with_helper_threads_records_the_same_rows(helpers):
+    """Round 6: the walking thread only counts accepted attempts and hands blocks of 128 iterations to helper threads
+    (positions, rows, accept tests; the walker takes blocks itself while it would only wait).  Rows, expanded numbers and the
+    stream's end state are the one-thread walk's bit for bit -- with frequent rejected gamma draws (small shapes: a block that
+    is not good takes everything issued behind it with it) as well as with the fit's shapes, several times over (the threads
+    meet differently every time)."""
+    for shapes in (_shapes, lambda p: (1.2, 1.7)):
+        sizes = [70, 7, 300, 2, 33, 150]
+        state = _state(9, pos=1)
+        want, sw = _new_tapes(state, sizes, 900, shapes)
+        for _ in range(3):
+            got, sg = _new_tapes(state, sizes, 900, shapes, helpers=helpers)
+            for a, b in zip(got, want):
+                assert np.array_equal(a.rows, b.rows)
+                _assert_same_tape(a, b)
+            assert _same_state(sg.as_numpy_state(), sw.as_numpy_state())
 
 
 def test_a_cached_normal_handed_over_with_the_state_opens_the_first_row():
