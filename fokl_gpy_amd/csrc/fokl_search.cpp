@@ -1092,7 +1092,9 @@ void release_outcome(fokl_search *s, Outcome *o)
             unref(s, o->tape);
         } else {
             o->spec->refs += 1;
-            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec});
+            // (the chain thread writes the new terms' statistics behind the chain: they stay alive as long as the job)
+            s->chain_limbo.push_back({o->chain, o->w, o->w_classes, o->w_pinned, o->tape, o->flag, o->spec, o->tstats});
+            o->tstats = nullptr;
             o->chain = nullptr;
             o->chain_waited = true;
             o->chain_status = FOKL_ERR_STATE;
