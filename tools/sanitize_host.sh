@@ -26,7 +26,7 @@ tests=${*:-"tests/test_sampler_host.py tests/test_stream_engine.py tests/test_na
 # OpenBLAS on one thread: its own (uninstrumented) thread pool dead-locks under ThreadSanitizer's interposed pthread calls
 # in numpy's dot as well as in scipy's eigh -- with or without this library's threads in the process.
 OPENBLAS_NUM_THREADS=1 FOKL_HIP_LIBRARY=$PWD/fokl_gpy_amd/libfokl_host_$kind.so FOKL_HOST_ONLY_LIBRARY=1 FOKL_PIN_L3=0 \
-  bash -c "LD_PRELOAD='$runtime' timeout 1500 python -m pytest $tests -q -p no:cacheprovider" >> "$out" 2>&1
+  bash -c "LD_PRELOAD='$runtime' timeout 1500 python -m pytest $tests -q -s -p no:cacheprovider" >> "$out" 2>&1
 rc=$?
 echo "# exit code $rc; reports: $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error:' "$out")" >> "$out"
 tail -5 "$out"
