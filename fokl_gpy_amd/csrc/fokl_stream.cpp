@@ -214,9 +214,26 @@ FOKL_WIDE_TARGET inline __m512d polar_squares(const uint32_t *p)
     return _mm512_mul_pd(x, x);
 }
 
-FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *raw)
+// FOKL_SEGMENT_STORES=cached: the tempered words are written to the segment with ordinary stores (round 5)
+static const bool g_segment_stream = !(std::getenv("FOKL_SEGMENT_STORES") && std::strcmp(std::getenv("FOKL_SEGMENT_STORES"), "cached") == 0);
+
+// `raw` (the calling thread's scratch) is tempered IN PLACE: the flags read it there -- it stays in that core's L2 from
+// segment to segment -- and the segment, which last saw use hundreds of segments ago, receives the words through
+// non-temporal stores: no line of it is fetched to be overwritten, none displaces the scratch (round 6).
+// ... in pieces of FOKL_TEMPER_CHUNK words (a power of two): a non-temporal store per flag group -- two lines at a time between
+// the flags' own loads and stores -- leaves the write-combining buffers half filled
+static const int g_temper_chunk = [] {
+    const char *v = std::getenv("FOKL_TEMPER_CHUNK");
+    int n = v ? std::atoi(v) : 256;
+    if (n < 16 || (n & (n - 1))) n = 256;
+    return n;
+}();
+FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, uint32_t *raw)
 {
-    uint32_t *w = seg->words();
+    uint32_t *dst = seg->words();
+    const bool stream = g_segment_stream;
+    const uint32_t *w = stream ? raw : dst;                 // what the flags below read
+    const int chunk = g_temper_chunk - 1;
     const __m512i m7 = _mm512_set1_epi32((int)0x9d2c5680u), m15 = _mm512_set1_epi32((int)0xefc60000u);
     // tempering runs a few groups ahead of the flags that read its output (one pass over the segment: the flags find the
     // words in the first-level cache instead of fetching 640 KB a second time)
@@ -229,7 +246,12 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
             y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 7), m7, 0x78);      // y ^ (shifted & mask)
             y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 15), m15, 0x78);
             y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
-            _mm512_storeu_si512(w + tempered, y);
+            if (stream) {
+                _mm512_storeu_si512(raw + tempered, y);
+                _mm512_stream_si512(reinterpret_cast<__m512i *>(dst + tempered), y);
+            } else {
+                _mm512_storeu_si512(dst + tempered, y);
+            }
         }
     };
     temper_to(128);
@@ -253,7 +275,7 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
             for (int j = 0; j < 4; ++j) {
                 const int l0 = 128 * word + 64 * half + 16 * j;                  // first double of the group
                 // (the last group's successor lies in the tail words behind the segment: 32 of them, 16 doubles)
-                temper_to(2 * (l0 + 32) + 16);                                   // (nxt reads words up to o + 2 l0 + 63)
+                temper_to(stream ? (2 * (l0 + 32) + 16 + chunk) & ~chunk : 2 * (l0 + 32) + 16);                                   // (nxt reads words up to o + 2 l0 + 63)
                 const __m512 nxt = polar_squares16(p + 2 * (l0 + 16));
                 const __m512 r2 = _mm512_add_ps(cur, _mm512_castsi512_ps(_mm512_alignr_epi32(_mm512_castps_si512(nxt),
                                                                                               _mm512_castps_si512(cur), 1)));
@@ -276,6 +298,7 @@ FOKL_WIDE_TARGET void finish_segment_wide(Segment *seg, int o, const uint32_t *r
         m1[word] = odd;
     }
     temper_to(kSegWords + kSegTail);
+    if (stream) _mm_sfence();                               // the words are in place before the segment is published
     build_rank_tables(seg);
 }
 
