@@ -103,6 +103,7 @@ SIGNATURES = {
     'fokl_stream_expand': (c_int, [c_vp, c_int, c_dbl, c_dbl, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_stats': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'fokl_stream_set_helpers': (c_int, [c_vp, c_int, c_vp]),
+    'fokl_stream_place_bulk': (c_int, [c_vp, c_vp, c_int]),
     'fokl_stream_fast_ln_error': (c_dbl, [c_i64]),
     'fokl_search_create': (c_int, [c_vp, c_vp, c_vp, c_vp]),
     'fokl_search_bind_spectral': (c_int, [c_vp, c_vp, c_int, c_dbl, c_int]),
@@ -781,6 +782,11 @@ class HostPool:
         if cpus is not None:
             arr = np.ascontiguousarray(list(cpus)[:count] + [-1] * max(0, count - len(cpus)), dtype=np.int32)
         _check(self._lib.fokl_stream_set_helpers(c_vp(self.stream_handle()), int(count), _ptr(arr) if arr is not None else None))
+
+    def place_bulk_threads(self, cpus):
+        """fokl_stream_place_bulk on the pool's stream: bulk thread i on logical CPU cpus[i % len(cpus)]."""
+        arr = np.ascontiguousarray(list(cpus), dtype=np.int32)
+        _check(self._lib.fokl_stream_place_bulk(c_vp(self.stream_handle()), _ptr(arr), arr.shape[0]))
 
     def close(self):
         """Runs everything still queued (each submitted tape advances the stream), then stops the threads."""

@@ -63,6 +63,11 @@ constexpr int kSegMaskWords = kSegSlots / 64;               // 624 mask words pe
 constexpr int kSegTail = 32;                                // words of the next segment kept behind this one's
 constexpr int kTable = 8192;                                // segments that can be alive at a time (524 M doubles)
 constexpr int kAhead = 24;                                  // segments produced ahead of the walker (a 585-column tape is 19)
+// ... to begin with.  A walker that keeps arriving at segments not made yet is production bound (configs[3]: 1 490 doubles per
+// Gibbs iteration, a segment per microsecond of walking) while the bulk threads sleep through every pause of the walk: the
+// distance grows with the time the walker has waited -- 8 segments per half millisecond, up to kAheadMax -- so that pauses
+// are used; a fit whose walker hardly waits (configs[2]: 0.3 ms) stays at kAhead and wastes nothing at its end (round 6).
+constexpr int kAheadMax = 192;
 constexpr uint64_t kLeadBit = FOKL_ROW_LEAD;                // fokl_tape_row.start: the row opens with the cached normal
 constexpr uint64_t kCachedHalf = FOKL_SOURCE_X1_HALF;       // a normal's source: the x1 half of the attempt (else x2)
 constexpr uint64_t kGivenGauss = FOKL_SOURCE_GIVEN;         // source position: the cached value of the state handed over
@@ -365,7 +370,7 @@ std::mutex g_spare_m;
 std::vector<Segment *> g_spares;
 // (a configs[2] fit ends with ~330 segments alive -- tapes on the device hold theirs until their chains are confirmed; with
 // 192 spares the other 140 were unmapped at the end of every fit, 2-4 ms, and page-faulted in again by the next)
-constexpr size_t kSpareMax = 512;                           // 410 MB
+constexpr size_t kSpareMax = 1024;                          // 720 MB (configs[3]: 450 segments held for the device + 192 ahead)
 
 Segment *take_segment()
 {
@@ -379,7 +384,7 @@ Segment *take_segment()
     }
     void *mem = nullptr;
     if (posix_memalign(&mem, 64, sizeof(Segment)) != 0) return nullptr;
-    return new (mem) Segment();
+    return new (mem) Segment;                               // (not value-initialised: 700 KB of zeroes nobody reads)
 }
 
 void give_segment(Segment *s)
@@ -419,6 +424,7 @@ struct fokl_stream {
     int64_t next_raw = 0;                                   // next segment to be generated
     int64_t oldest_alive = 0;                               // segments below were given back
     std::atomic<int64_t> limit{kAhead};                     // segments < limit may be produced
+    std::atomic<int> ahead{kAhead};                         // how far in front of the walker (kAhead .. kAheadMax)
     std::atomic<int64_t> low_water{0};                      // segments < low_water will not be read again
     // raw pre-states for a second consumer of the stream (the device regenerates segments from them): entry index %
     // pre_entries = [624 raw words of the block in front of segment `index` (segment 0: block 0 itself) | index as two
@@ -431,6 +437,7 @@ struct fokl_stream {
     std::vector<std::thread> threads;
     std::atomic<Segment *> table[kTable];
     std::atomic<int64_t> bulk_busy_ns{0}, segments_made{0};
+    std::atomic<int64_t> token_ns{0}, token_recurrence_ns{0}, token_wait_ns{0};     // FOKL_WALK_PROFILE: the serial section
     // holds: positions (doubles) somebody may still read from -- open tapes, expansions in flight
     std::mutex hold_m;
     std::multiset<uint64_t> holds;
@@ -502,6 +509,8 @@ void generate_raw(fokl_stream *e, uint32_t *buf, int64_t index)
     }
 }
 
+static const bool g_bulk_profile = std::getenv("FOKL_WALK_PROFILE") != nullptr;
+
 void bulk_worker(fokl_stream *e)
 {
     struct Note {
@@ -523,13 +532,29 @@ void bulk_worker(fokl_stream *e)
     } scratch_owner{scratch_mem};
     uint32_t *scratch = static_cast<uint32_t *>(scratch_mem);
     for (;;) {
-        Segment *seg = nullptr;
+        // the segment to fill is in hand BEFORE the token is taken: mapping a fresh one (a fit of wide models has hundreds alive)
+        // took half of the serial section of configs[3]'s production
+        Segment *seg = take_segment();
+        if (!seg) {
+            std::lock_guard<std::mutex> lock(e->token_m);
+            e->error = "fokl_stream: out of memory";
+            e->stop = true;
+            e->stop_flag.store(true, std::memory_order_release);
+            e->room_cv.notify_all();
+            return;
+        }
         int64_t index = 0;
         std::vector<Segment *> retired;
         {
+            const int64_t t_want = g_bulk_profile ? now_ns() : 0;
             std::unique_lock<std::mutex> lock(e->token_m);
+            int64_t t_got = g_bulk_profile ? now_ns() : 0;
+            if (g_bulk_profile) e->token_wait_ns.fetch_add(t_got - t_want, std::memory_order_relaxed);
             for (;;) {
-                if (e->stop) return;
+                if (e->stop) {
+                    give_segment(seg);
+                    return;
+                }
                 const int64_t low = e->low_water.load(std::memory_order_acquire);
                 if (e->next_raw < e->limit.load(std::memory_order_acquire) && e->next_raw - low < kTable - 2) break;
                 const int64_t next = e->next_raw;
@@ -553,6 +578,7 @@ void bulk_worker(fokl_stream *e)
                     e->sleepers.fetch_sub(1, std::memory_order_seq_cst);
                 }
                 lock.lock();
+                if (g_bulk_profile) t_got = now_ns();
             }
             // segments nobody will read again go back first (their table entries are about to be reused)
             const int64_t low = e->low_water.load(std::memory_order_acquire);
@@ -561,25 +587,16 @@ void bulk_worker(fokl_stream *e)
                 ++e->oldest_alive;
             }
             index = e->next_raw;
-            seg = nullptr;
-            if (!retired.empty()) {
-                seg = retired.back();
-                retired.pop_back();
-            }
-            if (!seg) seg = take_segment();
-            if (!seg) {
-                e->error = "fokl_stream: out of memory";
-                e->stop = true;
-                e->stop_flag.store(true, std::memory_order_release);
-                e->room_cv.notify_all();
-                return;
-            }
             seg->index = index;
             seg->ready.store(0, std::memory_order_relaxed);
             const int64_t t0 = now_ns();
             generate_raw(e, scratch, index);
             e->bulk_busy_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
             ++e->next_raw;
+            if (g_bulk_profile) {
+                e->token_recurrence_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+                e->token_ns.fetch_add(now_ns() - t_got, std::memory_order_relaxed);
+            }
         }
         for (Segment *s : retired) give_segment(s);
         const int64_t t0 = now_ns();
@@ -595,14 +612,17 @@ void bulk_worker(fokl_stream *e)
     }
 }
 
+static const bool g_ahead_adapts = !(std::getenv("FOKL_STREAM_AHEAD") && std::strcmp(std::getenv("FOKL_STREAM_AHEAD"), "fixed") == 0);
+
 // The segment that owns double D (blocks until a bulk thread has published it).  Callers hold a position <= D.
 Segment *segment_of(fokl_stream *e, uint64_t D, bool walker)
 {
     const int64_t index = (int64_t)(D / kSegDoubles);
     Segment *seg = e->table[index % kTable].load(std::memory_order_acquire);
     if (seg && seg->index == index) return seg;
-    if (walker && index + kAhead > e->limit.load(std::memory_order_relaxed)) {
-        e->limit.store(index + kAhead, std::memory_order_seq_cst);
+    const int ahead = e->ahead.load(std::memory_order_relaxed);
+    if (walker && index + ahead > e->limit.load(std::memory_order_relaxed)) {
+        e->limit.store(index + ahead, std::memory_order_seq_cst);
         if (e->sleepers.load(std::memory_order_seq_cst) > 0) {
             { std::lock_guard<std::mutex> lock(e->room_m); }
             e->room_cv.notify_all();
@@ -618,7 +638,11 @@ Segment *segment_of(fokl_stream *e, uint64_t D, bool walker)
             std::this_thread::sleep_for(std::chrono::microseconds(5));
         if ((spins & 1023) == 1023 && e->stop_flag.load(std::memory_order_acquire)) return nullptr;
     }
-    if (walker) e->walker_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+    if (walker) {
+        const int64_t waited = e->walker_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed) + (now_ns() - t0);
+        const int64_t want = kAhead + 8 * (waited / 500000);
+        if (want > ahead && ahead < kAheadMax && g_ahead_adapts) e->ahead.store((int)std::min<int64_t>(want, kAheadMax), std::memory_order_relaxed);
+    }
     return seg;
 }
 
@@ -650,8 +674,8 @@ struct Reader {
         lo = (D / kSegDoubles) * kSegDoubles;
         hi = lo + kSegDoubles;
         if (walker) {
-            // keep the producers kAhead segments in front of this one
-            const int64_t want = (int64_t)(D / kSegDoubles) + 1 + kAhead;
+            // keep the producers `ahead` segments in front of this one
+            const int64_t want = (int64_t)(D / kSegDoubles) + 1 + e->ahead.load(std::memory_order_relaxed);
             if (want > e->limit.load(std::memory_order_relaxed)) {
                 e->limit.store(want, std::memory_order_seq_cst);
                 if (e->sleepers.load(std::memory_order_seq_cst) > 0) {
@@ -1795,7 +1819,7 @@ extern "C" int fokl_stream_create(const uint32_t *mt_key, int32_t mt_pos, int32_
                                   int bulk_threads, uint32_t *prestate_ring, int prestate_entries, fokl_stream **out)
 {
     if (!out || !mt_key || mt_pos < 0 || mt_pos > MT_N || bulk_threads < 1 || bulk_threads > 16 ||
-        (prestate_ring && prestate_entries < 4 * kAhead * (kSegBlocks / FOKL_PRESTATE_BLOCKS))) {
+        (prestate_ring && prestate_entries < 4 * kAheadMax * (kSegBlocks / FOKL_PRESTATE_BLOCKS))) {
         fokl_set_global_error("fokl_stream_create: null pointer, invalid MT19937 position or thread count");
         return FOKL_ERR_ARG;
     }
@@ -1844,6 +1868,13 @@ extern "C" void fokl_stream_destroy(fokl_stream *e)
                      g_walk_ns[3].exchange(0) / std::max(1.0, (double)g_walk_by_position.load()));
         g_walk_by_position.store(0);
     }
+    if (g_walk_profile && e->segments_made.load() > 0) {
+        const double n = (double)e->segments_made.load();
+        std::fprintf(stderr, "fokl_stream: %.0f segments; per segment: token held %.2f us (recurrence + pre-states %.2f), waited for "
+                             "the token %.2f us, all of the bulk phase %.2f us; walker waited %.2f ms, ahead %d\n", n,
+                     e->token_ns.load() / 1e3 / n, e->token_recurrence_ns.load() / 1e3 / n, e->token_wait_ns.load() / 1e3 / n,
+                     e->bulk_busy_ns.load() / 1e3 / n, e->walker_wait_ns.load() / 1e6, e->ahead.load());
+    }
     {
         std::lock_guard<std::mutex> lock(e->token_m);
         e->stop = true;
@@ -1857,6 +1888,31 @@ extern "C" void fokl_stream_destroy(fokl_stream *e)
     for (auto &t : e->threads) t.join();
     for (auto &t : e->table) give_segment(t.exchange(nullptr));
     delete e;
+}
+
+// The bulk threads' CPUs: thread i may run on logical CPU cpus[i % count] only (round 6: with a segment's words written past
+// the cache nothing ties a bulk thread to the walker's last-level cache; a physical core each, elsewhere, is worth a third
+// of their time -- next to the driver's, chain and finish threads they ran two to a core).
+extern "C" int fokl_stream_place_bulk(fokl_stream *e, const int32_t *cpus, int count)
+{
+    if (!e || !cpus || count < 1) {
+        fokl_set_global_error("fokl_stream_place_bulk: null pointer or no CPUs");
+        return FOKL_ERR_ARG;
+    }
+    int failed = 0;
+    for (size_t i = 0; i < e->threads.size(); ++i) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const int cpu = (int)cpus[i % (size_t)count];
+        if (cpu < 0 || cpu >= CPU_SETSIZE) continue;
+        CPU_SET(cpu, &set);
+        failed += pthread_setaffinity_np(e->threads[i].native_handle(), sizeof(set), &set) != 0;
+    }
+    if (failed) {
+        fokl_set_global_error("fokl_stream_place_bulk: pthread_setaffinity_np failed");
+        return FOKL_ERR_STATE;
+    }
+    return FOKL_OK;
 }
 
 // Helper threads for the walk (walk_tape_crew): `count` of them (0: none; at most 4), helper i pinned to logical CPU cpus[i]

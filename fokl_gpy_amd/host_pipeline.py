@@ -95,8 +95,13 @@ def _second_domain(allowed, home):
 
 
 def _spectral_cpus(allowed, home, count):
-    """One logical CPU of each of `count` physical cores outside `home`'s last-level-cache domain(s), taken domain by
-    domain in CPU order after `home`: the eigen-decompositions are compute bound and share nothing -- two of them on the
+    picked = _other_cores(allowed, home, count)
+    return set(picked) if picked is not None else None
+
+
+def _other_cores(allowed, home, count):
+    """One logical CPU of each of `count` physical cores outside `home`'s last-level-cache domain(s), in the order picked: domain
+    by domain in CPU order after `home`: the eigen-decompositions are compute bound and share nothing -- two of them on the
     hardware threads of one core run at half speed each (EPYC 9575F: an L3 domain is FOUR cores; the eight spectral
     threads pinned to the eight logical CPUs of one domain took 0.42 ms per 66-column dsyevr against 0.21 alone).
     None when the topology cannot be read or offers fewer than `count` such cores."""
@@ -119,7 +124,7 @@ def _spectral_cpus(allowed, home, count):
                 cores.add(core)
                 picked.append(cpu)
                 if len(picked) == count:
-                    return set(picked)
+                    return picked
         return None
     except (OSError, ValueError):
         return None
@@ -379,7 +384,8 @@ class HostPipeline:
             # models that wide -- configs[3] defers the G2 of its 585-column models, which leaves them without a parent to
             # derive from (tools/r05_cfg3b.sh: 348-358 ms per fit either way).
             dgemm_from = int(os.environ.get('FOKL_EIGH_DGEMM_FROM', '0'))
-            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=_bulk_threads(wide_models=wide_models),
+            bulk = _bulk_threads(wide_models=wide_models)
+            self.pool = _capi.HostPool(stream, chain, finish, spectral, noise_cpu, bulk_threads=bulk,
                                        prestates=prestates,
                                        device_dgemm=(device, dgemm_from) if device is not None and dgemm_from > 0 else None)
             if prestates is not None:
@@ -389,17 +395,29 @@ class HostPipeline:
             # loop native the walk bounds a fit.  On physical cores of their OWN, outside this process's last-level-cache domain
             # -- next to the bulk threads, two to a core, their passes ran at half speed and bought nothing.  FOKL_WALK_HELPERS
             # overrides the count (0: the walking thread does everything), FOKL_WALK_CPUS=same leaves them unpinned.
-            helpers = int(os.environ.get('FOKL_WALK_HELPERS', str(_walk_helpers_default())))
+            # (wide models -- configs[3] -- are bound by the PRODUCTION of the stream, a segment per microsecond of walking:
+            # helpers there only spin, and cost the fit a fifth: 392 against 318 ms, same box)
+            helpers = int(os.environ.get('FOKL_WALK_HELPERS', str(0 if wide_models else _walk_helpers_default())))
             if helpers > 0:
                 cpus = None
                 if self._saved_affinity is not None and os.environ.get('FOKL_WALK_CPUS', 'other') != 'same':
-                    picked = _spectral_cpus(self._saved_affinity, os.sched_getaffinity(0), spectral + helpers)
+                    picked = _other_cores(self._saved_affinity, os.sched_getaffinity(0), spectral + helpers)
                     if picked is not None:
-                        cpus = sorted(picked)[-helpers:]      # (behind the cores the spectral threads get)
+                        cpus = picked[-helpers:]              # (behind the cores the spectral threads get)
                 try:
                     self.pool.set_walk_helpers(helpers, cpus)
                 except _capi.FoklNativeError:
                     pass
+            # The stream's bulk threads on physical cores of their own as well (round 6): since a segment's words go out
+            # past the cache nothing ties them to this domain, where they shared three cores with the driver's, chain and finish
+            # threads.  Only where the process has the CPUs to spread out (a fit alone); FOKL_BULK_CPUS=same leaves them here.
+            if (self._saved_affinity is not None and _cpu_budget() >= 12 and os.environ.get('FOKL_BULK_CPUS', 'other') != 'same'):
+                picked = _other_cores(self._saved_affinity, os.sched_getaffinity(0), spectral + max(0, helpers) + bulk)
+                if picked is not None:
+                    try:
+                        self.pool.place_bulk_threads(picked[-bulk:])
+                    except _capi.FoklNativeError:
+                        pass
             # the eigen-decompositions share nothing with the stream's threads: on a CPU with several last-level-cache
             # domains they get the next one to themselves (FOKL_SPECTRAL_DOMAIN=0: they stay where the others are)
             if self._saved_affinity is not None and os.environ.get('FOKL_SPECTRAL_DOMAIN', '1') != '0':

@@ -98,6 +98,8 @@ int fokl_stream_expand(fokl_stream *stream, int p1, double astar, double atau_st
  * iterations out; helpers turn ranks into positions / rows and run the gamma draws' accept tests.  count 0: none (default),
  * at most 4; cpus (may be NULL): the logical CPU of each helper (< 0: not pinned).  Call before the first walk. */
 int fokl_stream_set_helpers(fokl_stream *stream, int count, const int32_t *cpus);
+/* bulk thread i runs on logical CPU cpus[i % count] only (csrc/fokl_stream.cpp) */
+int fokl_stream_place_bulk(fokl_stream *stream, const int32_t *cpus, int count);
 int fokl_stream_stats(const fokl_stream *stream, double *bulk_busy_s, double *walker_wait_s, int64_t *segments,
                       int64_t *gamma_attempts, int64_t *gamma_attempts_exact);
 /* max |fast_ln(y) - log(y)| over a sweep of (0, 1): the approximation the walker's bounds are built on (tests) */
