@@ -93,6 +93,34 @@ def test_walk_with_helper_threads_records_the_same_rows(helpers):
             assert _same_state(sg.as_numpy_state(), sw.as_numpy_state())
 
 
+def test_bulk_threads_placed_on_given_cpus_and_wide_tapes_far_ahead():
+    """Round 6: fokl_stream_place_bulk pins the producers (bad arguments are refused); a walk through models of hundreds of
+    columns -- production bound: a segment per microsecond of walking, the producers' distance growing with the walker's waits,
+    segments taken before the token -- records the tapes of the plain walk."""
+    import os
+    lib = _capi.load()
+    state = _state(21, pos=5)
+    sizes = [585, 3, 585, 440, 585]
+    want, sw = _new_tapes(state, sizes, 120, bulk_threads=1)
+    stream = _capi.LegacyStream(state)
+    eng = _capi.StreamEngine(stream, 3)
+    cpus = np.ascontiguousarray(sorted(os.sched_getaffinity(0))[:2], dtype=np.int32)
+    _capi._check(lib.fokl_stream_place_bulk(eng._h, _capi._ptr(cpus), cpus.shape[0]))
+    assert lib.fokl_stream_place_bulk(eng._h, None, 0) != 0
+    got = []
+    for p1 in sizes:
+        tape = _capi.NoiseTape(p1, 120)
+        hold = eng.walk(tape, *_shapes(p1))
+        eng.expand(tape, *_shapes(p1))
+        eng.release(hold)
+        got.append(tape)
+    eng.close()
+    for a, b in zip(got, want):
+        assert np.array_equal(a.rows, b.rows)
+        _assert_same_tape(a, b)
+    assert _same_state(stream.as_numpy_state(), sw.as_numpy_state())
+
+
 def test_a_cached_normal_handed_over_with_the_state_opens_the_first_row():
     state = _state(11, pos=77, cached=-0.4321)
     old, so = _old_tapes(state, [5, 4], 40)
