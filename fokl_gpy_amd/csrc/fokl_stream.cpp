@@ -44,6 +44,7 @@
 
 #include <immintrin.h>
 #include <sched.h>
+#include <deque>
 
 #include "../../include/fokl_hip_internal.h"
 #include "fokl_spin.h"
@@ -1247,6 +1248,7 @@ static const bool g_walk_profile = std::getenv("FOKL_WALK_PROFILE") != nullptr;
 // FOKL_ROW_STORES=cached: ordinary stores for the tape rows (A/B; default: non-temporal)
 static const bool g_row_stream = !(std::getenv("FOKL_ROW_STORES") && std::strcmp(std::getenv("FOKL_ROW_STORES"), "cached") == 0);
 static std::atomic<int64_t> g_walk_ns[4];
+static std::atomic<int64_t> g_crew_wall_ns{0}, g_crew_idle_ns{0}, g_crew_tapes{0};     // FOKL_WALK_PROFILE: the walking thread inside walk_tape_crew
 static std::atomic<int64_t> g_walk_iterations{0}, g_walk_by_position{0};
 #define FOKL_LAP(i)                                                          \
     do {                                                                     \
@@ -1400,6 +1402,8 @@ FOKL_WIDE_TARGET static inline __attribute__((always_inline)) void iteration_sit
     }
 }
 
+static const bool g_prefetch_second = !(std::getenv("FOKL_WALK_PREFETCH") && std::strcmp(std::getenv("FOKL_WALK_PREFETCH"), "first") == 0);
+
 // pass 2: the block's rows, the sources of its gamma draws, the state behind every iteration
 FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut &out, int o)
 {
@@ -1424,6 +1428,11 @@ FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut 
         const char *site = reinterpret_cast<const char *>(in.seg->words() + o + 2 * ((out.source[2 * i] & ~kCachedHalf) - in.lo));
         __builtin_prefetch(site);
         __builtin_prefetch(site + 24);
+        if (g_prefetch_second) {
+            // (the second draw's attempt may lie a few attempts further on: another line as often as not)
+            const char *site2 = reinterpret_cast<const char *>(in.seg->words() + o + 2 * ((out.source[2 * i + 1] & ~kCachedHalf) - in.lo));
+            __builtin_prefetch(site2 + 24);
+        }
     }
 }
 
@@ -1436,7 +1445,12 @@ FOKL_WIDE_TARGET static inline void block_positions(const BlockIn &in, BlockOut 
 // run the accept tests and report the first iteration to redo, if any.  Verdicts are read in order; a block that is not good
 // takes everything issued behind it with it (the walker waits for those helpers, walks the one iteration by positions and
 // chases on from there).  Rows, positions and consumption are the one-thread walk's bit for bit.
-constexpr int kCrewRing = 8;                                // blocks in flight at most
+constexpr int kCrewRing = 16;                               // slots; blocks in flight at most g_crew_depth of them
+static const int g_crew_depth = [] {
+    const char *v = std::getenv("FOKL_CREW_DEPTH");
+    const int n = v ? std::atoi(v) : 8;
+    return n >= 2 && n <= kCrewRing ? n : 8;
+}();
 constexpr int kCrewMax = 4;
 
 struct alignas(64) CrewSlot {
@@ -1551,11 +1565,15 @@ void crew_stop(fokl_stream *e)
     e->crew = nullptr;
 }
 
+static const bool g_crew_inline = !(std::getenv("FOKL_CREW_INLINE") && std::strcmp(std::getenv("FOKL_CREW_INLINE"), "0") == 0);
+
 // the tape walked by the crew: the calling thread chases, the helpers do the rest
 FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double astar, double atau_star, fokl_tape_row *rows,
                                     int32_t *progress)
 {
     WalkCrew *crew = e->crew;
+    const int64_t t_enter = g_walk_profile ? now_ns() : 0;
+    int64_t idle_ns = 0;
     Walk w(e);
     const double b_sig = astar - 1.0 / 3.0, c_sig = 1.0 / std::sqrt(9 * b_sig);
     const double b_tau = atau_star - 1.0 / 3.0, c_tau = 1.0 / std::sqrt(9 * b_tau);
@@ -1567,20 +1585,29 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
         published = std::max(published, whole);
     };
     uint64_t first_open = crew->issued + 1;                 // the oldest block without a verdict
+    // iterations this thread walked by positions from the PRESUMED state behind blocks still open (the chase stops at every
+    // segment's end -- six times per tape of a hundred columns -- and waiting for every verdict there idled the whole crew):
+    // entry = the number of the last block issued before the iteration; it stands once that block and all before it are good
+    std::deque<uint64_t> inline_after;
     Walk lender(e, Walk::ReaderOnly{});                     // (reader of the blocks this thread processes itself)
     // a verdict this thread has to wait for: it takes published blocks nobody has claimed yet instead of only waiting
     auto wait_done = [&](uint64_t n) -> CrewSlot & {
         CrewSlot &slot = crew->slots[n % kCrewRing];
+        int64_t idle_from = 0;
         for (int spins = 0; slot.done.load(std::memory_order_acquire) != n; ++spins) {
             if (const uint64_t mine = crew_claim(crew)) {
+                if (idle_from) idle_ns += now_ns() - idle_from;
+                idle_from = 0;
                 crew_process(crew, mine, *crew->walker_out, lender);
                 spins = 0;
             } else if (spins < 50000) {
+                if (g_walk_profile && !idle_from) idle_from = now_ns();
                 _mm_pause();
             } else {
                 std::this_thread::yield();
             }
         }
+        if (idle_from) idle_ns += now_ns() - idle_from;
         return slot;
     };
     // the oldest open block's verdict (waited for).  -> false: it was not good: the walker stands at the iteration to redo
@@ -1591,11 +1618,17 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
         if (redo == -1) {
             k += slot.in.count;
             ++first_open;
+            while (!inline_after.empty() && inline_after.front() < first_open) {
+                ++k;
+                inline_after.pop_front();
+            }
             publish(k);
             return true;
         }
         for (uint64_t n = first_open + 1; n <= crew->issued; ++n) (void)wait_done(n);      // what was issued behind it goes with it
         first_open = crew->issued + 1;
+        by_position -= (int64_t)inline_after.size();
+        inline_after.clear();
         if (redo == -2) {
             w.r.failed = true;
             return false;
@@ -1613,7 +1646,7 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
         int64_t lap_ = g_walk_profile ? now_ns() : 0;
         bool exact_state = true;                            // w is the state behind the last iteration that stands
         if (k_issued < draws && w.r.locate(w.D) && w.D - w.r.lo < (uint64_t)kSegDoubles - 64) {
-            if (crew->issued - first_open + 1 >= (uint64_t)kCrewRing) {     // the ring is full: the oldest verdict first
+            if (crew->issued - first_open + 1 >= (uint64_t)g_crew_depth) {  // the ring is full: the oldest verdict first
                 if (judge_oldest()) continue;
             } else {
                 const Segment *seg = w.r.seg;
@@ -1662,8 +1695,19 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
                 }
             }
         }
-        // the chase stopped (the segment's end, a long run of rejected attempts, the tape's end) or a block was not good: the
-        // position walk needs the exact state, i.e. every block judged
+        // the chase stopped (the segment's end, a long run of rejected attempts, the tape's end) or a block was not good.
+        // With blocks still open and iterations left, the one iteration the tables do not cover is walked by positions from the
+        // state the open blocks will leave if they are good -- as the chase itself assumes; it stands when they have been judged
+        if (exact_state && g_crew_inline && k_issued < draws && first_open <= crew->issued) {
+            if (g_walk_profile) lap_ = now_ns();
+            walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k_issued]);
+            inline_after.push_back(crew->issued);
+            ++k_issued;
+            ++by_position;
+            FOKL_LAP(3);
+            continue;
+        }
+        // otherwise the position walk needs the exact state, i.e. every block judged
         while (exact_state && first_open <= crew->issued) exact_state = judge_oldest();
         if (w.r.failed) break;
         if (k < draws) {
@@ -1683,6 +1727,9 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
     if (g_walk_profile) {
         g_walk_iterations.fetch_add(k, std::memory_order_relaxed);
         g_walk_by_position.fetch_add(by_position, std::memory_order_relaxed);
+        g_crew_wall_ns.fetch_add(now_ns() - t_enter, std::memory_order_relaxed);
+        g_crew_idle_ns.fetch_add(idle_ns, std::memory_order_relaxed);
+        g_crew_tapes.fetch_add(1, std::memory_order_relaxed);
     }
     if (w.r.failed) {
         if (progress) __atomic_store_n(progress, -1, __ATOMIC_RELEASE);
@@ -1867,6 +1914,10 @@ extern "C" void fokl_stream_destroy(fokl_stream *e)
                      g_walk_ns[1].exchange(0) / n, g_walk_ns[2].exchange(0) / n, (double)g_walk_by_position.load(),
                      g_walk_ns[3].exchange(0) / std::max(1.0, (double)g_walk_by_position.load()));
         g_walk_by_position.store(0);
+        if (g_crew_tapes.load() > 0)
+            std::fprintf(stderr, "fokl_stream: walk crew: %lld tapes, the walking thread inside them %.3f ms, of which waiting for a "
+                                 "verdict with no block to take %.3f ms\n", (long long)g_crew_tapes.exchange(0),
+                         g_crew_wall_ns.exchange(0) / 1e6, g_crew_idle_ns.exchange(0) / 1e6);
     }
     if (g_walk_profile && e->segments_made.load() > 0) {
         const double n = (double)e->segments_made.load();
