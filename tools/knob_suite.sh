@@ -46,6 +46,18 @@ modes=(
   "FOKL_SYNC=blocking"
   "FOKL_HEAD_START=0"
   "FOKL_EIGH_DGEMM_FROM=32"
+  "FOKL_SUBSTAGE_LOOP=python"
+  "FOKL_WALK_HELPERS=0"
+  "FOKL_WALK_HELPERS=3"
+  "FOKL_WALK_CPUS=same"
+  "FOKL_BULK_CPUS=same"
+  "FOKL_CREW_INLINE=0"
+  "FOKL_STREAM_WALK=positions"
+  "FOKL_SEGMENT_STORES=cached"
+  "FOKL_TEMPER_CHUNK=16"
+  "FOKL_STREAM_AHEAD=fixed"
+  "FOKL_DCHAIN_RECURSION=serial"
+  "FOKL_ROW_STORES=cached"
 )
 # KNOB_PART=k/n: every n-th mode from the k-th on (a gpurun call is limited to 20 minutes)
 part=${KNOB_PART:-1/1}; k=${part%%/*}; n=${part##*/}; i=0
