@@ -1565,6 +1565,47 @@ void crew_stop(fokl_stream *e)
     e->crew = nullptr;
 }
 
+// Before an iteration is walked by positions near a segment's end: the lines that walk is about to miss on one after the other
+// -- the mask words under and behind w.D in both alignments, the next segment's first mask words, counts and table words (the
+// chase resumes there), the words around the place the iteration will end on (its gamma site: attempts / 0.785 attempts on) --
+// are requested together.  All of them were written by other cores; the walk's loads would fetch them in sequence, ~100 ns each.
+FOKL_WIDE_TARGET static inline void prefetch_crossing(fokl_stream *e, Walk &w, int p1)
+{
+    if (!w.r.seg || w.D - w.r.lo >= (uint64_t)kSegDoubles) return;
+    const Segment *seg = w.r.seg;
+    const uint64_t q = (w.D - w.r.lo) >> 1;
+    const size_t word = (size_t)(q >> 6);
+    __builtin_prefetch(&seg->mask[0][word]);
+    __builtin_prefetch(&seg->mask[1][word]);
+    if (word + 8 < (size_t)kSegMaskWords) {
+        __builtin_prefetch(&seg->mask[0][word + 8]);
+        __builtin_prefetch(&seg->mask[1][word + 8]);
+    }
+    const uint64_t site = (w.D - w.r.lo) + (uint64_t)(1.27 * (p1 + 1));       // doubles from the segment's start
+    const char *words = reinterpret_cast<const char *>(seg->words() + e->o);
+    const Segment *next = e->table[(seg->index + 1) % kTable].load(std::memory_order_acquire);
+    if (next && next->index != seg->index + 1) next = nullptr;
+    for (int line = -2; line <= 3; ++line) {
+        const int64_t d = (int64_t)site + 8 * line;
+        if (d < 0) continue;
+        if (d < kSegDoubles)
+            __builtin_prefetch(words + 8 * d);
+        else if (next)
+            __builtin_prefetch(reinterpret_cast<const char *>(next->words() + e->o) + 8 * (d - kSegDoubles));
+    }
+    if (next && site + 512 >= (uint64_t)kSegDoubles) {
+        for (int a = 0; a < 2; ++a) {
+            __builtin_prefetch(&next->mask[a][0]);
+            __builtin_prefetch(&next->cum[a][0]);
+            __builtin_prefetch(&next->g0[a][0]);
+            __builtin_prefetch(&next->g1[0][a][0]);
+            __builtin_prefetch(&next->g1[1][a][0]);
+            __builtin_prefetch(&next->g1[2][a][0]);
+        }
+        __builtin_prefetch(&next->safe[0]);
+    }
+}
+
 static const bool g_crew_inline = !(std::getenv("FOKL_CREW_INLINE") && std::strcmp(std::getenv("FOKL_CREW_INLINE"), "0") == 0);
 
 // the tape walked by the crew: the calling thread chases, the helpers do the rest
@@ -1700,6 +1741,7 @@ FOKL_WIDE_TARGET int walk_tape_crew(fokl_stream *e, int p1, int draws, double as
         // state the open blocks will leave if they are good -- as the chase itself assumes; it stands when they have been judged
         if (exact_state && g_crew_inline && k_issued < draws && first_open <= crew->issued) {
             if (g_walk_profile) lap_ = now_ns();
+            prefetch_crossing(e, w, p1);
             walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k_issued]);
             inline_after.push_back(crew->issued);
             ++k_issued;
@@ -1821,6 +1863,7 @@ FOKL_WIDE_TARGET int walk_tape_ranked(fokl_stream *e, int p1, int draws, double 
         // rejected attempts), from the exact state ----
         if (k < draws) {
             if (g_walk_profile) lap_ = now_ns();
+            prefetch_crossing(e, w, p1);
             walk_iteration<true>(w, p1, b_sig, c_sig, b_tau, c_tau, rows[k]);
             ++k;
             ++by_position;
