@@ -91,6 +91,7 @@ struct fokl_ctx {
     size_t gout_doubles = 0;
     size_t gram_pending = 0;            // doubles of the block fokl_gram_fetch will return; 0 = none on its way
     hipEvent_t gram_done = nullptr;
+    hipEvent_t resid_done = nullptr;     // behind the residual pass's result copy: its fetch waits for this, not for what was queued after it
 
     // timing
     bool timing = false;
@@ -340,7 +341,8 @@ extern "C" int fokl_ctx_create(int device, fokl_ctx **out)
     const hipError_t made = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (made != hipSuccess ||
         hipEventCreateWithFlags(&ctx->args_free, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->gram_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->gram_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->resid_done, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return fail(nullptr, FOKL_ERR_HIP, "fokl_ctx_create: cannot create stream / event");
     }
@@ -377,6 +379,7 @@ extern "C" void fokl_ctx_destroy(fokl_ctx *ctx)
     if (ctx->d_comm) (void)hipFree(ctx->d_comm);
     if (ctx->args_free) (void)hipEventDestroy(ctx->args_free);
     if (ctx->gram_done) (void)hipEventDestroy(ctx->gram_done);
+    if (ctx->resid_done) (void)hipEventDestroy(ctx->resid_done);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1586,6 +1589,7 @@ extern "C" int fokl_bic_resid_launch(fokl_ctx *ctx, const int32_t *slots, int nc
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->resid_done, ctx->stream));
     ctx->resid_pending = true;
     return FOKL_OK;
 }
@@ -1722,6 +1726,7 @@ extern "C" int fokl_bic_resid_terms_launch(fokl_ctx *ctx, const int32_t *terms, 
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->resid_done, ctx->stream));
     ctx->resid_pending = true;
     return FOKL_OK;
 }
@@ -1737,8 +1742,10 @@ extern "C" int fokl_bic_resid_fetch(fokl_ctx *ctx, double *out, int allreduce)
         int rc = comm_allreduce_device(ctx, ctx->d_rout, 2);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_rout, ctx->d_rout, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->resid_done, ctx->stream));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (not the stream: the driver may have queued the coming sub-stage's Gram launch behind this pass)
+    HIP_TRY(ctx, hipEventSynchronize(ctx->resid_done));
     out[0] = ctx->h_rout[0];
     out[1] = ctx->h_rout[1];
     return FOKL_OK;

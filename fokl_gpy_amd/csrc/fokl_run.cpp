@@ -156,6 +156,7 @@ struct Ahead {
     std::vector<int32_t> slots;
     int over = 0;                                           // active columns of the sub-stage it was launched under
     bool pending = false;                                   // the Gram block is still on the device
+    bool built = false;                                     // K1 went out, K2 not yet (valid stays false until it has)
     std::vector<double> block;                              // [T][over + T + 1]
 };
 
@@ -265,6 +266,14 @@ int matrix_free_pay_from(const fokl_backend_ops &ops, const std::vector<int32_t>
     return ops.kernel_id != 0 ? 0 : (int)(3.5 * best);
 }
 
+// FOKL_BUILD_AHEAD_AT=model: K1 + K2 of the coming sub-stage are launched behind the model's evaluation (round 6's first form);
+// default `start`: K1 (the coming columns) at the sub-stage's start, in front of the wait for the model's eigenpairs -- the device
+// builds them while the host waits --, K2 (their Gram rows) right behind the model's residual pass in the device's queue: the
+// coming model's G2 can then be requested a quarter of a millisecond earlier and is waited for that much less at the next
+// sub-stage's start.  (Both in front of the residual pass: the pass, which the model's BIC waits for, queued behind them -- 1.8 ms
+// per fit in t_resid for 1.3 gained in t_eigh.)
+static const bool g_build_at_start = !(std::getenv("FOKL_BUILD_AHEAD_AT") && std::strcmp(std::getenv("FOKL_BUILD_AHEAD_AT"), "model") == 0);
+
 // the loop's state
 struct Loop {
     fokl_run *r;
@@ -335,20 +344,37 @@ struct Loop {
     int build_ahead(const std::vector<int32_t> &indvec, const std::vector<int32_t> &active, Ahead *out)
     {
         Ahead a;
-        a.vecs = arrangements(indvec);
-        a.T = (int)(a.vecs.size() / (size_t)m);
-        int rc = r->pool.take(a.T, &a.slots);
+        int rc = build_ahead_columns(indvec, &a);
+        if (rc == FOKL_OK) rc = launch_ahead_gram(active, &a);
         if (rc != FOKL_OK) return rc;
-        if ((rc = ops.build_terms(ops.ctx, a.vecs.data(), a.T, a.slots.data())) != FOKL_OK) return rc;
-        r->stats[R_TERMS_PHYSICAL] += a.T;
-        a.over = (int)active.size();
-        std::vector<int32_t> cols(active);
-        cols.insert(cols.end(), a.slots.begin(), a.slots.end());
-        cols.push_back(FOKL_SLOT_Y);
-        if ((rc = ops.gram_launch(ops.ctx, a.slots.data(), a.T, cols.data(), (int)cols.size(), 0)) != FOKL_OK) return rc;
-        a.pending = true;
-        a.valid = true;
         *out = std::move(a);
+        return FOKL_OK;
+    }
+
+    // ... in two halves: K1 (the columns) ...
+    int build_ahead_columns(const std::vector<int32_t> &indvec, Ahead *a)
+    {
+        a->vecs = arrangements(indvec);
+        a->T = (int)(a->vecs.size() / (size_t)m);
+        int rc = r->pool.take(a->T, &a->slots);
+        if (rc != FOKL_OK) return rc;
+        if ((rc = ops.build_terms(ops.ctx, a->vecs.data(), a->T, a->slots.data())) != FOKL_OK) return rc;
+        r->stats[R_TERMS_PHYSICAL] += a->T;
+        a->built = true;
+        return FOKL_OK;
+    }
+
+    // ... and K2 (their Gram rows against [active | new | y])
+    int launch_ahead_gram(const std::vector<int32_t> &active, Ahead *a)
+    {
+        a->over = (int)active.size();
+        std::vector<int32_t> cols(active);
+        cols.insert(cols.end(), a->slots.begin(), a->slots.end());
+        cols.push_back(FOKL_SLOT_Y);
+        const int rc = ops.gram_launch(ops.ctx, a->slots.data(), a->T, cols.data(), (int)cols.size(), 0);
+        if (rc != FOKL_OK) return rc;
+        a->pending = true;
+        a->valid = true;
         return FOKL_OK;
     }
 
@@ -612,6 +638,14 @@ int Loop::run()
         if ((rc = fokl_search_model_begin(s, cur->data(), A + 1, idx.data(), A, spectral_job.h, then_sizes.data(),
                                           then_model.data(), (int)then_sizes.size(), &spectrum, &tape)) != FOKL_OK)
             return rc;
+        // K1 of the coming sub-stage: launched while this thread would only wait for the model's eigenpairs (the model's tape
+        // is on request, its G2 on its way)
+        if (g_build_at_start && have_coming && prm.foresight > 0) {
+            if ((rc = build_ahead_columns(coming_indvec, &ahead)) != FOKL_OK) {
+                fokl_spectrum_release(s, spectrum);
+                return rc;
+            }
+        }
         const double *buffer = nullptr;
         int p1_check = 0;
         if ((rc = fokl_spectrum_wait(s, spectrum, &buffer, &p1_check)) != FOKL_OK) {
@@ -625,6 +659,8 @@ int Loop::run()
         } else {
             rc = ops.bic_resid_launch(ops.ctx, active_slots.data(), A, betahat);
         }
+        // (the coming sub-stage's columns went out at this sub-stage's start: their Gram rows right behind the residual pass)
+        if (rc == FOKL_OK && ahead.built && !ahead.valid) rc = launch_ahead_gram(active_slots, &ahead);
         if (rc == FOKL_OK && !guessed && prm.lookahead > 0 && vm > 0) {
             // G2 of the model has just arrived: the likely first tests' G2 jobs and tapes go out now, under the device's
             // residual pass, not after it
@@ -639,11 +675,25 @@ int Loop::run()
         }
         release(spectral_job);
         outcomes.push_back(full);
+        // the coming model's G2 for the kill set this model's least-squares fit predicts: its Gram block was launched at the
+        // sub-stage's start and lies in front of the residual pass in the device's queue
+        auto forecast_now = [&]() {
+            if (!(g_build_at_start && prm.forecast_early && ahead.valid && ahead.pending && have_predicted && ops.gram_ready &&
+                  forecasts.empty()))
+                return;
+            if (!ops.gram_ready(ops.ctx)) return;
+            foresee(predicted_kills.data(), (int)predicted_kills.size());
+            if (rc_cb == FOKL_OK) R->stats[R_FORECASTS_EARLY] += 1;
+        };
+        forecast_now();
+        if (rc_cb != FOKL_OK) return rc_cb;
         {
             const double t0 = now_s();
             double mom[2] = {0, 0};
             if ((rc = ops.bic_resid_fetch(ops.ctx, mom, 0)) != FOKL_OK) return rc;
             R->stats[R_T_RESID] += now_s() - t0;
+            forecast_now();
+            if (rc_cb != FOKL_OK) return rc_cb;
             double ev_model = 0;
             if ((rc = fokl_search_score(s, full, mom[0], mom[1], n_prev, 0, &ev_model)) != FOKL_OK) return rc;
         }
@@ -662,7 +712,7 @@ int Loop::run()
         }
         // K1 + K2 of the coming sub-stage now, while this thread would only wait for the model's chain
         release_retired();
-        if (have_coming && prm.foresight > 0) {
+        if (have_coming && prm.foresight > 0 && !ahead.valid && !ahead.built) {
             if ((rc = build_ahead(coming_indvec, active_slots, &ahead)) != FOKL_OK) return rc;
         }
         // ... and G2 of the coming model for the kill set the least-squares downdate predicts, as soon as the coming columns'
