@@ -99,7 +99,20 @@ def _spectral_cpus(allowed, home, count):
     return set(picked) if picked is not None else None
 
 
+_OTHER_CORES = {}                                           # (allowed, home, count) -> picked: the topology does not change
+
+
 def _other_cores(allowed, home, count):
+    key = (frozenset(allowed), frozenset(home), count)
+    if key not in _OTHER_CORES:
+        if len(_OTHER_CORES) > 64:
+            _OTHER_CORES.clear()
+        _OTHER_CORES[key] = _other_cores_uncached(allowed, home, count)
+    picked = _OTHER_CORES[key]
+    return list(picked) if picked is not None else None
+
+
+def _other_cores_uncached(allowed, home, count):
     """One logical CPU of each of `count` physical cores outside `home`'s last-level-cache domain(s), in the order picked: domain
     by domain in CPU order after `home`: the eigen-decompositions are compute bound and share nothing -- two of them on the
     hardware threads of one core run at half speed each (EPYC 9575F: an L3 domain is FOUR cores; the eight spectral

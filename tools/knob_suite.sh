@@ -58,6 +58,9 @@ modes=(
   "FOKL_STREAM_AHEAD=fixed"
   "FOKL_DCHAIN_RECURSION=serial"
   "FOKL_ROW_STORES=cached"
+  "FOKL_BUILD_AHEAD_AT=model"
+  "FOKL_WALK_PREFETCH=first"
+  "FOKL_CREW_DEPTH=16"
 )
 # KNOB_PART=k/n: every n-th mode from the k-th on (a gpurun call is limited to 20 minutes)
 part=${KNOB_PART:-1/1}; k=${part%%/*}; n=${part##*/}; i=0
