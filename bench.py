@@ -1083,7 +1083,7 @@ def main():
                     t_final_draws=0.0, t_search_body=0.0, t_teardown=0.0, seconds=0.0, t_kill_loop=0.0, pool_bulk_s=0.0,
                     walker_wait_s=0.0, stream_segments=0, gamma_attempts_exact=0, tapes_wasted=0, tapes_materialised=0,
                     rows_chains=0, path_repredicted=0, t_pool_up=0.0, spectral_device=0, spectral_updated=0,
-                    direct_tests=0, chains_cancelled=0, t_settle=0.0)
+                    direct_tests=0, chains_cancelled=0, t_settle=0.0, t_head_start=0.0, t_pool_create=0.0)
         direct_max_rel = guess_max_dev = 0.0                  # (maxima, not sums: kept out of `host`)
         drivers = set()
         for _ in range(args.steps):

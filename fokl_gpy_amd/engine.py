@@ -1077,6 +1077,7 @@ class ForwardSelection:
                 forecast_polls=0 if os.environ.get('FOKL_SYNC') == 'blocking' else self._forecast_polls,
                 matrix_free=int(self._matrix_free), update_from=0, update_depth=0, update_lookahead=0,
                 head_start=int(os.environ.get('FOKL_HEAD_START', '1') != '0'), slot_capacity=self.pool.capacity)
+        self.stats['t_head_start'] = time.perf_counter() - t_begin_run
         if (self._nrun is None and pipelined and hasattr(self.backend, 'gram_launch')
                 and not (self.allreduce or self.candidate_sharded)
                 and os.environ.get('FOKL_HEAD_START', '1') != '0'):
