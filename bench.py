@@ -996,10 +996,17 @@ def main():
             if mode in ('rows', 'hybrid'):
                 # rank r holds rows [lo, hi) of the one dataset; the data-driven defaults of b / btau (FR:1322-1348)
                 # need the global mean and variance of y: one all-gather.  A shard must not be rescaled by its own
-                # min / max: the synthetic inputs are U[0,1) already.
+                # min / max: clean's normalisation (FR:436-437) is applied here with the bounds of the WHOLE dataset (one
+                # more all-gather) -- the inputs of the single-process fit, and of the golden, bit for bit (round 6: the
+                # raw U[0,1) columns, 1e-6 from their min-max form, left the sharded fit 5e-7 from the golden's BICs)
                 lo, hi = dist.shard_range(spec['rows'], rank, world)
                 x, y = x[lo:hi], y[lo:hi]
                 n_local = hi - lo
+                ends = control.allgather([float(v) for v in x.min(axis=0)] + [float(v) for v in x.max(axis=0)])
+                lows, highs = ends[:, :x.shape[1]].min(axis=0), ends[:, x.shape[1]:].max(axis=0)
+                x = np.ascontiguousarray(x, dtype=np.float64).copy()
+                for k in range(x.shape[1]):
+                    x[:, k] = (x[:, k] - lows[k]) / (highs[k] - lows[k])
                 mom = control.allgather([n_local, float(np.sum(y)), float(np.sum(y * y))])
                 mean = float(np.sum(mom[:, 1]) / spec['rows'])
                 var = float(np.sum(mom[:, 2]) / spec['rows'] - mean * mean)
