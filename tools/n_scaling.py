@@ -43,7 +43,10 @@ for n in rows:
           f"{st['terms_logical'] / min(ts):,.0f} candidate terms/s, evaluations {st['gibbs_calls']}, BIC from Gram "
           f"{st['bic_from_gram']}, matrix-free K3 {st['resid_matrix_free']}; roofline fractions "
           + ' '.join(f"{k} {v:.2f}" for k, v in frac.items())
-          + f"; MFMA flops issued / algorithmic on the MFMA-bound Gram launches {flops_run_over_algorithmic(open(TRACE).read().splitlines()):.3f}",
+          + f"; MFMA flops issued / algorithmic on the MFMA-bound Gram launches {flops_run_over_algorithmic(open(TRACE).read().splitlines()):.3f}"
+          # (profiles/k2_clock_r05.txt: through launches of milliseconds the chip holds 1.92-1.98 GHz of the 2.4 the 78.6 TFLOP/s
+          # peak is quoted at; through the 0.1-0.3 ms launches of N = 1e6 2.1-2.35)
+          + (f"; K2 against the roof at the clock the chip holds (1.95 of 2.4 GHz): {frac['K2'] / (1.95 / 2.4):.2f}" if n >= 10_000_000 else ""),
           flush=True)
     ctx.upload(np.zeros((1, 1)), np.zeros(1), 1, np.zeros(2), 1, 2)          # let go of the big dataset
 try:
