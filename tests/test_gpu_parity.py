@@ -266,6 +266,12 @@ def test_k2_paths_agree_and_are_reproducible(device_ctx, monkeypatch):
     assert device_ctx.bic_resid_fetch() == moments
     with pytest.raises(_capi.FoklNativeError):
         device_ctx.gram_fetch(shape)                                     # nothing on its way any more
+    # round 6: the native sub-stage loop queues the coming sub-stage's Gram launch BEHIND the model's residual pass; the
+    # pass's fetch waits for an event of its own (not for the stream) and returns the pass's moments, the block follows
+    device_ctx.bic_resid_launch(cs[:-1], beta)
+    shape = device_ctx.gram_launch(rs, cs)
+    assert device_ctx.bic_resid_fetch() == moments
+    assert np.array_equal(device_ctx.gram_fetch(shape), auto)
     device_ctx.gram_launch(rs[:2], cs[:4])
     with pytest.raises(_capi.FoklNativeError):
         device_ctx.gram_fetch((3, 4))                                    # not the block that was launched
